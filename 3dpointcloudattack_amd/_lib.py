@@ -1,0 +1,66 @@
+"""ctypes binding of libpc3d_hip.so (the C-ABI declared in include/pc3d.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails, this module raises.
+Build it with ``python -c "import __graft_entry__ as g; g.build()"`` or ``make -C 3dpointcloudattack_amd/csrc``.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpc3d_hip.so")
+
+_P = c_void_p
+_I = c_int
+_L = c_int64
+_F = c_float
+_PTS = [_P, _L, _L, _L]  # pointer + (batch, point, channel) element strides
+
+# name -> argtypes; every entry returns int (0 ok) except the two noted below.
+SIGNATURES = {
+    "pc3d_nn_f32": _PTS + _PTS + [_I, _I, _I, _P, _P, _P],
+    "pc3d_nn_bidir_f32": _PTS + _PTS + [_I, _I, _I, _P, _P, _P, _P, _P],
+    "pc3d_rowreduce_f32": [_P, _I, _I, _I, _I, _P, _P],
+    "pc3d_nn_bwd_f32": _PTS + _PTS + [_I, _I, _I]
+    + [_P, _P, _L, _L, _F] + [_P, _P, _L, _L, _F]
+    + _PTS + _PTS + [_I, _P],
+}
+
+_lib = None
+
+
+class Pc3dError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises Pc3dError when the HIP library is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise Pc3dError(
+            f"{LIB_PATH} not found: the HIP extension is not built. There is no CPU fallback — run "
+            "`make -C 3dpointcloudattack_amd/csrc` (or __graft_entry__.build())."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.pc3d_version.restype = c_int
+    lib.pc3d_version.argtypes = []
+    lib.pc3d_last_error.restype = c_char_p
+    lib.pc3d_last_error.argtypes = []
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = c_int
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    """Invoke an int-returning entry point and raise Pc3dError with the library's message on failure."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.pc3d_last_error().decode("utf-8", "replace")
+        raise Pc3dError(f"{name} failed (rc={rc}): {msg}")
+    return rc

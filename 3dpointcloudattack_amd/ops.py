@@ -1,0 +1,197 @@
+"""Host-side operators over the C-ABI (include/pc3d.h): thin ctypes shims + torch.autograd.Functions.
+
+PyTorch is plumbing here (device memory, streams, autograd graph); all arithmetic of these ops runs in the
+hand-written gfx950 kernels of libpc3d_hip.so. There is no CPU/eager fallback: tensors must live on the GPU.
+"""
+import torch
+
+from . import _lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _check(t, name):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor, got {type(t)}")
+    if not t.is_cuda:
+        raise _lib.Pc3dError(f"{name}: tensor is on {t.device}; pc3d ops run on the GPU only (no CPU fallback)")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name}: expected float32, got {t.dtype}")
+
+
+def _pts(t, channel_first, name="points"):
+    """(ptr, batch_stride, point_stride, channel_stride, B, N) of a [B,N,3] or [B,3,N] fp32 GPU tensor."""
+    _check(t, name)
+    if t.dim() != 3:
+        raise ValueError(f"{name}: expected 3 dims, got shape {tuple(t.shape)}")
+    if channel_first:
+        B, C, N = t.shape
+        bs, cs, ps = t.stride()
+    else:
+        B, N, C = t.shape
+        bs, ps, cs = t.stride()
+    if C != 3:
+        raise ValueError(f"{name}: expected 3 coordinates, got shape {tuple(t.shape)} (channel_first={channel_first})")
+    return t.data_ptr(), bs, ps, cs, B, N
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+# ------------------------------------------------------------------------------------------------------
+# raw (non-differentiable) ops
+# ------------------------------------------------------------------------------------------------------
+def nn_raw(q, r, q_cf=False, r_cf=False, want_idx=True):
+    """Nearest reference point of every query: (min_d2 [B,N] f32, idx [B,N] i32)."""
+    qp, qbs, qps, qcs, B, N = _pts(q, q_cf, "q")
+    rp, rbs, rps, rcs, B2, M = _pts(r, r_cf, "r")
+    if B != B2:
+        raise ValueError("q and r must have the same batch dimension")
+    if M < 1:
+        raise ValueError("reference set is empty")
+    d = torch.empty((B, N), dtype=torch.float32, device=q.device)
+    i = torch.empty((B, N), dtype=torch.int32, device=q.device) if want_idx else None
+    with torch.cuda.device(q.device):
+        _lib.call("pc3d_nn_f32", qp, qbs, qps, qcs, rp, rbs, rps, rcs, B, N, M, d.data_ptr(), _ptr(i), _stream())
+    return d, i
+
+
+def nn_bidir_raw(a, b, a_cf=False, b_cf=False):
+    """Both directions in one launch: (dA [B,N], iA [B,N], dB [B,M], iB [B,M])."""
+    ap, abs_, aps, acs, B, N = _pts(a, a_cf, "a")
+    bp, bbs, bps, bcs, B2, M = _pts(b, b_cf, "b")
+    if B != B2:
+        raise ValueError("a and b must have the same batch dimension")
+    if N < 1 or M < 1:
+        raise ValueError("empty point set")
+    dev = a.device
+    dA = torch.empty((B, N), dtype=torch.float32, device=dev)
+    iA = torch.empty((B, N), dtype=torch.int32, device=dev)
+    dB = torch.empty((B, M), dtype=torch.float32, device=dev)
+    iB = torch.empty((B, M), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.call("pc3d_nn_bidir_f32", ap, abs_, aps, acs, bp, bbs, bps, bcs, B, N, M,
+                  dA.data_ptr(), iA.data_ptr(), dB.data_ptr(), iB.data_ptr(), _stream())
+    return dA, iA, dB, iB
+
+
+_OPS = {"mean": 0, "max": 1, "sum": 2}
+
+
+def rowreduce(x, op="mean", sqrt=False):
+    """[B,N] f32 -> [B]; op in {mean,max,sum}; sqrt=True applies sqrt(max(x,0)) per element first."""
+    _check(x, "x")
+    x = x.contiguous()
+    B, N = x.shape
+    out = torch.empty((B,), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.call("pc3d_rowreduce_f32", x.data_ptr(), B, N, _OPS[op], 1 if sqrt else 0, out.data_ptr(), _stream())
+    return out
+
+
+def _nn_bwd(a, a_cf, b, b_cf, iA, wA, sA, iB, wB, sB, need_a, need_b, deterministic):
+    ap, abs_, aps, acs, B, N = _pts(a, a_cf, "a")
+    bp, bbs, bps, bcs, _, M = _pts(b, b_cf, "b")
+    ga = torch.empty_like(a, memory_format=torch.contiguous_format) if need_a else None
+    gb = torch.empty_like(b, memory_format=torch.contiguous_format) if need_b else None
+
+    def gview(g, cf):
+        if g is None:
+            return (0, 0, 0, 0)
+        p, bs, ps, cs, _, _ = _pts(g, cf, "grad")
+        return (p, bs, ps, cs)
+
+    def wview(w):
+        if w is None:
+            return (0, 0, 0)
+        _check(w, "upstream grad")
+        return (w.data_ptr(), w.stride(0), w.stride(1))
+
+    with torch.cuda.device(a.device):
+        _lib.call("pc3d_nn_bwd_f32", ap, abs_, aps, acs, bp, bbs, bps, bcs, B, N, M,
+                  _ptr(iA), *wview(wA), float(sA), _ptr(iB), *wview(wB), float(sB),
+                  *gview(ga, a_cf), *gview(gb, b_cf), 1 if deterministic else 0, _stream())
+    return ga, gb
+
+
+# ------------------------------------------------------------------------------------------------------
+# differentiable ops
+# ------------------------------------------------------------------------------------------------------
+class _NNBidirFn(torch.autograd.Function):
+    """(a, b) -> (dA, dB, iA, iB): per-point squared NN distances both ways, differentiable in a and b."""
+
+    @staticmethod
+    def forward(ctx, a, b, a_cf, b_cf, deterministic):
+        dA, iA, dB, iB = nn_bidir_raw(a, b, a_cf, b_cf)
+        ctx.save_for_backward(a, b, iA, iB)
+        ctx.cfg = (a_cf, b_cf, deterministic)
+        ctx.mark_non_differentiable(iA, iB)
+        ctx.set_materialize_grads(False)
+        return dA, dB, iA, iB
+
+    @staticmethod
+    def backward(ctx, gA, gB, _gia, _gib):
+        a, b, iA, iB = ctx.saved_tensors
+        a_cf, b_cf, det = ctx.cfg
+        need_a, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if gA is None and gB is None:
+            return None, None, None, None, None
+        ga, gb = _nn_bwd(a, a_cf, b, b_cf, iA if gA is not None else None, gA, 1.0,
+                         iB if gB is not None else None, gB, 1.0, need_a, need_b, det)
+        return ga, gb, None, None, None
+
+
+def nn_bidir(a, b, a_cf=False, b_cf=False, deterministic=False):
+    """Differentiable bidirectional NN: returns (dA [B,N], dB [B,M], iA, iB)."""
+    return _NNBidirFn.apply(a, b, a_cf, b_cf, deterministic)
+
+
+class _SetDistFn(torch.autograd.Function):
+    """Fused (a,b) -> (loss_a2b [B], loss_b2a [B]) with reduce in {mean (Chamfer), max (Hausdorff)} over
+    squared NN distances — distance.py:40-50 (ChamferDistance) / :58-70 (HausdorffDistance)."""
+
+    @staticmethod
+    def forward(ctx, a, b, a_cf, b_cf, reduce, deterministic):
+        dA, iA, dB, iB = nn_bidir_raw(a, b, a_cf, b_cf)
+        l1 = rowreduce(dA, reduce)
+        l2 = rowreduce(dB, reduce)
+        if reduce == "max":
+            # gradient flows to the arg-max point only (torch.max backward); keep one-hot weights
+            ctx.hot = (dA == l1[:, None]), (dB == l2[:, None])
+        ctx.save_for_backward(a, b, iA, iB)
+        ctx.cfg = (a_cf, b_cf, reduce, deterministic, dA.shape[1], dB.shape[1])
+        ctx.set_materialize_grads(False)
+        return l1, l2
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        a, b, iA, iB = ctx.saved_tensors
+        a_cf, b_cf, reduce, det, N, M = ctx.cfg
+        need_a, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if (g1 is None and g2 is None) or not (need_a or need_b):
+            return None, None, None, None, None, None
+        if reduce == "mean":
+            wA = None if g1 is None else g1.contiguous().view(-1, 1).expand(-1, N)  # stride (1,0): no copy
+            wB = None if g2 is None else g2.contiguous().view(-1, 1).expand(-1, M)
+            sA, sB = 1.0 / N, 1.0 / M
+        else:
+            hotA, hotB = ctx.hot
+            # first arg-max only, like torch.max(dim) backward
+            def first_hot(h, g):
+                if g is None:
+                    return None
+                first = (h.int().cumsum(1) == 1) & h
+                return first.float() * g.view(-1, 1)
+            wA, wB = first_hot(hotA, g1), first_hot(hotB, g2)
+            sA = sB = 1.0
+        ga, gb = _nn_bwd(a, a_cf, b, b_cf, iA if wA is not None else None, wA, sA,
+                         iB if wB is not None else None, wB, sB, need_a, need_b, det)
+        return ga, gb, None, None, None, None
+
+
+def set_distance(a, b, reduce="mean", a_cf=False, b_cf=False, deterministic=False):
+    """(loss_a2b [B], loss_b2a [B]) — squared Chamfer (reduce='mean') or Hausdorff (reduce='max') terms."""
+    return _SetDistFn.apply(a, b, a_cf, b_cf, reduce, deterministic)

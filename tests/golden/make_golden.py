@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REAL reference (read-only at /root/reference) on seeded inputs.
+
+Run in the build container only (the reference does not travel to the GPU box):
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [section ...]
+Each fixture stores the inputs AND the reference's outputs, so the tests need nothing but the .npz.
+Only data is written — no reference source is copied.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+REF = os.environ.get("PC3D_REFERENCE", "/root/reference")
+OUT = os.path.dirname(os.path.abspath(__file__))
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+
+
+def unit_cloud(rng, n):
+    """Uniform-in-ball cloud, centred and scaled to the unit sphere like dataset/bosphorus_dataset.py:74-76."""
+    g = rng.standard_normal((n, 3))
+    g /= np.linalg.norm(g, axis=1, keepdims=True)
+    p = g * rng.random((n, 1)) ** (1.0 / 3.0)
+    p = p - p.mean(axis=0, keepdims=True)
+    p = p / np.max(np.linalg.norm(p, axis=1))
+    return p.astype(np.float32)
+
+
+def perturbed(rng, p, sigma=0.01, budget=0.18):
+    d = (sigma * rng.standard_normal(p.shape)).astype(np.float32)
+    n = np.linalg.norm(d, axis=1, keepdims=True)
+    d = d * np.minimum(1.0, budget / (n + 1e-9))
+    return (p + d).astype(np.float32)
+
+
+def load_real_clouds():
+    """A few in-repo clouds (data files, not code): saved CW / AOF outputs and a raw scan."""
+    out = {}
+    p = os.path.join(REF, "attack/CW/AdvData/PointNet/0-88-63.txt")
+    if os.path.exists(p):
+        out["cw_adv_0_88_63"] = np.loadtxt(p, dtype=np.float32)[:, :3]
+    for k in (0, 1):
+        p = os.path.join(REF, f"attack/AOF/AdvData/PointNet/{k}.txt")
+        if os.path.exists(p):
+            out[f"aof_adv_{k}"] = np.loadtxt(p, dtype=np.float32)[:, :3]
+    p = os.path.join(REF, "AddData/face0424.txt")
+    if os.path.exists(p):
+        try:
+            arr = np.loadtxt(p, delimiter=",", dtype=np.float32)
+        except ValueError:
+            arr = np.loadtxt(p, dtype=np.float32)
+        out["face0424"] = arr[:, :3]
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+def gen_metrics():
+    from utils import dis_utils_numpy as dun
+    from utils import dis_utils_torch as dut
+    from attack.CW.CW_utils.distance import chamfer as cw_chamfer, hausdorff as cw_hausdorff
+
+    rng = np.random.default_rng(1234)
+    fx = {}
+
+    # --- numpy metrics: worked examples + hand case + random + real clouds
+    pairs = {
+        "kat_ones_twos": (np.ones((3, 3), np.float32), 2 * np.ones((3, 3), np.float32)),
+        "hand_asym": (np.array([[0, 0, 0], [1, 0, 0], [0, 2, 0]], np.float32),
+                      np.array([[0, 0, 1], [3, 0, 0]], np.float32)),
+        "single_point": (np.array([[0.5, -0.25, 1.0]], np.float32), np.array([[0.5, -0.25, 1.0]], np.float32)),
+    }
+    for n in (64, 257, 1024, 2048):
+        p = unit_cloud(rng, n)
+        pairs[f"rand_{n}"] = (perturbed(rng, p), p)
+    pa, pb = unit_cloud(rng, 300), unit_cloud(rng, 1000)
+    pairs["ragged_300_1000"] = (pa, pb)
+    real = load_real_clouds()
+    names = sorted(real)
+    for nm in names:
+        c = real[nm]
+        sub = c[:: max(1, c.shape[0] // 1500)][:1500]
+        pairs[f"real_{nm}"] = (perturbed(rng, sub, sigma=0.01 * float(np.abs(sub).max())), sub)
+    fx["np_names"] = np.array(sorted(pairs))
+    for nm in sorted(pairs):
+        a, b = pairs[nm]
+        fx[f"np_{nm}_a"], fx[f"np_{nm}_b"] = a, b
+        fx[f"np_{nm}_out"] = np.array([dun.chamfer(a, b), dun.sgd_hausdorff_dis(a, b),
+                                       dun.sgd_hausdorff_dis(b, a), dun.bid_hausdorff_dis(a, b)], np.float64)
+    a, b = pairs["hand_asym"]
+    fx["np_hand_asym_M"] = dun.pairwise_distances(a, b)
+    a, b = pairs["rand_64"]
+    fx["np_rand_64_M"] = dun.pairwise_distances(a, b)
+
+    # --- torch metrics on [B,3,N]
+    tpairs = {
+        "kat": (np.array([[[1, 1, 1], [1, 1, 1], [1, 1, 1]]], np.float32),
+                np.array([[[2, 2, 3], [2, 2, 2], [2, 2, 2]]], np.float32)),
+    }
+    for n, bsz in ((128, 2), (1024, 2)):
+        p = np.stack([unit_cloud(rng, n) for _ in range(bsz)])
+        q = np.stack([perturbed(rng, x) for x in p])
+        tpairs[f"rand_{n}"] = (q.transpose(0, 2, 1).copy(), p.transpose(0, 2, 1).copy())
+    fx["t_names"] = np.array(sorted(tpairs))
+    for nm in sorted(tpairs):
+        a, b = tpairs[nm]
+        ta, tb = torch.from_numpy(a), torch.from_numpy(b)
+        fx[f"t_{nm}_a"], fx[f"t_{nm}_b"] = a, b
+        fx[f"t_{nm}_out"] = np.array([float(dut.euclidean_distances(ta, tb)), float(dut.chamfer(ta, tb)),
+                                      float(dut.sgd_hausdorff_dis(ta, tb)), float(dut.bid_hausdorff_dis(ta, tb))],
+                                     np.float64)
+    a, b = tpairs["rand_128"]
+    fx["t_rand_128_M"] = dut.pairwise_distances(torch.from_numpy(a), torch.from_numpy(b)).numpy()
+    # gradient of the (quirky) chamfer wrt a
+    ta = torch.from_numpy(a).clone().requires_grad_()
+    dut.chamfer(ta, torch.from_numpy(b)).backward()
+    fx["t_rand_128_grad_a"] = ta.grad.numpy()
+
+    # --- CW functors: (loss1, loss2) [B] for preds/gts [B,N,3] + gradients through the reference autograd
+    cw = {}
+    for nm, (n1, n2, bsz) in {"b4_256": (256, 256, 4), "b2_1024": (1024, 1024, 2), "ragged": (200, 333, 3)}.items():
+        g = np.stack([unit_cloud(rng, n2) for _ in range(bsz)])
+        if n1 == n2:
+            p = np.stack([perturbed(rng, x) for x in g])
+        else:
+            p = np.stack([unit_cloud(rng, n1) for _ in range(bsz)])
+        cw[nm] = (p, g)
+    fx["cw_names"] = np.array(sorted(cw))
+    for nm in sorted(cw):
+        p, g = cw[nm]
+        fx[f"cw_{nm}_preds"], fx[f"cw_{nm}_gts"] = p, g
+        # values from a float64 run of the reference code (its fp32 expansion is itself ~1e-5 off, SURVEY A-3)
+        tp64, tg64 = torch.from_numpy(p).double(), torch.from_numpy(g).double()
+        l1, l2 = cw_chamfer(tp64, tg64)
+        h1, h2 = cw_hausdorff(tp64, tg64)
+        fx[f"cw_{nm}_chamfer"] = np.stack([l1.numpy(), l2.numpy()])
+        fx[f"cw_{nm}_hausdorff"] = np.stack([h1.numpy(), h2.numpy()])
+        # and the reference's own fp32 outputs, for the record (tolerance documented in the test)
+        l1f, l2f = cw_chamfer(torch.from_numpy(p), torch.from_numpy(g))
+        fx[f"cw_{nm}_chamfer_f32"] = np.stack([l1f.numpy(), l2f.numpy()])
+        # gradients (float64 reference autograd): d(sum_b w1*l1 + w2*l2)/dpreds
+        w1 = torch.linspace(0.5, 1.5, p.shape[0], dtype=torch.float64)
+        w2 = torch.linspace(2.0, 1.0, p.shape[0], dtype=torch.float64)
+        tp = tp64.clone().requires_grad_()
+        tg = tg64.clone().requires_grad_()
+        l1, l2 = cw_chamfer(tp, tg)
+        ((l1 * w1).sum() + (l2 * w2).sum()).backward()
+        fx[f"cw_{nm}_w"] = np.stack([w1.numpy(), w2.numpy()])
+        fx[f"cw_{nm}_chamfer_gpreds"], fx[f"cw_{nm}_chamfer_ggts"] = tp.grad.numpy(), tg.grad.numpy()
+        tp = tp64.clone().requires_grad_()
+        h1, h2 = cw_hausdorff(tp, tg64)
+        ((h1 * w1).sum() + (h2 * w2).sum()).backward()
+        fx[f"cw_{nm}_hausdorff_gpreds"] = tp.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "metrics.npz"), **fx)
+    print("metrics.npz:", len(fx), "arrays")
+
+
+SECTIONS = {"metrics": gen_metrics}
+
+if __name__ == "__main__":
+    todo = sys.argv[1:] or list(SECTIONS)
+    for s in todo:
+        SECTIONS[s]()

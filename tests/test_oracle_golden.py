@@ -1,0 +1,70 @@
+"""CPU: the oracle (oracle/ref_numpy.py) against the golden vectors captured from the real reference."""
+import numpy as np
+import pytest
+
+from oracle import ref_numpy as orc
+
+
+def test_known_answers_from_reference_comments(metrics_fx):
+    # utils/dis_utils_numpy.py:40-46 worked example: chamfer 2*sqrt(3), hausdorff sqrt(3)
+    a, b = np.ones((3, 3)), 2 * np.ones((3, 3))
+    assert orc.chamfer(a, b) == pytest.approx(2 * np.sqrt(3), rel=1e-12)
+    assert orc.sgd_hausdorff_dis(a, b) == pytest.approx(np.sqrt(3), rel=1e-12)
+    assert orc.bid_hausdorff_dis(a, b) == pytest.approx(np.sqrt(3), rel=1e-12)
+    # SURVEY §8(c) hand case
+    a = np.array([[0, 0, 0], [1, 0, 0], [0, 2, 0]], float)
+    b = np.array([[0, 0, 1], [3, 0, 0]], float)
+    assert orc.chamfer(a, b) == pytest.approx(3.0500938466, rel=1e-9)
+    assert orc.sgd_hausdorff_dis(a, b) == pytest.approx(2.2360679775, rel=1e-9)
+    assert orc.sgd_hausdorff_dis(b, a) == pytest.approx(2.0, rel=1e-12)
+
+
+def test_numpy_metrics_match_reference(metrics_fx):
+    fx = metrics_fx
+    for nm in fx["np_names"]:
+        a, b = fx[f"np_{nm}_a"], fx[f"np_{nm}_b"]
+        ref = fx[f"np_{nm}_out"]
+        got = [orc.chamfer(a, b), orc.sgd_hausdorff_dis(a, b), orc.sgd_hausdorff_dis(b, a), orc.bid_hausdorff_dis(a, b)]
+        np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-14, err_msg=str(nm))
+    np.testing.assert_allclose(orc.pairwise_distances(fx["np_hand_asym_a"], fx["np_hand_asym_b"]),
+                               fx["np_hand_asym_M"], rtol=1e-13)
+    np.testing.assert_allclose(orc.pairwise_distances(fx["np_rand_64_a"], fx["np_rand_64_b"]),
+                               fx["np_rand_64_M"], rtol=1e-13)
+
+
+def test_torch_twin_metrics_match_reference(metrics_fx):
+    fx = metrics_fx
+    for nm in fx["t_names"]:
+        a, b = fx[f"t_{nm}_a"], fx[f"t_{nm}_b"]
+        ref = fx[f"t_{nm}_out"]  # produced by the reference in fp32 through cdist's mm-expansion
+        got = [orc.torch_euclidean_distances(a, b), orc.torch_chamfer(a, b),
+               orc.torch_sgd_hausdorff_dis(a, b), orc.torch_bid_hausdorff_dis(a, b)]
+        # fp32 cdist expansion is 1e-6..5e-5 off the exact value: tolerance 2e-4
+        np.testing.assert_allclose(got, ref, rtol=2e-4, err_msg=str(nm))
+    # the worked example commented at utils/dis_utils_torch.py:30-35
+    a, b = fx["t_kat_a"], fx["t_kat_b"]
+    assert orc.torch_euclidean_distances(a, b) == pytest.approx(5.9135914, rel=1e-6)
+    assert orc.torch_chamfer(a, b) == pytest.approx(3.7032480, rel=1e-6)
+    assert orc.torch_sgd_hausdorff_dis(a, b) == pytest.approx(1.7320508, rel=1e-6)
+    assert orc.torch_bid_hausdorff_dis(a, b) == pytest.approx(2.4494898, rel=1e-6)
+    np.testing.assert_allclose(orc.torch_pairwise_distances(fx["t_rand_128_a"], fx["t_rand_128_b"]),
+                               fx["t_rand_128_M"], rtol=1e-3, atol=2e-4)
+
+
+def test_cw_functors_match_reference(metrics_fx):
+    fx = metrics_fx
+    for nm in fx["cw_names"]:
+        p, g = fx[f"cw_{nm}_preds"], fx[f"cw_{nm}_gts"]
+        l1, l2 = orc.cw_chamfer(p, g)
+        np.testing.assert_allclose(np.stack([l1, l2]), fx[f"cw_{nm}_chamfer"], rtol=1e-9, atol=1e-14)
+        h1, h2 = orc.cw_hausdorff(p, g)
+        np.testing.assert_allclose(np.stack([h1, h2]), fx[f"cw_{nm}_hausdorff"], rtol=1e-9, atol=1e-14)
+
+
+def test_fp32_fma_emulation_is_close_to_f64(metrics_fx):
+    fx = metrics_fx
+    a, b = fx["np_rand_1024_a"], fx["np_rand_1024_b"]
+    d64, i64 = orc.nn_sq(a, b)
+    d32, i32 = orc.nn_sq_f32(a, b)
+    np.testing.assert_allclose(d32, d64, rtol=1e-6)
+    assert (i32 == i64).mean() > 0.999
