@@ -5,6 +5,12 @@ Build it with ``python -c "import __graft_entry__ as g; g.build()"`` or ``make -
 """
 import ctypes
 import os
+
+# torch MUST be imported before libpc3d_hip.so is dlopen'ed: the torch wheel bundles its own libamdhip64.so
+# (SONAME libamdhip64.so.7). Loaded first, it satisfies our library's NEEDED entry, so both share ONE HIP
+# runtime (streams and device pointers are interchangeable). The other order loads a second runtime.
+import torch  # noqa: F401,E402
+
 from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

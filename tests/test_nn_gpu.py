@@ -15,7 +15,8 @@ def _cloud(rng, n):
     g /= np.linalg.norm(g, axis=1, keepdims=True)
     p = g * rng.random((n, 1)) ** (1 / 3)
     p -= p.mean(0, keepdims=True)
-    return (p / np.linalg.norm(p, axis=1).max()).astype(np.float32)
+    m = np.linalg.norm(p, axis=1).max()
+    return (p / (m if m > 0 else 1.0) + (0.25 if n == 1 else 0.0)).astype(np.float32)
 
 
 def _check_idx(q, r, d_gpu, i_gpu):
