@@ -20,6 +20,7 @@ _P = c_void_p
 _I = c_int
 _L = c_int64
 _F = c_float
+_D = ctypes.c_double
 _PTS = [_P, _L, _L, _L]  # pointer + (batch, point, channel) element strides
 
 # name -> argtypes; every entry returns int (0 ok) except the two noted below.
@@ -30,6 +31,15 @@ SIGNATURES = {
     "pc3d_nn_bwd_f32": _PTS + _PTS + [_I, _I, _I]
     + [_P, _P, _L, _L, _F] + [_P, _P, _L, _L, _F]
     + _PTS + _PTS + [_I, _P],
+    "pc3d_knn_f32": _PTS + _PTS + [_I, _I, _I, _I, _P, _P, _P],
+    "pc3d_knn_bwd_f32": _PTS + _PTS + [_I, _I, _I, _I, _P, _P] + _PTS + _PTS + [_I, _P],
+    "pc3d_clip_f32": _PTS + _PTS + _PTS + [_I, _I, _I, _F] + _PTS + [_P],
+    "pc3d_adam_clip_step_f32": _PTS + _PTS + [_P, _P] + _PTS + _PTS + [_I, _I, _D, _D, _D, _D, _F, _P, _I, _P],
+    "pc3d_i32_add": [_P, _I, _P],
+    "pc3d_pairwise_f32": _PTS + _PTS + [_I, _I, _I, _I, _P, _P],
+    "pc3d_pointmlp3_tile_points": [],
+    "pc3d_pointmlp3_max_fwd_f32": _PTS + [_I, _I] + [_P] * 7 + [_I, _I, _I, _I] + [_P] * 4 + [_P],
+    "pc3d_pointmlp3_max_bwd_f32": _PTS + [_I, _I] + [_P] * 6 + [_I, _I, _I] + [_P, _P] + _PTS + [_P],
 }
 
 _lib = None

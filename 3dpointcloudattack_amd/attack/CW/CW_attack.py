@@ -1,0 +1,207 @@
+"""C&W point-perturbation attack with binary search — MI355X mirror of attack/CW/CW_attack.py.
+
+Same constructor / ``attack(data, target)`` signature and return values as the reference
+(attack/CW/CW_attack.py:26-27,57,260). What changes is where the work happens:
+
+* the hot loop (reference :111-178) never leaves the GPU: the per-iteration ``.cpu().numpy()`` of the whole
+  adversarial cloud and the Python per-sample best-attack loop (:129-153) become device-side selects, so an
+  iteration has no host synchronisation; the host is consulted once per binary-search step (:182-200);
+* batches B > 1 work (the reference's prints / ``.item()`` calls at :84,:216-257 force B = 1; the fail counters
+  are kept as attributes and become sums over the batch);
+* when the functors are this package's own (``ClipPointsLinf`` / ``ProjectInnerClipLinf``), Adam + clip run as ONE
+  fused HIP launch (pc3d_adam_clip_step_f32) instead of torch.optim.Adam + ~10 elementwise kernels. Arbitrary
+  user callables still work through the generic path (same protocol as the reference:
+  ``adv_func(logits, target)``, ``dist_func(adv[B,3,K], ori[B,3,K], weights[B])``, ``clip_func(pc, ori)``).
+"""
+import numpy as np
+import torch
+import torch.optim as optim
+
+from ... import ops
+from .CW_utils import clip_utils as _clip_utils
+from .CW_utils import dist_utils as _dist_utils
+
+
+def rand_row(array):
+    """attack/CW/CW_attack.py:16-20 — shuffle the points of [B,K,3] with numpy's global RNG."""
+    row_total = array.shape[1]
+    row_sequence = np.arange(row_total)
+    np.random.shuffle(row_sequence)
+    return array[:, row_sequence, :]
+
+
+def _logits_of(out):
+    return out[0] if isinstance(out, tuple) else out
+
+
+class CW:
+    """Class for CW attack."""
+
+    def __init__(self, model, trans_model, adv_func, clip_func, dist_func, attack_lr=1e-2,
+                 init_weight=10., max_weight=80., binary_step=10, num_iter=500, attack_method="untarget",
+                 device=None, verbose=False, fused=True):
+        """Arguments as attack/CW/CW_attack.py:26-38. Extra keyword-only style options (defaults keep the
+        reference behaviour): device (default: current CUDA device), verbose (reference prints), fused (use the
+        fused Adam+clip launch when clip_func is recognised)."""
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.model = model.to(self.device)
+        self.model.eval()
+        self.trans_model = trans_model.to(self.device)
+        self.trans_model.eval()
+        self.adv_func = adv_func
+        self.dist_func = dist_func
+        self.attack_lr = attack_lr
+        self.init_weight = init_weight
+        self.max_weight = max_weight
+        self.binary_step = binary_step
+        self.num_iter = num_iter
+        self.clip_func = clip_func
+        self.attack_method = attack_method
+        self.shuffle_fail = 0
+        self.trans_fail = 0
+        self.attack_fail = 0
+        self.verbose = verbose
+        self.fused = fused
+
+    # -- helpers ---------------------------------------------------------------------------------------
+    def _success(self, pred, label):
+        return (pred != label) if self.attack_method == 'untarget' else (pred == label)
+
+    def _fused_clip_budget(self):
+        """budget of a recognised per-point clip functor, else None (generic path)."""
+        cf = self.clip_func
+        if not self.fused or cf is None:
+            return None
+        if type(cf) in (_clip_utils.ClipPointsLinf, _dist_utils.ClipPointsLinf):
+            return float(cf.budget)
+        return None
+
+    def attack(self, data, target):
+        """Attack on given data to target.
+        Args:
+            data (torch.FloatTensor): victim data, [B, num_points, 3]
+            target (torch.LongTensor): target output, [B]
+        Returns (o_bestdist [B] float64, o_bestattack [B,K,3] float64, success_num) like the reference (:260).
+        """
+        dev = self.device
+        B, K = data.shape[:2]
+        data = data.float().to(dev).detach()
+        data = data.transpose(1, 2).contiguous()
+        ori_data = data.clone().detach()
+
+        target = target.long().to(dev).detach().view(-1)
+        label = target
+
+        # weight factor for budget regularization (host, consulted once per binary step)
+        lower_bound = np.zeros((B,))
+        upper_bound = np.ones((B,)) * self.max_weight
+        current_weight = np.ones((B,)) * self.init_weight
+
+        # best results over the whole binary search — device resident
+        o_bestdist = torch.full((B,), 1e10, dtype=torch.float32, device=dev)
+        o_bestscore = torch.full((B,), -1, dtype=torch.long, device=dev)
+        o_bestattack = torch.zeros((B, 3, K), dtype=torch.float32, device=dev)
+
+        with torch.no_grad():
+            logits = _logits_of(self.model(ori_data))
+            pred = torch.argmax(logits, dim=1)
+        if self.verbose:
+            print("ori label:", pred.tolist())
+
+        if self.attack_method == 'top1_error':
+            # reference (:86-89, B=1): target := runner-up class of the clean prediction
+            target = label = logits.topk(2, dim=1, largest=True, sorted=True)[1][:, 1].detach()
+
+        budget = self._fused_clip_budget()
+        input_val = ori_data
+        pred = None
+        for binary_step in range(self.binary_step):
+            # same RNG stream as the reference: CPU generator, then upload (:94)
+            adv_data = ori_data.clone().detach() + torch.randn((B, 3, K)).to(dev) * 1e-7
+            adv_data.requires_grad_()
+            bestdist = torch.full((B,), 1e10, dtype=torch.float32, device=dev)
+            bestscore = torch.full((B,), -1, dtype=torch.long, device=dev)
+            weights = torch.from_numpy(current_weight).to(dev)
+
+            if budget is None:
+                opt = optim.Adam([adv_data], lr=self.attack_lr, weight_decay=0.)
+            else:
+                exp_avg = torch.zeros_like(adv_data)
+                exp_avg_sq = torch.zeros_like(adv_data)
+
+            for iteration in range(self.num_iter):
+                logits = _logits_of(self.model(adv_data))
+                pred = torch.argmax(logits, dim=1)  # [B]
+
+                # record values (device side; reference :129-153)
+                with torch.no_grad():
+                    cur = adv_data.detach()
+                    dist_val = torch.sqrt(torch.sum((cur - ori_data) ** 2, dim=[1, 2]))  # [B]
+                    succ = self._success(pred, label)
+                    upd = succ & (dist_val < bestdist)
+                    bestdist = torch.where(upd, dist_val, bestdist)
+                    bestscore = torch.where(upd, pred, bestscore)
+                    upd_o = succ & (dist_val < o_bestdist)
+                    o_bestdist = torch.where(upd_o, dist_val, o_bestdist)
+                    o_bestscore = torch.where(upd_o, pred, o_bestscore)
+                    o_bestattack = torch.where(upd_o[:, None, None], cur, o_bestattack)
+                    if iteration == self.num_iter - 1:
+                        input_val = cur.clone()
+
+                # compute loss and backward
+                adv_loss = self.adv_func(logits, target).mean()
+                dist_loss = self.dist_func(adv_data, ori_data, weights).mean()
+                loss = adv_loss + dist_loss
+
+                if budget is None:
+                    opt.zero_grad()
+                    loss.backward()
+                    opt.step()
+                    if self.clip_func is not None:
+                        adv_data.data = self.clip_func(adv_data.clone().detach(), ori_data)
+                else:
+                    adv_data.grad = None
+                    loss.backward()
+                    ops.adam_clip_step(adv_data.data, adv_data.grad, exp_avg, exp_avg_sq, iteration + 1,
+                                       self.attack_lr, ori=ori_data, budget=budget)
+
+            # adjust weight factor (reference :182-200) — one host round trip per binary step
+            bs = bestscore.cpu().numpy()
+            bd = bestdist.double().cpu().numpy()
+            obd = o_bestdist.double().cpu().numpy()
+            lab = label.cpu().numpy()
+            for e in range(B):
+                if self.attack_method == 'untarget':
+                    ok = bs[e] != lab[e] and bs[e] != -1 and bd[e] <= obd[e]
+                else:
+                    ok = bs[e] == lab[e] and bs[e] != -1 and bd[e] <= obd[e]
+                if ok:
+                    lower_bound[e] = max(lower_bound[e], current_weight[e])
+                else:
+                    upper_bound[e] = min(upper_bound[e], current_weight[e])
+                current_weight[e] = (lower_bound[e] + upper_bound[e]) / 2.
+
+        success_num = int(self._success(pred, label).sum().item()) if pred is not None else 0
+
+        # fail to attack some examples: assign them the last iterate (reference :205-209)
+        fail_idx = torch.from_numpy(lower_bound == 0.).to(dev)
+        o_bestattack = torch.where(fail_idx[:, None, None], input_val, o_bestattack)
+
+        with torch.no_grad():
+            # Test attack (:211-224)
+            attack_pred = torch.argmax(_logits_of(self.model(o_bestattack)), dim=1)
+            self.attack_fail += int((~self._success(attack_pred, target)).sum().item())
+            # Test shuffle attack (:226-241) — numpy global RNG like the reference
+            best_np = o_bestattack.double().cpu().numpy()  # [B,3,K]
+            shuffled = rand_row(best_np.transpose((0, 2, 1)))
+            shuffled = torch.from_numpy(shuffled.transpose((0, 2, 1)).copy()).float().to(dev)
+            shuffle_pred = torch.argmax(_logits_of(self.model(shuffled)), dim=1)
+            self.shuffle_fail += int((~self._success(shuffle_pred, target)).sum().item())
+            # Test transfer attack (:244-257)
+            trans_pred = torch.argmax(_logits_of(self.trans_model(o_bestattack)), dim=1)
+            self.trans_fail += int((~self._success(trans_pred, target)).sum().item())
+        if self.verbose:
+            print('attack result: ', attack_pred.tolist(), 'shuffle result: ', shuffle_pred.tolist(),
+                  'transfer result: ', trans_pred.tolist())
+
+        return o_bestdist.double().cpu().numpy(), best_np.transpose((0, 2, 1)), success_num

@@ -1,0 +1,51 @@
+"""MI355X mirror of attack/CW/CW_utils/adv_utils.py — adversarial (margin / CE) losses on the logits [B,k].
+Tiny [B,k] tensors: expressed with device-side torch ops (no host sync, no per-call H2D like the reference's
+torch.zeros(B,K).cuda() at adv_utils.py:27,74)."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def _real_other(logits, targets):
+    B, K = logits.shape
+    if len(targets.shape) == 1:
+        targets = targets.view(-1, 1)
+    targets = targets.long()
+    one_hot = torch.zeros(B, K, device=logits.device).scatter_(1, targets, 1).float()
+    real = torch.sum(one_hot * logits, dim=1)
+    other = torch.max((1. - one_hot) * logits - one_hot * 10000., dim=1)[0]
+    return real, other
+
+
+class LogitsAdvLoss(nn.Module):
+    """adv_utils.py:6-33 — targeted margin loss clamp(other - real + kappa, 0).mean()."""
+
+    def __init__(self, kappa=0.):
+        super(LogitsAdvLoss, self).__init__()
+        self.kappa = kappa
+
+    def forward(self, logits, targets):
+        real, other = _real_other(logits, targets)
+        return torch.clamp(other - real + self.kappa, min=0.).mean()
+
+
+class CrossEntropyAdvLoss(nn.Module):
+    """adv_utils.py:36-51 — nll_loss on the model's log-probabilities."""
+
+    def __init__(self):
+        super(CrossEntropyAdvLoss, self).__init__()
+
+    def forward(self, logits, targets):
+        return F.nll_loss(logits, targets)
+
+
+class UntargetedLogitsAdvLoss(nn.Module):
+    """adv_utils.py:53-80 — untargeted margin loss clamp(real - other + kappa, 0).mean()."""
+
+    def __init__(self, kappa=0.):
+        super(UntargetedLogitsAdvLoss, self).__init__()
+        self.kappa = kappa
+
+    def forward(self, logits, targets):
+        real, other = _real_other(logits, targets)
+        return torch.clamp(real - other + self.kappa, min=0.).mean()

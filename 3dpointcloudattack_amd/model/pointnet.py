@@ -1,0 +1,173 @@
+"""PointNet classifier — MI355X mirror of the reference's ``model/pointnet.py`` (same class names, constructor
+arguments, sub-module names and ``state_dict`` keys, so reference checkpoints load unchanged).
+
+The attack path runs the victim in eval mode with frozen weights (attack/CW/CW_attack.py:40-41). In that mode
+``forward`` does not run Conv1d/BatchNorm/max as separate ops: eval BatchNorm is folded into the conv/linear
+weights once, and each tower (3 -> 64 -> 128 -> 1024 + max over points) is ONE fused HIP launch pair
+(``pc3d_pointmlp3_max_{fwd,bwd}_f32``, fp32 MFMA) that never writes the [B,C,N] activations.
+
+Reference: STN3d model/pointnet.py:14-48, PointNetfeat :89-128, PointNetCls :130-148.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+
+
+def _fold_bn(weight, bias, bn):
+    """Fold eval-mode BatchNorm1d into the preceding 1x1 conv / linear: y = s*(Wx+b-mean)+beta."""
+    w = weight.detach().reshape(weight.shape[0], -1).float()
+    s = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+    b = bias.detach().float() if bias is not None else torch.zeros_like(s)
+    return (w * s[:, None]).contiguous(), ((b - bn.running_mean.detach().float()) * s + bn.bias.detach().float()).contiguous()
+
+
+def _plain(weight, bias):
+    return weight.detach().reshape(weight.shape[0], -1).float().contiguous(), bias.detach().float().contiguous()
+
+
+class _FrozenFusedMixin:
+    """Shared machinery: folded-weight cache, invalidated whenever parameters may have changed."""
+
+    def _invalidate(self):
+        object.__setattr__(self, "_folded_cache", None)
+
+    def train(self, mode=True):
+        self._invalidate()
+        return super().train(mode)
+
+    def _apply(self, fn, *a, **k):
+        self._invalidate()
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._invalidate()
+        return super().load_state_dict(*a, **k)
+
+    def _require_fused(self, x):
+        if self.training:
+            raise NotImplementedError(
+                f"{type(self).__name__}: only the eval-mode (frozen-weight) attack path is implemented on MI355X; "
+                "training the victim is out of scope (SURVEY §2.1 train.py)")
+        if not x.is_cuda:
+            raise ops._lib.Pc3dError(f"{type(self).__name__}: input is on {x.device}; the fused path runs on the GPU only")
+
+
+class STN3d(_FrozenFusedMixin, nn.Module):
+    """Input transform net (model/pointnet.py:14-48)."""
+
+    def __init__(self):
+        super(STN3d, self).__init__()
+        self.conv1 = torch.nn.Conv1d(3, 64, 1)
+        self.conv2 = torch.nn.Conv1d(64, 128, 1)
+        self.conv3 = torch.nn.Conv1d(128, 1024, 1)
+        self.fc1 = nn.Linear(1024, 512)
+        self.fc2 = nn.Linear(512, 256)
+        self.fc3 = nn.Linear(256, 9)
+        self.relu = nn.ReLU()
+
+        self.bn1 = nn.BatchNorm1d(64)
+        self.bn2 = nn.BatchNorm1d(128)
+        self.bn3 = nn.BatchNorm1d(1024)
+        self.bn4 = nn.BatchNorm1d(512)
+        self.bn5 = nn.BatchNorm1d(256)
+        self._folded_cache = None
+
+    def folded(self):
+        if self._folded_cache is None:
+            tower = _fold_bn(self.conv1.weight, self.conv1.bias, self.bn1) + \
+                _fold_bn(self.conv2.weight, self.conv2.bias, self.bn2) + \
+                _fold_bn(self.conv3.weight, self.conv3.bias, self.bn3)
+            head = (_fold_bn(self.fc1.weight, self.fc1.bias, self.bn4),
+                    _fold_bn(self.fc2.weight, self.fc2.bias, self.bn5),
+                    _plain(self.fc3.weight, self.fc3.bias))
+            iden = torch.eye(3, dtype=torch.float32, device=self.fc3.weight.device).reshape(1, 9)
+            object.__setattr__(self, "_folded_cache", (tower, head, iden))
+        return self._folded_cache
+
+    def forward(self, x):
+        self._require_fused(x)
+        tower, head, iden = self.folded()
+        g = ops.pointmlp3_max(x, tower, True)                 # relu(bn3(conv3)) then max == max then relu
+        g = F.relu(F.linear(g, *head[0]))
+        g = F.relu(F.linear(g, *head[1]))
+        g = F.linear(g, *head[2]) + iden
+        return g.view(-1, 3, 3)
+
+
+class PointNetfeat(_FrozenFusedMixin, nn.Module):
+    """Global feature trunk (model/pointnet.py:89-128), global_feat=True / feature_transform=False path."""
+
+    def __init__(self, global_feat=True, feature_transform=False):
+        super(PointNetfeat, self).__init__()
+        self.stn = STN3d()
+        self.conv1 = torch.nn.Conv1d(3, 64, 1)
+        self.conv2 = torch.nn.Conv1d(64, 128, 1)
+        self.conv3 = torch.nn.Conv1d(128, 1024, 1)
+        self.bn1 = nn.BatchNorm1d(64)
+        self.bn2 = nn.BatchNorm1d(128)
+        self.bn3 = nn.BatchNorm1d(1024)
+        self.global_feat = global_feat
+        self.feature_transform = feature_transform
+        if self.feature_transform or not self.global_feat:
+            raise NotImplementedError(
+                "PointNetfeat: feature_transform=True / global_feat=False are not on the attack path "
+                "(every attack driver builds PointNetCls(k, feature_transform=False): attack/CW/Eval_CW.py:97)")
+        self._folded_cache = None
+
+    def folded(self):
+        if self._folded_cache is None:
+            tower = _fold_bn(self.conv1.weight, self.conv1.bias, self.bn1) + \
+                _fold_bn(self.conv2.weight, self.conv2.bias, self.bn2) + \
+                _fold_bn(self.conv3.weight, self.conv3.bias, self.bn3)
+            object.__setattr__(self, "_folded_cache", tower)
+        return self._folded_cache
+
+    def forward(self, x):
+        self._require_fused(x)
+        trans = self.stn(x)
+        xt = torch.bmm(x.transpose(2, 1), trans).transpose(2, 1)   # [B,3,N] strided view; kernel takes strides
+        g = ops.pointmlp3_max(xt, self.folded(), False)            # bn3(conv3) has no ReLU (:121)
+        return g, trans, None
+
+
+class PointNetCls(_FrozenFusedMixin, nn.Module):
+    """model/pointnet.py:130-148 — returns (log_softmax logits [B,k], trans [B,3,3], trans_feat None)."""
+
+    def __init__(self, k=2, feature_transform=False):
+        super(PointNetCls, self).__init__()
+        self.feature_transform = feature_transform
+        self.feat = PointNetfeat(global_feat=True, feature_transform=feature_transform)
+        self.fc1 = nn.Linear(1024, 512)
+        self.fc2 = nn.Linear(512, 256)
+        self.fc3 = nn.Linear(256, k)
+        self.dropout = nn.Dropout(p=0.3)
+        self.bn1 = nn.BatchNorm1d(512)
+        self.bn2 = nn.BatchNorm1d(256)
+        self.relu = nn.ReLU()
+        self._folded_cache = None
+
+    def folded(self):
+        if self._folded_cache is None:
+            head = (_fold_bn(self.fc1.weight, self.fc1.bias, self.bn1),
+                    _fold_bn(self.fc2.weight, self.fc2.bias, self.bn2),   # dropout is identity in eval
+                    _plain(self.fc3.weight, self.fc3.bias))
+            object.__setattr__(self, "_folded_cache", head)
+        return self._folded_cache
+
+    def forward(self, x):
+        self._require_fused(x)
+        head = self.folded()
+        g, trans, trans_feat = self.feat(x)
+        g = F.relu(F.linear(g, *head[0]))
+        g = F.relu(F.linear(g, *head[1]))
+        g = F.linear(g, *head[2])
+        return F.log_softmax(g, dim=1), trans, trans_feat
+
+
+def feature_transform_regularizer(trans):
+    """model/pointnet.py:178-185."""
+    d = trans.size()[1]
+    I = torch.eye(d, device=trans.device)[None, :, :]
+    return torch.mean(torch.norm(torch.bmm(trans, trans.transpose(2, 1)) - I, dim=(1, 2)))

@@ -195,3 +195,192 @@ class _SetDistFn(torch.autograd.Function):
 def set_distance(a, b, reduce="mean", a_cf=False, b_cf=False, deterministic=False):
     """(loss_a2b [B], loss_b2a [B]) — squared Chamfer (reduce='mean') or Hausdorff (reduce='max') terms."""
     return _SetDistFn.apply(a, b, a_cf, b_cf, reduce, deterministic)
+
+
+# ------------------------------------------------------------------------------------------------------
+# K8: fused PointNet per-point MLP + max-pool
+# ------------------------------------------------------------------------------------------------------
+_PM_TILE = None
+
+
+def _pm_tile():
+    global _PM_TILE
+    if _PM_TILE is None:
+        _PM_TILE = _lib.load().pc3d_pointmlp3_tile_points()
+    return _PM_TILE
+
+
+def pointmlp3_max_fwd_raw(x, weights, relu_last, T=None, x_cf=True):
+    """x [B,3,N] (x_cf) or [B,N,3]; weights = (W1[64,3], b1, W2[128,64], b2, W3[C3,128], b3) with eval-BN folded.
+    Returns (pooled [B,C3] f32, argidx [B,C3] i32)."""
+    xp, xbs, xps, xcs, B, N = _pts(x, x_cf, "x")
+    W1, b1, W2, b2, W3, b3 = weights
+    for w in weights:
+        _check(w, "weight")
+        if not w.is_contiguous():
+            raise ValueError("pointmlp3 weights must be contiguous")
+    C1, C2, C3 = W1.shape[0], W2.shape[0], W3.shape[0]
+    if T is not None:
+        _check(T, "T")
+        T = T.contiguous()
+    ntiles = (N + _pm_tile() - 1) // _pm_tile()
+    dev = x.device
+    part_val = torch.empty((B, ntiles, C3), dtype=torch.float32, device=dev)
+    part_idx = torch.empty((B, ntiles, C3), dtype=torch.int32, device=dev)
+    pooled = torch.empty((B, C3), dtype=torch.float32, device=dev)
+    argidx = torch.empty((B, C3), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.call("pc3d_pointmlp3_max_fwd_f32", xp, xbs, xps, xcs, B, N, _ptr(T),
+                  W1.data_ptr(), b1.data_ptr(), W2.data_ptr(), b2.data_ptr(), W3.data_ptr(), b3.data_ptr(),
+                  C1, C2, C3, 1 if relu_last else 0, part_val.data_ptr(), part_idx.data_ptr(),
+                  pooled.data_ptr(), argidx.data_ptr(), _stream())
+    return pooled, argidx
+
+
+def pointmlp3_max_bwd_raw(x, weights, argidx, g_pooled, T=None, x_cf=True):
+    """Gradient w.r.t. the tower input (the transformed points when T is given); same layout as x."""
+    xp, xbs, xps, xcs, B, N = _pts(x, x_cf, "x")
+    W1, b1, W2, b2, W3, b3 = weights
+    C1, C2, C3 = W1.shape[0], W2.shape[0], W3.shape[0]
+    _check(g_pooled, "g_pooled")
+    g_pooled = g_pooled.contiguous()
+    gx = torch.empty((B, 3, N) if x_cf else (B, N, 3), dtype=torch.float32, device=x.device)
+    gp, gbs, gps, gcs, _, _ = _pts(gx, x_cf, "grad_x")
+    with torch.cuda.device(x.device):
+        _lib.call("pc3d_pointmlp3_max_bwd_f32", xp, xbs, xps, xcs, B, N, _ptr(T),
+                  W1.data_ptr(), b1.data_ptr(), W2.data_ptr(), b2.data_ptr(), W3.data_ptr(),
+                  C1, C2, C3, argidx.data_ptr(), g_pooled.data_ptr(), gp, gbs, gps, gcs, _stream())
+    return gx
+
+
+class _PointMLP3MaxFn(torch.autograd.Function):
+    """x [B,3,N] -> pooled [B,C3] through the fused tower; differentiable in x only (frozen weights)."""
+
+    @staticmethod
+    def forward(ctx, x, relu_last, W1, b1, W2, b2, W3, b3):
+        weights = (W1, b1, W2, b2, W3, b3)
+        pooled, argidx = pointmlp3_max_fwd_raw(x, weights, relu_last)
+        ctx.save_for_backward(x, argidx, pooled, *weights)
+        ctx.relu_last = relu_last
+        return pooled
+
+    @staticmethod
+    def backward(ctx, g):
+        x, argidx, pooled, *weights = ctx.saved_tensors
+        if ctx.relu_last:
+            g = g * (pooled > 0)
+        gx = pointmlp3_max_bwd_raw(x, tuple(weights), argidx, g)
+        return (gx,) + (None,) * 7
+
+
+def pointmlp3_max(x, weights, relu_last):
+    return _PointMLP3MaxFn.apply(x, relu_last, *weights)
+
+
+# ------------------------------------------------------------------------------------------------------
+# K9 / K10 / pairwise
+# ------------------------------------------------------------------------------------------------------
+def _pv(t, cf, name):
+    """(ptr, bs, ps, cs) or four zeros for None."""
+    if t is None:
+        return (0, 0, 0, 0)
+    p, bs, ps, cs, _, _ = _pts(t, cf, name)
+    return (p, bs, ps, cs)
+
+
+def clip(pc, ori, normal=None, budget=0.0, mode="point", cf=True, out=None):
+    """clip_utils.py semantics in one launch. mode 'point': optional inner-point projection (normal given) then
+    per-point L2 clip (budget<=0: none). mode 'global': ClipPointsL2. Tensors [B,3,K] (cf) or [B,K,3]."""
+    _, _, _, _, B, K = _pts(pc, cf, "pc")
+    if out is None:
+        out = torch.empty(pc.shape, dtype=torch.float32, device=pc.device)
+    with torch.cuda.device(pc.device):
+        _lib.call("pc3d_clip_f32", *_pv(pc, cf, "pc"), *_pv(ori, cf, "ori"), *_pv(normal, cf, "normal"),
+                  B, K, 0 if mode == "point" else 1, float(budget), *_pv(out, cf, "out"), _stream())
+    return out
+
+
+def adam_clip_step(p, g, m, v, step, lr, betas=(0.9, 0.999), eps=1e-8, ori=None, normal=None, budget=0.0,
+                   cf=True):
+    """In-place Adam step on p (+ fused per-point clip/projection against ori). `step` is an int (host) or a
+    1-element int32 GPU tensor holding t."""
+    _, _, _, _, B, K = _pts(p, cf, "p")
+    if m.stride() != p.stride() or v.stride() != p.stride():
+        raise ValueError("adam state must share the parameter's strides")
+    if isinstance(step, torch.Tensor):
+        step_dev, step_host = step.data_ptr(), 0
+    else:
+        step_dev, step_host = 0, int(step)
+    with torch.cuda.device(p.device):
+        _lib.call("pc3d_adam_clip_step_f32", *_pv(p, cf, "p"), *_pv(g, cf, "g"), m.data_ptr(), v.data_ptr(),
+                  *_pv(ori, cf, "ori"), *_pv(normal, cf, "normal"), B, K, float(lr), float(betas[0]),
+                  float(betas[1]), float(eps), float(budget), step_dev, step_host, _stream())
+    return p
+
+
+def i32_add(ctr, delta=1):
+    with torch.cuda.device(ctr.device):
+        _lib.call("pc3d_i32_add", ctr.data_ptr(), int(delta), _stream())
+
+
+def pairwise(x, y, x_cf=False, y_cf=False, euclid=False):
+    """Dense [B,N,M] (squared) distance matrix, direct-difference fp32."""
+    xp, xbs, xps, xcs, B, N = _pts(x, x_cf, "x")
+    yp, ybs, yps, ycs, B2, M = _pts(y, y_cf, "y")
+    if B != B2:
+        raise ValueError("x and y must have the same batch dimension")
+    out = torch.empty((B, N, M), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.call("pc3d_pairwise_f32", xp, xbs, xps, xcs, yp, ybs, yps, ycs, B, N, M, 1 if euclid else 0,
+                  out.data_ptr(), _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------
+# K2/K4: K nearest neighbours
+# ------------------------------------------------------------------------------------------------------
+def knn_raw(q, r, K, q_cf=False, r_cf=False):
+    """(dists [B,N,K] f32 ascending, idx [B,N,K] i32)."""
+    qp, qbs, qps, qcs, B, N = _pts(q, q_cf, "q")
+    rp, rbs, rps, rcs, B2, M = _pts(r, r_cf, "r")
+    if B != B2:
+        raise ValueError("q and r must have the same batch dimension")
+    if not (1 <= K <= min(32, M)):
+        raise ValueError(f"K={K} out of range [1, min(32, M={M})]")
+    d = torch.empty((B, N, K), dtype=torch.float32, device=q.device)
+    i = torch.empty((B, N, K), dtype=torch.int32, device=q.device)
+    with torch.cuda.device(q.device):
+        _lib.call("pc3d_knn_f32", qp, qbs, qps, qcs, rp, rbs, rps, rcs, B, N, M, K, d.data_ptr(), i.data_ptr(),
+                  _stream())
+    return d, i
+
+
+class _KnnFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, r, K, q_cf, r_cf, deterministic):
+        d, i = knn_raw(q, r, K, q_cf, r_cf)
+        ctx.save_for_backward(q, r, i)
+        ctx.cfg = (K, q_cf, r_cf, deterministic)
+        ctx.mark_non_differentiable(i)
+        return d, i
+
+    @staticmethod
+    def backward(ctx, gd, _gi):
+        q, r, idx = ctx.saved_tensors
+        K, q_cf, r_cf, det = ctx.cfg
+        need_q, need_r = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        gd = gd.contiguous()
+        _, _, _, _, B, N = _pts(q, q_cf, "q")
+        _, _, _, _, _, M = _pts(r, r_cf, "r")
+        gq = torch.empty(q.shape, dtype=torch.float32, device=q.device) if need_q else None
+        gr = torch.empty(r.shape, dtype=torch.float32, device=r.device) if need_r else None
+        with torch.cuda.device(q.device):
+            _lib.call("pc3d_knn_bwd_f32", *_pv(q, q_cf, "q"), *_pv(r, r_cf, "r"), B, N, M, K, idx.data_ptr(),
+                      gd.data_ptr(), *_pv(gq, q_cf, "gq"), *_pv(gr, r_cf, "gr"), 1 if det else 0, _stream())
+        return gq, gr, None, None, None, None
+
+
+def knn(q, r, K, q_cf=False, r_cf=False, deterministic=False):
+    """Differentiable K-NN: (dists [B,N,K], idx [B,N,K] int32). For self-kNN pass the same tensor twice
+    (autograd sums the two gradient roles)."""
+    return _KnnFn.apply(q, r, K, q_cf, r_cf, deterministic)

@@ -77,6 +77,94 @@ int pc3d_nn_bwd_f32(const float* a, int64_t a_bs, int64_t a_ps, int64_t a_cs,
                     float* grad_b, int64_t gb_bs, int64_t gb_ps, int64_t gb_cs,
                     int deterministic, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * K8  PointNet per-point MLP 3 -> 64 -> 128 -> C3 (1x1 conv, eval-mode BatchNorm folded into W/b by the caller,
+ * ReLU after layers 1-2 and optionally after the pool) fused with max-pool over the N points.
+ * Replaces model/pointnet.py:34-37 (STN3d tower, relu_last=1) and :110-123 (PointNetfeat trunk, relu_last=0),
+ * i.e. three Conv1d+BN(+ReLU) and torch.max(x, 2) with their [B,C,N] activations.
+ *   x      B x N points (element strides); T optional [B,3,3] row-major input transform, x'[n,:] = x[n,:] @ T[b]
+ *          (the torch.bmm of model/pointnet.py:106-109), NULL = identity
+ *   W1 [64,3] b1[64]  W2 [128,64] b2[128]  W3 [C3,128] b3[C3]   row-major, BN already folded; C3 % 32 == 0
+ *   part_val/part_idx  caller workspace [B, ceil(N / pc3d_pointmlp3_tile_points()), C3] f32 / i32
+ *   pooled [B,C3] f32 (after the optional ReLU), argidx [B,C3] i32 = lowest point index attaining the max
+ * fp32 throughout: layer 2/3 run on v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains).
+ * ------------------------------------------------------------------------------------------------------- */
+int pc3d_pointmlp3_tile_points(void);
+int pc3d_pointmlp3_max_fwd_f32(const float* x, int64_t x_bs, int64_t x_ps, int64_t x_cs, int B, int N,
+                               const float* T, const float* W1, const float* b1, const float* W2,
+                               const float* b2, const float* W3, const float* b3, int C1, int C2, int C3,
+                               int relu_last, float* part_val, int32_t* part_idx,
+                               float* pooled, int32_t* argidx, void* stream);
+
+/* Backward-to-input of the above (weights are frozen during an attack: no weight gradients, SURVEY A-14).
+ * g_pooled [B,C3] is the upstream gradient on `pooled`; with relu_last the caller zeroes it where pooled <= 0.
+ * grad_x receives d/dx' (gradient w.r.t. the TRANSFORMED points x' = x @ T when T is given), dense, overwritten.
+ * The max-pool routes each channel to one point, so the layer-3 dgrad is a sparse ordered gather: deterministic. */
+int pc3d_pointmlp3_max_bwd_f32(const float* x, int64_t x_bs, int64_t x_ps, int64_t x_cs, int B, int N,
+                               const float* T, const float* W1, const float* b1, const float* W2,
+                               const float* b2, const float* W3, int C1, int C2, int C3,
+                               const int32_t* argidx, const float* g_pooled,
+                               float* grad_x, int64_t gx_bs, int64_t gx_ps, int64_t gx_cs, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * K9  clip / projection of the perturbation pc - ori, one launch (attack/CW/CW_utils/clip_utils.py).
+ *   mode 0: per-point L2 norm <= budget  — ClipPointsLinf (:43-56; the reference's "Linf" is a per-point L2 clip,
+ *           SURVEY A-10); with `normal` != NULL the inner-point tangent projection ProjectInnerPoints (:67-108)
+ *           runs first = ProjectInnerClipLinf (:124-136). budget <= 0 skips the clip (projection only).
+ *   mode 1: global L2 norm of the whole perturbation <= budget — ClipPointsL2 (:16-29). `normal` ignored.
+ * All tensors B x K points with element strides; out may alias pc.
+ * ------------------------------------------------------------------------------------------------------- */
+int pc3d_clip_f32(const float* pc, int64_t pc_bs, int64_t pc_ps, int64_t pc_cs,
+                  const float* ori, int64_t o_bs, int64_t o_ps, int64_t o_cs,
+                  const float* normal, int64_t n_bs, int64_t n_ps, int64_t n_cs,
+                  int B, int K, int mode, float budget,
+                  float* out, int64_t out_bs, int64_t out_ps, int64_t out_cs, void* stream);
+
+/* K10 (+K9)  one torch.optim.Adam step (weight_decay 0, amsgrad off) on the adversarial points, optionally fused
+ * with the mode-0 clip/projection against `ori` (ori NULL = plain Adam). Replaces opt.step() + clip_func of
+ * attack/CW/CW_attack.py:169-174 and attack/KNN/KNN_attack.py:129-136.
+ * m, v (exp_avg, exp_avg_sq) share p's strides and are updated in place. The step number t (>= 1) comes from the
+ * device word *step_dev when non-NULL (hipGraph replay), else from step_host. */
+int pc3d_adam_clip_step_f32(float* p, int64_t p_bs, int64_t p_ps, int64_t p_cs,
+                            const float* g, int64_t g_bs, int64_t g_ps, int64_t g_cs,
+                            float* m, float* v,
+                            const float* ori, int64_t o_bs, int64_t o_ps, int64_t o_cs,
+                            const float* normal, int64_t n_bs, int64_t n_ps, int64_t n_cs,
+                            int B, int K, double lr, double beta1, double beta2, double eps, float budget,
+                            const int32_t* step_dev, int step_host, void* stream);
+
+/* *ctr += delta on the stream (advances the Adam step word between graph replays). */
+int pc3d_i32_add(int32_t* ctr, int delta, void* stream);
+
+/* Dense pairwise distances out[b,i,j] (contiguous [B,N,M] f32): mode 0 = |x_i-y_j|^2, mode 1 = Euclidean.
+ * For callers that really consume the matrix: _Distance.batch_pairwise_dist (distance.py:15-32),
+ * dis_utils_torch.pairwise_distances (:8-11), dis_utils_numpy.pairwise_distances (:13-20),
+ * pointnet2_utils.square_distance (model/pointnet2_utils.py:19-38). Direct-difference form. */
+int pc3d_pairwise_f32(const float* x, int64_t x_bs, int64_t x_ps, int64_t x_cs,
+                      const float* y, int64_t y_bs, int64_t y_ps, int64_t y_cs,
+                      int B, int N, int M, int mode, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * K2/K4  K nearest reference points (xyz, squared L2, direct-difference form) of every query, ascending;
+ * ties put the lower reference index first. 1 <= K <= min(32, M). dists/idx: [B,N,K] f32 / i32 (either may be NULL).
+ * Replaces the [B,N,M] matrix + topk of attack/CW/CW_utils/dist_utils.py:133-144 (KNNDist),
+ * attack/GeoA3/knn_utils.py:10-55 (knn_points), attack/AOF/TAOF_attack.py:13-28, model/dgcnn.py:194-200 on xyz,
+ * model/curvenet_util.py:10-17. Self-kNN (q == r) returns the point itself first (distance 0), like the reference.
+ * ------------------------------------------------------------------------------------------------------- */
+int pc3d_knn_f32(const float* q, int64_t q_bs, int64_t q_ps, int64_t q_cs,
+                 const float* r, int64_t r_bs, int64_t r_ps, int64_t r_cs,
+                 int B, int N, int M, int K, float* dists, int32_t* idx, void* stream);
+
+/* Backward of the K distances with upstream w [B,N,K]: grad_q dense, grad_r scattered (float atomics, or an
+ * ordered scan when deterministic != 0). Both are OVERWRITTEN; either may be NULL. When q and r are the same
+ * cloud (self-kNN) the caller adds the two results. */
+int pc3d_knn_bwd_f32(const float* q, int64_t q_bs, int64_t q_ps, int64_t q_cs,
+                     const float* r, int64_t r_bs, int64_t r_ps, int64_t r_cs,
+                     int B, int N, int M, int K, const int32_t* idx, const float* w,
+                     float* grad_q, int64_t gq_bs, int64_t gq_ps, int64_t gq_cs,
+                     float* grad_r, int64_t gr_bs, int64_t gr_ps, int64_t gr_cs,
+                     int deterministic, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -156,7 +156,106 @@ def gen_metrics():
     print("metrics.npz:", len(fx), "arrays")
 
 
-SECTIONS = {"metrics": gen_metrics}
+def install_cpu_shim():
+    """SURVEY §8(c) harness shim: lets the reference's hard-coded .cuda() calls run on this GPU-less box.
+    Lives only in this generator; never edits the reference, never ships in the product."""
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    torch.cuda.empty_cache = lambda: None
+    # On a GPU `.cpu()` COPIES device memory to the host. With everything already on the CPU it would return
+    # `self`, and the reference's `input_val = adv_data.detach().cpu().numpy()` (CW_attack.py:133) would alias the
+    # tensor Adam then updates in place — an artefact of the shim, not reference behaviour. Emulate the copy.
+    _orig_cpu = torch.Tensor.cpu
+    torch.Tensor.cpu = lambda self, *a, **k: _orig_cpu(self, *a, **k).clone()
+
+
+def _seeded_pointnet(cls, k, seed):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))  # repo root, for oracle.ref_torch helpers
+    from oracle.ref_torch import seeded_state_dict, state_sha256
+    m = cls(k=k, feature_transform=False)
+    sd = seeded_state_dict(m, seed)
+    m.load_state_dict(sd)
+    m.eval()
+    return m, state_sha256(sd)
+
+
+def gen_pointnet():
+    """Logits / STN transform / input-gradient of the reference PointNetCls on seeded weights."""
+    from model.pointnet import PointNetCls
+    rng = np.random.default_rng(4321)
+    fx = {}
+    model, sha = _seeded_pointnet(PointNetCls, 40, 0)
+    fx["sha256"] = np.array(sha)
+    for nm, (B, N) in {"b2_n1024": (2, 1024), "b3_n200": (3, 200)}.items():
+        x = np.stack([unit_cloud(rng, N) for _ in range(B)]).transpose(0, 2, 1).copy()  # [B,3,N]
+        tx = torch.from_numpy(x).requires_grad_()
+        logp, trans, _ = model(tx)
+        w = torch.from_numpy(rng.standard_normal(logp.shape).astype(np.float32))
+        (logp * w).sum().backward()
+        fx[f"{nm}_x"], fx[f"{nm}_logp"], fx[f"{nm}_trans"] = x, logp.detach().numpy(), trans.detach().numpy()
+        fx[f"{nm}_w"], fx[f"{nm}_gx"] = w.numpy(), tx.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "pointnet.npz"), **fx)
+    print("pointnet.npz:", len(fx), "arrays")
+
+
+def gen_cw():
+    """Short runs of the REAL reference CW.attack (B=1, as the reference requires) on seeded PointNet weights.
+    Trajectories are captured through the dist_func hook (the loop hands it adv_data every iteration)."""
+    install_cpu_shim()
+    import contextlib
+    import io
+    from model.pointnet import PointNetCls
+    from attack.CW.CW_attack import CW
+    from attack.CW.CW_utils.adv_utils import UntargetedLogitsAdvLoss, LogitsAdvLoss
+    from attack.CW.CW_utils.dist_utils import L2Dist, ChamferDist
+    from attack.CW.CW_utils.clip_utils import ClipPointsLinf
+
+    class Recorder(torch.nn.Module):
+        def __init__(self, inner, transpose):
+            super().__init__()
+            self.inner, self.transpose, self.log = inner, transpose, []
+
+        def forward(self, adv, ori, weights=None, batch_avg=True):
+            self.log.append(adv.detach().numpy().copy())
+            if self.transpose:  # point-set functor documented for [B,K,3] (additional_exp/CW_attack.py:151-153)
+                return self.inner(adv.transpose(1, 2).contiguous(), ori.transpose(1, 2).contiguous(), weights, batch_avg)
+            return self.inner(adv, ori, weights, batch_avg)
+
+    rng = np.random.default_rng(777)
+    model, sha = _seeded_pointnet(PointNetCls, 40, 0)
+    trans_model, _ = _seeded_pointnet(PointNetCls, 40, 1)
+    fx = {"sha256": np.array(sha)}
+    cases = {
+        "l2_untarget": dict(dist="l2", method="untarget", kappa=5., N=256, steps=3, iters=15),
+        "chamfer_untarget": dict(dist="chamfer", method="untarget", kappa=5., N=256, steps=3, iters=15),
+        "l2_target": dict(dist="l2", method="target", kappa=0., N=200, steps=2, iters=25),
+    }
+    fx["names"] = np.array(sorted(cases))
+    for nm in sorted(cases):
+        c = cases[nm]
+        pc = unit_cloud(rng, c["N"])[None]  # [1,N,3]
+        with torch.no_grad():
+            clean = int(torch.argmax(model(torch.from_numpy(pc).transpose(1, 2).contiguous())[0], dim=1))
+        tgt = clean if c["method"] == "untarget" else int(torch.topk(model(torch.from_numpy(pc).transpose(1, 2).contiguous())[0], 2)[1][0, 1])
+        adv_func = UntargetedLogitsAdvLoss(kappa=c["kappa"]) if c["method"] == "untarget" else LogitsAdvLoss(kappa=c["kappa"])
+        rec = Recorder(L2Dist() if c["dist"] == "l2" else ChamferDist(), transpose=(c["dist"] != "l2"))
+        atk = CW(model, trans_model, adv_func=adv_func, clip_func=ClipPointsLinf(budget=0.18), dist_func=rec,
+                 attack_lr=1e-2, init_weight=10., max_weight=80., binary_step=c["steps"], num_iter=c["iters"],
+                 attack_method=c["method"])
+        torch.manual_seed(1000)
+        np.random.seed(1000)
+        with contextlib.redirect_stdout(io.StringIO()):
+            bd, ba, sn = atk.attack(torch.from_numpy(pc), torch.tensor([tgt]))
+        fx[f"{nm}_pc"], fx[f"{nm}_target"] = pc, np.array([tgt])
+        fx[f"{nm}_cfg"] = np.array([c["steps"], c["iters"], c["kappa"]])
+        fx[f"{nm}_bestdist"], fx[f"{nm}_bestattack"], fx[f"{nm}_success"] = bd, ba.astype(np.float32), np.array(sn)
+        fx[f"{nm}_traj"] = np.stack(rec.log).astype(np.float32)[:, 0]  # [steps*iters, 3, K]
+        fx[f"{nm}_fails"] = np.array([atk.attack_fail, atk.shuffle_fail, atk.trans_fail])
+    np.savez_compressed(os.path.join(OUT, "cw.npz"), **fx)
+    print("cw.npz:", len(fx), "arrays")
+
+
+SECTIONS = {"metrics": gen_metrics, "pointnet": gen_pointnet, "cw": gen_cw}
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(SECTIONS)

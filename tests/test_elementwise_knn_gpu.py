@@ -1,0 +1,111 @@
+"""GPU parity: clip / projection, fused Adam(+clip), dense pairwise and K-NN kernels vs the oracle / torch."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import unit_cloud
+from oracle import ref_numpy as orc
+from oracle import ref_torch as ort
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(dev, B=3, K=500, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    ori = torch.randn(B, 3, K, generator=g)
+    pc = ori + 0.2 * torch.randn(B, 3, K, generator=g)
+    nrm = torch.nn.functional.normalize(torch.randn(B, 3, K, generator=g), dim=1)
+    return pc, ori, nrm
+
+
+def test_clip_functors_match_oracle(dev):
+    clip = importlib.import_module("3dpointcloudattack_amd.attack.CW.CW_utils.clip_utils")
+    pc, ori, nrm = _rand(dev)
+    nrm[:, :, :7] = (pc - ori)[:, :, :7] * -3.0   # exactly opposite to the normal -> the "opposite" branch
+    cases = [(clip.ClipPointsLinf(0.18), ort.ClipPointsLinf(0.18), False),
+             (clip.ClipPointsL2(1.5), ort.ClipPointsL2(1.5), False),
+             (clip.ProjectInnerPoints(), ort.ProjectInnerPoints(), True),
+             (clip.ProjectInnerClipLinf(0.18), ort.ProjectInnerClipLinf(0.18), True)]
+    for hip, ora, with_n in cases:
+        args_d = (pc.to(dev), ori.to(dev)) + ((nrm.to(dev),) if with_n else ())
+        args_c = (pc, ori) + ((nrm,) if with_n else ())
+        got = hip(*args_d).cpu()
+        torch.testing.assert_close(got, ora(*args_c), rtol=1e-5, atol=1e-6)
+    # no normal -> ProjectInnerPoints returns its input untouched (clip_utils.py:76-77)
+    x = pc.to(dev)
+    assert clip.ProjectInnerPoints()(x, ori.to(dev)) is x
+
+
+def test_fused_adam_clip_matches_torch_adam(ops, dev):
+    pc, ori, _ = _rand(dev, B=2, K=300, seed=3)
+    p_ref = pc.clone().requires_grad_()
+    opt = torch.optim.Adam([p_ref], lr=1e-2, weight_decay=0.)
+    p = pc.clone().to(dev)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+    g = torch.Generator().manual_seed(9)
+    clipper = ort.ClipPointsLinf(0.18)
+    for t in range(1, 8):
+        grad = torch.randn(pc.shape, generator=g) * (10.0 ** (-t % 3))
+        opt.zero_grad()
+        p_ref.grad = grad.clone()
+        opt.step()
+        p_ref.data = clipper(p_ref.data.clone(), ori)
+        ops.i32_add(step_dev, 1)
+        ops.adam_clip_step(p, grad.to(dev), m, v, step_dev if t % 2 else t, 1e-2, ori=ori.to(dev), budget=0.18)
+        torch.testing.assert_close(p.cpu(), p_ref.data, rtol=2e-6, atol=2e-7)
+    st = opt.state[p_ref]
+    torch.testing.assert_close(m.cpu(), st["exp_avg"], rtol=1e-5, atol=1e-5)  # |grad| up to ~1e2: fp32 rounding
+    torch.testing.assert_close(v.cpu(), st["exp_avg_sq"], rtol=1e-5, atol=1e-6)
+
+
+def test_pairwise_matches_oracle(ops, dev, metrics_fx):
+    fx = metrics_fx
+    a, b = fx["np_rand_64_a"], fx["np_rand_64_b"]
+    M = ops.pairwise(torch.from_numpy(a)[None].to(dev), torch.from_numpy(b)[None].to(dev), euclid=True)[0]
+    np.testing.assert_allclose(M.cpu().numpy(), fx["np_rand_64_M"], rtol=2e-6, atol=1e-7)
+    x = torch.randn(2, 37, 3, device=dev)
+    y = torch.randn(2, 53, 3, device=dev)   # M % 4 != 0 -> scalar store tail
+    P = ops.pairwise(x, y)
+    ref = ((x.cpu().double()[:, :, None, :] - y.cpu().double()[:, None, :, :]) ** 2).sum(-1)
+    np.testing.assert_allclose(P.cpu().numpy(), ref.numpy(), rtol=2e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("B,N,M,K", [(2, 100, 100, 6), (1, 64, 300, 17), (2, 1024, 1024, 21), (1, 50, 40, 31),
+                                     (1, 5000, 70, 1), (2, 33, 4500, 4)])
+def test_knn_matches_exact_topk(ops, dev, B, N, M, K):
+    rng = np.random.default_rng(N + M + K)
+    r = np.stack([unit_cloud(rng, M) for _ in range(B)])
+    q = r.copy() if N == M else np.stack([unit_cloud(rng, N) for _ in range(B)])
+    d, i = ops.knn_raw(torch.from_numpy(q).to(dev), torch.from_numpy(r).to(dev), K)
+    d, i = d.cpu().numpy(), i.cpu().numpy()
+    D = ((q.astype(np.float64)[:, :, None, :] - r.astype(np.float64)[:, None, :, :]) ** 2).sum(-1)
+    ref = np.sort(D, axis=2)[:, :, :K]
+    np.testing.assert_allclose(d, ref, rtol=2e-6, atol=1e-12)
+    assert np.all(np.diff(d, axis=2) >= 0)
+    np.testing.assert_allclose(np.take_along_axis(D, i.astype(np.int64), axis=2), ref, rtol=2e-6, atol=1e-12)
+    for bb in range(B):                         # K distinct neighbours per query
+        assert all(len(set(row)) == K for row in i[bb][:: max(1, N // 50)])
+    if N == M:
+        assert np.array_equal(i[:, :, 0], np.broadcast_to(np.arange(N), (B, N)))
+
+
+@pytest.mark.parametrize("det", [False, True])
+def test_knn_dist_functor_value_and_grad(dev, det):
+    dist = importlib.import_module("3dpointcloudattack_amd.attack.CW.CW_utils.dist_utils")
+    rng = np.random.default_rng(1)
+    pc = np.stack([unit_cloud(rng, 400) for _ in range(3)])
+    w = torch.tensor([1.0, 2.0, 0.5])
+    x = torch.from_numpy(pc).double().requires_grad_()       # float64 oracle (its expansion is fp32-noisy)
+    ref = ort.KNNDist(5, 1.05)(x, w.double(), batch_avg=False)
+    ref.sum().backward()
+    xd = torch.from_numpy(pc).to(dev).requires_grad_()
+    got = dist.KNNDist(5, 1.05)(xd, w, batch_avg=False)
+    got.sum().backward()
+    np.testing.assert_allclose(got.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-5)
+    np.testing.assert_allclose(xd.grad.cpu().numpy(), x.grad.numpy(), rtol=1e-3, atol=1e-7)
+    # channel-first input gives the same value
+    got_cf = dist.KNNDist(5, 1.05)(torch.from_numpy(pc).to(dev).transpose(1, 2).contiguous(), w, batch_avg=False)
+    torch.testing.assert_close(got_cf, got.detach(), rtol=1e-6, atol=0)

@@ -68,3 +68,57 @@ def test_fp32_fma_emulation_is_close_to_f64(metrics_fx):
     d32, i32 = orc.nn_sq_f32(a, b)
     np.testing.assert_allclose(d32, d64, rtol=1e-6)
     assert (i32 == i64).mean() > 0.999
+
+
+# ---------------------------------------------------------------------------------------------------------
+# torch oracle (victim model + CW loop) against the real reference's outputs
+# ---------------------------------------------------------------------------------------------------------
+import os
+
+import torch
+
+from conftest import GOLDEN
+from oracle import ref_torch as ort
+
+
+def _oracle_pointnet(seed, k=40):
+    m = ort.PointNetCls(k=k)
+    sd = ort.seeded_state_dict(m, seed)
+    m.load_state_dict(sd)
+    m.eval()
+    return m, ort.state_sha256(sd)
+
+
+def test_oracle_pointnet_matches_reference():
+    fx = np.load(os.path.join(GOLDEN, "pointnet.npz"))
+    model, sha = _oracle_pointnet(0)
+    assert sha == str(fx["sha256"]), "seeded weights differ from the ones the reference was run with"
+    for nm in ("b2_n1024", "b3_n200"):
+        x = torch.from_numpy(fx[f"{nm}_x"]).requires_grad_()
+        logp, trans, _ = model(x)
+        np.testing.assert_allclose(logp.detach().numpy(), fx[f"{nm}_logp"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(trans.detach().numpy(), fx[f"{nm}_trans"], rtol=1e-5, atol=1e-6)
+        (logp * torch.from_numpy(fx[f"{nm}_w"])).sum().backward()
+        np.testing.assert_allclose(x.grad.numpy(), fx[f"{nm}_gx"], rtol=1e-4, atol=1e-6)
+
+
+def test_oracle_cw_attack_matches_reference():
+    fx = np.load(os.path.join(GOLDEN, "cw.npz"))
+    model, sha = _oracle_pointnet(0)
+    assert sha == str(fx["sha256"])
+    for nm in fx["names"]:
+        steps, iters, kappa = fx[f"{nm}_cfg"]
+        method = "untarget" if "untarget" in str(nm) else "target"
+        adv_func = ort.UntargetedLogitsAdvLoss(kappa) if method == "untarget" else ort.LogitsAdvLoss(kappa)
+        dist = ort.L2Dist() if str(nm).startswith("l2") else ort.ChannelFirst(ort.ChamferDist())
+        traj = []
+        torch.manual_seed(1000)
+        bd, ba, sn, _ = ort.cw_attack(model, torch.from_numpy(fx[f"{nm}_pc"]), torch.from_numpy(fx[f"{nm}_target"]),
+                                      adv_func, dist, ort.ClipPointsLinf(0.18), attack_lr=1e-2,
+                                      binary_step=int(steps), num_iter=int(iters), attack_method=method,
+                                      record=lambda s, i, a: traj.append(a[0].copy()))
+        # same ops on the same CPU: trajectories agree to fp32 rounding
+        np.testing.assert_allclose(np.stack(traj), fx[f"{nm}_traj"], rtol=0, atol=2e-6, err_msg=str(nm))
+        np.testing.assert_allclose(bd, fx[f"{nm}_bestdist"], rtol=1e-5, err_msg=str(nm))
+        np.testing.assert_allclose(ba, fx[f"{nm}_bestattack"], atol=2e-6, err_msg=str(nm))
+        assert sn == int(fx[f"{nm}_success"])

@@ -1,0 +1,86 @@
+"""GPU numerics: fused per-point MLP + max-pool (K8) vs a plain PyTorch fp32 reference of the same op."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _weights(dev, C3, seed):
+    g = torch.Generator().manual_seed(seed)
+
+    def u(*s, k):
+        return ((torch.rand(*s, generator=g) * 2 - 1) / np.sqrt(k)).to(dev)
+    return (u(64, 3, k=3), u(64, k=3), u(128, 64, k=64), u(128, k=64), u(C3, 128, k=128), u(C3, k=128))
+
+
+def _torch_full(x, w):
+    W1, b1, W2, b2, W3, b3 = w
+    h = F.relu(F.conv1d(x, W1[:, :, None], b1))
+    h = F.relu(F.conv1d(h, W2[:, :, None], b2))
+    return F.conv1d(h, W3[:, :, None], b3)
+
+
+def _torch_ref(x, w, relu_last):
+    h = _torch_full(x, w)
+    if relu_last:
+        h = F.relu(h)
+    return h.max(dim=2)
+
+
+@pytest.mark.parametrize("B,N,C3", [(2, 128, 1024), (3, 200, 256), (1, 1, 32), (2, 1024, 1024), (1, 1500, 1024)])
+@pytest.mark.parametrize("relu_last", [False, True])
+def test_forward_matches_torch(ops, dev, B, N, C3, relu_last):
+    torch.manual_seed(N + C3)
+    x = torch.randn(B, 3, N, device=dev) * 0.5
+    w = _weights(dev, C3, 1)
+    pooled, idx = ops.pointmlp3_max_fwd_raw(x, w, relu_last)
+    ref, ridx = _torch_ref(x, w, relu_last)
+    torch.testing.assert_close(pooled, ref, rtol=2e-5, atol=2e-6)
+    # argmax: equal, or a tie within fp32 rounding of the max
+    full = _torch_full(x, w)
+    assert torch.all((idx >= 0) & (idx < N))
+    picked = torch.gather(full, 2, idx.long()[:, :, None])[:, :, 0]
+    torch.testing.assert_close(picked, full.max(dim=2)[0], rtol=2e-5, atol=2e-6)
+    if not relu_last:
+        assert (idx.long() == ridx).float().mean() > 0.98
+
+
+@pytest.mark.parametrize("B,N,C3", [(2, 128, 1024), (2, 333, 256), (4, 1024, 1024)])
+@pytest.mark.parametrize("relu_last", [False, True])
+def test_backward_matches_torch_autograd(ops, dev, B, N, C3, relu_last):
+    torch.manual_seed(7 * N + C3)
+    x = (torch.randn(B, 3, N, device=dev) * 0.5).requires_grad_()
+    w = _weights(dev, C3, 2)
+    gout = torch.randn(B, C3, device=dev)
+    pooled = ops.pointmlp3_max(x, w, relu_last)
+    pooled.backward(gout)
+    g_hip = x.grad.clone()
+    x.grad = None
+    ref, _ = _torch_ref(x, w, relu_last)
+    ref.backward(gout)
+    scale = x.grad.abs().max()
+    torch.testing.assert_close(g_hip, x.grad, rtol=1e-3, atol=float(scale) * 2e-5)
+
+
+def test_transform_argument(ops, dev):
+    torch.manual_seed(3)
+    x = torch.randn(2, 3, 300, device=dev)
+    T = torch.randn(2, 3, 3, device=dev)
+    w = _weights(dev, 1024, 3)
+    pooled, _ = ops.pointmlp3_max_fwd_raw(x, w, False, T=T)
+    xt = torch.bmm(x.transpose(1, 2), T).transpose(1, 2).contiguous()
+    ref, _ = _torch_ref(xt, w, False)
+    torch.testing.assert_close(pooled, ref, rtol=2e-5, atol=2e-6)
+
+
+def test_backward_is_deterministic(ops, dev):
+    torch.manual_seed(5)
+    x = torch.randn(3, 3, 512, device=dev)
+    w = _weights(dev, 1024, 4)
+    pooled, idx = ops.pointmlp3_max_fwd_raw(x, w, False)
+    g = torch.randn_like(pooled)
+    a = ops.pointmlp3_max_bwd_raw(x, w, idx, g)
+    b = ops.pointmlp3_max_bwd_raw(x, w, idx, g)
+    assert torch.equal(a, b)
