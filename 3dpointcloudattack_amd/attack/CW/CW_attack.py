@@ -76,6 +76,107 @@ class CW:
             return float(cf.budget)
         return None
 
+    # -- the hot loop, split so that bench.py / graph capture can drive single iterations ---------------
+    def _begin(self, data, target):
+        """Upload + clean prediction (reference :63-89). Returns the state dict the iteration works on."""
+        dev = self.device
+        B, K = data.shape[:2]
+        data = data.float().to(dev).detach()
+        data = data.transpose(1, 2).contiguous()
+        ori_data = data.clone().detach()
+        target = target.long().to(dev).detach().view(-1)
+        label = target
+        with torch.no_grad():
+            logits = _logits_of(self.model(ori_data))
+            pred = torch.argmax(logits, dim=1)
+        if self.verbose:
+            print("ori label:", pred.tolist())
+        if self.attack_method == 'top1_error':
+            # reference (:86-89, B=1): target := runner-up class of the clean prediction
+            target = label = logits.topk(2, dim=1, largest=True, sorted=True)[1][:, 1].detach()
+        return dict(
+            B=B, K=K, ori=ori_data, target=target, label=label, budget=self._fused_clip_budget(),
+            # weight factor for budget regularization (host, consulted once per binary step)
+            lower_bound=np.zeros((B,)), upper_bound=np.ones((B,)) * self.max_weight,
+            current_weight=np.ones((B,)) * self.init_weight,
+            # best results over the whole binary search — device resident
+            o_bestdist=torch.full((B,), 1e10, dtype=torch.float32, device=dev),
+            o_bestscore=torch.full((B,), -1, dtype=torch.long, device=dev),
+            o_bestattack=torch.zeros((B, 3, K), dtype=torch.float32, device=dev),
+            input_val=ori_data, pred=None)
+
+    def _begin_binary_step(self, st):
+        """Fresh start point, Adam state and per-step bests (reference :94-100)."""
+        dev, B, K = self.device, st["B"], st["K"]
+        # same RNG stream as the reference: CPU generator, then upload (:94)
+        adv_data = st["ori"].clone().detach() + torch.randn((B, 3, K)).to(dev) * 1e-7
+        adv_data.requires_grad_()
+        st["adv"] = adv_data
+        st["bestdist"] = torch.full((B,), 1e10, dtype=torch.float32, device=dev)
+        st["bestscore"] = torch.full((B,), -1, dtype=torch.long, device=dev)
+        st["weights"] = torch.from_numpy(st["current_weight"]).to(dev)
+        if st["budget"] is None:
+            st["opt"] = optim.Adam([adv_data], lr=self.attack_lr, weight_decay=0.)
+        else:
+            st["exp_avg"] = torch.zeros_like(adv_data)
+            st["exp_avg_sq"] = torch.zeros_like(adv_data)
+
+    def _iterate(self, st, iteration, last=False):
+        """One pass of the hot-loop body (reference :111-174), entirely on the device."""
+        adv_data, ori_data, label = st["adv"], st["ori"], st["label"]
+        logits = _logits_of(self.model(adv_data))
+        pred = torch.argmax(logits, dim=1)  # [B]
+        # record values (device side; reference :129-153)
+        with torch.no_grad():
+            cur = adv_data.detach()
+            dist_val = torch.sqrt(torch.sum((cur - ori_data) ** 2, dim=[1, 2]))  # [B]
+            succ = self._success(pred, label)
+            upd = succ & (dist_val < st["bestdist"])
+            st["bestdist"] = torch.where(upd, dist_val, st["bestdist"])
+            st["bestscore"] = torch.where(upd, pred, st["bestscore"])
+            upd_o = succ & (dist_val < st["o_bestdist"])
+            st["o_bestdist"] = torch.where(upd_o, dist_val, st["o_bestdist"])
+            st["o_bestscore"] = torch.where(upd_o, pred, st["o_bestscore"])
+            st["o_bestattack"] = torch.where(upd_o[:, None, None], cur, st["o_bestattack"])
+            if last:
+                st["input_val"] = cur.clone()
+        st["pred"] = pred
+        # compute loss and backward
+        adv_loss = self.adv_func(logits, st["target"]).mean()
+        dist_loss = self.dist_func(adv_data, ori_data, st["weights"]).mean()
+        loss = adv_loss + dist_loss
+        if st["budget"] is None:
+            opt = st["opt"]
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            if self.clip_func is not None:
+                adv_data.data = self.clip_func(adv_data.clone().detach(), ori_data)
+        else:
+            adv_data.grad = None
+            loss.backward()
+            ops.adam_clip_step(adv_data.data, adv_data.grad, st["exp_avg"], st["exp_avg_sq"], iteration + 1,
+                               self.attack_lr, ori=ori_data, budget=st["budget"])
+
+    def _end_binary_step(self, st):
+        """Adjust the weight factor (reference :182-200) — one host round trip per binary step."""
+        B = st["B"]
+        bs = st["bestscore"].cpu().numpy()
+        bd = st["bestdist"].double().cpu().numpy()
+        obd = st["o_bestdist"].double().cpu().numpy()
+        lab = st["label"].cpu().numpy()
+        lower_bound, upper_bound, current_weight = st["lower_bound"], st["upper_bound"], st["current_weight"]
+        for e in range(B):
+            if self.attack_method == 'untarget':
+                ok = bs[e] != lab[e] and bs[e] != -1 and bd[e] <= obd[e]
+            else:
+                ok = bs[e] == lab[e] and bs[e] != -1 and bd[e] <= obd[e]
+            if ok:
+                lower_bound[e] = max(lower_bound[e], current_weight[e])
+            else:
+                upper_bound[e] = min(upper_bound[e], current_weight[e])
+            current_weight[e] = (lower_bound[e] + upper_bound[e]) / 2.
+
     def attack(self, data, target):
         """Attack on given data to target.
         Args:
@@ -84,108 +185,21 @@ class CW:
         Returns (o_bestdist [B] float64, o_bestattack [B,K,3] float64, success_num) like the reference (:260).
         """
         dev = self.device
-        B, K = data.shape[:2]
-        data = data.float().to(dev).detach()
-        data = data.transpose(1, 2).contiguous()
-        ori_data = data.clone().detach()
-
-        target = target.long().to(dev).detach().view(-1)
-        label = target
-
-        # weight factor for budget regularization (host, consulted once per binary step)
-        lower_bound = np.zeros((B,))
-        upper_bound = np.ones((B,)) * self.max_weight
-        current_weight = np.ones((B,)) * self.init_weight
-
-        # best results over the whole binary search — device resident
-        o_bestdist = torch.full((B,), 1e10, dtype=torch.float32, device=dev)
-        o_bestscore = torch.full((B,), -1, dtype=torch.long, device=dev)
-        o_bestattack = torch.zeros((B, 3, K), dtype=torch.float32, device=dev)
-
-        with torch.no_grad():
-            logits = _logits_of(self.model(ori_data))
-            pred = torch.argmax(logits, dim=1)
-        if self.verbose:
-            print("ori label:", pred.tolist())
-
-        if self.attack_method == 'top1_error':
-            # reference (:86-89, B=1): target := runner-up class of the clean prediction
-            target = label = logits.topk(2, dim=1, largest=True, sorted=True)[1][:, 1].detach()
-
-        budget = self._fused_clip_budget()
-        input_val = ori_data
-        pred = None
+        st = self._begin(data, target)
+        target = st["target"]
         for binary_step in range(self.binary_step):
-            # same RNG stream as the reference: CPU generator, then upload (:94)
-            adv_data = ori_data.clone().detach() + torch.randn((B, 3, K)).to(dev) * 1e-7
-            adv_data.requires_grad_()
-            bestdist = torch.full((B,), 1e10, dtype=torch.float32, device=dev)
-            bestscore = torch.full((B,), -1, dtype=torch.long, device=dev)
-            weights = torch.from_numpy(current_weight).to(dev)
-
-            if budget is None:
-                opt = optim.Adam([adv_data], lr=self.attack_lr, weight_decay=0.)
-            else:
-                exp_avg = torch.zeros_like(adv_data)
-                exp_avg_sq = torch.zeros_like(adv_data)
-
+            self._begin_binary_step(st)
             for iteration in range(self.num_iter):
-                logits = _logits_of(self.model(adv_data))
-                pred = torch.argmax(logits, dim=1)  # [B]
+                self._iterate(st, iteration, last=(iteration == self.num_iter - 1))
+            self._end_binary_step(st)
 
-                # record values (device side; reference :129-153)
-                with torch.no_grad():
-                    cur = adv_data.detach()
-                    dist_val = torch.sqrt(torch.sum((cur - ori_data) ** 2, dim=[1, 2]))  # [B]
-                    succ = self._success(pred, label)
-                    upd = succ & (dist_val < bestdist)
-                    bestdist = torch.where(upd, dist_val, bestdist)
-                    bestscore = torch.where(upd, pred, bestscore)
-                    upd_o = succ & (dist_val < o_bestdist)
-                    o_bestdist = torch.where(upd_o, dist_val, o_bestdist)
-                    o_bestscore = torch.where(upd_o, pred, o_bestscore)
-                    o_bestattack = torch.where(upd_o[:, None, None], cur, o_bestattack)
-                    if iteration == self.num_iter - 1:
-                        input_val = cur.clone()
-
-                # compute loss and backward
-                adv_loss = self.adv_func(logits, target).mean()
-                dist_loss = self.dist_func(adv_data, ori_data, weights).mean()
-                loss = adv_loss + dist_loss
-
-                if budget is None:
-                    opt.zero_grad()
-                    loss.backward()
-                    opt.step()
-                    if self.clip_func is not None:
-                        adv_data.data = self.clip_func(adv_data.clone().detach(), ori_data)
-                else:
-                    adv_data.grad = None
-                    loss.backward()
-                    ops.adam_clip_step(adv_data.data, adv_data.grad, exp_avg, exp_avg_sq, iteration + 1,
-                                       self.attack_lr, ori=ori_data, budget=budget)
-
-            # adjust weight factor (reference :182-200) — one host round trip per binary step
-            bs = bestscore.cpu().numpy()
-            bd = bestdist.double().cpu().numpy()
-            obd = o_bestdist.double().cpu().numpy()
-            lab = label.cpu().numpy()
-            for e in range(B):
-                if self.attack_method == 'untarget':
-                    ok = bs[e] != lab[e] and bs[e] != -1 and bd[e] <= obd[e]
-                else:
-                    ok = bs[e] == lab[e] and bs[e] != -1 and bd[e] <= obd[e]
-                if ok:
-                    lower_bound[e] = max(lower_bound[e], current_weight[e])
-                else:
-                    upper_bound[e] = min(upper_bound[e], current_weight[e])
-                current_weight[e] = (lower_bound[e] + upper_bound[e]) / 2.
-
-        success_num = int(self._success(pred, label).sum().item()) if pred is not None else 0
+        pred = st["pred"]
+        success_num = int(self._success(pred, st["label"]).sum().item()) if pred is not None else 0
 
         # fail to attack some examples: assign them the last iterate (reference :205-209)
-        fail_idx = torch.from_numpy(lower_bound == 0.).to(dev)
-        o_bestattack = torch.where(fail_idx[:, None, None], input_val, o_bestattack)
+        fail_idx = torch.from_numpy(st["lower_bound"] == 0.).to(dev)
+        o_bestattack = torch.where(fail_idx[:, None, None], st["input_val"], st["o_bestattack"])
+        o_bestdist = st["o_bestdist"]
 
         with torch.no_grad():
             # Test attack (:211-224)

@@ -339,16 +339,20 @@ extern "C" int pc3d_pointmlp3_max_fwd_f32(const float* x, int64_t x_bs, int64_t 
                "pc3d_pointmlp3_max_fwd_f32: unsupported widths %d/%d/%d (need 64/128/multiple of 32)", C1, C2, C3);
   PC3D_REQUIRE(B <= 65535, "pc3d_pointmlp3_max_fwd_f32: B=%d exceeds grid.y limit", B);
   if (B == 0) return PC3D_OK;
-  PC3D_REQUIRE(x && W1 && b1 && W2 && b2 && W3 && b3 && part_val && part_idx && pooled && argidx,
+  PC3D_REQUIRE(x && W1 && b1 && W2 && b2 && W3 && b3 && part_val && part_idx,
                "pc3d_pointmlp3_max_fwd_f32: null pointer");
+  PC3D_REQUIRE((pooled == nullptr) == (argidx == nullptr),
+               "pc3d_pointmlp3_max_fwd_f32: pooled and argidx must both be given or both be NULL");
   const int ntiles = cdiv(N, PM_TP);
   PMFwdArgs a{{x, x_bs, x_ps, x_cs}, N, C3, ntiles, T, W1, b1, W2, b2, W3, b3, part_val, part_idx};
   hipStream_t st = as_stream(stream);
   hipLaunchKernelGGL(pointmlp3_max_fwd_kernel, dim3(ntiles, B), dim3(256), 0, st, a);
   PC3D_LAUNCH_CHECK("pc3d_pointmlp3_max_fwd_f32");
-  hipLaunchKernelGGL(pointmlp3_fold_kernel, dim3(cdiv(C3, 256), B), dim3(256), 0, st, part_val, part_idx, ntiles, C3,
-                     relu_last, pooled, argidx);
-  PC3D_LAUNCH_CHECK("pc3d_pointmlp3_max_fwd_f32/fold");
+  if (pooled) {  // NULL: leave the per-tile partials unfolded (a fused consumer, or kernel-only timing)
+    hipLaunchKernelGGL(pointmlp3_fold_kernel, dim3(cdiv(C3, 256), B), dim3(256), 0, st, part_val, part_idx, ntiles,
+                       C3, relu_last, pooled, argidx);
+    PC3D_LAUNCH_CHECK("pc3d_pointmlp3_max_fwd_f32/fold");
+  }
   return PC3D_OK;
 }
 

@@ -210,7 +210,7 @@ def _pm_tile():
     return _PM_TILE
 
 
-def pointmlp3_max_fwd_raw(x, weights, relu_last, T=None, x_cf=True):
+def pointmlp3_max_fwd_raw(x, weights, relu_last, T=None, x_cf=True, fold=True):
     """x [B,3,N] (x_cf) or [B,N,3]; weights = (W1[64,3], b1, W2[128,64], b2, W3[C3,128], b3) with eval-BN folded.
     Returns (pooled [B,C3] f32, argidx [B,C3] i32)."""
     xp, xbs, xps, xcs, B, N = _pts(x, x_cf, "x")
@@ -233,7 +233,9 @@ def pointmlp3_max_fwd_raw(x, weights, relu_last, T=None, x_cf=True):
         _lib.call("pc3d_pointmlp3_max_fwd_f32", xp, xbs, xps, xcs, B, N, _ptr(T),
                   W1.data_ptr(), b1.data_ptr(), W2.data_ptr(), b2.data_ptr(), W3.data_ptr(), b3.data_ptr(),
                   C1, C2, C3, 1 if relu_last else 0, part_val.data_ptr(), part_idx.data_ptr(),
-                  pooled.data_ptr(), argidx.data_ptr(), _stream())
+                  pooled.data_ptr() if fold else 0, argidx.data_ptr() if fold else 0, _stream())
+    if not fold:
+        return part_val, part_idx
     return pooled, argidx
 
 

@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""Headline benchmark: attack iterations per second of the CW attack on PointNet (B=32, N=1024, fp32) with the
+Chamfer regulariser, on N GPUs of one node (BASELINE.json configs[1]; one rank per GPU, independent attack
+instances per rank, one RCCL broadcast of the frozen weights, no per-iteration collective).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" = one pass of the hot-loop body for the whole batch: victim forward, adversarial + Chamfer loss,
+backward to the input points, Adam step, per-point clip, best-attack bookkeeping — inputs already resident in HBM.
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (dominant kernel, measured live
+with HIP events) and `cpu_baseline` (the oracle's torch-CPU restatement of the same loop, timed on the host cores).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+B, NPTS, NCLS = 32, 1024, 40
+KAPPA, BUDGET, LR = 30.0, 0.18, 1e-2
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA = vector peak
+VALU_LANE_OPS_PEAK = 256 * 4 * 32 * 2.4e9   # lanes issued per second (v_fma_f32 wave64 = 2 cycles / SIMD)
+
+
+def unit_cloud(rng, n):
+    g = rng.standard_normal((n, 3))
+    g /= np.linalg.norm(g, axis=1, keepdims=True)
+    p = g * rng.random((n, 1)) ** (1.0 / 3.0)
+    p = p - p.mean(axis=0, keepdims=True)
+    return (p / np.max(np.linalg.norm(p, axis=1))).astype(np.float32)
+
+
+def seeded_state(model, seed):
+    from oracle.ref_torch import seeded_state_dict  # weight recipe only (shared with the fixtures)
+    return seeded_state_dict(model, seed)
+
+
+def ev_ms(fn, iters, stream):
+    """Average ms per call of fn() over `iters` back-to-back calls, HIP events on `stream`."""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(iters):
+        fn()
+    e1.record(stream)
+    e1.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def cpu_baseline(pcs, labels, seconds_budget=20.0):
+    """The oracle's CPU restatement of the same CW iteration (torch-CPU, all host cores), bounded sample."""
+    from oracle import ref_torch as ort
+    torch.set_num_threads(os.cpu_count() or 1)
+    model = ort.PointNetCls(k=NCLS)
+    model.load_state_dict(seeded_state(model, 0))
+    model.eval()
+    data = torch.from_numpy(pcs).transpose(1, 2).contiguous()
+    ori = data.clone()
+    adv = (ori + torch.randn_like(ori) * 1e-7).requires_grad_()
+    opt = torch.optim.Adam([adv], lr=LR)
+    adv_func, dist, clip = ort.UntargetedLogitsAdvLoss(KAPPA), ort.ChannelFirst(ort.ChamferDist()), ort.ClipPointsLinf(BUDGET)
+    w = torch.full((B,), 10.0, dtype=torch.float64)
+    bestdist = np.full((B,), 1e10)
+    n, t0 = 0, None
+    while True:
+        if n == 1:
+            t0 = time.perf_counter()  # first iteration = warm-up
+        logits = model(adv)[0]
+        pred = logits.argmax(1).numpy()
+        dv = torch.sqrt(torch.sum((adv - ori) ** 2, dim=[1, 2])).detach().numpy()
+        upd = (pred != labels.numpy()) & (dv < bestdist)
+        bestdist = np.where(upd, dv, bestdist)
+        loss = adv_func(logits, labels).mean() + dist(adv, ori, w).mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        adv.data = clip(adv.clone().detach(), ori)
+        n += 1
+        if n > 1 and (time.perf_counter() - t0 > seconds_budget or n >= 41):
+            break
+    el = time.perf_counter() - t0
+    return {"value": (n - 1) / el, "unit": "iters/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n - 1} iterations of the same CW/PointNet/Chamfer step (B={B}, N={NPTS}) via oracle/ref_torch.py on torch-CPU"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist_on = world > 1
+    if dist_on:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    pc3d = importlib.import_module("3dpointcloudattack_amd")
+    pc3d.load()  # fail loudly if the HIP library is missing
+    ops = importlib.import_module("3dpointcloudattack_amd.ops")
+    M = importlib.import_module
+    PointNetCls = M("3dpointcloudattack_amd.model.pointnet").PointNetCls
+    CW = M("3dpointcloudattack_amd.attack.CW.CW_attack").CW
+    adv_utils = M("3dpointcloudattack_amd.attack.CW.CW_utils.adv_utils")
+    dist_utils = M("3dpointcloudattack_amd.attack.CW.CW_utils.dist_utils")
+    clip_utils = M("3dpointcloudattack_amd.attack.CW.CW_utils.clip_utils")
+    sharding = M("3dpointcloudattack_amd.sharding")
+
+    # frozen victim weights: built on rank 0, one RCCL broadcast of the flattened blob, never touched again
+    model = PointNetCls(k=NCLS, feature_transform=False)
+    trans_model = PointNetCls(k=NCLS, feature_transform=False)
+    if rank == 0:
+        model.load_state_dict(seeded_state(model, 0))
+        trans_model.load_state_dict(seeded_state(trans_model, 1))
+    model, trans_model = model.to(dev).eval(), trans_model.to(dev).eval()
+    if dist_on:
+        sharding.broadcast_frozen_weights([model, trans_model], src=0)
+
+    # synthetic inputs: every rank attacks its own B clouds (weak scaling, per-GPU work fixed)
+    rng = np.random.default_rng(1234 + 1 + 1000 * rank)
+    pcs = np.stack([unit_cloud(rng, NPTS) for _ in range(B)])
+    data = torch.from_numpy(pcs)
+    with torch.no_grad():
+        labels = model(data.transpose(1, 2).contiguous().to(dev))[0].argmax(1).cpu()
+
+    attacker = CW(model, trans_model, adv_func=adv_utils.UntargetedLogitsAdvLoss(kappa=KAPPA),
+                  clip_func=clip_utils.ClipPointsLinf(budget=BUDGET), dist_func=dist_utils.ChamferDist(),
+                  attack_lr=LR, binary_step=10, num_iter=500, device=dev)
+    torch.manual_seed(1000 + rank)
+    st = attacker._begin(data, labels)
+    attacker._begin_binary_step(st)
+    run = attacker._make_runner(st) if hasattr(attacker, "_make_runner") else None
+
+    def step(i):
+        if run is not None:
+            run(i)
+        else:
+            attacker._iterate(st, i)
+
+    it = 0
+    for _ in range(args.warmup):
+        step(it)
+        it += 1
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(it)
+        it += 1
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist_on:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed * 1e3 / args.steps
+    iters_per_s = world * args.steps / elapsed     # whole job: every rank advances its own batch each step
+
+    out = None
+    if rank == 0:
+        stream = torch.cuda.current_stream()
+        # ---- roofline of the dominant kernel: the fused per-point MLP + max forward (fp32 MFMA)
+        x = st["adv"].detach()
+        tower = model.feat.folded()
+        flops = 2.0 * B * NPTS * (3 * 64 + 64 * 128 + 128 * 1024)   # algorithmic flops per launch
+        for _ in range(5):
+            ops.pointmlp3_max_fwd_raw(x, tower, False, fold=False)
+        k_ms = ev_ms(lambda: ops.pointmlp3_max_fwd_raw(x, tower, False, fold=False), 50, stream)
+        ach = flops / (k_ms * 1e-3) / 1e12
+        roofline = {"kernel": "pointmlp3_max_fwd_kernel", "bound": "mfma", "achieved": ach,
+                    "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS,
+                    "traffic": None, "launch_us": k_ms * 1e3, "launches_per_step": 2}
+        # ---- the Chamfer kernel at N=4096 (north_star's second figure): VALU-bound, HBM share reported too
+        Nc = 4096
+        a = torch.randn(B, Nc, 3, device=dev)
+        b = a + 0.01 * torch.randn_like(a)
+        for _ in range(3):
+            ops.nn_bidir_raw(a, b)
+        c_ms = ev_ms(lambda: ops.nn_bidir_raw(a, b), 20, stream)
+        alg_bytes = B * (2 * Nc * 12 + 2 * Nc * 8)          # 40*N bytes per cloud pair
+        lane_ops = 2.0 * B * Nc * Nc * 9                     # 9 VALU ops per (query, ref) pair, both directions
+        chamfer = {"kernel": "nn_kernel", "config": f"B={B} N=M={Nc} bidirectional", "launch_us": c_ms * 1e3,
+                   "hbm_alg_GBps": alg_bytes / (c_ms * 1e-3) / 1e9,
+                   "hbm_frac": alg_bytes / (c_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                   "valu_frac": lane_ops / (c_ms * 1e-3) / VALU_LANE_OPS_PEAK, "bound": "valu"}
+        out = {
+            "metric": "attack iters/s (B=32, N=1024, PointNet) + Chamfer HBM GB/s vs peak",
+            "value": iters_per_s, "unit": "iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "CW attack on PointNet(k=40, seeded random init), B=32 N=1024 fp32, "
+                                   "UntargetedLogitsAdvLoss(kappa=30) + ChamferDist(adv2ori) + ClipPointsLinf(0.18), "
+                                   "Adam lr 1e-2; one step = one hot-loop iteration for the whole batch",
+                       "batch_per_gpu": B, "points": NPTS, "parallelism": f"independent attack instances x{world}",
+                       "cloud_iters_per_s": iters_per_s * B},
+            "roofline": roofline, "chamfer": chamfer,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(pcs, labels)
+        elif world == 1:
+            out["cpu_baseline"] = None
+    if dist_on:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

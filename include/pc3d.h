@@ -86,7 +86,8 @@ int pc3d_nn_bwd_f32(const float* a, int64_t a_bs, int64_t a_ps, int64_t a_cs,
  *          (the torch.bmm of model/pointnet.py:106-109), NULL = identity
  *   W1 [64,3] b1[64]  W2 [128,64] b2[128]  W3 [C3,128] b3[C3]   row-major, BN already folded; C3 % 32 == 0
  *   part_val/part_idx  caller workspace [B, ceil(N / pc3d_pointmlp3_tile_points()), C3] f32 / i32
- *   pooled [B,C3] f32 (after the optional ReLU), argidx [B,C3] i32 = lowest point index attaining the max
+ *   pooled [B,C3] f32 (after the optional ReLU), argidx [B,C3] i32 = lowest point index attaining the max;
+ *          pass both NULL to keep only the per-tile partials (no fold launch)
  * fp32 throughout: layer 2/3 run on v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains).
  * ------------------------------------------------------------------------------------------------------- */
 int pc3d_pointmlp3_tile_points(void);

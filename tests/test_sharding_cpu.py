@@ -1,0 +1,65 @@
+"""CPU (gloo, world_size 2): the multi-GPU plumbing of the attack path — shard split, the single weight
+broadcast and the final gather — exercised with real processes."""
+import importlib
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sharding = importlib.import_module("3dpointcloudattack_amd.sharding")
+    from oracle import ref_torch as ort  # any module tree with the victim's state_dict layout will do on CPU
+    torch.manual_seed(100 + rank)        # ranks start from DIFFERENT weights
+    model = ort.PointNetCls(k=40)
+    if rank == 0:
+        model.load_state_dict(ort.seeded_state_dict(model, 0))
+    nbytes = sharding.broadcast_frozen_weights([model], src=0)
+    sha = ort.state_sha256(model.state_dict())
+    lo, hi = sharding.shard_range(7, rank, world)
+    local = torch.arange(lo, hi, dtype=torch.float32).view(-1, 1).repeat(1, 3)
+    pad = torch.full((4 - local.shape[0], 3), -1.0)     # equal shapes across ranks for all_gather
+    (glob,) = sharding.gather_results([torch.cat([local, pad])])
+    ret[rank] = (sha, nbytes, (lo, hi), glob.numpy().copy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_broadcast_and_gather_world2():
+    from oracle import ref_torch as ort
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    ref = ort.PointNetCls(k=40)
+    sha0 = ort.state_sha256(ort.seeded_state_dict(ref, 0))
+    assert ret[0][0] == ret[1][0] == sha0, "weights differ after the broadcast"
+    assert ret[0][1] > 6e6                                    # one blob of ~1.6 M fp32 values (6.5 MB)
+    assert ret[0][2] == (0, 4) and ret[1][2] == (4, 7)
+    g = ret[0][3]
+    assert np.array_equal(g, ret[1][3])
+    assert g[:4, 0].tolist() == [0, 1, 2, 3] and g[4:7, 0].tolist() == [4, 5, 6] and g[7, 0] == -1
+
+
+def test_shard_range_covers_everything():
+    sharding = importlib.import_module("3dpointcloudattack_amd.sharding")
+    for total in (0, 1, 7, 32, 256):
+        for world in (1, 2, 3, 8):
+            spans = [sharding.shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
