@@ -18,6 +18,7 @@ import torch
 import torch.optim as optim
 
 from ... import ops
+from .CW_utils import adv_utils as _adv_utils
 from .CW_utils import clip_utils as _clip_utils
 from .CW_utils import dist_utils as _dist_utils
 
@@ -39,7 +40,7 @@ class CW:
 
     def __init__(self, model, trans_model, adv_func, clip_func, dist_func, attack_lr=1e-2,
                  init_weight=10., max_weight=80., binary_step=10, num_iter=500, attack_method="untarget",
-                 device=None, verbose=False, fused=True):
+                 device=None, verbose=False, fused=True, graph=True):
         """Arguments as attack/CW/CW_attack.py:26-38. Extra keyword-only style options (defaults keep the
         reference behaviour): device (default: current CUDA device), verbose (reference prints), fused (use the
         fused Adam+clip launch when clip_func is recognised)."""
@@ -62,6 +63,7 @@ class CW:
         self.attack_fail = 0
         self.verbose = verbose
         self.fused = fused
+        self.graph = graph
 
     # -- helpers ---------------------------------------------------------------------------------------
     def _success(self, pred, label):
@@ -75,6 +77,14 @@ class CW:
         if type(cf) in (_clip_utils.ClipPointsLinf, _dist_utils.ClipPointsLinf):
             return float(cf.budget)
         return None
+
+    def _capturable(self):
+        """hipGraph capture needs a body free of host syncs / allocations outside torch's pool. That is known for
+        this package's own functors and victim mirrors; arbitrary user callables run eagerly instead."""
+        own_adv = (_adv_utils.LogitsAdvLoss, _adv_utils.UntargetedLogitsAdvLoss, _adv_utils.CrossEntropyAdvLoss)
+        own_dist = (_dist_utils.L2Dist, _dist_utils.ChamferDist, _dist_utils.HausdorffDist, _dist_utils.ChamferkNNDist)
+        return (self.graph and self._fused_clip_budget() is not None and type(self.adv_func) in own_adv
+                and type(self.dist_func) in own_dist and hasattr(self.model, "_require_fused"))
 
     # -- the hot loop, split so that bench.py / graph capture can drive single iterations ---------------
     def _begin(self, data, target):
@@ -103,7 +113,8 @@ class CW:
             o_bestdist=torch.full((B,), 1e10, dtype=torch.float32, device=dev),
             o_bestscore=torch.full((B,), -1, dtype=torch.long, device=dev),
             o_bestattack=torch.zeros((B, 3, K), dtype=torch.float32, device=dev),
-            input_val=ori_data, pred=None)
+            input_val=ori_data.clone(), pred=torch.zeros((B,), dtype=torch.long, device=dev),
+            step=torch.zeros((1,), dtype=torch.int32, device=dev), graph=None)
 
     def _begin_binary_step(self, st):
         """Fresh start point, Adam state and per-step bests (reference :94-100)."""
@@ -111,18 +122,32 @@ class CW:
         # same RNG stream as the reference: CPU generator, then upload (:94)
         adv_data = st["ori"].clone().detach() + torch.randn((B, 3, K)).to(dev) * 1e-7
         adv_data.requires_grad_()
-        st["adv"] = adv_data
-        st["bestdist"] = torch.full((B,), 1e10, dtype=torch.float32, device=dev)
-        st["bestscore"] = torch.full((B,), -1, dtype=torch.long, device=dev)
-        st["weights"] = torch.from_numpy(st["current_weight"]).to(dev)
-        if st["budget"] is None:
-            st["opt"] = optim.Adam([adv_data], lr=self.attack_lr, weight_decay=0.)
+        if "adv" not in st:
+            # first binary step: allocate the per-step state once; later steps refill it IN PLACE so a captured
+            # hipGraph of the iteration stays valid across binary steps
+            st["adv"] = adv_data
+            st["bestdist"] = torch.full((B,), 1e10, dtype=torch.float32, device=dev)
+            st["bestscore"] = torch.full((B,), -1, dtype=torch.long, device=dev)
+            st["weights"] = torch.from_numpy(st["current_weight"]).float().to(dev)
+            if st["budget"] is not None:
+                st["exp_avg"] = torch.zeros_like(adv_data)
+                st["exp_avg_sq"] = torch.zeros_like(adv_data)
         else:
-            st["exp_avg"] = torch.zeros_like(adv_data)
-            st["exp_avg_sq"] = torch.zeros_like(adv_data)
+            with torch.no_grad():
+                st["adv"].copy_(adv_data)
+                st["bestdist"].fill_(1e10)
+                st["bestscore"].fill_(-1)
+                st["weights"].copy_(torch.from_numpy(st["current_weight"]).float())
+                if st["budget"] is not None:
+                    st["exp_avg"].zero_()
+                    st["exp_avg_sq"].zero_()
+        st["step"].zero_()
+        if st["budget"] is None:
+            st["opt"] = optim.Adam([st["adv"]], lr=self.attack_lr, weight_decay=0.)
 
-    def _iterate(self, st, iteration, last=False):
-        """One pass of the hot-loop body (reference :111-174), entirely on the device."""
+    def _iterate(self, st, iteration=None, last=False):
+        """One pass of the hot-loop body (reference :111-174), entirely on the device. The Adam step number lives
+        in st["step"] on the device, so the body is identical every pass (hipGraph-replayable)."""
         adv_data, ori_data, label = st["adv"], st["ori"], st["label"]
         logits = _logits_of(self.model(adv_data))
         pred = torch.argmax(logits, dim=1)  # [B]
@@ -132,15 +157,14 @@ class CW:
             dist_val = torch.sqrt(torch.sum((cur - ori_data) ** 2, dim=[1, 2]))  # [B]
             succ = self._success(pred, label)
             upd = succ & (dist_val < st["bestdist"])
-            st["bestdist"] = torch.where(upd, dist_val, st["bestdist"])
-            st["bestscore"] = torch.where(upd, pred, st["bestscore"])
+            st["bestdist"].copy_(torch.where(upd, dist_val, st["bestdist"]))
+            st["bestscore"].copy_(torch.where(upd, pred, st["bestscore"]))
             upd_o = succ & (dist_val < st["o_bestdist"])
-            st["o_bestdist"] = torch.where(upd_o, dist_val, st["o_bestdist"])
-            st["o_bestscore"] = torch.where(upd_o, pred, st["o_bestscore"])
-            st["o_bestattack"] = torch.where(upd_o[:, None, None], cur, st["o_bestattack"])
-            if last:
-                st["input_val"] = cur.clone()
-        st["pred"] = pred
+            st["o_bestdist"].copy_(torch.where(upd_o, dist_val, st["o_bestdist"]))
+            st["o_bestscore"].copy_(torch.where(upd_o, pred, st["o_bestscore"]))
+            st["o_bestattack"].copy_(torch.where(upd_o[:, None, None], cur, st["o_bestattack"]))
+            st["input_val"].copy_(cur)     # the iterate the LAST pass started from (reference :133, :208-209)
+            st["pred"].copy_(pred)
         # compute loss and backward
         adv_loss = self.adv_func(logits, st["target"]).mean()
         dist_loss = self.dist_func(adv_data, ori_data, st["weights"]).mean()
@@ -155,8 +179,34 @@ class CW:
         else:
             adv_data.grad = None
             loss.backward()
-            ops.adam_clip_step(adv_data.data, adv_data.grad, st["exp_avg"], st["exp_avg_sq"], iteration + 1,
+            ops.i32_add(st["step"], 1)
+            ops.adam_clip_step(adv_data.data, adv_data.grad, st["exp_avg"], st["exp_avg_sq"], st["step"],
                                self.attack_lr, ori=ori_data, budget=st["budget"])
+
+    def _make_runner(self, st, warmup=3):
+        """Capture one iteration into a hipGraph (after `warmup` eager passes on a side stream, as torch requires)
+        and return a callable that replays it. Only the fused path (recognised clip functor) is captured; the
+        generic path with arbitrary user callables returns an eager runner. Replays are bit-identical to eager
+        passes: same kernels, same order, same buffers."""
+        if not self._capturable():
+            return lambda i=None: self._iterate(st, i)
+        if st["graph"] is not None:
+            return st["graph_run"]
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._iterate(st)
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        # warm-up passes are real iterations; account for them by NOT rolling anything back: callers start counting
+        # after _make_runner (bench) or use _begin_binary_step to reset the state (attack()).
+        g = torch.cuda.CUDAGraph()
+        st["adv"].grad = None
+        with torch.cuda.graph(g):
+            self._iterate(st)
+        st["graph"] = g
+        st["graph_run"] = lambda i=None: g.replay()
+        return st["graph_run"]
 
     def _end_binary_step(self, st):
         """Adjust the weight factor (reference :182-200) — one host round trip per binary step."""
@@ -187,13 +237,33 @@ class CW:
         dev = self.device
         st = self._begin(data, target)
         target = st["target"]
+        run = None
         for binary_step in range(self.binary_step):
             self._begin_binary_step(st)
+            if run is None and self._capturable() and self.num_iter >= 8:
+                # capture once (its warm-up passes advance the state), then restart this binary step cleanly with
+                # the SAME start point so results do not depend on whether a graph is used
+                start = st["adv"].detach().clone()
+                o_keep = (st["o_bestdist"].clone(), st["o_bestscore"].clone(), st["o_bestattack"].clone())
+                run = self._make_runner(st)
+                with torch.no_grad():
+                    st["adv"].copy_(start)
+                    st["bestdist"].fill_(1e10)
+                    st["bestscore"].fill_(-1)
+                    st["exp_avg"].zero_()
+                    st["exp_avg_sq"].zero_()
+                    st["step"].zero_()
+                    st["o_bestdist"].copy_(o_keep[0])
+                    st["o_bestscore"].copy_(o_keep[1])
+                    st["o_bestattack"].copy_(o_keep[2])
             for iteration in range(self.num_iter):
-                self._iterate(st, iteration, last=(iteration == self.num_iter - 1))
+                if run is not None:
+                    run()
+                else:
+                    self._iterate(st, iteration)
             self._end_binary_step(st)
 
-        pred = st["pred"]
+        pred = st["pred"] if self.num_iter > 0 and self.binary_step > 0 else None
         success_num = int(self._success(pred, st["label"]).sum().item()) if pred is not None else 0
 
         # fail to attack some examples: assign them the last iterate (reference :205-209)

@@ -59,7 +59,8 @@ def ev_ms(fn, iters, stream):
 def cpu_baseline(pcs, labels, seconds_budget=20.0):
     """The oracle's CPU restatement of the same CW iteration (torch-CPU, all host cores), bounded sample."""
     from oracle import ref_torch as ort
-    torch.set_num_threads(os.cpu_count() or 1)
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(max(1, min(16, ncpu)))   # the GPU box gives one GPU a 16-core share
     model = ort.PointNetCls(k=NCLS)
     model.load_state_dict(seeded_state(model, 0))
     model.eval()

@@ -158,3 +158,24 @@ def test_cw_batched_equals_per_sample_and_oracle_labels(dev):
         hip_lab = model(torch.from_numpy(ba).float().transpose(1, 2).contiguous().to(dev))[0].argmax(1).cpu()
         ora_lab = omodel(torch.from_numpy(oba).float().transpose(1, 2).contiguous())[0].argmax(1)
     assert torch.equal(hip_lab, ora_lab)
+
+
+def test_graph_replay_equals_eager(dev):
+    """The hipGraph-captured iteration must reproduce the eager fused path bit for bit (same kernels, same order)."""
+    cwm, adv, dist, clip = _mods()
+    model, _ = hip_pointnet(0, dev)
+    trans_model, _ = hip_pointnet(1, dev)
+    rng = np.random.default_rng(31)
+    pcs = torch.from_numpy(np.stack([unit_cloud(rng, 320) for _ in range(3)]))
+    with torch.no_grad():
+        labels = model(pcs.transpose(1, 2).contiguous().to(dev))[0].argmax(1).cpu()
+    outs = []
+    for graph in (False, True):
+        atk = cwm.CW(model, trans_model, adv_func=adv.UntargetedLogitsAdvLoss(5.), clip_func=clip.ClipPointsLinf(0.18),
+                     dist_func=dist.ChamferDist(), binary_step=3, num_iter=12, graph=graph)
+        assert atk._capturable() == graph
+        torch.manual_seed(77)
+        np.random.seed(77)
+        outs.append(atk.attack(pcs, labels) + (atk.attack_fail, atk.shuffle_fail, atk.trans_fail))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    assert outs[0][2:] == outs[1][2:]
