@@ -69,7 +69,11 @@ __device__ __forceinline__ void layer1_to_lds(const float* xs, float* h1, const 
   }
 }
 
-__global__ __launch_bounds__(256) void pointmlp3_max_fwd_kernel(PMFwdArgs a) {
+constexpr int PM_MAXC3F = 1024;      // forward: widest layer 3 (cross-wave max scratch aliases the h2 tile)
+constexpr int PM_FT = 512;           // forward: threads per workgroup (8 waves = 2 per SIMD: one wave's epilogue /
+                                     // operand waits overlap the other's MFMAs)
+
+__global__ __launch_bounds__(PM_FT) __attribute__((amdgpu_waves_per_eu(2, 2))) void pointmlp3_max_fwd_kernel(PMFwdArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[PM_TP * PM_LD2 + 3 * PM_TP];  // 69,120 B static
   float* h1 = lds;                       // [128][68]   (dead after layer 2)
   float* h2 = lds;                       // [128][132]  (overwrites h1 behind a barrier)
@@ -87,26 +91,27 @@ __global__ __launch_bounds__(256) void pointmlp3_max_fwd_kernel(PMFwdArgs a) {
     xs[2 * PM_TP + threadIdx.x] = pz;
   }
   __syncthreads();
-  layer1_to_lds<PM_TP, 256>(xs, h1, a.W1, a.b1);
+  layer1_to_lds<PM_TP, PM_FT>(xs, h1, a.W1, a.b1);
   __syncthreads();
 
-  // ---- layer 2 on MFMA: D[pt][c2] = sum_k h1[pt][k] W2[c2][k]; wave owns c2 in [32*wave, +32), 4 point tiles
+  // ---- layer 2 on MFMA: D[pt][c2] = sum_k h1[pt][k] W2[c2][k]; wave owns c2 block (wave&3) and 2 of the 4 point tiles
   {
-    f32x16 acc[4];
+    const int c2b = wave & 3, tl0 = (wave >> 2) * 2;
+    f32x16 acc[2];
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-    const float* wrow = a.W2 + (32 * wave + r) * PM_C1 + 4 * h;
+    const float* wrow = a.W2 + (32 * c2b + r) * PM_C1 + 4 * h;
 #pragma unroll
     for (int t = 0; t < PM_C1 / 8; ++t) {
       const float4 bw = *reinterpret_cast<const float4*>(wrow + 8 * t);
-      float4 av[4];
+      float4 av[2];
 #pragma unroll
-      for (int tl = 0; tl < 4; ++tl)
-        av[tl] = *reinterpret_cast<const float4*>(h1 + (tl * 32 + r) * PM_LD1 + 8 * t + 4 * h);
+      for (int tl = 0; tl < 2; ++tl)
+        av[tl] = *reinterpret_cast<const float4*>(h1 + ((tl0 + tl) * 32 + r) * PM_LD1 + 8 * t + 4 * h);
 #pragma unroll
-      for (int tl = 0; tl < 4; ++tl) {
+      for (int tl = 0; tl < 2; ++tl) {
         acc[tl] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tl].x, bw.x, acc[tl], 0, 0, 0);
         acc[tl] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tl].y, bw.y, acc[tl], 0, 0, 0);
         acc[tl] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tl].z, bw.z, acc[tl], 0, 0, 0);
@@ -114,55 +119,71 @@ __global__ __launch_bounds__(256) void pointmlp3_max_fwd_kernel(PMFwdArgs a) {
       }
     }
     __syncthreads();  // every wave is done reading h1
-    const float bias = a.b2[32 * wave + r];
+    const float bias = a.b2[32 * c2b + r];
 #pragma unroll
-    for (int tl = 0; tl < 4; ++tl)
+    for (int tl = 0; tl < 2; ++tl)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int pt = tl * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        h2[pt * PM_LD2 + 32 * wave + r] = fmaxf(acc[tl][e] + bias, 0.f);
+        const int pt = (tl0 + tl) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        h2[pt * PM_LD2 + 32 * c2b + r] = fmaxf(acc[tl][e] + bias, 0.f);
       }
   }
   __syncthreads();
 
-  // ---- layer 3 + max over the tile's points
+  // ---- layer 3 + max over the tile's points.
+  // Wave w owns point tile (w & 3) = 32 points and half of the channel blocks ((w >> 2) selects blocks
+  // [16*(w>>2), +16) of 32 channels when C3 = 1024). Its A operands (h2 of its 32 points, all 128 k) are read from LDS
+  // ONCE into 64 VGPRs; only W3 streams (float4 per lane per 8 k, L2-resident, 4 waves share each row block).
+  // One 16-register accumulator per channel block: a single dependent MFMA chain issues back-to-back on gfx950
+  // (32x32x2 f32: issue interval = dependent latency = 64 cycles), and the SIMD's second wave fills every gap.
+  const int ptile = wave & 3, cgrp = wave >> 2;
+  float4 areg[PM_C2 / 8];
+#pragma unroll
+  for (int t = 0; t < PM_C2 / 8; ++t)
+    areg[t] = *reinterpret_cast<const float4*>(h2 + (ptile * 32 + r) * PM_LD2 + 8 * t + 4 * h);
+  __syncthreads();  // h2 fully consumed into registers: the LDS region is reused for the cross-wave max below
+  float* pv = lds;                                        // [4 point tiles][C3]
+  int* pi = reinterpret_cast<int*>(lds + 4 * PM_MAXC3F);  // [4 point tiles][C3]
   const int nblk = a.C3 / 32;
-  for (int cb = wave; cb < nblk; cb += 4) {
-    const int ch = cb * 32 + r;
-    f32x16 acc[4];
+  const int blk_per_grp = (nblk + 1) / 2;
+  const int cb_end = (cgrp + 1) * blk_per_grp < nblk ? (cgrp + 1) * blk_per_grp : nblk;
+  // W3 rows are double-buffered in registers ACROSS channel blocks: while block cb runs its 64 MFMAs, the 16 float4
+  // of block cb+1 are fetched (one load per 4 MFMAs, pinned with sched_group_barrier so hipcc cannot sink them to
+  // just-in-time), i.e. every load has a full block (~4k cycles) to land.
+  auto load_row = [&](float4 (&dst)[PM_C2 / 8], int cb) {
+    const int cbc = cb < cb_end ? cb : cb_end - 1;  // past the end: harmless re-load of the last block
+    const float* wrow = a.W3 + (int64_t)(cbc * 32 + r) * PM_C2 + 4 * h;
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < PM_C2 / 8; ++t) dst[t] = *reinterpret_cast<const float4*>(wrow + 8 * t);
+  };
+  auto run_block = [&](const float4 (&cur)[PM_C2 / 8], float4 (&nxt)[PM_C2 / 8], int cb) {
+    const int cbn = (cb + 1 < cb_end) ? cb + 1 : cb_end - 1;
+    const float* nrow = a.W3 + (int64_t)(cbn * 32 + r) * PM_C2 + 4 * h;
+    f32x16 acc;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-    const float* wrow = a.W3 + (int64_t)ch * PM_C2 + 4 * h;
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
     for (int t = 0; t < PM_C2 / 8; ++t) {
-      const float4 bw = *reinterpret_cast<const float4*>(wrow + 8 * t);
-      float4 av[4];
+      nxt[t] = *reinterpret_cast<const float4*>(nrow + 8 * t);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[t].x, cur[t].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[t].y, cur[t].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[t].z, cur[t].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[t].w, cur[t].w, acc, 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // 4 MFMA
+    }
+    const int ch = cb * 32 + r;
+    float best = -__builtin_inff();
+    int bi = n0 + ptile * 32;
 #pragma unroll
-      for (int tl = 0; tl < 4; ++tl)
-        av[tl] = *reinterpret_cast<const float4*>(h2 + (tl * 32 + r) * PM_LD2 + 8 * t + 4 * h);
-#pragma unroll
-      for (int tl = 0; tl < 4; ++tl) {
-        acc[tl] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tl].x, bw.x, acc[tl], 0, 0, 0);
-        acc[tl] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tl].y, bw.y, acc[tl], 0, 0, 0);
-        acc[tl] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tl].z, bw.z, acc[tl], 0, 0, 0);
-        acc[tl] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tl].w, bw.w, acc[tl], 0, 0, 0);
+    for (int e = 0; e < 16; ++e) {
+      const int pt = n0 + ptile * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;  // ascending in e for fixed h
+      const float v = acc[e];
+      if (pt < a.N && v > best) {
+        best = v;
+        bi = pt;
       }
     }
-    float best = -__builtin_inff();
-    int bi = n0;
-#pragma unroll
-    for (int tl = 0; tl < 4; ++tl)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int pt = n0 + tl * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;  // ascending in (tl, e) for fixed h
-        const float v = acc[tl][e];
-        if (pt < a.N && v > best) {
-          best = v;
-          bi = pt;
-        }
-      }
     const float ov = __shfl_xor(best, 32, 64);
     const int oi = __shfl_xor(bi, 32, 64);
     if (ov > best || (ov == best && oi < bi)) {
@@ -170,10 +191,34 @@ __global__ __launch_bounds__(256) void pointmlp3_max_fwd_kernel(PMFwdArgs a) {
       bi = oi;
     }
     if (h == 0) {
-      const int64_t o = ((int64_t)b * a.ntiles + tile) * a.C3 + ch;
-      a.part_val[o] = best + a.b3[ch];
-      a.part_idx[o] = bi;
+      pv[ptile * a.C3 + ch] = best;
+      pi[ptile * a.C3 + ch] = bi;
     }
+  };
+  float4 bwA[PM_C2 / 8], bwB[PM_C2 / 8];
+  const int cb_begin = cgrp * blk_per_grp;
+  if (cb_begin < cb_end) {
+    load_row(bwA, cb_begin);
+    for (int cb = cb_begin; cb < cb_end; cb += 2) {
+      run_block(bwA, bwB, cb);
+      if (cb + 1 < cb_end) run_block(bwB, bwA, cb + 1);
+    }
+  }
+  __syncthreads();
+  for (int ch = threadIdx.x; ch < a.C3; ch += PM_FT) {
+    float best = pv[ch];
+    int bi = pi[ch];
+#pragma unroll
+    for (int t = 1; t < 4; ++t) {  // ascending point tile: strict > keeps the lowest point index on ties
+      const float v = pv[t * a.C3 + ch];
+      if (v > best) {
+        best = v;
+        bi = pi[t * a.C3 + ch];
+      }
+    }
+    const int64_t o = ((int64_t)b * a.ntiles + tile) * a.C3 + ch;
+    a.part_val[o] = best + a.b3[ch];
+    a.part_idx[o] = bi;
   }
 }
 
@@ -204,32 +249,64 @@ struct PMBwdArgs {
   PtsView x;
   int N, C3;
   const float* T;
-  const float *W1, *b1, *W2, *b2, *W3;
+  const float *W1, *b1, *W2, *b2, *W3, *W2T;  // W2T = W2 transposed, [64][128] row-major
   const int32_t* argidx;  // [B,C3]
   const float* g;         // [B,C3] upstream gradient on pooled (already masked for relu_last by the caller)
   PtsViewMut gx;          // gradient wrt the (transformed) tower input x'
 };
 
+// Workgroup = (batch b, 64 points), 4 waves.
+//  A. channels whose arg-max lies in the tile are compacted IN CHANNEL ORDER (block prefix sum) into two lists
+//     (points 0-31 / 32-63) and their rows g[c]*W3[c,:] are accumulated into g2s[pt][128] — ordered => deterministic;
+//  B. h1 = relu(W1 x + b1) is recomputed; the layer-2 pre-activation runs on MFMA (A = h1 from LDS, B = W2 rows from
+//     L2) and masks g2s in place;
+//  C. g1 = (g2 masked) . W2 runs on MFMA (A = g2s from LDS, B = W2T rows), is masked by h1 > 0 and overwrites h1s;
+//  D. gx' = g1 . W1 on the VALU.
 __global__ __launch_bounds__(256) void pointmlp3_max_bwd_kernel(PMBwdArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[PM_BTP * PM_LD2 + 2 * PM_BTP * PM_LD1 + 3 * PM_BTP + 2 * PM_MAXC3];
-  float* g2s = lds;                          // [64][132]
-  float* h1s = g2s + PM_BTP * PM_LD2;        // [64][68]
-  float* g1s = h1s + PM_BTP * PM_LD1;        // [64][68]
-  float* xs = g1s + PM_BTP * PM_LD1;         // [3][64]
-  float* s_g = xs + 3 * PM_BTP;              // [C3] (C3 <= PM_MAXC3)
+  __shared__ __attribute__((aligned(16))) float lds[PM_BTP * PM_LD2 + PM_BTP * PM_LD1 + 4 * PM_BTP + 4 * PM_MAXC3];
+  float* g2s = lds;                                   // [64][132]
+  float* h1s = g2s + PM_BTP * PM_LD2;                 // [64][68]   (later holds g1)
+  float* xs = h1s + PM_BTP * PM_LD1;                  // [3][64] (+64 spare: scan scratch)
+  int* s_scan = reinterpret_cast<int*>(xs + 3 * PM_BTP);   // [64] wave totals etc.
+  float* s_g = xs + 4 * PM_BTP;                       // [C3]
   int* s_n = reinterpret_cast<int*>(s_g + PM_MAXC3);  // [C3]
+  int* list0 = s_n + PM_MAXC3;                        // [C3] channels hitting points 0..31, ascending
+  int* list1 = list0 + PM_MAXC3;                      // [C3] channels hitting points 32..63
   const int tile = blockIdx.x, b = blockIdx.y;
   const int n0 = tile * PM_BTP;
   const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
 
-  int any = 0;
-  for (int c = tid; c < a.C3; c += 256) {
-    const int n = a.argidx[(int64_t)b * a.C3 + c] - n0;
-    const float gv = a.g[(int64_t)b * a.C3 + c];
-    const bool in = (n >= 0) && (n < PM_BTP) && (gv != 0.f);
-    s_n[c] = in ? n : -1;
-    s_g[c] = gv;
-    any |= in ? 1 : 0;
+  // MFMA B operands of phases B and C depend on nothing: fetch them now so their L2 latency hides under phase A
+  float4 w2r[PM_C1 / 8], w2tr[PM_C2 / 8];
+  {
+    const float* wrow = a.W2 + (32 * wave + r) * PM_C1 + 4 * h;
+#pragma unroll
+    for (int t = 0; t < PM_C1 / 8; ++t) w2r[t] = *reinterpret_cast<const float4*>(wrow + 8 * t);
+    const float* wtrow = a.W2T + (32 * (wave >> 1) + r) * PM_C2 + 4 * h;
+#pragma unroll
+    for (int t = 0; t < PM_C2 / 8; ++t) w2tr[t] = *reinterpret_cast<const float4*>(wtrow + 8 * t);
+  }
+
+  // ---- A1. classify 4 consecutive channels per thread, block-wide ordered compaction
+  int cnt0 = 0, cnt1 = 0;
+  int myn[PM_MAXC3 / 256];
+#pragma unroll
+  for (int e = 0; e < PM_MAXC3 / 256; ++e) {
+    const int c = tid * (PM_MAXC3 / 256) + e;
+    int n = -1;
+    float gv = 0.f;
+    if (c < a.C3) {
+      n = a.argidx[(int64_t)b * a.C3 + c] - n0;
+      gv = a.g[(int64_t)b * a.C3 + c];
+      if (n < 0 || n >= PM_BTP || gv == 0.f) n = -1;
+      s_g[c] = gv;
+      s_n[c] = n;
+    }
+    myn[e] = n;
+    cnt0 += (n >= 0 && n < 32) ? 1 : 0;
+    cnt1 += (n >= 32) ? 1 : 0;
   }
   if (tid < PM_BTP) {
     float px, py, pz;
@@ -239,87 +316,141 @@ __global__ __launch_bounds__(256) void pointmlp3_max_bwd_kernel(PMBwdArgs a) {
     xs[2 * PM_BTP + tid] = pz;
   }
   for (int i = tid; i < PM_BTP * PM_LD2; i += 256) g2s[i] = 0.f;
-  any = __syncthreads_or(any);
-  if (!any) {  // no critical point in this tile: gradient is exactly zero
+  // inclusive scan of the packed counts inside the wave, then across the 4 waves
+  int packed = cnt0 | (cnt1 << 16);
+  int incl = packed;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += v;
+  }
+  if (lane == 63) s_scan[wave] = incl;
+  __syncthreads();
+  int base = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const int v = s_scan[w];
+    if (w < wave) base += v;
+    total += v;
+  }
+  const int len0 = total & 0xffff, len1 = total >> 16;
+  if (len0 + len1 == 0) {  // no critical point in this tile: gradient is exactly zero
     if (tid < 3 * PM_BTP) {
       const int p = tid & (PM_BTP - 1), c = tid >> 6;
       if (n0 + p < a.N) a.gx.p[(int64_t)b * a.gx.bs + (int64_t)(n0 + p) * a.gx.ps + c * a.gx.cs] = 0.f;
     }
     return;
   }
-
-  // ---- sparse dgrad of layer 3: g2[n][k] = sum_{c: argmax(c)==n} g[c] W3[c][k], ascending c
   {
-    const int k = tid & (PM_C2 - 1), ph = tid >> 7;
-    for (int c0 = 0; c0 < a.C3; c0 += 4) {
-      const int4 nn = *reinterpret_cast<const int4*>(s_n + c0);
-      const int ns[4] = {nn.x, nn.y, nn.z, nn.w};
+    const int excl = base + incl - packed;
+    int o0 = excl & 0xffff, o1 = excl >> 16;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int n = ns[e];
-        if (n >= 0 && (n >> 5) == ph) {  // wave-uniform
-          const float w = a.W3[(int64_t)(c0 + e) * PM_C2 + k];
-          g2s[n * PM_LD2 + k] = __builtin_fmaf(s_g[c0 + e], w, g2s[n * PM_LD2 + k]);
-        }
-      }
+    for (int e = 0; e < PM_MAXC3 / 256; ++e) {
+      const int n = myn[e];
+      const int c = tid * (PM_MAXC3 / 256) + e;
+      if (n >= 0 && n < 32) list0[o0++] = c;
+      if (n >= 32) list1[o1++] = c;
     }
   }
   layer1_to_lds<PM_BTP, 256>(xs, h1s, a.W1, a.b1);
   __syncthreads();
 
-  // ---- ReLU mask of layer 2 (recomputed): zero g2 where W2 h1 + b2 <= 0
+  // ---- A2. ordered accumulation: thread (k, half) walks its half's list; loads are independent -> pipelined
   {
-    const int k2 = tid & (PM_C2 - 1), ph = tid >> 7;
-    float w[PM_C1];
+    const int k = tid & (PM_C2 - 1), ph = tid >> 7;
+    const int* list = ph ? list1 : list0;
+    const int len = ph ? len1 : len0;
+    int i = 0;
+    for (; i + 4 <= len; i += 4) {
+      int c[4];
+      float w[4];
 #pragma unroll
-    for (int j = 0; j < PM_C1; j += 4) {
-      const float4 v = *reinterpret_cast<const float4*>(a.W2 + k2 * PM_C1 + j);
-      w[j] = v.x, w[j + 1] = v.y, w[j + 2] = v.z, w[j + 3] = v.w;
-    }
-    const float bb = a.b2[k2];
-    for (int p = ph * 32; p < ph * 32 + 32; ++p) {
-      float pre = bb;
-#pragma unroll
-      for (int j = 0; j < PM_C1; j += 4) {
-        const float4 hv = *reinterpret_cast<const float4*>(h1s + p * PM_LD1 + j);
-        pre = __builtin_fmaf(w[j], hv.x, pre);
-        pre = __builtin_fmaf(w[j + 1], hv.y, pre);
-        pre = __builtin_fmaf(w[j + 2], hv.z, pre);
-        pre = __builtin_fmaf(w[j + 3], hv.w, pre);
+      for (int e = 0; e < 4; ++e) {
+        c[e] = list[i + e];
+        w[e] = a.W3[(int64_t)c[e] * PM_C2 + k];
       }
-      if (!(pre > 0.f)) g2s[p * PM_LD2 + k2] = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float* dst = g2s + s_n[c[e]] * PM_LD2 + k;
+        *dst = __builtin_fmaf(s_g[c[e]], w[e], *dst);
+      }
+    }
+    for (; i < len; ++i) {
+      const int c = list[i];
+      float* dst = g2s + s_n[c] * PM_LD2 + k;
+      *dst = __builtin_fmaf(s_g[c], a.W3[(int64_t)c * PM_C2 + k], *dst);
     }
   }
   __syncthreads();
 
-  // ---- g1[p][j] = relu'(h1) * sum_k2 W2[k2][j] g2[p][k2]
+  // ---- B. layer-2 pre-activation on MFMA: D[pt][c2], wave owns c2 block [32*wave, +32), two point tiles; mask g2s
   {
-    const int j = tid & (PM_C1 - 1), pg = tid >> 6;
-    float w[PM_C2];
+    f32x16 acc[2];
 #pragma unroll
-    for (int k2 = 0; k2 < PM_C2; ++k2) w[k2] = a.W2[k2 * PM_C1 + j];
-    for (int p = pg * 16; p < pg * 16 + 16; ++p) {
-      float s = 0.f;
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int k2 = 0; k2 < PM_C2; k2 += 4) {
-        const float4 gv = *reinterpret_cast<const float4*>(g2s + p * PM_LD2 + k2);
-        s = __builtin_fmaf(w[k2], gv.x, s);
-        s = __builtin_fmaf(w[k2 + 1], gv.y, s);
-        s = __builtin_fmaf(w[k2 + 2], gv.z, s);
-        s = __builtin_fmaf(w[k2 + 3], gv.w, s);
+      for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+#pragma unroll
+    for (int t = 0; t < PM_C1 / 8; ++t) {
+      const float4 bw = w2r[t];
+      float4 av[2];
+#pragma unroll
+      for (int tl = 0; tl < 2; ++tl)
+        av[tl] = *reinterpret_cast<const float4*>(h1s + (tl * 32 + r) * PM_LD1 + 8 * t + 4 * h);
+#pragma unroll
+      for (int tl = 0; tl < 2; ++tl) {
+        acc[tl] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tl].x, bw.x, acc[tl], 0, 0, 0);
+        acc[tl] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tl].y, bw.y, acc[tl], 0, 0, 0);
+        acc[tl] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tl].z, bw.z, acc[tl], 0, 0, 0);
+        acc[tl] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tl].w, bw.w, acc[tl], 0, 0, 0);
       }
-      g1s[p * PM_LD1 + j] = (h1s[p * PM_LD1 + j] > 0.f) ? s : 0.f;
+    }
+    const float bias = a.b2[32 * wave + r];
+#pragma unroll
+    for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int pt = tl * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (!(acc[tl][e] + bias > 0.f)) g2s[pt * PM_LD2 + 32 * wave + r] = 0.f;
+      }
+  }
+  __syncthreads();
+
+  // ---- C. g1[pt][j] = sum_k2 g2[pt][k2] W2[k2][j] on MFMA: wave = (point tile wave&1, j block wave>>1), K = 128
+  {
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    const int tl = wave & 1, jb = wave >> 1;
+#pragma unroll
+    for (int t = 0; t < PM_C2 / 8; ++t) {
+      const float4 bw = w2tr[t];
+      const float4 av = *reinterpret_cast<const float4*>(g2s + (tl * 32 + r) * PM_LD2 + 8 * t + 4 * h);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bw.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bw.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bw.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bw.w, acc, 0, 0, 0);
+    }
+    // each (pt, j) of h1s is read (mask) and overwritten (g1) by exactly one lane: no barrier needed in between
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int pt = tl * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      float* q = h1s + pt * PM_LD1 + 32 * jb + r;
+      *q = (*q > 0.f) ? acc[e] : 0.f;
     }
   }
   __syncthreads();
 
-  // ---- gx'[p][c] = sum_j W1[j][c] g1[p][j]
+  // ---- D. gx'[p][c] = sum_j W1[j][c] g1[p][j]
   if (tid < 3 * PM_BTP) {
     const int p = tid & (PM_BTP - 1), c = tid >> 6;
-    float s = 0.f;
+    float s0 = 0.f, s1 = 0.f;
 #pragma unroll 8
-    for (int j = 0; j < PM_C1; ++j) s = __builtin_fmaf(a.W1[j * 3 + c], g1s[p * PM_LD1 + j], s);
-    if (n0 + p < a.N) a.gx.p[(int64_t)b * a.gx.bs + (int64_t)(n0 + p) * a.gx.ps + c * a.gx.cs] = s;
+    for (int j = 0; j < PM_C1; j += 2) {
+      s0 = __builtin_fmaf(a.W1[j * 3 + c], h1s[p * PM_LD1 + j], s0);
+      s1 = __builtin_fmaf(a.W1[(j + 1) * 3 + c], h1s[p * PM_LD1 + j + 1], s1);
+    }
+    if (n0 + p < a.N) a.gx.p[(int64_t)b * a.gx.bs + (int64_t)(n0 + p) * a.gx.ps + c * a.gx.cs] = s0 + s1;
   }
 }
 
@@ -335,8 +466,8 @@ extern "C" int pc3d_pointmlp3_max_fwd_f32(const float* x, int64_t x_bs, int64_t 
                                           int C3, int relu_last, float* part_val, int32_t* part_idx,
                                           float* pooled, int32_t* argidx, void* stream) {
   PC3D_REQUIRE(B >= 0 && N >= 1, "pc3d_pointmlp3_max_fwd_f32: bad sizes B=%d N=%d", B, N);
-  PC3D_REQUIRE(C1 == PM_C1 && C2 == PM_C2 && C3 >= 32 && C3 % 32 == 0,
-               "pc3d_pointmlp3_max_fwd_f32: unsupported widths %d/%d/%d (need 64/128/multiple of 32)", C1, C2, C3);
+  PC3D_REQUIRE(C1 == PM_C1 && C2 == PM_C2 && C3 >= 32 && C3 % 32 == 0 && C3 <= PM_MAXC3F,
+               "pc3d_pointmlp3_max_fwd_f32: unsupported widths %d/%d/%d (need 64/128/multiple of 32 <= 1024)", C1, C2, C3);
   PC3D_REQUIRE(B <= 65535, "pc3d_pointmlp3_max_fwd_f32: B=%d exceeds grid.y limit", B);
   if (B == 0) return PC3D_OK;
   PC3D_REQUIRE(x && W1 && b1 && W2 && b2 && W3 && b3 && part_val && part_idx,
@@ -346,7 +477,7 @@ extern "C" int pc3d_pointmlp3_max_fwd_f32(const float* x, int64_t x_bs, int64_t 
   const int ntiles = cdiv(N, PM_TP);
   PMFwdArgs a{{x, x_bs, x_ps, x_cs}, N, C3, ntiles, T, W1, b1, W2, b2, W3, b3, part_val, part_idx};
   hipStream_t st = as_stream(stream);
-  hipLaunchKernelGGL(pointmlp3_max_fwd_kernel, dim3(ntiles, B), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(pointmlp3_max_fwd_kernel, dim3(ntiles, B), dim3(PM_FT), 0, st, a);
   PC3D_LAUNCH_CHECK("pc3d_pointmlp3_max_fwd_f32");
   if (pooled) {  // NULL: leave the per-tile partials unfolded (a fused consumer, or kernel-only timing)
     hipLaunchKernelGGL(pointmlp3_fold_kernel, dim3(cdiv(C3, 256), B), dim3(256), 0, st, part_val, part_idx, ntiles,
@@ -358,17 +489,17 @@ extern "C" int pc3d_pointmlp3_max_fwd_f32(const float* x, int64_t x_bs, int64_t 
 
 extern "C" int pc3d_pointmlp3_max_bwd_f32(const float* x, int64_t x_bs, int64_t x_ps, int64_t x_cs, int B, int N,
                                           const float* T, const float* W1, const float* b1, const float* W2,
-                                          const float* b2, const float* W3, int C1, int C2, int C3,
-                                          const int32_t* argidx, const float* g_pooled, float* grad_x,
+                                          const float* b2, const float* W3, const float* W2T, int C1, int C2,
+                                          int C3, const int32_t* argidx, const float* g_pooled, float* grad_x,
                                           int64_t gx_bs, int64_t gx_ps, int64_t gx_cs, void* stream) {
   PC3D_REQUIRE(B >= 0 && N >= 1, "pc3d_pointmlp3_max_bwd_f32: bad sizes B=%d N=%d", B, N);
   PC3D_REQUIRE(C1 == PM_C1 && C2 == PM_C2 && C3 >= 32 && C3 % 32 == 0 && C3 <= PM_MAXC3,
                "pc3d_pointmlp3_max_bwd_f32: unsupported widths %d/%d/%d", C1, C2, C3);
   PC3D_REQUIRE(B <= 65535, "pc3d_pointmlp3_max_bwd_f32: B=%d exceeds grid.y limit", B);
   if (B == 0) return PC3D_OK;
-  PC3D_REQUIRE(x && W1 && b1 && W2 && b2 && W3 && argidx && g_pooled && grad_x,
+  PC3D_REQUIRE(x && W1 && b1 && W2 && b2 && W3 && W2T && argidx && g_pooled && grad_x,
                "pc3d_pointmlp3_max_bwd_f32: null pointer");
-  PMBwdArgs a{{x, x_bs, x_ps, x_cs}, N, C3, T, W1, b1, W2, b2, W3, argidx, g_pooled, {grad_x, gx_bs, gx_ps, gx_cs}};
+  PMBwdArgs a{{x, x_bs, x_ps, x_cs}, N, C3, T, W1, b1, W2, b2, W3, W2T, argidx, g_pooled, {grad_x, gx_bs, gx_ps, gx_cs}};
   hipLaunchKernelGGL(pointmlp3_max_bwd_kernel, dim3(cdiv(N, PM_BTP), B), dim3(256), 0, as_stream(stream), a);
   PC3D_LAUNCH_CHECK("pc3d_pointmlp3_max_bwd_f32");
   return PC3D_OK;

@@ -79,6 +79,7 @@ class STN3d(_FrozenFusedMixin, nn.Module):
             tower = _fold_bn(self.conv1.weight, self.conv1.bias, self.bn1) + \
                 _fold_bn(self.conv2.weight, self.conv2.bias, self.bn2) + \
                 _fold_bn(self.conv3.weight, self.conv3.bias, self.bn3)
+            tower = tower + (tower[2].t().contiguous(),)      # W2^T for the backward kernel
             head = (_fold_bn(self.fc1.weight, self.fc1.bias, self.bn4),
                     _fold_bn(self.fc2.weight, self.fc2.bias, self.bn5),
                     _plain(self.fc3.weight, self.fc3.bias))
@@ -121,6 +122,7 @@ class PointNetfeat(_FrozenFusedMixin, nn.Module):
             tower = _fold_bn(self.conv1.weight, self.conv1.bias, self.bn1) + \
                 _fold_bn(self.conv2.weight, self.conv2.bias, self.bn2) + \
                 _fold_bn(self.conv3.weight, self.conv3.bias, self.bn3)
+            tower = tower + (tower[2].t().contiguous(),)      # W2^T for the backward kernel
             object.__setattr__(self, "_folded_cache", tower)
         return self._folded_cache
 

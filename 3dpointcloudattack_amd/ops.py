@@ -214,7 +214,7 @@ def pointmlp3_max_fwd_raw(x, weights, relu_last, T=None, x_cf=True, fold=True):
     """x [B,3,N] (x_cf) or [B,N,3]; weights = (W1[64,3], b1, W2[128,64], b2, W3[C3,128], b3) with eval-BN folded.
     Returns (pooled [B,C3] f32, argidx [B,C3] i32)."""
     xp, xbs, xps, xcs, B, N = _pts(x, x_cf, "x")
-    W1, b1, W2, b2, W3, b3 = weights
+    W1, b1, W2, b2, W3, b3 = weights[:6]
     for w in weights:
         _check(w, "weight")
         if not w.is_contiguous():
@@ -242,7 +242,8 @@ def pointmlp3_max_fwd_raw(x, weights, relu_last, T=None, x_cf=True, fold=True):
 def pointmlp3_max_bwd_raw(x, weights, argidx, g_pooled, T=None, x_cf=True):
     """Gradient w.r.t. the tower input (the transformed points when T is given); same layout as x."""
     xp, xbs, xps, xcs, B, N = _pts(x, x_cf, "x")
-    W1, b1, W2, b2, W3, b3 = weights
+    W1, b1, W2, b2, W3, b3 = weights[:6]
+    W2T = weights[6] if len(weights) > 6 else W2.t().contiguous()
     C1, C2, C3 = W1.shape[0], W2.shape[0], W3.shape[0]
     _check(g_pooled, "g_pooled")
     g_pooled = g_pooled.contiguous()
@@ -250,7 +251,7 @@ def pointmlp3_max_bwd_raw(x, weights, argidx, g_pooled, T=None, x_cf=True):
     gp, gbs, gps, gcs, _, _ = _pts(gx, x_cf, "grad_x")
     with torch.cuda.device(x.device):
         _lib.call("pc3d_pointmlp3_max_bwd_f32", xp, xbs, xps, xcs, B, N, _ptr(T),
-                  W1.data_ptr(), b1.data_ptr(), W2.data_ptr(), b2.data_ptr(), W3.data_ptr(),
+                  W1.data_ptr(), b1.data_ptr(), W2.data_ptr(), b2.data_ptr(), W3.data_ptr(), W2T.data_ptr(),
                   C1, C2, C3, argidx.data_ptr(), g_pooled.data_ptr(), gp, gbs, gps, gcs, _stream())
     return gx
 
@@ -259,8 +260,8 @@ class _PointMLP3MaxFn(torch.autograd.Function):
     """x [B,3,N] -> pooled [B,C3] through the fused tower; differentiable in x only (frozen weights)."""
 
     @staticmethod
-    def forward(ctx, x, relu_last, W1, b1, W2, b2, W3, b3):
-        weights = (W1, b1, W2, b2, W3, b3)
+    def forward(ctx, x, relu_last, W1, b1, W2, b2, W3, b3, W2T):
+        weights = (W1, b1, W2, b2, W3, b3, W2T)
         pooled, argidx = pointmlp3_max_fwd_raw(x, weights, relu_last)
         ctx.save_for_backward(x, argidx, pooled, *weights)
         ctx.relu_last = relu_last
@@ -272,10 +273,13 @@ class _PointMLP3MaxFn(torch.autograd.Function):
         if ctx.relu_last:
             g = g * (pooled > 0)
         gx = pointmlp3_max_bwd_raw(x, tuple(weights), argidx, g)
-        return (gx,) + (None,) * 7
+        return (gx,) + (None,) * 8
 
 
 def pointmlp3_max(x, weights, relu_last):
+    """weights: (W1,b1,W2,b2,W3,b3[,W2T]) with eval-BN folded; W2T is derived when absent."""
+    if len(weights) == 6:
+        weights = tuple(weights) + (weights[2].t().contiguous(),)
     return _PointMLP3MaxFn.apply(x, relu_last, *weights)
 
 

@@ -100,10 +100,11 @@ int pc3d_pointmlp3_max_fwd_f32(const float* x, int64_t x_bs, int64_t x_ps, int64
 /* Backward-to-input of the above (weights are frozen during an attack: no weight gradients, SURVEY A-14).
  * g_pooled [B,C3] is the upstream gradient on `pooled`; with relu_last the caller zeroes it where pooled <= 0.
  * grad_x receives d/dx' (gradient w.r.t. the TRANSFORMED points x' = x @ T when T is given), dense, overwritten.
+ * W2T is W2 transposed ([64,128] row-major; lets the W2^T product read its operand rows contiguously).
  * The max-pool routes each channel to one point, so the layer-3 dgrad is a sparse ordered gather: deterministic. */
 int pc3d_pointmlp3_max_bwd_f32(const float* x, int64_t x_bs, int64_t x_ps, int64_t x_cs, int B, int N,
                                const float* T, const float* W1, const float* b1, const float* W2,
-                               const float* b2, const float* W3, int C1, int C2, int C3,
+                               const float* b2, const float* W3, const float* W2T, int C1, int C2, int C3,
                                const int32_t* argidx, const float* g_pooled,
                                float* grad_x, int64_t gx_bs, int64_t gx_ps, int64_t gx_cs, void* stream);
 
