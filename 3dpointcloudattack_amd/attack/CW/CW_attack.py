@@ -86,6 +86,20 @@ class CW:
         return (self.graph and self._fused_clip_budget() is not None and type(self.adv_func) in own_adv
                 and type(self.dist_func) in own_dist and hasattr(self.model, "_require_fused"))
 
+    def _fused_model_loss(self):
+        """(kind, kappa) when the victim offers the launch-minimal fused_loss_and_grad AND the adversarial functor is
+        one of this package's own (their gradients are built into pc3d_cls_loss_f32); else None (autograd path)."""
+        if not self.fused or not hasattr(self.model, "fused_loss_and_grad"):
+            return None
+        af = self.adv_func
+        if type(af) is _adv_utils.UntargetedLogitsAdvLoss:
+            return "untargeted_logits", float(af.kappa)
+        if type(af) is _adv_utils.LogitsAdvLoss:
+            return "logits", float(af.kappa)
+        if type(af) is _adv_utils.CrossEntropyAdvLoss:
+            return "cross_entropy", 0.0
+        return None
+
     # -- the hot loop, split so that bench.py / graph capture can drive single iterations ---------------
     def _begin(self, data, target):
         """Upload + clean prediction (reference :63-89). Returns the state dict the iteration works on."""
@@ -149,8 +163,14 @@ class CW:
         """One pass of the hot-loop body (reference :111-174), entirely on the device. The Adam step number lives
         in st["step"] on the device, so the body is identical every pass (hipGraph-replayable)."""
         adv_data, ori_data, label = st["adv"], st["ori"], st["label"]
-        logits = _logits_of(self.model(adv_data))
-        pred = torch.argmax(logits, dim=1)  # [B]
+        fml = self._fused_model_loss() if st["budget"] is not None else None
+        gx_model = None
+        if fml is not None:
+            with torch.no_grad():  # victim forward + adversarial loss + backward-to-input without autograd
+                logits, pred, _, gx_model = self.model.fused_loss_and_grad(adv_data.detach(), st["target"], *fml)
+        else:
+            logits = _logits_of(self.model(adv_data))
+            pred = torch.argmax(logits, dim=1)  # [B]
         # record values (device side; reference :129-153)
         with torch.no_grad():
             cur = adv_data.detach()
@@ -166,8 +186,16 @@ class CW:
             st["input_val"].copy_(cur)     # the iterate the LAST pass started from (reference :133, :208-209)
             st["pred"].copy_(pred)
         # compute loss and backward
-        adv_loss = self.adv_func(logits, st["target"]).mean()
         dist_loss = self.dist_func(adv_data, ori_data, st["weights"]).mean()
+        if gx_model is not None:
+            adv_data.grad = None
+            dist_loss.backward()
+            adv_data.grad.add_(gx_model)
+            ops.i32_add(st["step"], 1)
+            ops.adam_clip_step(adv_data.data, adv_data.grad, st["exp_avg"], st["exp_avg_sq"], st["step"],
+                               self.attack_lr, ori=ori_data, budget=st["budget"])
+            return
+        adv_loss = self.adv_func(logits, st["target"]).mean()
         loss = adv_loss + dist_loss
         if st["budget"] is None:
             opt = st["opt"]

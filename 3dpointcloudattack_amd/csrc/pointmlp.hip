@@ -252,7 +252,9 @@ struct PMBwdArgs {
   const float *W1, *b1, *W2, *b2, *W3, *W2T;  // W2T = W2 transposed, [64][128] row-major
   const int32_t* argidx;  // [B,C3]
   const float* g;         // [B,C3] upstream gradient on pooled (already masked for relu_last by the caller)
-  PtsViewMut gx;          // gradient wrt the (transformed) tower input x'
+  PtsViewMut gx;          // T == null: gradient wrt the tower input; T given: gradient wrt the RAW points x
+  float* part_gT;         // [B, ntiles, 16] per-tile partial of d/dT (9 used) or null
+  int accumulate;         // gx += instead of gx =
 };
 
 // Workgroup = (batch b, 64 points), 4 waves.
@@ -335,10 +337,11 @@ __global__ __launch_bounds__(256) void pointmlp3_max_bwd_kernel(PMBwdArgs a) {
   }
   const int len0 = total & 0xffff, len1 = total >> 16;
   if (len0 + len1 == 0) {  // no critical point in this tile: gradient is exactly zero
-    if (tid < 3 * PM_BTP) {
+    if (tid < 3 * PM_BTP && !a.accumulate) {
       const int p = tid & (PM_BTP - 1), c = tid >> 6;
       if (n0 + p < a.N) a.gx.p[(int64_t)b * a.gx.bs + (int64_t)(n0 + p) * a.gx.ps + c * a.gx.cs] = 0.f;
     }
+    if (a.part_gT && tid < 16) a.part_gT[((int64_t)b * gridDim.x + tile) * 16 + tid] = 0.f;
     return;
   }
   {
@@ -441,7 +444,8 @@ __global__ __launch_bounds__(256) void pointmlp3_max_bwd_kernel(PMBwdArgs a) {
   }
   __syncthreads();
 
-  // ---- D. gx'[p][c] = sum_j W1[j][c] g1[p][j]
+  // ---- D. g'[p][c] = sum_j W1[j][c] g1[p][j]  (gradient wrt the tower input x' = x @ T)
+  float* gp = g2s;  // [3][64] scratch (g2s is dead)
   if (tid < 3 * PM_BTP) {
     const int p = tid & (PM_BTP - 1), c = tid >> 6;
     float s0 = 0.f, s1 = 0.f;
@@ -450,7 +454,44 @@ __global__ __launch_bounds__(256) void pointmlp3_max_bwd_kernel(PMBwdArgs a) {
       s0 = __builtin_fmaf(a.W1[j * 3 + c], h1s[p * PM_LD1 + j], s0);
       s1 = __builtin_fmaf(a.W1[(j + 1) * 3 + c], h1s[p * PM_LD1 + j + 1], s1);
     }
-    if (n0 + p < a.N) a.gx.p[(int64_t)b * a.gx.bs + (int64_t)(n0 + p) * a.gx.ps + c * a.gx.cs] = s0 + s1;
+    gp[c * PM_BTP + p] = s0 + s1;
+  }
+  __syncthreads();
+  if (tid < PM_BTP) {  // wave 0: lane = point
+    const int p = tid;
+    const float g0 = gp[p], g1v = gp[PM_BTP + p], g2v = gp[2 * PM_BTP + p];
+    float o0 = g0, o1 = g1v, o2 = g2v;
+    if (a.T) {
+      // x' = x @ T  =>  dL/dx[c] = sum_c' g'[c'] T[c][c'] ;  dL/dT[c][c'] = sum_p x[p][c] g'[p][c']
+      const float* t = a.T + (int64_t)b * 9;
+      o0 = __builtin_fmaf(g2v, t[2], __builtin_fmaf(g1v, t[1], g0 * t[0]));
+      o1 = __builtin_fmaf(g2v, t[5], __builtin_fmaf(g1v, t[4], g0 * t[3]));
+      o2 = __builtin_fmaf(g2v, t[8], __builtin_fmaf(g1v, t[7], g0 * t[6]));
+      if (a.part_gT) {
+        float xr[3] = {0.f, 0.f, 0.f};
+        if (n0 + p < a.N) {
+          const float* xp = a.x.p + (int64_t)b * a.x.bs + (int64_t)(n0 + p) * a.x.ps;
+          xr[0] = xp[0], xr[1] = xp[a.x.cs], xr[2] = xp[2 * a.x.cs];
+        }
+        const float gv[3] = {g0, g1v, g2v};
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+          for (int d = 0; d < 3; ++d) {
+            const float sum = wave_sum(xr[c] * gv[d]);
+            if (p == 0) a.part_gT[((int64_t)b * gridDim.x + tile) * 16 + c * 3 + d] = sum;
+          }
+        if (p >= 9 && p < 16) a.part_gT[((int64_t)b * gridDim.x + tile) * 16 + p] = 0.f;
+      }
+    }
+    if (n0 + p < a.N) {
+      float* q = a.gx.p + (int64_t)b * a.gx.bs + (int64_t)(n0 + p) * a.gx.ps;
+      if (a.accumulate) {
+        q[0] += o0, q[a.gx.cs] += o1, q[2 * a.gx.cs] += o2;
+      } else {
+        q[0] = o0, q[a.gx.cs] = o1, q[2 * a.gx.cs] = o2;
+      }
+    }
   }
 }
 
@@ -459,6 +500,7 @@ __global__ __launch_bounds__(256) void pointmlp3_max_bwd_kernel(PMBwdArgs a) {
 using namespace pc3d;
 
 extern "C" int pc3d_pointmlp3_tile_points(void) { return PM_TP; }
+extern "C" int pc3d_pointmlp3_bwd_tile_points(void) { return PM_BTP; }
 
 extern "C" int pc3d_pointmlp3_max_fwd_f32(const float* x, int64_t x_bs, int64_t x_ps, int64_t x_cs, int B, int N,
                                           const float* T, const float* W1, const float* b1, const float* W2,
@@ -491,7 +533,8 @@ extern "C" int pc3d_pointmlp3_max_bwd_f32(const float* x, int64_t x_bs, int64_t 
                                           const float* T, const float* W1, const float* b1, const float* W2,
                                           const float* b2, const float* W3, const float* W2T, int C1, int C2,
                                           int C3, const int32_t* argidx, const float* g_pooled, float* grad_x,
-                                          int64_t gx_bs, int64_t gx_ps, int64_t gx_cs, void* stream) {
+                                          int64_t gx_bs, int64_t gx_ps, int64_t gx_cs, float* part_gT,
+                                          int accumulate, void* stream) {
   PC3D_REQUIRE(B >= 0 && N >= 1, "pc3d_pointmlp3_max_bwd_f32: bad sizes B=%d N=%d", B, N);
   PC3D_REQUIRE(C1 == PM_C1 && C2 == PM_C2 && C3 >= 32 && C3 % 32 == 0 && C3 <= PM_MAXC3,
                "pc3d_pointmlp3_max_bwd_f32: unsupported widths %d/%d/%d", C1, C2, C3);
@@ -499,7 +542,8 @@ extern "C" int pc3d_pointmlp3_max_bwd_f32(const float* x, int64_t x_bs, int64_t 
   if (B == 0) return PC3D_OK;
   PC3D_REQUIRE(x && W1 && b1 && W2 && b2 && W3 && W2T && argidx && g_pooled && grad_x,
                "pc3d_pointmlp3_max_bwd_f32: null pointer");
-  PMBwdArgs a{{x, x_bs, x_ps, x_cs}, N, C3, T, W1, b1, W2, b2, W3, W2T, argidx, g_pooled, {grad_x, gx_bs, gx_ps, gx_cs}};
+  PMBwdArgs a{{x, x_bs, x_ps, x_cs}, N, C3, T, W1, b1, W2, b2, W3, W2T, argidx, g_pooled, {grad_x, gx_bs, gx_ps, gx_cs},
+              part_gT, accumulate};
   hipLaunchKernelGGL(pointmlp3_max_bwd_kernel, dim3(cdiv(N, PM_BTP), B), dim3(256), 0, as_stream(stream), a);
   PC3D_LAUNCH_CHECK("pc3d_pointmlp3_max_bwd_f32");
   return PC3D_OK;

@@ -239,21 +239,29 @@ def pointmlp3_max_fwd_raw(x, weights, relu_last, T=None, x_cf=True, fold=True):
     return pooled, argidx
 
 
-def pointmlp3_max_bwd_raw(x, weights, argidx, g_pooled, T=None, x_cf=True):
-    """Gradient w.r.t. the tower input (the transformed points when T is given); same layout as x."""
+def pointmlp3_max_bwd_raw(x, weights, argidx, g_pooled, T=None, x_cf=True, out=None, accumulate=False,
+                          want_gT=False):
+    """Gradient w.r.t. the tower input (T None) or w.r.t. the raw points through x' = x @ T (T given); same layout
+    as x. want_gT: also return the per-tile partials [B, ntiles, 16] of dL/dT. out/accumulate: add into `out`."""
     xp, xbs, xps, xcs, B, N = _pts(x, x_cf, "x")
     W1, b1, W2, b2, W3, b3 = weights[:6]
     W2T = weights[6] if len(weights) > 6 else W2.t().contiguous()
     C1, C2, C3 = W1.shape[0], W2.shape[0], W3.shape[0]
     _check(g_pooled, "g_pooled")
     g_pooled = g_pooled.contiguous()
-    gx = torch.empty((B, 3, N) if x_cf else (B, N, 3), dtype=torch.float32, device=x.device)
+    gx = out if out is not None else torch.empty((B, 3, N) if x_cf else (B, N, 3), dtype=torch.float32,
+                                                 device=x.device)
     gp, gbs, gps, gcs, _, _ = _pts(gx, x_cf, "grad_x")
+    part_gT = None
+    if want_gT:
+        bt = _lib.load().pc3d_pointmlp3_bwd_tile_points()
+        part_gT = torch.empty((B, (N + bt - 1) // bt, 16), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         _lib.call("pc3d_pointmlp3_max_bwd_f32", xp, xbs, xps, xcs, B, N, _ptr(T),
                   W1.data_ptr(), b1.data_ptr(), W2.data_ptr(), b2.data_ptr(), W3.data_ptr(), W2T.data_ptr(),
-                  C1, C2, C3, argidx.data_ptr(), g_pooled.data_ptr(), gp, gbs, gps, gcs, _stream())
-    return gx
+                  C1, C2, C3, argidx.data_ptr(), g_pooled.data_ptr(), gp, gbs, gps, gcs, _ptr(part_gT),
+                  1 if accumulate else 0, _stream())
+    return (gx, part_gT) if want_gT else gx
 
 
 class _PointMLP3MaxFn(torch.autograd.Function):
@@ -390,3 +398,51 @@ def knn(q, r, K, q_cf=False, r_cf=False, deterministic=False):
     """Differentiable K-NN: (dists [B,N,K], idx [B,N,K] int32). For self-kNN pass the same tensor twice
     (autograd sums the two gradient roles)."""
     return _KnnFn.apply(q, r, K, q_cf, r_cf, deterministic)
+
+
+# ------------------------------------------------------------------------------------------------------
+# classifier heads
+# ------------------------------------------------------------------------------------------------------
+def linear(X, W, bias=None, relu=False, gate=None, parts=1, out=None):
+    """Y = epi(X @ W.T + bias). X [B,K] (or [B,parts,K] summed over parts), W [O,K] contiguous fp32."""
+    _check(X, "X")
+    _check(W, "W")
+    if parts == 1:
+        B, K = X.shape
+        ldx = X.stride(0)
+        if X.stride(1) != 1:
+            raise ValueError("linear: X rows must be contiguous")
+    else:
+        B, P, K = X.shape
+        if not X.is_contiguous() or P != parts:
+            raise ValueError("linear: partial slabs must be a contiguous [B,parts,K] tensor")
+        ldx = P * K
+    O = W.shape[0]
+    if W.shape[1] != K or not W.is_contiguous():
+        raise ValueError(f"linear: W must be contiguous [O,{K}], got {tuple(W.shape)}")
+    Y = out if out is not None else torch.empty((B, O), dtype=torch.float32, device=X.device)
+    with torch.cuda.device(X.device):
+        _lib.call("pc3d_linear_f32", X.data_ptr(), ldx, parts, B, K, W.data_ptr(), _ptr(bias), O, 1 if relu else 0,
+                  _ptr(gate), gate.stride(0) if gate is not None else 0, Y.data_ptr(), Y.stride(0), _stream())
+    return Y
+
+
+LOSS_KINDS = {"untargeted_logits": 0, "logits": 1, "cross_entropy": 2}
+
+
+def cls_loss(logits, target, kind, kappa=0.0, scale=1.0, want_grad=True):
+    """(logp [B,k], pred [B] int64, loss [B], g_logits [B,k] or None) — log_softmax + adversarial loss, one launch."""
+    _check(logits, "logits")
+    B, ncls = logits.shape
+    dev = logits.device
+    logp = torch.empty((B, ncls), dtype=torch.float32, device=dev)
+    pred = torch.empty((B,), dtype=torch.int64, device=dev)
+    loss = torch.empty((B,), dtype=torch.float32, device=dev)
+    g = torch.empty((B, ncls), dtype=torch.float32, device=dev) if want_grad else None
+    if target.dtype != torch.int64 or not target.is_cuda:
+        raise TypeError("cls_loss: target must be an int64 GPU tensor")
+    with torch.cuda.device(dev):
+        _lib.call("pc3d_cls_loss_f32", logits.data_ptr(), logits.stride(0), B, ncls, target.data_ptr(),
+                  LOSS_KINDS[kind] if isinstance(kind, str) else int(kind), float(kappa), float(scale),
+                  logp.data_ptr(), pred.data_ptr(), loss.data_ptr(), _ptr(g), _stream())
+    return logp, pred, loss, g

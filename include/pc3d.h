@@ -91,6 +91,7 @@ int pc3d_nn_bwd_f32(const float* a, int64_t a_bs, int64_t a_ps, int64_t a_cs,
  * fp32 throughout: layer 2/3 run on v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains).
  * ------------------------------------------------------------------------------------------------------- */
 int pc3d_pointmlp3_tile_points(void);
+int pc3d_pointmlp3_bwd_tile_points(void);
 int pc3d_pointmlp3_max_fwd_f32(const float* x, int64_t x_bs, int64_t x_ps, int64_t x_cs, int B, int N,
                                const float* T, const float* W1, const float* b1, const float* W2,
                                const float* b2, const float* W3, const float* b3, int C1, int C2, int C3,
@@ -99,14 +100,36 @@ int pc3d_pointmlp3_max_fwd_f32(const float* x, int64_t x_bs, int64_t x_ps, int64
 
 /* Backward-to-input of the above (weights are frozen during an attack: no weight gradients, SURVEY A-14).
  * g_pooled [B,C3] is the upstream gradient on `pooled`; with relu_last the caller zeroes it where pooled <= 0.
- * grad_x receives d/dx' (gradient w.r.t. the TRANSFORMED points x' = x @ T when T is given), dense, overwritten.
+ * T == NULL: grad_x receives the gradient w.r.t. the tower input. T given: the kernel chains through x' = x @ T:
+ * grad_x receives the gradient w.r.t. the RAW points x, and part_gT (if non-NULL, workspace
+ * [B, ceil(N / pc3d_pointmlp3_bwd_tile_points()), 16], 9 used) the per-tile partial sums of dL/dT (row-major 3x3);
+ * their sum over tiles is the gradient that flows on into the STN head. accumulate != 0: grad_x += (used to add the
+ * STN tower's contribution on top of the trunk's).
  * W2T is W2 transposed ([64,128] row-major; lets the W2^T product read its operand rows contiguously).
  * The max-pool routes each channel to one point, so the layer-3 dgrad is a sparse ordered gather: deterministic. */
 int pc3d_pointmlp3_max_bwd_f32(const float* x, int64_t x_bs, int64_t x_ps, int64_t x_cs, int B, int N,
                                const float* T, const float* W1, const float* b1, const float* W2,
                                const float* b2, const float* W3, const float* W2T, int C1, int C2, int C3,
                                const int32_t* argidx, const float* g_pooled,
-                               float* grad_x, int64_t gx_bs, int64_t gx_ps, int64_t gx_cs, void* stream);
+                               float* grad_x, int64_t gx_bs, int64_t gx_ps, int64_t gx_cs,
+                               float* part_gT, int accumulate, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Classifier heads. Y[b,o] = epi(sum_k X[b,k] W[o,k] + bias[o]) for small row counts (the B samples of a batch),
+ * fp32 MFMA. X may be given as P partial slabs per row ([B,P,K], summed on load; P=1 = plain matrix; ldx = row
+ * stride in floats). epi: optional ReLU, then optional gate (Y = gate[b,o] > 0 ? Y : 0 — the ReLU mask of a saved
+ * forward activation, which makes the same kernel the backward of Linear+ReLU when W is passed transposed).
+ * Replaces F.linear / BatchNorm1d(eval, folded) / ReLU of model/pointnet.py:38-47,144-147 and their autograd.
+ * ------------------------------------------------------------------------------------------------------- */
+int pc3d_linear_f32(const float* X, int ldx, int P, int B, int K, const float* W, const float* bias, int O,
+                    int relu, const float* gate, int ldg, float* Y, int ldy, void* stream);
+
+/* log_softmax (model/pointnet.py:148) + argmax + adversarial loss on the log-probabilities and its gradient w.r.t.
+ * the LOGITS, one launch. kind 0 = UntargetedLogitsAdvLoss, 1 = LogitsAdvLoss, 2 = CrossEntropyAdvLoss
+ * (attack/CW/CW_utils/adv_utils.py:64-80, 17-33, 42-51); per-sample loss[b] (before the batch mean), pred[b],
+ * logp [B,ncls], g_logits [B,ncls] = scale * dloss_b/dlogits (scale = 1/B reproduces .mean()). Outputs may be NULL. */
+int pc3d_cls_loss_f32(const float* logits, int ld, int B, int ncls, const int64_t* target, int kind, float kappa,
+                      float scale, float* logp, int64_t* pred, float* loss, float* g_logits, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * K9  clip / projection of the perturbation pc - ori, one launch (attack/CW/CW_utils/clip_utils.py).

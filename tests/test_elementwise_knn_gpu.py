@@ -109,3 +109,45 @@ def test_knn_dist_functor_value_and_grad(dev, det):
     # channel-first input gives the same value
     got_cf = dist.KNNDist(5, 1.05)(torch.from_numpy(pc).to(dev).transpose(1, 2).contiguous(), w, batch_avg=False)
     torch.testing.assert_close(got_cf, got.detach(), rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("B,K,O", [(32, 1024, 512), (5, 512, 256), (32, 256, 40), (3, 256, 9), (40, 40, 256), (2, 16, 256)])
+def test_linear_kernel_matches_torch(ops, dev, B, K, O):
+    g = torch.Generator().manual_seed(B + K + O)
+    X = torch.randn(B, K, generator=g).to(dev)
+    W = (torch.randn(O, K, generator=g) / K ** 0.5).to(dev)
+    bias = torch.randn(O, generator=g).to(dev)
+    gate = torch.randn(B, O, generator=g).to(dev)
+    ref = X.double() @ W.double().t() + bias.double()
+    torch.testing.assert_close(ops.linear(X, W, bias).double(), ref, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(ops.linear(X, W, bias, relu=True).double(), ref.clamp(min=0), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(ops.linear(X, W, None, gate=gate).double(),
+                               torch.where(gate > 0, (ref - bias.double()), torch.zeros_like(ref)), rtol=1e-5, atol=1e-5)
+    if K % 8 == 0:   # partial slabs summed on load
+        Xp = torch.randn(B, 3, K, generator=g).to(dev)
+        refp = Xp.double().sum(1) @ W.double().t()
+        torch.testing.assert_close(ops.linear(Xp, W, None, parts=3).double(), refp, rtol=1e-5, atol=1e-5)
+
+
+def test_ragged_k_linear(ops, dev):
+    X = torch.randn(7, 9, device=dev)
+    W = torch.randn(256, 9, device=dev)
+    torch.testing.assert_close(ops.linear(X, W).double(), X.double() @ W.double().t(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("kind", ["untargeted_logits", "logits", "cross_entropy"])
+def test_cls_loss_kernel_matches_torch(ops, dev, kind):
+    adv = importlib.import_module("3dpointcloudattack_amd.attack.CW.CW_utils.adv_utils")
+    torch.manual_seed(3)
+    B, k = 9, 40
+    z = (torch.randn(B, k, device=dev) * 3).requires_grad_()
+    tgt = torch.randint(0, k, (B,), device=dev)
+    fn = {"untargeted_logits": adv.UntargetedLogitsAdvLoss(2.0), "logits": adv.LogitsAdvLoss(2.0),
+          "cross_entropy": adv.CrossEntropyAdvLoss()}[kind]
+    logp_ref = torch.log_softmax(z, dim=1)
+    fn(logp_ref, tgt).mean().backward()
+    logp, pred, loss, g = ops.cls_loss(z.detach(), tgt, kind, 2.0, scale=1.0 / B)
+    torch.testing.assert_close(logp, logp_ref.detach(), rtol=1e-5, atol=1e-6)
+    assert torch.equal(pred, z.argmax(1))
+    torch.testing.assert_close(g, z.grad, rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(loss.mean(), fn(logp_ref.detach(), tgt), rtol=1e-5, atol=1e-6)

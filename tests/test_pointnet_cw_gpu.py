@@ -179,3 +179,28 @@ def test_graph_replay_equals_eager(dev):
         outs.append(atk.attack(pcs, labels) + (atk.attack_fail, atk.shuffle_fail, atk.trans_fail))
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
     assert outs[0][2:] == outs[1][2:]
+
+
+@pytest.mark.parametrize("kind,kappa", [("untargeted_logits", 5.0), ("logits", 0.0), ("cross_entropy", 0.0)])
+def test_fused_loss_and_grad_equals_autograd_path(dev, kind, kappa):
+    """The launch-minimal path (own head kernels, T chained inside the tower kernels) vs forward()+autograd."""
+    cwm, adv, dist, clip = _mods()
+    model, _ = hip_pointnet(0, dev)
+    rng = np.random.default_rng(8)
+    x = torch.from_numpy(np.stack([unit_cloud(rng, 700) for _ in range(5)])).transpose(1, 2).contiguous().to(dev)
+    with torch.no_grad():
+        tgt = model(x)[0].argmax(1)
+    if kind == "logits":
+        tgt = (tgt + 3) % 40
+    fn = {"untargeted_logits": adv.UntargetedLogitsAdvLoss(kappa), "logits": adv.LogitsAdvLoss(kappa),
+          "cross_entropy": adv.CrossEntropyAdvLoss()}[kind]
+    xa = x.clone().requires_grad_()
+    logp_a = model(xa)[0]
+    fn(logp_a, tgt).mean().backward()
+    logp, pred, loss, gx = model.fused_loss_and_grad(x, tgt, kind, kappa)
+    torch.testing.assert_close(logp, logp_a.detach(), rtol=1e-4, atol=2e-5)
+    assert torch.equal(pred, logp_a.argmax(1))
+    ref = xa.grad
+    close = torch.isclose(gx, ref, rtol=2e-3, atol=2e-5 * float(ref.abs().max()))
+    assert close.float().mean() > 0.995
+    assert float((gx - ref).norm() / ref.norm()) < 2e-3
