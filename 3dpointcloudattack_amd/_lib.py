@@ -36,6 +36,8 @@ SIGNATURES = {
     "pc3d_clip_f32": _PTS + _PTS + _PTS + [_I, _I, _I, _F] + _PTS + [_P],
     "pc3d_adam_clip_step_f32": _PTS + _PTS + [_P, _P] + _PTS + _PTS + [_I, _I, _D, _D, _D, _D, _F, _P, _I, _P],
     "pc3d_i32_add": [_P, _I, _P],
+    "pc3d_cw_bookkeep_f32": _PTS + _PTS + [_I, _I, _P, _P, _I, _P, _P, _P, _P] + _PTS + _PTS + [_P, _P, _P],
+    "pc3d_cw_step_f32": _PTS + _PTS + [_P, _P] + _PTS + [_I, _I, _D, _D, _D, _D, _F, _P, _I, _I, _P, _P, _P, _P],
     "pc3d_pairwise_f32": _PTS + _PTS + [_I, _I, _I, _I, _P, _P],
     "pc3d_pointmlp3_tile_points": [],
     "pc3d_pointmlp3_max_fwd_f32": _PTS + [_I, _I] + [_P] * 7 + [_I, _I, _I, _I] + [_P] * 4 + [_P],

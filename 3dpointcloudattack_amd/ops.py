@@ -446,3 +446,32 @@ def cls_loss(logits, target, kind, kappa=0.0, scale=1.0, want_grad=True):
                   LOSS_KINDS[kind] if isinstance(kind, str) else int(kind), float(kappa), float(scale),
                   logp.data_ptr(), pred.data_ptr(), loss.data_ptr(), _ptr(g), _stream())
     return logp, pred, loss, g
+
+
+# ------------------------------------------------------------------------------------------------------
+# CW-family loop: bookkeeping + fused update
+# ------------------------------------------------------------------------------------------------------
+def cw_bookkeep(adv, ori, pred, label, untarget, bestdist, bestscore, o_bestdist, o_bestscore, o_bestattack,
+                input_val=None, dist_val=None, step=None, cf=True):
+    """In-place update of the best-attack state for one iteration (see pc3d_cw_bookkeep_f32)."""
+    _, _, _, _, B, K = _pts(adv, cf, "adv")
+    with torch.cuda.device(adv.device):
+        _lib.call("pc3d_cw_bookkeep_f32", *_pv(adv, cf, "adv"), *_pv(ori, cf, "ori"), B, K, pred.data_ptr(),
+                  label.data_ptr(), 1 if untarget else 0, bestdist.data_ptr(), bestscore.data_ptr(),
+                  o_bestdist.data_ptr(), o_bestscore.data_ptr(), *_pv(o_bestattack, cf, "o_bestattack"),
+                  *_pv(input_val, cf, "input_val"), _ptr(dist_val), _ptr(step), _stream())
+
+
+def cw_step(p, g, m, v, step, lr, ori, budget, dist_kind=0, w=None, l2norm=None, nn_idx=None,
+            betas=(0.9, 0.999), eps=1e-8, cf=True):
+    """Fused total-gradient + Adam + clip (see pc3d_cw_step_f32). dist_kind: 0 none, 1 L2Dist, 2 Chamfer adv2ori."""
+    _, _, _, _, B, K = _pts(p, cf, "p")
+    if isinstance(step, torch.Tensor):
+        step_dev, step_host = step.data_ptr(), 0
+    else:
+        step_dev, step_host = 0, int(step)
+    with torch.cuda.device(p.device):
+        _lib.call("pc3d_cw_step_f32", *_pv(p, cf, "p"), *_pv(g, cf, "g"), m.data_ptr(), v.data_ptr(),
+                  *_pv(ori, cf, "ori"), B, K, float(lr), float(betas[0]), float(betas[1]), float(eps), float(budget),
+                  step_dev, step_host, int(dist_kind), _ptr(w), _ptr(l2norm), _ptr(nn_idx), _stream())
+    return p

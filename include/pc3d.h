@@ -190,6 +190,33 @@ int pc3d_knn_bwd_f32(const float* q, int64_t q_bs, int64_t q_ps, int64_t q_cs,
                      float* grad_r, int64_t gr_bs, int64_t gr_ps, int64_t gr_cs,
                      int deterministic, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * K11  per-iteration bookkeeping of the CW-family loops on the device (attack/CW/CW_attack.py:129-153): per-sample
+ * dist = ||adv-ori||_F, success = (pred != label) [untarget] or (pred == label); where success && dist < bestdist
+ * update (bestdist, bestscore); where success && dist < o_bestdist update (o_bestdist, o_bestscore) and copy adv[b]
+ * into o_bestattack[b]. input_val (may be NULL) always receives adv (the iterate this pass started from, :133).
+ * dist_val[B] (may be NULL) receives dist; *step (may be NULL) is incremented by one (the Adam step word).
+ * Replaces the D2H copy of the whole cloud + Python per-sample loop of every iteration.
+ * ------------------------------------------------------------------------------------------------------- */
+int pc3d_cw_bookkeep_f32(const float* adv, int64_t a_bs, int64_t a_ps, int64_t a_cs,
+                         const float* ori, int64_t o_bs, int64_t o_ps, int64_t o_cs, int B, int K,
+                         const int64_t* pred, const int64_t* label, int untarget,
+                         float* bestdist, int64_t* bestscore, float* o_bestdist, int64_t* o_bestscore,
+                         float* o_bestattack, int64_t ba_bs, int64_t ba_ps, int64_t ba_cs,
+                         float* input_val, int64_t iv_bs, int64_t iv_ps, int64_t iv_cs,
+                         float* dist_val, int32_t* step, void* stream);
+
+/* CW update in one launch: g = g_model + d/dadv[ mean_b w[b] * D(adv_b, ori_b) ]; Adam (as pc3d_adam_clip_step_f32);
+ * per-point clip to `budget` (ClipPointsLinf; <= 0: none). dist_kind 0: none; 1: L2Dist (needs l2norm[B] =
+ * ||adv-ori||_F, e.g. dist_val of the bookkeeping launch); 2: ChamferDist('adv2ori') (needs nn_idx [B,K] from
+ * pc3d_nn_f32). Replaces loss.backward() of the distance term + opt.step() + clip_func (CW_attack.py:161-174). */
+int pc3d_cw_step_f32(float* p, int64_t p_bs, int64_t p_ps, int64_t p_cs,
+                     const float* g, int64_t g_bs, int64_t g_ps, int64_t g_cs, float* m, float* v,
+                     const float* ori, int64_t o_bs, int64_t o_ps, int64_t o_cs, int B, int K,
+                     double lr, double beta1, double beta2, double eps, float budget,
+                     const int32_t* step_dev, int step_host, int dist_kind, const float* w,
+                     const float* l2norm, const int32_t* nn_idx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
