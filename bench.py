@@ -189,9 +189,18 @@ def main():
             ops.pointmlp3_max_fwd_raw(x, tower, False, fold=False)
         k_ms = ev_ms(lambda: ops.pointmlp3_max_fwd_raw(x, tower, False, fold=False), 50, stream)
         ach = flops / (k_ms * 1e-3) / 1e12
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm_counters.json")
+        if os.path.exists(pmc):
+            # HBM bytes per launch from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE
+            # runs of this same command, KiB units). gfx950 correction (MI355X_MICROARCH.md §HBM): FETCH_SIZE counts
+            # 64 B per 128-B request for 16-B-per-lane reads -> doubled; WRITE_SIZE is exact.
+            c = json.load(open(pmc)).get("pc3d::pointmlp3_max_fwd_kernel|grid=131072")
+            if c and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                traffic = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
         roofline = {"kernel": "pointmlp3_max_fwd_kernel", "bound": "mfma", "achieved": ach,
                     "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS,
-                    "traffic": None, "launch_us": k_ms * 1e3, "launches_per_step": 2}
+                    "traffic": traffic, "launch_us": k_ms * 1e3, "launches_per_step": 2}
         # ---- the Chamfer kernel at N=4096 (north_star's second figure): VALU-bound, HBM share reported too
         Nc = 4096
         a = torch.randn(B, Nc, 3, device=dev)
