@@ -1,0 +1,274 @@
+// K5/K6/K7 — PointNet++ sampling and grouping ops (model/pointnet2_utils.py:60-155, model/curvenet_util.py:69-140):
+//   * farthest-point sampling: the reference runs a Python loop of `npoint` steps x ~6 launches on [B,N] tensors;
+//     here ONE workgroup per cloud keeps the cloud and the running min-distances on chip and does all `npoint`
+//     dependent arg-max steps in one launch (registers + wave shuffles + one LDS exchange per step);
+//   * ball query: the reference builds [B,S,N] distances, masks, SORTS the int64 index tensor along N and slices;
+//     here one wave per centroid scans the cloud in index order and compacts the in-radius hits with a ballot /
+//     prefix-popcount — "first nsample in ascending index order" without any sort or [B,S,N] tensor;
+//   * group gather: xyz[idx]-centroid (+ features) written channels-last for the following 1x1-conv MLP, and its
+//     backward (scatter-add into points and features — the attack's gradient path through the grouping).
+#include "pc3d_common.h"
+
+namespace pc3d {
+
+// ---------------------------------------------------------------------------------------------------------
+// FPS.  distance[i] = min(distance[i], |p_i - p_far|^2) ; far = argmax distance (lowest index on ties).
+// Arithmetic = the reference's: ((dx*dx + dy*dy) + dz*dz) in fp32 without contraction, distance init 1e10.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int FPS_T = 256;
+constexpr int FPS_MAXPER = 32;  // points per thread -> N <= 8192
+
+struct FpsArgs {
+  PtsView x;
+  int N, S;
+  const int32_t* start;  // [B] or null (=0: model/curvenet_util.py:81)
+  int32_t* out;          // [B,S]
+};
+
+template <int PER>
+__global__ __launch_bounds__(FPS_T) void fps_kernel(FpsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* sx = lds;                 // [N] staged coordinates (winner lookup)
+  float* sy = lds + a.N;
+  float* sz = lds + 2 * a.N;
+  __shared__ float red_v[2][FPS_T / 64];
+  __shared__ int red_i[2][FPS_T / 64];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* xb = a.x.p + (int64_t)b * a.x.bs;
+  float px[PER], py[PER], pz[PER], dist[PER];
+#pragma unroll
+  for (int e = 0; e < PER; ++e) {
+    const int i = e * FPS_T + tid;  // strided ownership: coalesced loads, ascending index within a thread
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (i < a.N) {
+      const float* p = xb + (int64_t)i * a.x.ps;
+      x = p[0], y = p[a.x.cs], z = p[2 * a.x.cs];
+      sx[i] = x, sy[i] = y, sz[i] = z;
+    }
+    px[e] = x, py[e] = y, pz[e] = z;
+    dist[e] = (i < a.N) ? 1e10f : -1.f;  // padding can never win the arg-max
+  }
+  int far = a.start ? a.start[b] : 0;
+  __syncthreads();
+  for (int s = 0; s < a.S; ++s) {
+    if (tid == 0) a.out[(int64_t)b * a.S + s] = far;
+    const float cx = sx[far], cy = sy[far], cz = sz[far];
+    float bv = -2.f;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+      const float dx = px[e] - cx, dy = py[e] - cy, dz = pz[e] - cz;
+      const float d = (dx * dx + dy * dy) + dz * dz;
+      const float nd = (d < dist[e]) ? d : dist[e];
+      dist[e] = nd;
+      if (nd > bv) {  // ascending index inside the thread: strict > keeps the lowest index
+        bv = nd;
+        bi = e * FPS_T + tid;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > bv || (ov == bv && oi < bi)) bv = ov, bi = oi;
+    }
+    const int buf = s & 1;  // double-buffered exchange: one barrier per step
+    if (lane == 0) red_v[buf][wave] = bv, red_i[buf][wave] = bi;
+    __syncthreads();
+    float fv = red_v[buf][0];
+    int fi = red_i[buf][0];
+#pragma unroll
+    for (int w = 1; w < FPS_T / 64; ++w) {
+      const float ov = red_v[buf][w];
+      const int oi = red_i[buf][w];
+      if (ov > fv || (ov == fv && oi < fi)) fv = ov, fi = oi;
+    }
+    far = fi;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Ball query: out[b,s,:] = first `nsample` indices i (ascending) with |xyz_i - c_s|^2 <= r2, padded with the first hit
+// (model/pointnet2_utils.py:84-104). No hit at all -> N (what the reference's sort leaves there).
+// ---------------------------------------------------------------------------------------------------------
+struct BallArgs {
+  PtsView x, c;
+  int N, S, ns;
+  float r2;
+  int32_t* out;  // [B,S,ns]
+};
+
+__global__ __launch_bounds__(256) void ball_query_kernel(BallArgs a) {
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int s = blockIdx.x * 4 + wave;
+  if (s >= a.S) return;
+  const float* cp = a.c.p + (int64_t)b * a.c.bs + (int64_t)s * a.c.ps;
+  const float cx = cp[0], cy = cp[a.c.cs], cz = cp[2 * a.c.cs];
+  const float* xb = a.x.p + (int64_t)b * a.x.bs;
+  int32_t* o = a.out + ((int64_t)b * a.S + s) * a.ns;
+  int found = 0, first = a.N;
+  for (int i0 = 0; i0 < a.N && found < a.ns; i0 += 64) {
+    const int i = i0 + lane;
+    bool hit = false;
+    if (i < a.N) {
+      const float* p = xb + (int64_t)i * a.x.ps;
+      const float dx = p[0] - cx, dy = p[a.x.cs] - cy, dz = p[2 * a.x.cs] - cz;
+      hit = ((dx * dx + dy * dy) + dz * dz) <= a.r2;
+    }
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+    if (m) {
+      if (first == a.N) first = i0 + __builtin_ctzll(m);
+      const int rank = __builtin_popcountll(m & ((1ull << lane) - 1ull));
+      if (hit && found + rank < a.ns) o[found + rank] = i;
+      found += __builtin_popcountll(m);
+    }
+  }
+  if (found > a.ns) found = a.ns;
+  for (int j = found + lane; j < a.ns; j += 64) o[j] = first;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Group gather, channels-last: out[b,s,j,0:3] = xyz[b,idx]-center[b,s] (center optional), out[b,s,j,3:3+D] = feat[b,idx]
+// (model/pointnet2_utils.py:41-57,121-131). One thread per output element group of 4 channels.
+// ---------------------------------------------------------------------------------------------------------
+struct GatherArgs {
+  PtsView x;            // may be null (features only)
+  const float* feat;    // [B,N,D] row-major or null
+  const int32_t* idx;   // [B,S,ns]
+  PtsView center;       // [B,S] points or null
+  int N, S, ns, D, C;   // C = (x ? 3 : 0) + D
+  float* out;           // [B,S,ns,C]
+};
+
+__global__ __launch_bounds__(256) void group_gather_kernel(GatherArgs a) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // one wave per (b,s,j) row
+  const int lane = threadIdx.x & 63;
+  const int64_t rows = (int64_t)gridDim.y * a.S * a.ns;
+  (void)rows;
+  const int b = blockIdx.y;
+  if (row >= (int64_t)a.S * a.ns) return;
+  const int s = (int)(row / a.ns);
+  const int i = a.idx[((int64_t)b * a.S) * a.ns + row];
+  float* o = a.out + (((int64_t)b * a.S) * a.ns + row) * a.C;
+  int c0 = 0;
+  if (a.x.p) {
+    if (lane < 3) {
+      float v = a.x.p[(int64_t)b * a.x.bs + (int64_t)i * a.x.ps + lane * a.x.cs];
+      if (a.center.p) v -= a.center.p[(int64_t)b * a.center.bs + (int64_t)s * a.center.ps + lane * a.center.cs];
+      o[lane] = v;
+    }
+    c0 = 3;
+  }
+  if (a.feat) {
+    const float* f = a.feat + ((int64_t)b * a.N + i) * a.D;
+    for (int d = lane; d < a.D; d += 64) o[c0 + d] = f[d];
+  }
+}
+
+// backward: grad_x[b, idx] += g[...,0:3]; grad_x[b, cidx[s]] -= sum_j g[...,0:3]; grad_feat[b, idx] += g[...,3:]
+struct GatherBwdArgs {
+  const float* g;          // [B,S,ns,C]
+  const int32_t* idx;      // [B,S,ns]
+  const int32_t* cidx;     // [B,S] index of the centre point in x, or null (no centre term)
+  int N, S, ns, D, C, has_x;
+  float* gx;               // [B,N,3] contiguous (zero-filled by the caller of the kernel) or null
+  float* gf;               // [B,N,D] contiguous or null
+};
+
+__global__ __launch_bounds__(256) void group_gather_bwd_kernel(GatherBwdArgs a) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.y;
+  if (row >= (int64_t)a.S * a.ns) return;
+  const int s = (int)(row / a.ns);
+  const int i = a.idx[((int64_t)b * a.S) * a.ns + row];
+  const float* g = a.g + (((int64_t)b * a.S) * a.ns + row) * a.C;
+  int c0 = 0;
+  if (a.has_x) {
+    if (a.gx && lane < 3) {
+      const float v = g[lane];
+      atomicAdd(a.gx + ((int64_t)b * a.N + i) * 3 + lane, v);
+      if (a.cidx) atomicAdd(a.gx + ((int64_t)b * a.N + a.cidx[(int64_t)b * a.S + s]) * 3 + lane, -v);
+    }
+    c0 = 3;
+  }
+  if (a.gf) {
+    float* f = a.gf + ((int64_t)b * a.N + i) * a.D;
+    for (int d = lane; d < a.D; d += 64) atomicAdd(f + d, g[c0 + d]);
+  }
+}
+
+}  // namespace pc3d
+
+using namespace pc3d;
+
+extern "C" int pc3d_fps_f32(const float* xyz, int64_t x_bs, int64_t x_ps, int64_t x_cs, int B, int N, int S,
+                            const int32_t* start, int32_t* out, void* stream) {
+  PC3D_REQUIRE(B >= 0 && N >= 1 && S >= 1, "pc3d_fps_f32: bad sizes B=%d N=%d S=%d", B, N, S);
+  PC3D_REQUIRE(N <= FPS_T * FPS_MAXPER, "pc3d_fps_f32: N=%d exceeds %d", N, FPS_T * FPS_MAXPER);
+  if (B == 0) return PC3D_OK;
+  PC3D_REQUIRE(xyz && out, "pc3d_fps_f32: null pointer");
+  FpsArgs a{{xyz, x_bs, x_ps, x_cs}, N, S, start, out};
+  const size_t lds = (size_t)3 * N * sizeof(float);
+  hipStream_t st = as_stream(stream);
+  const int per = cdiv(N, FPS_T);
+  if (per <= 1) hipLaunchKernelGGL(fps_kernel<1>, dim3(B), dim3(FPS_T), lds, st, a);
+  else if (per <= 2) hipLaunchKernelGGL(fps_kernel<2>, dim3(B), dim3(FPS_T), lds, st, a);
+  else if (per <= 4) hipLaunchKernelGGL(fps_kernel<4>, dim3(B), dim3(FPS_T), lds, st, a);
+  else if (per <= 8) hipLaunchKernelGGL(fps_kernel<8>, dim3(B), dim3(FPS_T), lds, st, a);
+  else if (per <= 16) hipLaunchKernelGGL(fps_kernel<16>, dim3(B), dim3(FPS_T), lds, st, a);
+  else hipLaunchKernelGGL(fps_kernel<32>, dim3(B), dim3(FPS_T), lds, st, a);
+  PC3D_LAUNCH_CHECK("pc3d_fps_f32");
+  return PC3D_OK;
+}
+
+extern "C" int pc3d_ball_query_f32(const float* xyz, int64_t x_bs, int64_t x_ps, int64_t x_cs,
+                                   const float* centers, int64_t c_bs, int64_t c_ps, int64_t c_cs,
+                                   int B, int N, int S, float radius, int nsample, int32_t* out, void* stream) {
+  PC3D_REQUIRE(B >= 0 && N >= 1 && S >= 1 && nsample >= 1, "pc3d_ball_query_f32: bad sizes B=%d N=%d S=%d ns=%d", B, N,
+               S, nsample);
+  PC3D_REQUIRE(B <= 65535, "pc3d_ball_query_f32: B=%d exceeds grid.y limit", B);
+  if (B == 0) return PC3D_OK;
+  PC3D_REQUIRE(xyz && centers && out, "pc3d_ball_query_f32: null pointer");
+  BallArgs a{{xyz, x_bs, x_ps, x_cs}, {centers, c_bs, c_ps, c_cs}, N, S, nsample, radius * radius, out};
+  hipLaunchKernelGGL(ball_query_kernel, dim3(cdiv(S, 4), B), dim3(256), 0, as_stream(stream), a);
+  PC3D_LAUNCH_CHECK("pc3d_ball_query_f32");
+  return PC3D_OK;
+}
+
+extern "C" int pc3d_group_gather_f32(const float* xyz, int64_t x_bs, int64_t x_ps, int64_t x_cs, const float* feat,
+                                     int D, const int32_t* idx, const float* centers, int64_t c_bs, int64_t c_ps,
+                                     int64_t c_cs, int B, int N, int S, int ns, float* out, void* stream) {
+  PC3D_REQUIRE(B >= 0 && N >= 1 && S >= 1 && ns >= 1 && D >= 0, "pc3d_group_gather_f32: bad sizes");
+  PC3D_REQUIRE(xyz != nullptr || (feat != nullptr && D > 0), "pc3d_group_gather_f32: nothing to gather");
+  PC3D_REQUIRE(B <= 65535, "pc3d_group_gather_f32: B=%d exceeds grid.y limit", B);
+  if (B == 0) return PC3D_OK;
+  PC3D_REQUIRE(idx && out, "pc3d_group_gather_f32: null pointer");
+  if (feat == nullptr) D = 0;
+  GatherArgs a{{xyz, x_bs, x_ps, x_cs}, feat, idx, {centers, c_bs, c_ps, c_cs}, N, S, ns, D, (xyz ? 3 : 0) + D, out};
+  hipLaunchKernelGGL(group_gather_kernel, dim3(cdiv(S * ns, 4), B), dim3(256), 0, as_stream(stream), a);
+  PC3D_LAUNCH_CHECK("pc3d_group_gather_f32");
+  return PC3D_OK;
+}
+
+extern "C" int pc3d_group_gather_bwd_f32(const float* g_out, const int32_t* idx, const int32_t* center_idx, int B,
+                                         int N, int S, int ns, int D, int has_xyz, float* grad_xyz, float* grad_feat,
+                                         void* stream) {
+  PC3D_REQUIRE(B >= 0 && N >= 1 && S >= 1 && ns >= 1 && D >= 0, "pc3d_group_gather_bwd_f32: bad sizes");
+  PC3D_REQUIRE(B <= 65535, "pc3d_group_gather_bwd_f32: B=%d exceeds grid.y limit", B);
+  if (B == 0) return PC3D_OK;
+  PC3D_REQUIRE(g_out && idx, "pc3d_group_gather_bwd_f32: null pointer");
+  hipStream_t st = as_stream(stream);
+  hipError_t e = hipSuccess;
+  if (grad_xyz) e = hipMemsetAsync(grad_xyz, 0, (size_t)B * N * 3 * sizeof(float), st);
+  if (e == hipSuccess && grad_feat) e = hipMemsetAsync(grad_feat, 0, (size_t)B * N * D * sizeof(float), st);
+  if (e != hipSuccess) {
+    set_error("pc3d_group_gather_bwd_f32: memset failed: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  GatherBwdArgs a{g_out, idx, center_idx, N, S, ns, D, (has_xyz ? 3 : 0) + D, has_xyz, grad_xyz, grad_feat};
+  hipLaunchKernelGGL(group_gather_bwd_kernel, dim3(cdiv(S * ns, 4), B), dim3(256), 0, st, a);
+  PC3D_LAUNCH_CHECK("pc3d_group_gather_bwd_f32");
+  return PC3D_OK;
+}

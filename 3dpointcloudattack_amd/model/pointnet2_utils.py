@@ -1,0 +1,243 @@
+"""PointNet++ sampling / grouping ops and set-abstraction modules — MI355X mirror of model/pointnet2_utils.py
+(same function names, argument order, return layouts, ``state_dict`` keys ``mlp_convs.N`` / ``mlp_bns.N`` /
+``conv_blocks.i.j`` / ``bn_blocks.i.j``).
+
+What runs where: farthest_point_sample, query_ball_point, index_points and the grouped gather (with its backward — the
+attack's gradient path through the grouping) are single HIP launches (pc3d_fps_f32, pc3d_ball_query_f32,
+pc3d_group_gather_f32). The reference's versions are a Python loop of npoint x 6 launches, a full sort of a [B,S,N]
+int64 tensor and advanced-indexing gathers. The grouped 1x1-conv MLPs run channels-last (no permute / contiguous
+copies); eval-mode BatchNorm2d is folded into the conv weights.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from .pointnet import _FrozenFusedMixin
+
+
+def pc_normalize(pc):
+    """model/pointnet2_utils.py:11-17."""
+    centroid = np.mean(pc, axis=0)
+    pc = pc - centroid
+    m = np.max(np.sqrt(np.sum(pc ** 2, axis=1)))
+    return pc / m
+
+
+def square_distance(src, dst):
+    """:19-38 — [B,N,C=3],[B,M,3] -> [B,N,M] squared distances (dense; direct-difference form)."""
+    return ops.pairwise(src.float(), dst.float())
+
+
+def _i32(idx):
+    return idx if idx.dtype == torch.int32 else idx.to(torch.int32)
+
+
+def index_points(points, idx):
+    """:41-57 — points [B,N,C], idx [B,S] or [B,S,ns] -> [B,S,C] / [B,S,ns,C]. Differentiable in points."""
+    points = points.float()
+    if idx.dim() == 2:
+        B, S = idx.shape
+        return ops.group_gather(None, points, _i32(idx).reshape(B, S, 1).contiguous()).view(B, S, -1)
+    return ops.group_gather(None, points, _i32(idx).contiguous())
+
+
+def _fps_start(B, N, device):
+    # the reference draws the first index from the GLOBAL CPU generator every forward (:72, SURVEY A-4); same call,
+    # same stream position -> same start indices under the same seed
+    return torch.randint(0, N, (B,), dtype=torch.long).to(device=device, dtype=torch.int32)
+
+
+def farthest_point_sample(xyz, npoint, start=None):
+    """:60-81 — xyz [B,N,3] -> centroids [B,npoint] int64. start (optional int tensor [B]) overrides the random draw."""
+    B, N, _ = xyz.shape
+    st = _fps_start(B, N, xyz.device) if start is None else start.to(device=xyz.device, dtype=torch.int32)
+    return ops.fps(xyz.float(), npoint, st).long()
+
+
+def query_ball_point(radius, nsample, xyz, new_xyz):
+    """:84-104 — [B,S,nsample] int64."""
+    return ops.ball_query(radius, nsample, xyz.float(), new_xyz.float()).long()
+
+
+def _sample_and_group_i32(npoint, radius, nsample, xyz, points):
+    B, N, C = xyz.shape
+    fps_idx = ops.fps(xyz, npoint, _fps_start(B, N, xyz.device))                      # [B,S] i32
+    new_xyz = ops.group_gather(xyz, None, fps_idx.view(B, npoint, 1)).view(B, npoint, 3)
+    idx = ops.ball_query(radius, nsample, xyz, new_xyz)                              # [B,S,ns] i32
+    # [B,S,ns,3+D] = [xyz[idx]-new_xyz, points[idx]]; the centre's gradient is folded into xyz's inside the kernel
+    new_points = ops.group_gather(xyz, points, idx, centers=new_xyz.detach(), center_idx=fps_idx)
+    return new_xyz, new_points, idx, fps_idx
+
+
+def sample_and_group(npoint, radius, nsample, xyz, points, returnfps=False):
+    """:107-135 — new_xyz [B,npoint,3], new_points [B,npoint,nsample,3+D]."""
+    xyz = xyz.float()
+    points = None if points is None else points.float()
+    new_xyz, new_points, idx, fps_idx = _sample_and_group_i32(npoint, radius, nsample, xyz, points)
+    if returnfps:
+        grouped_xyz = ops.group_gather(xyz, None, idx)
+        return new_xyz, new_points, grouped_xyz, fps_idx.long()
+    return new_xyz, new_points
+
+
+def sample_and_group_all(xyz, points):
+    """:138-155 — new_xyz zeros [B,1,3], new_points [B,1,N,3+D]."""
+    B, N, C = xyz.shape
+    new_xyz = torch.zeros(B, 1, C, device=xyz.device)
+    grouped_xyz = xyz.view(B, 1, N, C)
+    if points is not None:
+        new_points = torch.cat([grouped_xyz, points.view(B, 1, N, -1)], dim=-1)
+    else:
+        new_points = grouped_xyz
+    return new_xyz, new_points
+
+
+def _fold_bn2d(conv, bn, perm=None):
+    w = conv.weight.detach().reshape(conv.weight.shape[0], -1).float()
+    s = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+    b = conv.bias.detach().float() if conv.bias is not None else torch.zeros_like(s)
+    w = w * s[:, None]
+    if perm is not None:
+        w = w[:, perm]
+    return w.contiguous(), ((b - bn.running_mean.detach().float()) * s + bn.bias.detach().float()).contiguous()
+
+
+def _cl(points):
+    """[B,D,N] channels-first API tensor -> [B,N,D] contiguous (free when it is a view of channels-last storage)."""
+    return None if points is None else points.permute(0, 2, 1).contiguous().float()
+
+
+class PointNetSetAbstraction(_FrozenFusedMixin, nn.Module):
+    """:158-199."""
+
+    def __init__(self, npoint, radius, nsample, in_channel, mlp, group_all):
+        super(PointNetSetAbstraction, self).__init__()
+        self.npoint = npoint
+        self.radius = radius
+        self.nsample = nsample
+        self.mlp_convs = nn.ModuleList()
+        self.mlp_bns = nn.ModuleList()
+        last_channel = in_channel
+        for out_channel in mlp:
+            self.mlp_convs.append(nn.Conv2d(last_channel, out_channel, 1))
+            self.mlp_bns.append(nn.BatchNorm2d(out_channel))
+            last_channel = out_channel
+        self.group_all = group_all
+        self._folded_cache = None
+
+    def folded(self):
+        if self._folded_cache is None:
+            object.__setattr__(self, "_folded_cache",
+                               [_fold_bn2d(c, b) for c, b in zip(self.mlp_convs, self.mlp_bns)])
+        return self._folded_cache
+
+    def forward(self, xyz, points):
+        """xyz [B,3,N], points [B,D,N] or None -> new_xyz [B,3,S], new_points [B,D',S]."""
+        self._require_fused(xyz)
+        xyz_t = xyz.permute(0, 2, 1).float()      # strided view; the kernels take strides
+        pts = _cl(points)
+        if self.group_all:
+            new_xyz, new_points = sample_and_group_all(xyz_t, pts)
+        else:
+            new_xyz, new_points, _, _ = _sample_and_group_i32(self.npoint, self.radius, self.nsample, xyz_t, pts)
+        for w, b in self.folded():                 # channels-last 1x1 convs: one GEMM each, no permutes
+            new_points = F.relu(F.linear(new_points, w, b))
+        new_points = torch.max(new_points, 2)[0]   # [B,S,D']
+        return new_xyz.permute(0, 2, 1), new_points.permute(0, 2, 1)
+
+
+class PointNetSetAbstractionMsg(_FrozenFusedMixin, nn.Module):
+    """:202-259 — multi-scale grouping; per scale the reference concatenates [features, xyz] (features FIRST)."""
+
+    def __init__(self, npoint, radius_list, nsample_list, in_channel, mlp_list):
+        super(PointNetSetAbstractionMsg, self).__init__()
+        self.npoint = npoint
+        self.radius_list = radius_list
+        self.nsample_list = nsample_list
+        self.conv_blocks = nn.ModuleList()
+        self.bn_blocks = nn.ModuleList()
+        self.in_channel = in_channel
+        for i in range(len(mlp_list)):
+            convs = nn.ModuleList()
+            bns = nn.ModuleList()
+            last_channel = in_channel + 3
+            for out_channel in mlp_list[i]:
+                convs.append(nn.Conv2d(last_channel, out_channel, 1))
+                bns.append(nn.BatchNorm2d(out_channel))
+                last_channel = out_channel
+            self.conv_blocks.append(convs)
+            self.bn_blocks.append(bns)
+        self._folded_cache = None
+
+    def folded(self):
+        if self._folded_cache is None:
+            D = self.in_channel
+            # kernel layout is [xyz(3), feat(D)]; the reference's first conv expects [feat(D), xyz(3)]
+            perm = torch.cat([torch.arange(D, D + 3), torch.arange(0, D)]) if D > 0 else None
+            out = []
+            for convs, bns in zip(self.conv_blocks, self.bn_blocks):
+                layers = []
+                for j, (c, b) in enumerate(zip(convs, bns)):
+                    layers.append(_fold_bn2d(c, b, perm.to(c.weight.device) if (j == 0 and perm is not None) else None))
+                out.append(layers)
+            object.__setattr__(self, "_folded_cache", out)
+        return self._folded_cache
+
+    def forward(self, xyz, points):
+        self._require_fused(xyz)
+        xyz_t = xyz.permute(0, 2, 1).float()
+        pts = _cl(points)
+        B, N, C = xyz_t.shape
+        S = self.npoint
+        fps_idx = ops.fps(xyz_t, S, _fps_start(B, N, xyz_t.device))
+        new_xyz = ops.group_gather(xyz_t, None, fps_idx.view(B, S, 1)).view(B, S, 3)
+        outs = []
+        for i, radius in enumerate(self.radius_list):
+            idx = ops.ball_query(radius, self.nsample_list[i], xyz_t, new_xyz)
+            g = ops.group_gather(xyz_t, pts, idx, centers=new_xyz.detach(), center_idx=fps_idx)
+            for w, b in self.folded()[i]:
+                g = F.relu(F.linear(g, w, b))
+            outs.append(torch.max(g, 2)[0])
+        return new_xyz.permute(0, 2, 1), torch.cat(outs, dim=-1).permute(0, 2, 1)
+
+
+class PointNetFeaturePropagation(_FrozenFusedMixin, nn.Module):
+    """:262-312 — 3-NN inverse-distance interpolation + MLP (segmentation head; not used by the attacks)."""
+
+    def __init__(self, in_channel, mlp):
+        super(PointNetFeaturePropagation, self).__init__()
+        self.mlp_convs = nn.ModuleList()
+        self.mlp_bns = nn.ModuleList()
+        last_channel = in_channel
+        for out_channel in mlp:
+            self.mlp_convs.append(nn.Conv1d(last_channel, out_channel, 1))
+            self.mlp_bns.append(nn.BatchNorm1d(out_channel))
+            last_channel = out_channel
+        self._folded_cache = None
+
+    def folded(self):
+        if self._folded_cache is None:
+            object.__setattr__(self, "_folded_cache",
+                               [_fold_bn2d(c, b) for c, b in zip(self.mlp_convs, self.mlp_bns)])
+        return self._folded_cache
+
+    def forward(self, xyz1, xyz2, points1, points2):
+        self._require_fused(xyz1)
+        x1 = xyz1.permute(0, 2, 1).float()
+        x2 = xyz2.permute(0, 2, 1).float()
+        p2 = _cl(points2)
+        B, N, _ = x1.shape
+        S = x2.shape[1]
+        if S == 1:
+            interpolated = p2.repeat(1, N, 1)
+        else:
+            dists, idx = ops.knn(x1, x2, 3)                       # the reference sorts [B,N,S] and keeps 3
+            recip = 1.0 / (dists + 1e-8)
+            weight = recip / torch.sum(recip, dim=2, keepdim=True)
+            interpolated = torch.sum(ops.group_gather(None, p2, idx) * weight.view(B, N, 3, 1), dim=2)
+        new_points = interpolated if points1 is None else torch.cat([_cl(points1), interpolated], dim=-1)
+        for w, b in self.folded():
+            new_points = F.relu(F.linear(new_points, w, b))
+        return new_points.permute(0, 2, 1)

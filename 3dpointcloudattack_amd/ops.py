@@ -475,3 +475,75 @@ def cw_step(p, g, m, v, step, lr, ori, budget, dist_kind=0, w=None, l2norm=None,
                   *_pv(ori, cf, "ori"), B, K, float(lr), float(betas[0]), float(betas[1]), float(eps), float(budget),
                   step_dev, step_host, int(dist_kind), _ptr(w), _ptr(l2norm), _ptr(nn_idx), _stream())
     return p
+
+
+# ------------------------------------------------------------------------------------------------------
+# K5/K6/K7: PointNet++ sampling & grouping
+# ------------------------------------------------------------------------------------------------------
+def fps(xyz, npoint, start=None, cf=False):
+    """Farthest-point sampling: xyz [B,N,3] (or [B,3,N] with cf) -> int32 [B,npoint]. start: int32 [B] or None (0)."""
+    p, bs, ps, cs, B, N = _pts(xyz, cf, "xyz")
+    out = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device)
+    if start is not None and (start.dtype != torch.int32 or not start.is_cuda):
+        raise TypeError("fps: start must be an int32 GPU tensor")
+    with torch.cuda.device(xyz.device):
+        _lib.call("pc3d_fps_f32", p, bs, ps, cs, B, N, int(npoint), _ptr(start), out.data_ptr(), _stream())
+    return out
+
+
+def ball_query(radius, nsample, xyz, new_xyz, cf=False):
+    """int32 [B,S,nsample]: first nsample in-radius indices in ascending order, padded with the first."""
+    p, bs, ps, cs, B, N = _pts(xyz, cf, "xyz")
+    c, cbs, cps, ccs, B2, S = _pts(new_xyz, cf, "new_xyz")
+    out = torch.empty((B, S, nsample), dtype=torch.int32, device=xyz.device)
+    with torch.cuda.device(xyz.device):
+        _lib.call("pc3d_ball_query_f32", p, bs, ps, cs, c, cbs, cps, ccs, B, N, S, float(radius), int(nsample),
+                  out.data_ptr(), _stream())
+    return out
+
+
+class _GroupGatherFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xyz, feat, idx, centers, center_idx):
+        # xyz [B,N,3] or None; feat [B,N,D] or None; idx int32 [B,S,ns]; centers [B,S,3] or None
+        B, S, ns = idx.shape
+        ref = xyz if xyz is not None else feat
+        N = ref.shape[1]
+        D = 0 if feat is None else feat.shape[2]
+        if feat is not None:
+            _check(feat, "feat")
+            feat = feat.contiguous()
+        out = torch.empty((B, S, ns, (3 if xyz is not None else 0) + D), dtype=torch.float32, device=ref.device)
+        with torch.cuda.device(ref.device):
+            _lib.call("pc3d_group_gather_f32", *_pv(xyz, False, "xyz"), _ptr(feat), D, idx.data_ptr(),
+                      *_pv(centers, False, "centers"), B, N, S, ns, out.data_ptr(), _stream())
+        ctx.save_for_backward(idx, center_idx)
+        ctx.cfg = (B, N, S, ns, D, xyz is not None, feat is not None, centers is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        idx, center_idx = ctx.saved_tensors
+        B, N, S, ns, D, has_x, has_f, has_c = ctx.cfg
+        g = g.contiguous()
+        need_x = has_x and ctx.needs_input_grad[0]
+        need_f = has_f and ctx.needs_input_grad[1]
+        need_c = has_c and ctx.needs_input_grad[3]
+        gx = torch.empty((B, N, 3), dtype=torch.float32, device=g.device) if (need_x or need_c) else None
+        gf = torch.empty((B, N, D), dtype=torch.float32, device=g.device) if need_f else None
+        gc = None
+        if need_c and center_idx is None:
+            # centres are an independent tensor: their gradient is minus the group sums
+            gc = -g[..., :3].sum(dim=2)
+        with torch.cuda.device(g.device):
+            _lib.call("pc3d_group_gather_bwd_f32", g.data_ptr(), idx.data_ptr(),
+                      _ptr(center_idx) if (has_c and center_idx is not None) else 0, B, N, S, ns, D,
+                      1 if has_x else 0, _ptr(gx) if need_x or (need_c and center_idx is not None) else 0, _ptr(gf),
+                      _stream())
+        return (gx if need_x else None), gf, None, gc, None
+
+
+def group_gather(xyz, feat, idx, centers=None, center_idx=None):
+    """[B,S,ns,(3)+D] = [xyz[idx]-centers, feat[idx]]. When the centres are xyz[center_idx] pass center_idx (int32
+    [B,S]) so their gradient is folded into grad_xyz inside the kernel; otherwise centers gets its own gradient."""
+    return _GroupGatherFn.apply(xyz, feat, idx, centers, center_idx)

@@ -217,6 +217,36 @@ int pc3d_cw_step_f32(float* p, int64_t p_bs, int64_t p_ps, int64_t p_cs,
                      const int32_t* step_dev, int step_host, int dist_kind, const float* w,
                      const float* l2norm, const int32_t* nn_idx, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * K5  farthest-point sampling (model/pointnet2_utils.py:60-81; model/curvenet_util.py:69-90 with start 0).
+ * One workgroup per cloud performs all S dependent arg-max steps on chip. start[B] = first sampled index per
+ * cloud (the reference draws it with torch.randint every forward, SURVEY A-4; NULL = 0). out [B,S] i32.
+ * Same fp32 arithmetic as the reference (((dx*dx+dy*dy)+dz*dz), running min initialised to 1e10, lowest index on
+ * ties) so the index sequence is reproduced bit for bit. N <= 8192.
+ * ------------------------------------------------------------------------------------------------------- */
+int pc3d_fps_f32(const float* xyz, int64_t x_bs, int64_t x_ps, int64_t x_cs, int B, int N, int S,
+                 const int32_t* start, int32_t* out, void* stream);
+
+/* K6  ball query (model/pointnet2_utils.py:84-104): out[b,s,:] = the first `nsample` point indices in ascending
+ * order with |xyz_i - centers_s|^2 <= radius^2, padded with the first hit (N if there is none). out [B,S,nsample] i32.
+ * Direct-difference distances (the reference's -2ab+a^2+b^2 differs by fp32 rounding at the ball's surface). */
+int pc3d_ball_query_f32(const float* xyz, int64_t x_bs, int64_t x_ps, int64_t x_cs,
+                        const float* centers, int64_t c_bs, int64_t c_ps, int64_t c_cs,
+                        int B, int N, int S, float radius, int nsample, int32_t* out, void* stream);
+
+/* K7  group gather, channels-last (model/pointnet2_utils.py:41-57,121-131): out[b,s,j,:] =
+ * [xyz[b,idx[b,s,j]] - centers[b,s] (3, xyz may be NULL), feat[b,idx[b,s,j],:] (D, feat [B,N,D] contiguous or NULL)].
+ * centers NULL = no subtraction (plain index_points). out [B,S,ns,3+D] contiguous. */
+int pc3d_group_gather_f32(const float* xyz, int64_t x_bs, int64_t x_ps, int64_t x_cs, const float* feat, int D,
+                          const int32_t* idx, const float* centers, int64_t c_bs, int64_t c_ps, int64_t c_cs,
+                          int B, int N, int S, int ns, float* out, void* stream);
+
+/* Backward of K7: grad_xyz [B,N,3] / grad_feat [B,N,D] (contiguous, OVERWRITTEN, either may be NULL) receive the
+ * scatter-add of g_out [B,S,ns,(3)+D]; center_idx [B,S] (index of each centre in xyz, or NULL) receives minus the
+ * sum over its group. Float atomics (order-dependent in the last bits). */
+int pc3d_group_gather_bwd_f32(const float* g_out, const int32_t* idx, const int32_t* center_idx, int B, int N, int S,
+                              int ns, int D, int has_xyz, float* grad_xyz, float* grad_feat, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -389,3 +389,193 @@ def state_sha256(sd):
         h.update(k.encode())
         h.update(sd[k].detach().cpu().contiguous().numpy().tobytes())
     return h.hexdigest()
+
+
+# ----------------------------------------------------------------------------------------------------------
+# PointNet++ ops and classifiers (model/pointnet2_utils.py, model/pointnet2_SSG.py, model/pointnet2_MSG.py)
+# ----------------------------------------------------------------------------------------------------------
+def square_distance(src, dst):
+    """pointnet2_utils.py:19-38 (the reference's -2ab + a^2 + b^2 arithmetic)."""
+    B, N, _ = src.shape
+    _, M, _ = dst.shape
+    dist = -2 * torch.matmul(src, dst.permute(0, 2, 1))
+    dist += torch.sum(src ** 2, -1).view(B, N, 1)
+    dist += torch.sum(dst ** 2, -1).view(B, 1, M)
+    return dist
+
+
+def index_points(points, idx):
+    """:41-57."""
+    B = points.shape[0]
+    view_shape = list(idx.shape)
+    view_shape[1:] = [1] * (len(view_shape) - 1)
+    repeat_shape = list(idx.shape)
+    repeat_shape[0] = 1
+    batch_indices = torch.arange(B, dtype=torch.long).view(view_shape).repeat(repeat_shape)
+    return points[batch_indices, idx, :]
+
+
+def farthest_point_sample(xyz, npoint, start=None):
+    """:60-81; start=None draws torch.randint from the global generator exactly like the reference (:72)."""
+    B, N, C = xyz.shape
+    centroids = torch.zeros(B, npoint, dtype=torch.long)
+    distance = torch.ones(B, N) * 1e10
+    farthest = torch.randint(0, N, (B,), dtype=torch.long) if start is None else start.long().clone()
+    batch_indices = torch.arange(B, dtype=torch.long)
+    for i in range(npoint):
+        centroids[:, i] = farthest
+        centroid = xyz[batch_indices, farthest, :].view(B, 1, 3)
+        dist = torch.sum((xyz - centroid) ** 2, -1)
+        mask = dist < distance
+        distance[mask] = dist[mask]
+        farthest = torch.max(distance, -1)[1]
+    return centroids
+
+
+def query_ball_point(radius, nsample, xyz, new_xyz, exact=False):
+    """:84-104. exact=True evaluates the distances in the direct-difference form (what the HIP kernel does) instead
+    of the reference's expansion; the two differ only for points within fp32 rounding of the ball's surface."""
+    B, N, C = xyz.shape
+    _, S, _ = new_xyz.shape
+    group_idx = torch.arange(N, dtype=torch.long).view(1, 1, N).repeat([B, S, 1])
+    if exact:
+        d = new_xyz[:, :, None, :] - xyz[:, None, :, :]
+        sqrdists = (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
+    else:
+        sqrdists = square_distance(new_xyz, xyz)
+    group_idx[sqrdists > radius ** 2] = N
+    group_idx = group_idx.sort(dim=-1)[0][:, :, :nsample]
+    group_first = group_idx[:, :, 0].view(B, S, 1).repeat([1, 1, nsample])
+    mask = group_idx == N
+    group_idx[mask] = group_first[mask]
+    return group_idx
+
+
+def sample_and_group(npoint, radius, nsample, xyz, points, exact=False):
+    """:107-135."""
+    B, N, C = xyz.shape
+    fps_idx = farthest_point_sample(xyz, npoint)
+    new_xyz = index_points(xyz, fps_idx)
+    idx = query_ball_point(radius, nsample, xyz, new_xyz, exact)
+    grouped_xyz_norm = index_points(xyz, idx) - new_xyz.view(B, npoint, 1, C)
+    if points is not None:
+        new_points = torch.cat([grouped_xyz_norm, index_points(points, idx)], dim=-1)
+    else:
+        new_points = grouped_xyz_norm
+    return new_xyz, new_points
+
+
+class PointNetSetAbstraction(nn.Module):
+    """:158-199."""
+
+    def __init__(self, npoint, radius, nsample, in_channel, mlp, group_all, exact=False):
+        super().__init__()
+        self.npoint, self.radius, self.nsample, self.group_all, self.exact = npoint, radius, nsample, group_all, exact
+        self.mlp_convs, self.mlp_bns = nn.ModuleList(), nn.ModuleList()
+        last = in_channel
+        for oc in mlp:
+            self.mlp_convs.append(nn.Conv2d(last, oc, 1))
+            self.mlp_bns.append(nn.BatchNorm2d(oc))
+            last = oc
+
+    def forward(self, xyz, points):
+        xyz = xyz.permute(0, 2, 1)
+        if points is not None:
+            points = points.permute(0, 2, 1)
+        if self.group_all:
+            B, N, C = xyz.shape
+            new_xyz = torch.zeros(B, 1, C)
+            g = xyz.view(B, 1, N, C)
+            new_points = torch.cat([g, points.view(B, 1, N, -1)], dim=-1) if points is not None else g
+        else:
+            new_xyz, new_points = sample_and_group(self.npoint, self.radius, self.nsample, xyz, points, self.exact)
+        new_points = new_points.permute(0, 3, 2, 1)
+        for conv, bn in zip(self.mlp_convs, self.mlp_bns):
+            new_points = F.relu(bn(conv(new_points)))
+        new_points = torch.max(new_points, 2)[0]
+        return new_xyz.permute(0, 2, 1), new_points
+
+
+class PointNetSetAbstractionMsg(nn.Module):
+    """:202-259."""
+
+    def __init__(self, npoint, radius_list, nsample_list, in_channel, mlp_list, exact=False):
+        super().__init__()
+        self.npoint, self.radius_list, self.nsample_list, self.exact = npoint, radius_list, nsample_list, exact
+        self.conv_blocks, self.bn_blocks = nn.ModuleList(), nn.ModuleList()
+        for mlp in mlp_list:
+            convs, bns = nn.ModuleList(), nn.ModuleList()
+            last = in_channel + 3
+            for oc in mlp:
+                convs.append(nn.Conv2d(last, oc, 1))
+                bns.append(nn.BatchNorm2d(oc))
+                last = oc
+            self.conv_blocks.append(convs)
+            self.bn_blocks.append(bns)
+
+    def forward(self, xyz, points):
+        xyz = xyz.permute(0, 2, 1)
+        if points is not None:
+            points = points.permute(0, 2, 1)
+        B, N, C = xyz.shape
+        S = self.npoint
+        new_xyz = index_points(xyz, farthest_point_sample(xyz, S))
+        outs = []
+        for i, radius in enumerate(self.radius_list):
+            group_idx = query_ball_point(radius, self.nsample_list[i], xyz, new_xyz, self.exact)
+            grouped_xyz = index_points(xyz, group_idx) - new_xyz.view(B, S, 1, C)
+            g = torch.cat([index_points(points, group_idx), grouped_xyz], dim=-1) if points is not None else grouped_xyz
+            g = g.permute(0, 3, 2, 1)
+            for conv, bn in zip(self.conv_blocks[i], self.bn_blocks[i]):
+                g = F.relu(bn(conv(g)))
+            outs.append(torch.max(g, 2)[0])
+        return new_xyz.permute(0, 2, 1), torch.cat(outs, dim=1)
+
+
+class PointNet_Ssg(nn.Module):
+    """pointnet2_SSG.py:230-254."""
+
+    def __init__(self, num_classes=40, exact=False):
+        super().__init__()
+        self.sa1 = PointNetSetAbstraction(512, 0.2, 32, 3, [64, 64, 128], False, exact)
+        self.sa2 = PointNetSetAbstraction(128, 0.4, 64, 128 + 3, [128, 128, 256], False, exact)
+        self.sa3 = PointNetSetAbstraction(None, None, None, 256 + 3, [256, 512, 1024], True, exact)
+        self.fc1, self.bn1, self.drop1 = nn.Linear(1024, 512), nn.BatchNorm1d(512), nn.Dropout(0.4)
+        self.fc2, self.bn2, self.drop2 = nn.Linear(512, 256), nn.BatchNorm1d(256), nn.Dropout(0.4)
+        self.fc3 = nn.Linear(256, num_classes)
+
+    def forward(self, xyz):
+        B = xyz.shape[0]
+        l1_xyz, l1_points = self.sa1(xyz, None)
+        l2_xyz, l2_points = self.sa2(l1_xyz, l1_points)
+        l3_xyz, l3_points = self.sa3(l2_xyz, l2_points)
+        x = l3_points.view(B, 1024)
+        x = self.drop1(F.relu(self.bn1(self.fc1(x))))
+        x = self.drop2(F.relu(self.bn2(self.fc2(x))))
+        x = F.log_softmax(self.fc3(x), -1)
+        return x, x, x
+
+
+class PointNet_Msg(nn.Module):
+    """pointnet2_MSG.py:194-226 (normal_channel=False as the attack drivers build it)."""
+
+    def __init__(self, num_class, normal_channel=False, exact=False):
+        super().__init__()
+        assert not normal_channel
+        self.sa1 = PointNetSetAbstractionMsg(512, [0.1, 0.2, 0.4], [16, 32, 128], 0, [[32, 32, 64], [64, 64, 128], [64, 96, 128]], exact)
+        self.sa2 = PointNetSetAbstractionMsg(128, [0.2, 0.4, 0.8], [32, 64, 128], 320, [[64, 64, 128], [128, 128, 256], [128, 128, 256]], exact)
+        self.sa3 = PointNetSetAbstraction(None, None, None, 640 + 3, [256, 512, 1024], True, exact)
+        self.fc1, self.bn1, self.drop1 = nn.Linear(1024, 512), nn.BatchNorm1d(512), nn.Dropout(0.4)
+        self.fc2, self.bn2, self.drop2 = nn.Linear(512, 256), nn.BatchNorm1d(256), nn.Dropout(0.5)
+        self.fc3 = nn.Linear(256, num_class)
+
+    def forward(self, xyz):
+        B = xyz.shape[0]
+        l1_xyz, l1_points = self.sa1(xyz, None)
+        l2_xyz, l2_points = self.sa2(l1_xyz, l1_points)
+        l3_xyz, l3_points = self.sa3(l2_xyz, l2_points)
+        x = l3_points.view(B, 1024)
+        x = self.drop1(F.relu(self.bn1(self.fc1(x))))
+        x = self.drop2(F.relu(self.bn2(self.fc2(x))))
+        x = F.log_softmax(self.fc3(x), -1)
+        return x, x, x

@@ -255,7 +255,66 @@ def gen_cw():
     print("cw.npz:", len(fx), "arrays")
 
 
-SECTIONS = {"metrics": gen_metrics, "pointnet": gen_pointnet, "cw": gen_cw}
+def gen_pointnet2():
+    """PointNet++ ops (FPS / ball query / grouping) and the SSG / MSG classifiers of the reference on seeded inputs.
+    The reference draws the FPS start index from the global CPU generator (pointnet2_utils.py:72): every call below is
+    preceded by torch.manual_seed so the tests can replay the same stream."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from oracle.ref_torch import seeded_state_dict, state_sha256
+    from model import pointnet2_utils as pu
+    from model.pointnet2_SSG import PointNet_Ssg
+    from model.pointnet2_MSG import PointNet_Msg
+    rng = np.random.default_rng(2468)
+    fx = {}
+    real = load_real_clouds()
+    face = real.get("face0424")
+    clouds = {"rand_b3_n1024": np.stack([unit_cloud(rng, 1024) for _ in range(3)]),
+              "rand_b2_n300": np.stack([unit_cloud(rng, 300) for _ in range(2)])}
+    if face is not None:
+        sub = face[:: max(1, face.shape[0] // 2048)][:2048].astype(np.float64)
+        sub = sub - sub.mean(0, keepdims=True)
+        sub = (sub / np.max(np.linalg.norm(sub, axis=1))).astype(np.float32)
+        clouds["face_b1_n2048"] = sub[None]
+    fx["names"] = np.array(sorted(clouds))
+    for nm in sorted(clouds):
+        xyz = torch.from_numpy(clouds[nm])
+        B, N, _ = xyz.shape
+        S, r, ns = min(128, N // 2), 0.25, 16
+        fx[f"{nm}_xyz"] = clouds[nm]
+        fx[f"{nm}_cfg"] = np.array([S, r, ns])
+        torch.manual_seed(11)
+        fps = pu.farthest_point_sample(xyz, S)
+        fx[f"{nm}_fps"] = fps.numpy()
+        new_xyz = pu.index_points(xyz, fps)
+        idx = pu.query_ball_point(r, ns, xyz, new_xyz)
+        fx[f"{nm}_ball"] = idx.numpy()
+        # distance of every point to the ball surface, so tests can tolerate the expansion's rounding at the rim
+        d = ((new_xyz[:, :, None, :].double() - xyz[:, None, :, :].double()) ** 2).sum(-1)
+        fx[f"{nm}_rim"] = np.abs(d.numpy() - r * r).min(axis=2).astype(np.float32)
+        feats = torch.from_numpy(rng.standard_normal((B, N, 5)).astype(np.float32))
+        fx[f"{nm}_feats"] = feats.numpy()
+        torch.manual_seed(11)
+        nx, npts = pu.sample_and_group(S, r, ns, xyz, feats)
+        fx[f"{nm}_sg_new_xyz"], fx[f"{nm}_sg_new_points"] = nx.numpy(), npts.numpy()
+    # classifiers
+    for cname, cls, kw in (("ssg", PointNet_Ssg, dict(num_classes=40)), ("msg", PointNet_Msg, dict(num_class=40, normal_channel=False))):
+        m = cls(**kw)
+        sd = seeded_state_dict(m, 3)
+        m.load_state_dict(sd)
+        m.eval()
+        fx[f"{cname}_sha256"] = np.array(state_sha256(sd))
+        x = np.stack([unit_cloud(rng, 1024) for _ in range(2)]).transpose(0, 2, 1).copy()
+        tx = torch.from_numpy(x).requires_grad_()
+        torch.manual_seed(21)
+        logp = m(tx)[0]
+        w = torch.from_numpy(rng.standard_normal(logp.shape).astype(np.float32))
+        (logp * w).sum().backward()
+        fx[f"{cname}_x"], fx[f"{cname}_logp"], fx[f"{cname}_w"], fx[f"{cname}_gx"] = x, logp.detach().numpy(), w.numpy(), tx.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "pointnet2.npz"), **fx)
+    print("pointnet2.npz:", len(fx), "arrays")
+
+
+SECTIONS = {"metrics": gen_metrics, "pointnet": gen_pointnet, "cw": gen_cw, "pointnet2": gen_pointnet2}
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(SECTIONS)

@@ -122,3 +122,32 @@ def test_oracle_cw_attack_matches_reference():
         np.testing.assert_allclose(bd, fx[f"{nm}_bestdist"], rtol=1e-5, err_msg=str(nm))
         np.testing.assert_allclose(ba, fx[f"{nm}_bestattack"], atol=2e-6, err_msg=str(nm))
         assert sn == int(fx[f"{nm}_success"])
+
+
+def test_oracle_pointnet2_matches_reference():
+    fx = np.load(os.path.join(GOLDEN, "pointnet2.npz"))
+    for nm in fx["names"]:
+        xyz = torch.from_numpy(fx[f"{nm}_xyz"])
+        S, r, ns = fx[f"{nm}_cfg"]
+        S, ns = int(S), int(ns)
+        torch.manual_seed(11)
+        fps = ort.farthest_point_sample(xyz, S)
+        assert np.array_equal(fps.numpy(), fx[f"{nm}_fps"]), nm
+        new_xyz = ort.index_points(xyz, fps)
+        assert np.array_equal(ort.query_ball_point(float(r), ns, xyz, new_xyz).numpy(), fx[f"{nm}_ball"]), nm
+        torch.manual_seed(11)
+        nx, npts = ort.sample_and_group(S, float(r), ns, xyz, torch.from_numpy(fx[f"{nm}_feats"]))
+        np.testing.assert_array_equal(nx.numpy(), fx[f"{nm}_sg_new_xyz"])
+        np.testing.assert_array_equal(npts.numpy(), fx[f"{nm}_sg_new_points"])
+    for cname, cls in (("ssg", ort.PointNet_Ssg), ("msg", ort.PointNet_Msg)):
+        m = cls(40)
+        sd = ort.seeded_state_dict(m, 3)
+        m.load_state_dict(sd)
+        m.eval()
+        assert ort.state_sha256(sd) == str(fx[f"{cname}_sha256"])
+        x = torch.from_numpy(fx[f"{cname}_x"]).requires_grad_()
+        torch.manual_seed(21)
+        logp = m(x)[0]
+        np.testing.assert_allclose(logp.detach().numpy(), fx[f"{cname}_logp"], rtol=1e-5, atol=1e-6)
+        (logp * torch.from_numpy(fx[f"{cname}_w"])).sum().backward()
+        np.testing.assert_allclose(x.grad.numpy(), fx[f"{cname}_gx"], rtol=1e-4, atol=1e-6)

@@ -1,0 +1,155 @@
+"""GPU parity: FPS / ball query / grouping kernels and the PointNet++ SSG / MSG mirrors vs the reference's golden
+outputs and the oracle."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from helpers import unit_cloud
+from oracle import ref_torch as ort
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fx():
+    return np.load(os.path.join(GOLDEN, "pointnet2.npz"))
+
+
+@pytest.fixture(scope="module")
+def pu():
+    return importlib.import_module("3dpointcloudattack_amd.model.pointnet2_utils")
+
+
+def test_fps_indices_bit_exact_vs_reference(pu, dev, fx):
+    for nm in fx["names"]:
+        xyz = torch.from_numpy(fx[f"{nm}_xyz"]).to(dev)
+        S = int(fx[f"{nm}_cfg"][0])
+        torch.manual_seed(11)                       # same global-RNG stream as the reference's randint (:72)
+        got = pu.farthest_point_sample(xyz, S)
+        assert got.dtype == torch.int64
+        assert np.array_equal(got.cpu().numpy(), fx[f"{nm}_fps"]), nm
+
+
+@pytest.mark.parametrize("B,N,S", [(1, 1, 1), (2, 7, 7), (3, 257, 100), (2, 4096, 1024), (1, 8192, 16)])
+def test_fps_edge_sizes_vs_oracle(ops, dev, B, N, S):
+    rng = np.random.default_rng(N)
+    xyz = torch.from_numpy(np.stack([unit_cloud(rng, N) for _ in range(B)]))
+    start = torch.from_numpy(rng.integers(0, N, size=B).astype(np.int32))
+    ref = ort.farthest_point_sample(xyz, S, start)
+    got = ops.fps(xyz.to(dev), S, start.to(dev))
+    assert np.array_equal(got.cpu().numpy(), ref.numpy())
+    # channel-first view and default start 0 (CurveNet convention)
+    got0 = ops.fps(xyz.to(dev).transpose(1, 2).contiguous(), S, None, cf=True)
+    assert np.array_equal(got0.cpu().numpy(), ort.farthest_point_sample(xyz, S, torch.zeros(B, dtype=torch.long)).numpy())
+
+
+def test_fps_duplicate_points_lowest_index(ops, dev):
+    xyz = torch.zeros(1, 10, 3)
+    xyz[0, 5:] = 1.0                                # two clusters of identical points
+    got = ops.fps(xyz.to(dev), 4, torch.tensor([2], dtype=torch.int32, device=dev)).cpu().numpy()
+    assert got.tolist() == ort.farthest_point_sample(xyz, 4, torch.tensor([2])).numpy().tolist()
+
+
+def test_ball_query_vs_reference_with_rim_band(pu, dev, fx):
+    """Identical to the reference except for points within fp32 rounding of the ball surface (its expansion vs our
+    direct difference); and bit-identical to the oracle evaluated in the direct form."""
+    for nm in fx["names"]:
+        xyz = torch.from_numpy(fx[f"{nm}_xyz"])
+        S, r, ns = fx[f"{nm}_cfg"]
+        S, ns, r = int(S), int(ns), float(r)
+        new_xyz = ort.index_points(xyz, torch.from_numpy(fx[f"{nm}_fps"]))
+        got = pu.query_ball_point(r, ns, xyz.to(dev), new_xyz.to(dev)).cpu().numpy()
+        exact = ort.query_ball_point(r, ns, xyz, new_xyz, exact=True).numpy()
+        assert np.array_equal(got, exact), nm
+        ref = fx[f"{nm}_ball"]
+        diff_rows = np.any(got != ref, axis=2)
+        assert np.all(fx[f"{nm}_rim"][diff_rows] < 1e-6), nm      # only centroids with a point on the rim may differ
+        assert diff_rows.mean() < 0.01
+
+
+def test_ball_query_no_hit_and_padding(ops, dev):
+    xyz = torch.tensor([[[0., 0, 0], [1, 0, 0], [0.05, 0, 0], [5, 5, 5]]], device=dev)
+    ctr = torch.tensor([[[0., 0, 0], [9, 9, 9]]], device=dev)
+    out = ops.ball_query(0.1, 4, xyz, ctr).cpu().numpy()
+    assert out[0, 0].tolist() == [0, 2, 0, 0]       # two hits, padded with the first
+    assert out[0, 1].tolist() == [4, 4, 4, 4]       # no hit: N, like the reference's sort leaves it
+
+
+def test_sample_and_group_matches_reference(pu, dev, fx):
+    for nm in fx["names"]:
+        xyz = torch.from_numpy(fx[f"{nm}_xyz"]).to(dev)
+        feats = torch.from_numpy(fx[f"{nm}_feats"]).to(dev)
+        S, r, ns = fx[f"{nm}_cfg"]
+        torch.manual_seed(11)
+        nx, npts = pu.sample_and_group(int(S), float(r), int(ns), xyz, feats)
+        np.testing.assert_array_equal(nx.cpu().numpy(), fx[f"{nm}_sg_new_xyz"])
+        ref = fx[f"{nm}_sg_new_points"]
+        same = np.all(np.isclose(npts.cpu().numpy(), ref, rtol=0, atol=1e-6), axis=(2, 3))
+        assert same.mean() > 0.99                      # rows with a rim point may group differently
+        assert np.all(fx[f"{nm}_rim"][~same] < 1e-6)
+
+
+def test_group_gather_backward_vs_torch(ops, dev):
+    torch.manual_seed(0)
+    B, N, S, ns, D = 2, 50, 7, 5, 6
+    xyz = torch.randn(B, N, 3, device=dev, requires_grad=True)
+    feat = torch.randn(B, N, D, device=dev, requires_grad=True)
+    idx = torch.randint(0, N, (B, S, ns), device=dev, dtype=torch.int32)
+    cidx = torch.randint(0, N, (B, S), device=dev, dtype=torch.int32)
+    centers = torch.gather(xyz, 1, cidx.long()[:, :, None].expand(-1, -1, 3))
+    out = ops.group_gather(xyz, feat, idx, centers=centers.detach(), center_idx=cidx)
+    w = torch.randn_like(out)
+    (out * w).sum().backward()
+    gx, gf = xyz.grad.clone(), feat.grad.clone()
+    xyz.grad = feat.grad = None
+    bi = torch.arange(B, device=dev)[:, None, None]
+    ref = torch.cat([xyz[bi, idx.long()] - xyz[torch.arange(B, device=dev)[:, None], cidx.long()][:, :, None, :],
+                     feat[bi, idx.long()]], dim=-1)
+    torch.testing.assert_close(out, ref.detach())
+    (ref * w).sum().backward()
+    torch.testing.assert_close(gx, xyz.grad, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(gf, feat.grad, rtol=1e-5, atol=1e-5)
+
+
+def _hip_model(name, dev):
+    mod = importlib.import_module(f"3dpointcloudattack_amd.model.pointnet2_{name.upper()}")
+    m = mod.PointNet_Ssg(40) if name == "ssg" else mod.PointNet_Msg(40, normal_channel=False)
+    sd = ort.seeded_state_dict(m, 3)
+    m.load_state_dict(sd)
+    return m.eval().to(dev), ort.state_sha256(sd)
+
+
+@pytest.mark.parametrize("name", ["ssg", "msg"])
+def test_classifier_logits_and_input_grad_vs_reference(dev, fx, name):
+    model, sha = _hip_model(name, dev)
+    assert sha == str(fx[f"{name}_sha256"])
+    x = torch.from_numpy(fx[f"{name}_x"]).to(dev).requires_grad_()
+    torch.manual_seed(21)
+    out = model(x)
+    assert len(out) == 3
+    logp = out[0]
+    ref = fx[f"{name}_logp"]
+    # a rim point entering/leaving a group (see above) changes a max-pooled feature: compare with a loose bound and
+    # demand equal predictions
+    np.testing.assert_allclose(logp.detach().cpu().numpy(), ref, rtol=5e-3, atol=5e-3)
+    assert np.array_equal(logp.argmax(1).cpu().numpy(), ref.argmax(1))
+    (logp * torch.from_numpy(fx[f"{name}_w"]).to(dev)).sum().backward()
+    got, gref = x.grad.cpu().numpy(), fx[f"{name}_gx"]
+    assert np.linalg.norm(got - gref) / np.linalg.norm(gref) < 5e-2
+    # strict check against the oracle run with the SAME (direct-difference) ball membership
+    oc = (ort.PointNet_Ssg if name == "ssg" else ort.PointNet_Msg)(40, exact=True)
+    oc.load_state_dict(ort.seeded_state_dict(oc, 3))
+    oc.eval()
+    xo = torch.from_numpy(fx[f"{name}_x"]).requires_grad_()
+    torch.manual_seed(21)
+    lo = oc(xo)[0]
+    np.testing.assert_allclose(logp.detach().cpu().numpy(), lo.detach().numpy(), rtol=1e-4, atol=5e-5)
+    (lo * torch.from_numpy(fx[f"{name}_w"])).sum().backward()
+    go = xo.grad.numpy()
+    close = np.isclose(got, go, rtol=5e-3, atol=2e-5 * np.abs(go).max())
+    assert close.mean() > 0.97       # max-pool arg-max near-ties move single contributions (9 max-pools in MSG)
+    assert np.linalg.norm(got - go) / np.linalg.norm(go) < 1e-2
