@@ -1,0 +1,155 @@
+"""kNN attack (AAAI'20) — MI355X mirror of attack/KNN/KNN_attack.py: one long Adam run (no binary search) with a
+Chamfer (+ optional kNN-distance) regulariser and inner-point projection + per-point clip.
+
+Same constructor / ``attack(data, target)`` signature and return values (attack/KNN/KNN_attack.py:19-20,56,244-246).
+The loop (:99-141) runs on the device without host synchronisation: the per-iteration ``.item()`` success count
+(:113-115) is dropped from the loop (it only fed a discarded local), Adam + ProjectInnerClipLinf are ONE HIP launch
+when the clip functor is this package's own, and the regularisers are the fused NN / kNN kernels. B > 1 works; the
+transfer / fail counters are sums over the batch. Transfer models may be ``None`` (skipped).
+"""
+import numpy as np
+import torch
+import torch.optim as optim
+
+from ... import ops
+from ..CW.CW_utils import clip_utils as _clip_utils
+from ..CW.CW_utils import dist_utils as _dist_utils
+
+
+def rand_row(array, dim_needed):
+    """attack/KNN/KNN_attack.py:8-13."""
+    row_total = array.shape[0]
+    row_sequence = np.arange(row_total)
+    np.random.shuffle(row_sequence)
+    return array[row_sequence[0:dim_needed], :]
+
+
+def _logits_of(out):
+    return out[0] if isinstance(out, tuple) else out
+
+
+class CWKNN:
+    """Class for CW attack."""
+
+    def __init__(self, model, pt_model, ptm_model, pts_model, dgcnn_model, cur_model, adv_func, dist_func, clip_func,
+                 attack_lr=1e-3, num_iter=2500, attack_method='untarget', device=None, verbose=False, fused=True):
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+
+        def prep(m):
+            if m is None:
+                return None
+            m = m.to(self.device)
+            m.eval()
+            return m
+
+        self.model = prep(model)
+        self.pt_model = prep(pt_model)
+        self.ptm_model = prep(ptm_model)
+        self.pts_model = prep(pts_model)
+        self.dgcnn_model = prep(dgcnn_model)
+        self.cur_model = prep(cur_model)
+        self.adv_func = adv_func
+        self.dist_func = dist_func
+        self.clip_func = clip_func
+        self.attack_lr = attack_lr
+        self.num_iter = num_iter
+        self.attack_method = attack_method
+        self.shuffle_fail = 0
+        self.trans_fail = 0
+        self.attack_fail = 0
+        self.pt_fail = 0
+        self.ptm_fail = 0
+        self.pts_fail = 0
+        self.dgcnn_fail = 0
+        self.cur_fail = 0
+        self.verbose = verbose
+        self.fused = fused
+
+    def _success(self, pred, target):
+        return (pred != target) if self.attack_method == 'untarget' else (pred == target)
+
+    def _fused_clip(self):
+        """(budget, use_normal) for a recognised clip functor, else None."""
+        cf = self.clip_func
+        if not self.fused or cf is None:
+            return None
+        if type(cf) is _clip_utils.ProjectInnerClipLinf:
+            return float(cf.budget), True
+        if type(cf) in (_clip_utils.ClipPointsLinf, _dist_utils.ClipPointsLinf):
+            return float(cf.budget), False
+        return None
+
+    def attack(self, data, target):
+        """Attack on given data to target.
+        Args:
+            data (torch.FloatTensor): victim data, [B, num_points, 3] (or 6 with normals)
+            target (torch.LongTensor): target output, [B]
+        Returns (adv [B,K,3] float32 numpy, success_num) like the reference (:244-246).
+        """
+        dev = self.device
+        B, K = data.shape[:2]
+        data = data.float().to(dev).detach()
+        data = data.transpose(1, 2).contiguous()
+        ori_data = data.clone().detach()
+        ori_data.requires_grad = False
+
+        # points and normals (:68-73; with xyz only the positions double as "normals", SURVEY A-11)
+        if ori_data.shape[1] == 3:
+            normal = ori_data
+        else:
+            normal = ori_data[:, 3:, :]
+            ori_data = ori_data[:, :3, :]
+
+        # clean forward (:76-78). Kept even when nothing is printed: a PointNet++ victim draws its FPS start indices
+        # from the global RNG on every forward, so skipping it would shift the stream the reference sees.
+        with torch.no_grad():
+            clean_pred = torch.argmax(_logits_of(self.model(ori_data)), dim=1)
+        if self.verbose:
+            print("ori label:", clean_pred.tolist())
+        target = target.long().to(dev).detach().view(-1)
+
+        # init variables with small perturbation (CPU generator like the reference, :84-85)
+        adv_data = ori_data.clone().detach() + torch.randn((B, 3, K)).to(dev) * 1e-7
+        adv_data.requires_grad_()
+        fc = self._fused_clip()
+        if fc is None:
+            opt = optim.Adam([adv_data], lr=self.attack_lr, weight_decay=0.)
+        else:
+            exp_avg, exp_avg_sq = torch.zeros_like(adv_data), torch.zeros_like(adv_data)
+        ori_t = ori_data.transpose(1, 2).contiguous()
+
+        for iteration in range(self.num_iter):
+            logits = _logits_of(self.model(adv_data))  # [B, num_classes]
+            adv_loss = self.adv_func(logits, target).mean()
+            # in the official tensorflow code they use sum instead of mean, hence * K (:119-123)
+            dist_loss = self.dist_func(adv_data.transpose(1, 2).contiguous(), ori_t).mean() * K
+            loss = adv_loss + dist_loss
+            if fc is None:
+                opt.zero_grad()
+                loss.backward()
+                opt.step()
+                adv_data.data = self.clip_func(adv_data.clone().detach(), ori_data, normal)
+            else:
+                adv_data.grad = None
+                loss.backward()
+                ops.adam_clip_step(adv_data.data, adv_data.grad, exp_avg, exp_avg_sq, iteration + 1, self.attack_lr,
+                                   ori=ori_data, normal=normal if fc[1] else None, budget=fc[0])
+
+        # end of CW attack
+        with torch.no_grad():
+            pred = torch.argmax(_logits_of(self.model(adv_data)), dim=-1)  # [B]
+            success_num = int(self._success(pred, target).sum().item())
+            if self.verbose:
+                print('Successfully attack {}/{}'.format(success_num, B))
+            result = adv_data.detach().float()
+            # Test attack + transfer models (:160-240)
+            self.attack_fail += int((~self._success(torch.argmax(_logits_of(self.model(result)), dim=1), target)).sum().item())
+            for name, m in (("pt_fail", self.pt_model), ("ptm_fail", self.ptm_model), ("pts_fail", self.pts_model),
+                            ("dgcnn_fail", self.dgcnn_model), ("cur_fail", self.cur_model)):
+                if m is None:
+                    continue
+                p = torch.argmax(_logits_of(m(result)), dim=1)
+                setattr(self, name, getattr(self, name) + int((~self._success(p, target)).sum().item()))
+
+        adv_np = adv_data.detach().transpose(1, 2).contiguous().cpu().numpy()  # [B, K, 3]
+        return adv_np, success_num

@@ -579,3 +579,42 @@ class PointNet_Msg(nn.Module):
         x = self.drop2(F.relu(self.bn2(self.fc2(x))))
         x = F.log_softmax(self.fc3(x), -1)
         return x, x, x
+
+
+# ----------------------------------------------------------------------------------------------------------
+# KNN attack loop (attack/KNN/KNN_attack.py:56-246)
+# ----------------------------------------------------------------------------------------------------------
+def knn_attack(model, data, target, adv_func, dist_func, clip_func, attack_lr=1e-3, num_iter=2500,
+               attack_method='untarget', record=None):
+    """Returns (adv [B,K,3] float32 numpy, success_num)."""
+    B, K = data.shape[:2]
+    data = data.float().transpose(1, 2).contiguous()
+    ori = data.clone().detach()
+    if ori.shape[1] == 3:
+        normal = ori
+    else:
+        normal, ori = ori[:, 3:, :], ori[:, :3, :]
+    with torch.no_grad():
+        model(ori)                                                   # :76 clean forward (consumes RNG for PointNet++)
+    target = target.long().view(-1)
+    adv = ori.clone().detach() + torch.randn((B, 3, K)) * 1e-7      # :84-85
+    adv.requires_grad_()
+    opt = torch.optim.Adam([adv], lr=attack_lr, weight_decay=0.)
+    for it in range(num_iter):
+        logits = model(adv)
+        logits = logits[0] if isinstance(logits, tuple) else logits
+        if record is not None:
+            record(it, adv.detach().numpy().copy())
+        adv_loss = adv_func(logits, target).mean()
+        dist_loss = dist_func(adv.transpose(1, 2).contiguous(), ori.transpose(1, 2).contiguous()).mean() * K   # :121-123
+        loss = adv_loss + dist_loss
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        adv.data = clip_func(adv.clone().detach(), ori, normal)      # :136
+    with torch.no_grad():
+        logits = model(adv)
+        logits = logits[0] if isinstance(logits, tuple) else logits
+        pred = torch.argmax(logits, dim=-1)
+        succ = (pred != target) if attack_method == 'untarget' else (pred == target)
+    return adv.detach().transpose(1, 2).contiguous().numpy(), int(succ.sum())

@@ -314,7 +314,55 @@ def gen_pointnet2():
     print("pointnet2.npz:", len(fx), "arrays")
 
 
-SECTIONS = {"metrics": gen_metrics, "pointnet": gen_pointnet, "cw": gen_cw, "pointnet2": gen_pointnet2}
+def gen_knn():
+    """Short runs of the REAL reference CWKNN.attack (B=1): PointNet victim (deterministic) with ChamferkNNDist +
+    ProjectInnerClipLinf, and a PointNet++ SSG victim with ChamferDist (Eval_KNN.py:243-244 wiring)."""
+    install_cpu_shim()
+    import contextlib
+    import io
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from oracle.ref_torch import seeded_state_dict
+    from model.pointnet import PointNetCls
+    from model.pointnet2_SSG import PointNet_Ssg
+    from attack.KNN.KNN_attack import CWKNN
+    from attack.CW.CW_utils.adv_utils import UntargetedLogitsAdvLoss
+    from attack.CW.CW_utils.dist_utils import ChamferkNNDist, ChamferDist
+    from attack.CW.CW_utils.clip_utils import ProjectInnerClipLinf
+
+    def seeded(cls, seed, **kw):
+        m = cls(**kw)
+        m.load_state_dict(seeded_state_dict(m, seed))
+        return m.eval()
+
+    rng = np.random.default_rng(999)
+    pn = seeded(PointNetCls, 0, k=40, feature_transform=False)
+    ssg = seeded(PointNet_Ssg, 3, num_classes=40)
+    fx = {}
+    cases = {"pointnet_chamferknn": dict(victim=pn, dist=ChamferkNNDist(), N=256, iters=20, lr=1e-2, kappa=5.),
+             "ssg_chamfer": dict(victim=ssg, dist=ChamferDist(), N=600, iters=6, lr=1e-2, kappa=5.)}
+    fx["names"] = np.array(sorted(cases))
+    for nm in sorted(cases):
+        c = cases[nm]
+        pc = unit_cloud(rng, c["N"])[None]
+        torch.manual_seed(50)
+        with torch.no_grad():
+            clean = int(torch.argmax(c["victim"](torch.from_numpy(pc).transpose(1, 2).contiguous())[0], dim=1))
+        atk = CWKNN(c["victim"], pn, pn, pn, pn, pn, adv_func=UntargetedLogitsAdvLoss(kappa=c["kappa"]),
+                    dist_func=c["dist"], clip_func=ProjectInnerClipLinf(budget=0.18), attack_lr=c["lr"],
+                    num_iter=c["iters"], attack_method='untarget')
+        torch.manual_seed(1000)
+        np.random.seed(1000)
+        with contextlib.redirect_stdout(io.StringIO()):
+            adv, sn = atk.attack(torch.from_numpy(pc), torch.tensor([clean]))
+        fx[f"{nm}_pc"], fx[f"{nm}_target"] = pc, np.array([clean])
+        fx[f"{nm}_cfg"] = np.array([c["iters"], c["lr"], c["kappa"]])
+        fx[f"{nm}_adv"], fx[f"{nm}_success"] = adv.astype(np.float32), np.array(sn)
+        fx[f"{nm}_fails"] = np.array([atk.attack_fail, atk.pt_fail])
+    np.savez_compressed(os.path.join(OUT, "knn.npz"), **fx)
+    print("knn.npz:", len(fx), "arrays")
+
+
+SECTIONS = {"metrics": gen_metrics, "pointnet": gen_pointnet, "cw": gen_cw, "pointnet2": gen_pointnet2, "knn": gen_knn}
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(SECTIONS)

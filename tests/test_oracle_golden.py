@@ -151,3 +151,21 @@ def test_oracle_pointnet2_matches_reference():
         np.testing.assert_allclose(logp.detach().numpy(), fx[f"{cname}_logp"], rtol=1e-5, atol=1e-6)
         (logp * torch.from_numpy(fx[f"{cname}_w"])).sum().backward()
         np.testing.assert_allclose(x.grad.numpy(), fx[f"{cname}_gx"], rtol=1e-4, atol=1e-6)
+
+
+def test_oracle_knn_attack_matches_reference():
+    fx = np.load(os.path.join(GOLDEN, "knn.npz"))
+    pn, _ = _oracle_pointnet(0)
+    ssg = ort.PointNet_Ssg(40)
+    ssg.load_state_dict(ort.seeded_state_dict(ssg, 3))
+    ssg.eval()
+    for nm in fx["names"]:
+        iters, lr, kappa = fx[f"{nm}_cfg"]
+        victim = pn if str(nm).startswith("pointnet") else ssg
+        dist = ort.ChamferkNNDist() if "chamferknn" in str(nm) else ort.ChamferDist()
+        torch.manual_seed(1000)
+        adv, sn = ort.knn_attack(victim, torch.from_numpy(fx[f"{nm}_pc"]), torch.from_numpy(fx[f"{nm}_target"]),
+                                 ort.UntargetedLogitsAdvLoss(kappa), dist, ort.ProjectInnerClipLinf(0.18),
+                                 attack_lr=float(lr), num_iter=int(iters))
+        np.testing.assert_allclose(adv, fx[f"{nm}_adv"], atol=2e-6, err_msg=str(nm))
+        assert sn == int(fx[f"{nm}_success"])
