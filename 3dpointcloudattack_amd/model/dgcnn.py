@@ -1,0 +1,108 @@
+"""DGCNN classifier — MI355X mirror of model/dgcnn.py (``knn``, ``get_graph_feature``, ``DGCNN``; same module tree and
+``state_dict`` keys, incl. the BatchNorm modules registered twice as ``bnX`` and ``convX.1``).
+
+EdgeConv is evaluated without the [B,2C,N,k] edge tensor: with W = [Wa | Wb] (1x1 conv on [x_j - x_i ; x_i]),
+    W [x_j - x_i ; x_i] = Wa x_j + (Wb - Wa) x_i = P_j + Q_i ,
+and because eval-BatchNorm (folded into Wa, Wb) and LeakyReLU are monotone per channel once the BN scale is folded,
+    max_j leaky(bn(W e_ij)) = leaky(max_j P_j + Q_i + t).
+So an EdgeConv layer = two point-wise GEMMs + one neighbour gather-max launch (pc3d_gather_max_f32); the dynamic graph
+comes from pc3d_knn_f32 (xyz) / pc3d_knn_feat_f32 (fp32 MFMA, LDS-resident similarity strips). The reference builds
+335-671 MB edge tensors per layer at B=32.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from .pointnet import _FrozenFusedMixin, _fold_bn, _plain
+
+
+def knn(x, k):
+    """model/dgcnn.py:194-200 — x [B,C,N] -> idx [B,N,k] int64 (self included, nearest first)."""
+    xt = x.transpose(2, 1).contiguous().float()
+    if xt.shape[2] == 3:
+        return ops.knn_raw(xt, xt, k)[1].long()
+    return ops.knn_feat(xt, k).long()
+
+
+def get_graph_feature(x, k=20, idx=None):
+    """:203-227 — dense edge features [B,2C,N,k] = [x_j - x_i ; x_i] for callers that want the tensor."""
+    B, C, N = x.shape
+    xt = x.transpose(2, 1).contiguous().float()                       # [B,N,C]
+    if idx is None:
+        idx = knn(x, k)
+    nb = ops.group_gather(None, xt, idx.to(torch.int32).contiguous())  # [B,N,k,C]
+    ctr = xt.view(B, N, 1, C).expand(-1, -1, nb.shape[2], -1)
+    return torch.cat((nb - ctr, ctr), dim=3).permute(0, 3, 1, 2).contiguous()
+
+
+def _fold_edge(conv, bn):
+    """Conv2d(2C -> C', bias=False) + BatchNorm2d -> (U [C',C], V [C',C], t [C']) with y_ij = U x_j + V x_i + t."""
+    w = conv.weight.detach().reshape(conv.weight.shape[0], -1).float()
+    C = w.shape[1] // 2
+    s = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+    t = bn.bias.detach().float() - bn.running_mean.detach().float() * s
+    wa, wb = w[:, :C], w[:, C:]
+    return (wa * s[:, None]).contiguous(), ((wb - wa) * s[:, None]).contiguous(), t.contiguous()
+
+
+class DGCNN(_FrozenFusedMixin, nn.Module):
+    """model/dgcnn.py:262-328. ``args`` needs ``k``, ``emb_dims``, ``dropout``."""
+
+    def __init__(self, args, output_channels=105 + 1):
+        super(DGCNN, self).__init__()
+        self.args = args
+        self.k = args.k
+
+        self.bn1 = nn.BatchNorm2d(64)
+        self.bn2 = nn.BatchNorm2d(64)
+        self.bn3 = nn.BatchNorm2d(128)
+        self.bn4 = nn.BatchNorm2d(256)
+        self.bn5 = nn.BatchNorm1d(args.emb_dims)
+
+        self.conv1 = nn.Sequential(nn.Conv2d(6, 64, kernel_size=1, bias=False), self.bn1, nn.LeakyReLU(negative_slope=0.2))
+        self.conv2 = nn.Sequential(nn.Conv2d(64 * 2, 64, kernel_size=1, bias=False), self.bn2, nn.LeakyReLU(negative_slope=0.2))
+        self.conv3 = nn.Sequential(nn.Conv2d(64 * 2, 128, kernel_size=1, bias=False), self.bn3, nn.LeakyReLU(negative_slope=0.2))
+        self.conv4 = nn.Sequential(nn.Conv2d(128 * 2, 256, kernel_size=1, bias=False), self.bn4, nn.LeakyReLU(negative_slope=0.2))
+        self.conv5 = nn.Sequential(nn.Conv1d(512, args.emb_dims, kernel_size=1, bias=False), self.bn5, nn.LeakyReLU(negative_slope=0.2))
+        self.linear1 = nn.Linear(args.emb_dims * 2, 512, bias=False)
+        self.bn6 = nn.BatchNorm1d(512)
+        self.dp1 = nn.Dropout(p=args.dropout)
+        self.linear2 = nn.Linear(512, 256)
+        self.bn7 = nn.BatchNorm1d(256)
+        self.dp2 = nn.Dropout(p=args.dropout)
+        self.linear3 = nn.Linear(256, output_channels)
+        self._folded_cache = None
+
+    def folded(self):
+        if self._folded_cache is None:
+            edges = [_fold_edge(self.conv1[0], self.bn1), _fold_edge(self.conv2[0], self.bn2),
+                     _fold_edge(self.conv3[0], self.bn3), _fold_edge(self.conv4[0], self.bn4)]
+            c5 = _fold_bn(self.conv5[0].weight, None, self.bn5)
+            head = (_fold_bn(self.linear1.weight, None, self.bn6), _fold_bn(self.linear2.weight, self.linear2.bias, self.bn7),
+                    _plain(self.linear3.weight, self.linear3.bias))
+            object.__setattr__(self, "_folded_cache", (edges, c5, head))
+        return self._folded_cache
+
+    def forward(self, x):
+        self._require_fused(x)
+        edges, c5, head = self.folded()
+        B = x.size(0)
+        f = x.transpose(2, 1).contiguous().float()          # [B,N,3] channels-last from here on
+        feats = []
+        for li, (U, V, t) in enumerate(edges):
+            with torch.no_grad():                           # graph indices are constants for autograd (topk indices)
+                fd = f.detach()
+                idx = ops.knn_raw(fd, fd, self.k)[1] if li == 0 else ops.knn_feat(fd, self.k)
+            P = F.linear(f, U)                              # U x_j
+            Q = F.linear(f, V, t)                           # V x_i + t
+            f = F.leaky_relu(ops.gather_max(P, idx) + Q, negative_slope=0.2)   # == max_j leaky(bn(conv(e_ij)))
+            feats.append(f)
+        g = torch.cat(feats, dim=2)                         # [B,N,512]
+        g = F.leaky_relu(F.linear(g, *c5), negative_slope=0.2)
+        g = torch.cat((g.max(dim=1)[0], g.mean(dim=1)), 1)  # adaptive max / avg pool over N
+        g = F.leaky_relu(F.linear(g, *head[0]), negative_slope=0.2)
+        g = F.leaky_relu(F.linear(g, *head[1]), negative_slope=0.2)
+        g = F.linear(g, *head[2])
+        g = F.log_softmax(g, -1)
+        return g, g, g

@@ -547,3 +547,48 @@ def group_gather(xyz, feat, idx, centers=None, center_idx=None):
     """[B,S,ns,(3)+D] = [xyz[idx]-centers, feat[idx]]. When the centres are xyz[center_idx] pass center_idx (int32
     [B,S]) so their gradient is folded into grad_xyz inside the kernel; otherwise centers gets its own gradient."""
     return _GroupGatherFn.apply(xyz, feat, idx, centers, center_idx)
+
+
+# ------------------------------------------------------------------------------------------------------
+# K3: DGCNN dynamic graph
+# ------------------------------------------------------------------------------------------------------
+def knn_feat(x, K):
+    """x [B,N,C] channels-last features -> int32 [B,N,K] nearest (self first) in feature space."""
+    _check(x, "x")
+    x = x.contiguous()
+    B, N, C = x.shape
+    idx = torch.empty((B, N, K), dtype=torch.int32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.call("pc3d_knn_feat_f32", x.data_ptr(), B, N, C, int(K), idx.data_ptr(), _stream())
+    return idx
+
+
+class _GatherMaxFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, P, idx):
+        P = P.contiguous()
+        B, N, C = P.shape
+        K = idx.shape[2]
+        out = torch.empty_like(P)
+        arg = torch.empty((B, N, C), dtype=torch.int32, device=P.device)
+        with torch.cuda.device(P.device):
+            _lib.call("pc3d_gather_max_f32", P.data_ptr(), idx.data_ptr(), 0, B, N, C, K, out.data_ptr(),
+                      arg.data_ptr(), _stream())
+        ctx.save_for_backward(arg)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (arg,) = ctx.saved_tensors
+        g = g.contiguous()
+        B, N, C = g.shape
+        gP = torch.empty_like(g)
+        with torch.cuda.device(g.device):
+            _lib.call("pc3d_gather_max_bwd_f32", g.data_ptr(), arg.data_ptr(), B, N, C, gP.data_ptr(), _stream())
+        return gP, None
+
+
+def gather_max(P, idx):
+    """out[b,i,c] = max_j P[b, idx[b,i,j], c]; differentiable in P (gradient to the arg-max neighbour)."""
+    _check(P, "P")
+    return _GatherMaxFn.apply(P, idx.contiguous())

@@ -247,6 +247,21 @@ int pc3d_group_gather_f32(const float* xyz, int64_t x_bs, int64_t x_ps, int64_t 
 int pc3d_group_gather_bwd_f32(const float* g_out, const int32_t* idx, const int32_t* center_idx, int B, int N, int S,
                               int ns, int D, int has_xyz, float* grad_xyz, float* grad_feat, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * K3  DGCNN dynamic graph (model/dgcnn.py:194-227,299-313).
+ * pc3d_knn_feat_f32: idx[b,i,:] = the K nearest points of i in C-dimensional feature space (self included, nearest
+ * first, lowest index on ties) for channels-last features x [B,N,C]; C % 8 == 0, C <= 128, N <= 1024. The
+ * similarity -|xi-xj|^2 = 2 xi.xj - |xi|^2 - |xj|^2 strip of 32 queries is formed by fp32 MFMA in LDS and reduced by
+ * wave arg-max rounds; nothing of size N*N reaches HBM (the reference writes [B,N,N] and calls topk).
+ * pc3d_gather_max_f32: out[b,i,c] = max (sign[c] < 0: min; sign NULL: max) over j in idx[b,i,:] of P[b,j,c], with
+ * the winning j in arg (may be NULL) — the neighbour reduction of an EdgeConv expressed as W[xj-xi; xi] = P_j + Q_i.
+ * pc3d_gather_max_bwd_f32: gP[b,arg,c] += g (gP overwritten; float atomics).
+ * ------------------------------------------------------------------------------------------------------- */
+int pc3d_knn_feat_f32(const float* x, int B, int N, int C, int K, int32_t* idx, void* stream);
+int pc3d_gather_max_f32(const float* P, const int32_t* idx, const float* sign, int B, int N, int C, int K,
+                        float* out, int32_t* arg, void* stream);
+int pc3d_gather_max_bwd_f32(const float* g, const int32_t* arg, int B, int N, int C, float* gP, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -618,3 +618,60 @@ def knn_attack(model, data, target, adv_func, dist_func, clip_func, attack_lr=1e
         pred = torch.argmax(logits, dim=-1)
         succ = (pred != target) if attack_method == 'untarget' else (pred == target)
     return adv.detach().transpose(1, 2).contiguous().numpy(), int(succ.sum())
+
+
+# ----------------------------------------------------------------------------------------------------------
+# DGCNN (model/dgcnn.py:194-227, 262-328)
+# ----------------------------------------------------------------------------------------------------------
+def dgcnn_knn(x, k):
+    """:194-200 — top-k of the negative squared distance (expansion form), self included."""
+    inner = -2 * torch.matmul(x.transpose(2, 1), x)
+    xx = torch.sum(x ** 2, dim=1, keepdim=True)
+    pairwise_distance = -xx - inner - xx.transpose(2, 1)
+    return pairwise_distance.topk(k=k, dim=-1)[1]
+
+
+def get_graph_feature(x, k=20, idx=None):
+    """:203-227."""
+    batch_size, num_dims, num_points = x.shape
+    if idx is None:
+        idx = dgcnn_knn(x, k=k)
+    idx_base = torch.arange(0, batch_size).view(-1, 1, 1) * num_points
+    idx = (idx + idx_base).view(-1)
+    xt = x.transpose(2, 1).contiguous()
+    feature = xt.view(batch_size * num_points, -1)[idx, :].view(batch_size, num_points, k, num_dims)
+    xr = xt.view(batch_size, num_points, 1, num_dims).repeat(1, 1, k, 1)
+    return torch.cat((feature - xr, xr), dim=3).permute(0, 3, 1, 2).contiguous()
+
+
+class DGCNN(nn.Module):
+    def __init__(self, args, output_channels=40):
+        super().__init__()
+        self.k = args.k
+        self.bn1, self.bn2, self.bn3, self.bn4 = nn.BatchNorm2d(64), nn.BatchNorm2d(64), nn.BatchNorm2d(128), nn.BatchNorm2d(256)
+        self.bn5 = nn.BatchNorm1d(args.emb_dims)
+        self.conv1 = nn.Sequential(nn.Conv2d(6, 64, 1, bias=False), self.bn1, nn.LeakyReLU(0.2))
+        self.conv2 = nn.Sequential(nn.Conv2d(128, 64, 1, bias=False), self.bn2, nn.LeakyReLU(0.2))
+        self.conv3 = nn.Sequential(nn.Conv2d(128, 128, 1, bias=False), self.bn3, nn.LeakyReLU(0.2))
+        self.conv4 = nn.Sequential(nn.Conv2d(256, 256, 1, bias=False), self.bn4, nn.LeakyReLU(0.2))
+        self.conv5 = nn.Sequential(nn.Conv1d(512, args.emb_dims, 1, bias=False), self.bn5, nn.LeakyReLU(0.2))
+        self.linear1 = nn.Linear(args.emb_dims * 2, 512, bias=False)
+        self.bn6 = nn.BatchNorm1d(512)
+        self.dp1 = nn.Dropout(p=args.dropout)
+        self.linear2 = nn.Linear(512, 256)
+        self.bn7 = nn.BatchNorm1d(256)
+        self.dp2 = nn.Dropout(p=args.dropout)
+        self.linear3 = nn.Linear(256, output_channels)
+
+    def forward(self, x):
+        B = x.size(0)
+        x1 = self.conv1(get_graph_feature(x, k=self.k)).max(dim=-1)[0]
+        x2 = self.conv2(get_graph_feature(x1, k=self.k)).max(dim=-1)[0]
+        x3 = self.conv3(get_graph_feature(x2, k=self.k)).max(dim=-1)[0]
+        x4 = self.conv4(get_graph_feature(x3, k=self.k)).max(dim=-1)[0]
+        x = self.conv5(torch.cat((x1, x2, x3, x4), dim=1))
+        x = torch.cat((F.adaptive_max_pool1d(x, 1).view(B, -1), F.adaptive_avg_pool1d(x, 1).view(B, -1)), 1)
+        x = self.dp1(F.leaky_relu(self.bn6(self.linear1(x)), negative_slope=0.2))
+        x = self.dp2(F.leaky_relu(self.bn7(self.linear2(x)), negative_slope=0.2))
+        x = F.log_softmax(self.linear3(x), -1)
+        return x, x, x

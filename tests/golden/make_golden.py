@@ -167,6 +167,9 @@ def install_cpu_shim():
     # tensor Adam then updates in place — an artefact of the shim, not reference behaviour. Emulate the copy.
     _orig_cpu = torch.Tensor.cpu
     torch.Tensor.cpu = lambda self, *a, **k: _orig_cpu(self, *a, **k).clone()
+    # model/dgcnn.py:209 and curvenet hard-code torch.device('cuda...') in torch.arange: drop the device kwarg
+    _orig_arange = torch.arange
+    torch.arange = lambda *a, **k: _orig_arange(*a, **{kk: vv for kk, vv in k.items() if kk != "device"})
 
 
 def _seeded_pointnet(cls, k, seed):
@@ -362,7 +365,38 @@ def gen_knn():
     print("knn.npz:", len(fx), "arrays")
 
 
-SECTIONS = {"metrics": gen_metrics, "pointnet": gen_pointnet, "cw": gen_cw, "pointnet2": gen_pointnet2, "knn": gen_knn}
+def gen_dgcnn():
+    """Reference DGCNN: kNN indices (xyz + feature space), dense graph feature, logits and input gradient."""
+    install_cpu_shim()
+    import types
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from oracle.ref_torch import seeded_state_dict, state_sha256
+    from model import dgcnn as rd
+    rng = np.random.default_rng(1357)
+    fx = {}
+    args = types.SimpleNamespace(k=20, emb_dims=1024, dropout=0.5)
+    m = rd.DGCNN(args, output_channels=40)
+    sd = seeded_state_dict(m, 5)
+    m.load_state_dict(sd)
+    m.eval()
+    fx["sha256"] = np.array(state_sha256(sd))
+    x = np.stack([unit_cloud(rng, 512) for _ in range(2)]).transpose(0, 2, 1).copy()
+    tx = torch.from_numpy(x).requires_grad_()
+    logp = m(tx)[0]
+    w = torch.from_numpy(rng.standard_normal(logp.shape).astype(np.float32))
+    (logp * w).sum().backward()
+    fx["x"], fx["logp"], fx["w"], fx["gx"] = x, logp.detach().numpy(), w.numpy(), tx.grad.numpy()
+    # primitives
+    feat = rng.standard_normal((2, 64, 300)).astype(np.float32)
+    fx["feat"] = feat
+    fx["feat_knn"] = rd.knn(torch.from_numpy(feat), 20).numpy()
+    fx["xyz_knn"] = rd.knn(torch.from_numpy(x), 20).numpy()
+    fx["graph_feature"] = rd.get_graph_feature(torch.from_numpy(x[:, :, :64].copy()), k=8).numpy()
+    np.savez_compressed(os.path.join(OUT, "dgcnn.npz"), **fx)
+    print("dgcnn.npz:", len(fx), "arrays")
+
+
+SECTIONS = {"dgcnn": gen_dgcnn, "metrics": gen_metrics, "pointnet": gen_pointnet, "cw": gen_cw, "pointnet2": gen_pointnet2, "knn": gen_knn}
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(SECTIONS)

@@ -169,3 +169,21 @@ def test_oracle_knn_attack_matches_reference():
                                  attack_lr=float(lr), num_iter=int(iters))
         np.testing.assert_allclose(adv, fx[f"{nm}_adv"], atol=2e-6, err_msg=str(nm))
         assert sn == int(fx[f"{nm}_success"])
+
+
+def test_oracle_dgcnn_matches_reference():
+    import types
+    fx = np.load(os.path.join(GOLDEN, "dgcnn.npz"))
+    m = ort.DGCNN(types.SimpleNamespace(k=20, emb_dims=1024, dropout=0.5), 40)
+    sd = ort.seeded_state_dict(m, 5)
+    m.load_state_dict(sd)
+    m.eval()
+    assert ort.state_sha256(sd) == str(fx["sha256"])
+    x = torch.from_numpy(fx["x"]).requires_grad_()
+    logp = m(x)[0]
+    np.testing.assert_allclose(logp.detach().numpy(), fx["logp"], rtol=1e-5, atol=1e-6)
+    (logp * torch.from_numpy(fx["w"])).sum().backward()
+    np.testing.assert_allclose(x.grad.numpy(), fx["gx"], rtol=1e-4, atol=1e-6)
+    assert np.array_equal(ort.dgcnn_knn(torch.from_numpy(fx["feat"]), 20).numpy(), fx["feat_knn"])
+    np.testing.assert_array_equal(ort.get_graph_feature(torch.from_numpy(fx["x"][:, :, :64].copy()), k=8).numpy(),
+                                  fx["graph_feature"])
