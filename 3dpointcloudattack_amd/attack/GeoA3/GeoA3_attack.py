@@ -1,0 +1,281 @@
+"""GeoA3 (geometry-aware adversarial attack) — MI355X mirror of attack/GeoA3/GeoA3_attack.py.
+
+``geoA3_attack(net, pt_model, ptm_model, pts_model, dgcnn_model, cur_model, pc, label, cfg, i, loader_len,
+saved_dir=None)`` keeps the reference's signature and 5-tuple return (:185,:473). Differences, all documented in
+DESIGN.md / SURVEY App. A:
+  * the loop is device-resident: the per-step ``.item()`` / ``.tolist()`` calls and the B batch-1 forwards used for
+    the success check (:308-330) are one batched forward + device-side selects; loss curves are transferred once;
+  * the adv->ori nearest-neighbour search is done ONCE per step and shared by the Chamfer, Hausdorff, normal-transfer
+    and curvature terms (the reference repeats it four times, each through a [B,N,N] matrix);
+  * neighbour searches return true squared distances (A-2); the per-sample label drives the scale-constant update
+    (A-7); transfer models get [B,3,N] (A-6) and may be None; debug .xyz dumps (is_debug) are not written.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.optim as optim
+
+from .knn_utils import knn_gather, knn_points
+from .loss_utils import (_get_kappa_adv, _get_kappa_ori, chamfer_loss, curvature_loss, hausdorff_loss, norm_l2_loss,
+                         pseudo_chamfer_loss, uniform_loss)
+from .utility import (_compare, estimate_normal, estimate_perpendicular, farthest_points_sample,
+                      pad_larger_tensor_with_index_batch)
+
+
+def _logits_of(out):
+    return out[0] if isinstance(out, tuple) else out
+
+
+def offset_proj(offset, ori_pc, ori_normal, project='dir'):
+    """GeoA3_attack.py:62-80 — project each offset onto the normal of its nearest ori point (as written: the KNN query
+    is the OFFSET itself, and the 'inner' condition is all-false so every offset is replaced by its projection)."""
+    intra_KNN = knn_points(offset.permute(0, 2, 1), ori_pc.permute(0, 2, 1), K=1)
+    normal = knn_gather(ori_normal.permute(0, 2, 1).contiguous(), intra_KNN.idx).permute(0, 3, 1, 2).squeeze(3).contiguous()
+    normal_len = (normal ** 2).sum(1, keepdim=True).sqrt().expand_as(offset)
+    return (offset * normal / (normal_len + 1e-6)).sum(1, keepdim=True) * normal / (normal_len + 1e-6)
+
+
+def find_offset(ori_pc, adv_pc):
+    """:82-89."""
+    intra_KNN = knn_points(adv_pc.permute(0, 2, 1), ori_pc.permute(0, 2, 1), K=1)
+    knn_pc = knn_gather(ori_pc.permute(0, 2, 1).contiguous(), intra_KNN.idx).permute(0, 3, 1, 2).squeeze(3).contiguous()
+    return adv_pc - knn_pc
+
+
+def lp_clip(offset, cc_linf):
+    """:92-102."""
+    lengths = (offset ** 2).sum(1, keepdim=True).sqrt().expand_as(offset)
+    offset_scaled = torch.where(lengths > 1e-6, offset / lengths * cc_linf, torch.zeros_like(offset))
+    return torch.where(lengths < cc_linf, offset, offset_scaled)
+
+
+def _forward_step(net, pc_ori, input_curr_iter, normal_ori, ori_kappa, target, scale_const, cfg, targeted):
+    """:103-183 — one forward of the victim and all loss terms; returns the reference's 10-tuple."""
+    b, _, n = input_curr_iter.size()
+    dev = input_curr_iter.device
+    output_curr_iter = _logits_of(net(input_curr_iter))
+
+    if cfg.cls_loss_type == 'Margin':
+        target_onehot = torch.zeros(target.size() + (cfg.classes,), device=dev)
+        target_onehot.scatter_(1, target.unsqueeze(1), 1.)
+        fake = (target_onehot * output_curr_iter).sum(1)
+        other = ((1. - target_onehot) * output_curr_iter - target_onehot * 10000.).max(1)[0]
+        if targeted:
+            cls_loss = torch.clamp(other - fake + cfg.confidence, min=0.)
+        else:
+            cls_loss = torch.clamp(fake - other + cfg.confidence, min=0.)
+    elif cfg.cls_loss_type == 'CE':
+        ce = nn.CrossEntropyLoss(reduction='none')(output_curr_iter, target.long())
+        cls_loss = ce if targeted else -ce
+    elif cfg.cls_loss_type == 'None':
+        cls_loss = torch.zeros(b, device=dev)
+    else:
+        assert False, 'Not support such clssification loss'
+
+    # one adv -> ori nearest-neighbour search for every term that needs it
+    need_nn = (cfg.dis_loss_type == 'CD') or cfg.hd_loss_weight != 0 or cfg.curv_loss_weight != 0
+    nn_ao = knn_points(input_curr_iter.permute(0, 2, 1), pc_ori.permute(0, 2, 1), K=1) if need_nn else None
+
+    if cfg.dis_loss_type == 'CD':
+        if cfg.is_cd_single_side:
+            dis_loss = pseudo_chamfer_loss(input_curr_iter, pc_ori, nn_ao)
+        else:
+            dis_loss = chamfer_loss(input_curr_iter, pc_ori, nn_ao)
+        constrain_loss = cfg.dis_loss_weight * dis_loss
+    elif cfg.dis_loss_type == 'L2':
+        assert cfg.hd_loss_weight == 0
+        dis_loss = norm_l2_loss(input_curr_iter, pc_ori)
+        constrain_loss = cfg.dis_loss_weight * dis_loss
+    elif cfg.dis_loss_type == 'None':
+        dis_loss = 0
+        constrain_loss = 0
+    else:
+        assert False, 'Not support such distance loss'
+
+    if cfg.hd_loss_weight != 0:
+        hd_loss = hausdorff_loss(input_curr_iter, pc_ori, nn_ao)
+        constrain_loss = constrain_loss + cfg.hd_loss_weight * hd_loss
+    else:
+        hd_loss = 0
+
+    if cfg.curv_loss_weight != 0:
+        adv_kappa, normal_curr_iter = _get_kappa_adv(input_curr_iter, pc_ori, normal_ori, cfg.curv_loss_knn, nn_ao)
+        curv_loss = curvature_loss(input_curr_iter, pc_ori, adv_kappa, ori_kappa, nn_ao=nn_ao)
+        constrain_loss = constrain_loss + cfg.curv_loss_weight * curv_loss
+    else:
+        normal_curr_iter = torch.zeros(b, 3, n, device=dev)
+        curv_loss = 0
+
+    if cfg.uniform_loss_weight != 0:
+        uniform = uniform_loss(input_curr_iter)
+        constrain_loss = constrain_loss + cfg.uniform_loss_weight * uniform
+
+    scale_const = scale_const.float().to(dev)
+    loss_n = cls_loss + scale_const * constrain_loss
+    loss = loss_n.mean()
+    info = ''
+    return output_curr_iter, normal_curr_iter, loss, loss_n, cls_loss, dis_loss, hd_loss, curv_loss, constrain_loss, info
+
+
+def geoA3_attack(net, pt_model, ptm_model, pts_model, dgcnn_model, cur_model, pc, label, cfg, i, loader_len,
+                 saved_dir=None):
+    """:185-473. pc [B,N,3], label [B]. Returns (best_attack [B,3,N] tensor, target [B], success mask np.bool [B],
+    best_attack_step list[B], all_loss_list [iter_max_steps][B])."""
+    dev = next(net.parameters()).device if any(True for _ in net.parameters()) else torch.device("cuda")
+    transfer = []
+    for m in (pt_model, ptm_model, pts_model, dgcnn_model, cur_model):
+        if m is not None:
+            m = m.to(dev)
+            m.eval()
+        transfer.append(m)
+    targeted = cfg.attack_method != 'untarget'
+
+    pc = pc.transpose(2, 1).float().to(dev)
+    normal = estimate_normal(pc, k=3)
+    b, _, n = pc.size()
+    pc_ori = pc.contiguous().view(b, 3, n)
+    normal_ori = normal.view(b, 3, n)
+    gt_target = label.view(-1).to(dev)
+    target = gt_target
+
+    kappa_ori = _get_kappa_ori(pc_ori, normal_ori, cfg.curv_loss_knn) if cfg.curv_loss_weight != 0 else None
+
+    lower_bound = torch.zeros(b)
+    scale_const = torch.ones(b) * cfg.initial_const
+    upper_bound = torch.ones(b) * 1e10
+
+    best_loss = torch.full((b,), 1e10, device=dev)
+    best_attack = torch.ones(b, 3, n, device=dev)
+    best_attack_step = torch.full((b,), -1, dtype=torch.long, device=dev)
+    best_attack_BS_idx = torch.full((b,), -1, dtype=torch.long, device=dev)
+    loss_curves = []
+    output_label = torch.zeros(b, dtype=torch.long, device=dev)
+    for search_step in range(cfg.binary_max_steps):
+        iter_best_loss = torch.full((b,), 1e10, device=dev)
+        iter_best_score = torch.full((b,), -1, dtype=torch.long, device=dev)
+        constrain_loss = torch.full((b,), 1e10, device=dev)
+        input_all = None
+        loss_curves = []
+
+        for step in range(cfg.iter_max_steps):
+            if cfg.is_partial_var:
+                if step % 50 == 0:
+                    with torch.no_grad():
+                        init_point_idx = np.random.randint(n)
+                        intra_KNN = knn_points(pc_ori[:, :, init_point_idx].unsqueeze(2).permute(0, 2, 1),
+                                               pc_ori.permute(0, 2, 1), K=cfg.knn_range + 1)
+                    part_offset = torch.zeros(b, 3, cfg.knn_range, device=dev)
+                    nn.init.normal_(part_offset, mean=0, std=1e-3)
+                    part_offset.requires_grad_()
+                    if cfg.optim == 'adam':
+                        optimizer = torch.optim.Adam([part_offset], lr=cfg.lr)
+                    elif cfg.optim == 'sgd':
+                        optimizer = torch.optim.SGD([part_offset], lr=cfg.lr, momentum=0.9)
+                    else:
+                        assert False, 'Wrong optimizer!'
+                    lr_scheduler = torch.optim.lr_scheduler.ExponentialLR(optimizer, gamma=0.9990, last_epoch=-1)
+                    periodical_pc = input_all.detach().clone() if input_all is not None else pc_ori.clone()
+            else:
+                if step == 0:
+                    offset = torch.zeros(b, 3, n, device=dev)
+                    nn.init.normal_(offset, mean=0, std=1e-3)
+                    offset.requires_grad_()
+                    if cfg.optim == 'adam':
+                        optimizer = optim.Adam([offset], lr=cfg.lr)
+                    elif cfg.optim == 'sgd':
+                        optimizer = optim.SGD([offset], lr=cfg.lr)
+                    else:
+                        assert False, 'Not support such optimizer.'
+                    lr_scheduler = torch.optim.lr_scheduler.ExponentialLR(optimizer, gamma=0.9990, last_epoch=-1)
+                    periodical_pc = pc_ori.clone()
+
+            if cfg.is_partial_var:
+                offset = pad_larger_tensor_with_index_batch(part_offset, intra_KNN.idx.tolist(), n)
+            input_all = periodical_pc + offset
+
+            if (input_all.size(2) > cfg.npoint) and (not cfg.is_partial_var) and cfg.is_subsample_opt:
+                input_curr_iter = farthest_points_sample(input_all, cfg.npoint)
+            else:
+                input_curr_iter = input_all
+
+            with torch.no_grad():
+                if input_curr_iter.size(2) < input_all.size(2):
+                    votes = torch.zeros(b, device=dev)
+                    for _ in range(cfg.eval_num):
+                        lab = torch.max(_logits_of(net(farthest_points_sample(input_all, cfg.npoint))), 1)[1]
+                        votes += _compare(lab, target, gt_target, targeted).float()
+                        output_label = lab
+                    attack_success = votes > 0.5 * cfg.eval_num
+                else:
+                    output_label = torch.argmax(_logits_of(net(input_curr_iter)), dim=1)
+                    attack_success = _compare(output_label, target, gt_target, targeted)
+                metric = constrain_loss.detach()
+                upd = attack_success & (metric < best_loss)
+                best_loss = torch.where(upd, metric, best_loss)
+                best_attack = torch.where(upd[:, None, None], input_all.detach(), best_attack)
+                best_attack_BS_idx = torch.where(upd, torch.full_like(best_attack_BS_idx, search_step), best_attack_BS_idx)
+                best_attack_step = torch.where(upd, torch.full_like(best_attack_step, step), best_attack_step)
+                upd_i = attack_success & (metric < iter_best_loss)
+                iter_best_loss = torch.where(upd_i, metric, iter_best_loss)
+                iter_best_score = torch.where(upd_i, output_label, iter_best_score)
+
+            if cfg.is_pre_jitter_input:
+                if step % cfg.calculate_project_jitter_noise_iter == 0:
+                    project_jitter_noise = estimate_perpendicular(input_curr_iter, cfg.jitter_k, sigma=cfg.jitter_sigma,
+                                                                  clip=cfg.jitter_clip)
+                else:
+                    project_jitter_noise = project_jitter_noise.clone()
+                input_curr_iter.data = input_curr_iter.data + project_jitter_noise
+
+            _, normal_curr_iter, loss, loss_n, cls_loss, dis_loss, hd_loss, nor_loss, constrain_loss, info = \
+                _forward_step(net, pc_ori, input_curr_iter, normal_ori, kappa_ori, target, scale_const, cfg, targeted)
+            loss_curves.append(loss_n.detach())
+
+            optimizer.zero_grad()
+            if cfg.is_pre_jitter_input:
+                input_curr_iter.retain_grad()
+            loss.backward()
+            if cfg.is_pre_jitter_input:
+                input_all.grad = input_curr_iter.grad
+            optimizer.step()
+            if cfg.is_use_lr_scheduler:
+                lr_scheduler.step()
+
+            if cfg.is_pro_grad:
+                with torch.no_grad():
+                    if cfg.is_real_offset:
+                        offset.data = find_offset(pc_ori, periodical_pc + offset).data
+                    offset.data = offset_proj(offset, pc_ori, normal_ori).data
+
+            if cfg.cc_linf != 0:
+                with torch.no_grad():
+                    offset.data = lp_clip(offset, cfg.cc_linf).data
+
+        # adjust the scale constants (:393-404), one host round trip per search step
+        succ_now = _compare(output_label, target, gt_target, targeted).cpu()
+        ibs = iter_best_score.cpu()
+        for k in range(b):
+            if bool(succ_now[k]) and int(ibs[k]) != -1:
+                lower_bound[k] = max(lower_bound[k], scale_const[k])
+                if upper_bound[k] < 1e9:
+                    scale_const[k] = (lower_bound[k] + upper_bound[k]) * 0.5
+                else:
+                    scale_const[k] *= 2
+            else:
+                upper_bound[k] = min(upper_bound[k], scale_const[k])
+                if upper_bound[k] < 1e9:
+                    scale_const[k] = (lower_bound[k] + upper_bound[k]) * 0.5
+
+    # transfer attack evaluation (:406-471), batched; counters exposed as a function attribute
+    fails = []
+    with torch.no_grad():
+        for m in transfer:
+            if m is None:
+                fails.append(None)
+                continue
+            lab = torch.argmax(_logits_of(m(best_attack.float())), dim=1)
+            fails.append(int(((lab == target) if not targeted else (lab != target)).sum().item()))
+    geoA3_attack.last_transfer_fails = dict(zip(("pt", "ptm", "pts", "dgcnn", "cur"), fails))
+
+    all_loss_list = torch.stack(loss_curves).cpu().tolist() if loss_curves else []
+    return (best_attack, target, (best_loss.cpu().numpy() < 1e10), best_attack_step.cpu().tolist(), all_loss_list)

@@ -1,0 +1,44 @@
+"""MI355X mirror of attack/GeoA3/knn_utils.py — the pytorch3d-compatible ``knn_points`` / ``knn_gather`` pair.
+
+``knn_points`` is one fused HIP launch (pc3d_knn_f32, K <= 32; K == 1 uses the nearest-neighbour kernel) instead of a
+[B,N,M] matrix + topk, and returns TRUE squared distances: the reference adds the squared norms on the wrong axes
+(knn_utils.py:12-15), which is exact only for self-kNN and raises for N != M; this build implements
+the pytorch3d semantics the file stands in for (attack/GeoA3/loss_utils.py:13-14). ``lengths*``, ``version`` and
+``return_sorted`` are accepted and ignored exactly like the reference.
+"""
+from collections import namedtuple
+from typing import Union
+
+import torch
+
+from ... import ops
+
+_KNN = namedtuple("KNN", "dists idx knn")
+
+
+def apply_knn(p1, p2, lengths1, lengths2, K, version, return_sorted):
+    """knn_utils.py:10-20 — (values [B,N,K] ascending, positions [B,N,K] int64)."""
+    d, i = ops.knn(p1.float(), p2.float(), K)
+    return d, i.long()
+
+
+def knn_points(p1: torch.Tensor, p2: torch.Tensor, lengths1: Union[torch.Tensor, None] = None,
+               lengths2: Union[torch.Tensor, None] = None, K: int = 1, version: int = -1,
+               return_nn: bool = False, return_sorted: bool = True) -> _KNN:
+    """knn_utils.py:22-55."""
+    if p1.shape[0] != p2.shape[0]:
+        raise ValueError("pts1 and pts2 must have the same batch dimension.")
+    if p1.shape[2] != p2.shape[2]:
+        raise ValueError("pts1 and pts2 must have the same point dimension.")
+    p1_dists, p1_idx = apply_knn(p1, p2, lengths1, lengths2, K, version, return_sorted)
+    p2_nn = knn_gather(p2, p1_idx, lengths2) if return_nn else None
+    return _KNN(dists=p1_dists, idx=p1_idx, knn=p2_nn)
+
+
+def knn_gather(x: torch.Tensor, idx: torch.Tensor, lengths: Union[torch.Tensor, None] = None):
+    """knn_utils.py:58-86 — x [N,M,U], idx [N,L,K] -> [N,L,K,U] (differentiable in x)."""
+    N, M, U = x.shape
+    _N, L, K = idx.shape
+    if N != _N:
+        raise ValueError("x and idx must have same batch dimension.")
+    return ops.group_gather(None, x.float(), idx.to(torch.int32).contiguous())

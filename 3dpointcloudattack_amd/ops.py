@@ -361,6 +361,9 @@ def knn_raw(q, r, K, q_cf=False, r_cf=False):
         raise ValueError("q and r must have the same batch dimension")
     if not (1 <= K <= min(32, M)):
         raise ValueError(f"K={K} out of range [1, min(32, M={M})]")
+    if K == 1:  # the dedicated nearest-neighbour kernel (split-M, several queries per lane) is faster
+        d1, i1 = nn_raw(q, r, q_cf, r_cf)
+        return d1.unsqueeze(-1), i1.unsqueeze(-1)
     d = torch.empty((B, N, K), dtype=torch.float32, device=q.device)
     i = torch.empty((B, N, K), dtype=torch.int32, device=q.device)
     with torch.cuda.device(q.device):
@@ -384,6 +387,7 @@ class _KnnFn(torch.autograd.Function):
         K, q_cf, r_cf, det = ctx.cfg
         need_q, need_r = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         gd = gd.contiguous()
+        idx = idx.contiguous()
         _, _, _, _, B, N = _pts(q, q_cf, "q")
         _, _, _, _, _, M = _pts(r, r_cf, "r")
         gq = torch.empty(q.shape, dtype=torch.float32, device=q.device) if need_q else None

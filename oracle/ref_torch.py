@@ -675,3 +675,171 @@ class DGCNN(nn.Module):
         x = self.dp2(F.leaky_relu(self.bn7(self.linear2(x)), negative_slope=0.2))
         x = F.log_softmax(self.linear3(x), -1)
         return x, x, x
+
+
+# ----------------------------------------------------------------------------------------------------------
+# GeoA3 (attack/GeoA3/{knn_utils,utility,loss_utils,GeoA3_attack}.py)
+# ----------------------------------------------------------------------------------------------------------
+class GeoA3Oracle:
+    """Restatement of the GeoA3 loop. ``as_written=True`` reproduces knn_utils.py:12-15 literally (squared norms
+    broadcast on the wrong axes, SURVEY App. A-2) — used to pin this oracle against the real reference;
+    ``as_written=False`` uses true squared distances — what the build implements and is compared against."""
+
+    def __init__(self, as_written=True, dtype=None):
+        self.as_written, self.dtype = as_written, dtype
+
+    # -- knn_utils.py
+    def knn_points(self, p1, p2, K=1):
+        if self.dtype is not None:
+            p1, p2 = p1.to(self.dtype), p2.to(self.dtype)
+        inner = -2. * torch.matmul(p1, p2.transpose(2, 1))
+        p1_2 = torch.sum((p1.transpose(2, 1)) ** 2, dim=1, keepdim=True)      # [B,1,N]
+        p2_2 = torch.sum((p2.transpose(2, 1)) ** 2, dim=1, keepdim=True)      # [B,1,M]
+        if self.as_written:
+            dist = p1_2 + inner + p2_2.transpose(2, 1)                        # :15 (wrong axes; N must equal M)
+        else:
+            dist = p1_2.transpose(2, 1) + inner + p2_2
+        value, pos = (-dist).topk(k=K, dim=-1)
+        return (-value).float(), pos
+
+    @staticmethod
+    def knn_gather(x, idx):
+        N, M, U = x.shape
+        _, L, K = idx.shape
+        return x[:, :, None].expand(-1, -1, K, -1).gather(1, idx[:, :, :, None].expand(-1, -1, -1, U))
+
+    @staticmethod
+    def _normalize(v, eps=1e-12):
+        return v / v.norm(2, 1, keepdim=True).clamp(min=eps).expand_as(v)
+
+    # -- utility.py:43-92
+    def estimate_normal(self, pc, k):
+        with torch.no_grad():
+            b, _, n = pc.size()
+            _, idx = self.knn_points(pc.permute(0, 2, 1), pc.permute(0, 2, 1), K=k + 1)
+            nn_pts = self.knn_gather(pc.permute(0, 2, 1), idx).permute(0, 3, 1, 2)[:, :, :, 1:].contiguous()
+            out = []
+            for i in range(b):
+                cps = nn_pts[i].detach().permute(1, 0, 2)
+                cps = cps - torch.mean(cps, dim=2, keepdim=True)
+                cov = (1.0 / (k - 1)) * torch.bmm(cps, cps.permute(0, 2, 1))
+                ev, evec = torch.linalg.eigh(cov)
+                nv = torch.gather(evec, 2, torch.argmin(ev, dim=1).unsqueeze(1).unsqueeze(2).expand(n, 3, 1)).squeeze()
+                sign = -torch.sign(torch.bmm(nv.view(n, 1, 3), cps.sum(dim=2).view(n, 3, 1))).squeeze(2)
+                out.append((sign * nv).permute(1, 0))
+            return torch.stack(out, 0).float()
+
+    # -- loss_utils.py
+    def chamfer_loss(self, adv, ori):
+        d1, _ = self.knn_points(adv.permute(0, 2, 1), ori.permute(0, 2, 1), 1)
+        d2, _ = self.knn_points(ori.permute(0, 2, 1), adv.permute(0, 2, 1), 1)
+        return d1.squeeze(-1).mean(-1) + d2.squeeze(-1).mean(-1)
+
+    def pseudo_chamfer_loss(self, adv, ori):
+        return self.knn_points(adv.permute(0, 2, 1), ori.permute(0, 2, 1), 1)[0].squeeze(-1).mean(-1)
+
+    def hausdorff_loss(self, adv, ori):
+        return self.knn_points(adv.permute(0, 2, 1), ori.permute(0, 2, 1), 1)[0].squeeze(-1).max(-1)[0]
+
+    def _kappa(self, pc, normal, k):
+        _, idx = self.knn_points(pc.permute(0, 2, 1), pc.permute(0, 2, 1), k + 1)
+        nn_pts = self.knn_gather(pc.permute(0, 2, 1), idx).permute(0, 3, 1, 2)[:, :, :, 1:].contiguous()
+        vectors = self._normalize(nn_pts - pc.unsqueeze(3))
+        return torch.abs((vectors * normal.unsqueeze(3)).sum(1)).mean(2)
+
+    def kappa_adv(self, adv, ori, ori_normal, k):
+        _, idx = self.knn_points(adv.permute(0, 2, 1), ori.permute(0, 2, 1), 1)
+        normal = self.knn_gather(ori_normal.permute(0, 2, 1), idx).permute(0, 3, 1, 2).squeeze(3).contiguous()
+        return self._kappa(adv, normal, k), normal
+
+    def curvature_loss(self, adv, ori, adv_kappa, ori_kappa):
+        _, idx = self.knn_points(adv.permute(0, 2, 1), ori.permute(0, 2, 1), 1)
+        return ((adv_kappa - torch.gather(ori_kappa, 1, idx.squeeze(-1))) ** 2).mean(-1)
+
+    # -- GeoA3_attack.py:103-183
+    def forward_step(self, net, pc_ori, x, normal_ori, ori_kappa, target, scale_const, cfg, targeted):
+        out = net(x)[0]
+        if cfg.cls_loss_type == 'Margin':
+            oh = torch.zeros(target.size() + (cfg.classes,)).scatter_(1, target.unsqueeze(1), 1.)
+            fake = (oh * out).sum(1)
+            other = ((1. - oh) * out - oh * 10000.).max(1)[0]
+            cls_loss = torch.clamp((other - fake if targeted else fake - other) + cfg.confidence, min=0.)
+        elif cfg.cls_loss_type == 'CE':
+            ce = nn.CrossEntropyLoss(reduction='none')(out, target.long())
+            cls_loss = ce if targeted else -ce
+        else:
+            cls_loss = torch.zeros(x.shape[0])
+        if cfg.dis_loss_type == 'CD':
+            dis = self.pseudo_chamfer_loss(x, pc_ori) if cfg.is_cd_single_side else self.chamfer_loss(x, pc_ori)
+            constrain = cfg.dis_loss_weight * dis
+        elif cfg.dis_loss_type == 'L2':
+            dis = ((x - pc_ori) ** 2).sum(1).sum(1)
+            constrain = cfg.dis_loss_weight * dis
+        else:
+            dis, constrain = 0, 0
+        hd = 0
+        if cfg.hd_loss_weight != 0:
+            hd = self.hausdorff_loss(x, pc_ori)
+            constrain = constrain + cfg.hd_loss_weight * hd
+        curv = 0
+        if cfg.curv_loss_weight != 0:
+            ak, _ = self.kappa_adv(x, pc_ori, normal_ori, cfg.curv_loss_knn)
+            curv = self.curvature_loss(x, pc_ori, ak, ori_kappa)
+            constrain = constrain + cfg.curv_loss_weight * curv
+        loss_n = cls_loss + scale_const.float() * constrain
+        return out, loss_n.mean(), loss_n, cls_loss, dis, hd, curv, constrain
+
+    # -- GeoA3_attack.py:185-473 (default mode: full offset variable, Adam, no jitter / projection / clip)
+    def attack(self, net, pc, label, cfg, per_sample_label=False):
+        targeted = cfg.attack_method != 'untarget'
+        pc = pc.transpose(2, 1).float()
+        normal = self.estimate_normal(pc, k=3)
+        b, _, n = pc.size()
+        pc_ori, normal_ori = pc.contiguous(), normal
+        gt = label.view(-1)
+        target = gt
+        kappa_ori = self._kappa(pc_ori, normal_ori, cfg.curv_loss_knn) if cfg.curv_loss_weight != 0 else None
+        lower, scale_const, upper = torch.zeros(b), torch.ones(b) * cfg.initial_const, torch.ones(b) * 1e10
+        best_loss = [1e10] * b
+        best_attack = torch.ones(b, 3, n)
+        best_step = [-1] * b
+        all_loss = [[-1] * b] * cfg.iter_max_steps
+        labels_now = [0] * b
+        for search_step in range(cfg.binary_max_steps):
+            iter_best_loss, iter_best_score = [1e10] * b, [-1] * b
+            constrain = torch.ones(b) * 1e10
+            for step in range(cfg.iter_max_steps):
+                if step == 0:
+                    offset = torch.zeros(b, 3, n)
+                    nn.init.normal_(offset, mean=0, std=1e-3)
+                    offset.requires_grad_()
+                    opt = torch.optim.Adam([offset], lr=cfg.lr)
+                x = pc_ori + offset
+                with torch.no_grad():
+                    for k in range(b):
+                        lab = int(torch.argmax(net(x[k].unsqueeze(0))[0]))
+                        labels_now[k] = lab
+                        ok = (lab == int(target[k])) if targeted else (lab != int(gt[k]))
+                        metric = float(constrain[k])
+                        if ok and metric < best_loss[k]:
+                            best_loss[k], best_step[k] = metric, step
+                            best_attack[k] = x.data[k].clone()
+                        if ok and metric < iter_best_loss[k]:
+                            iter_best_loss[k], iter_best_score[k] = metric, lab
+                _, loss, loss_n, _, _, _, _, constrain = self.forward_step(net, pc_ori, x, normal_ori, kappa_ori, target,
+                                                                          scale_const, cfg, targeted)
+                all_loss[step] = loss_n.detach().tolist()
+                opt.zero_grad()
+                loss.backward()
+                opt.step()
+            for k in range(b):
+                lab = labels_now[k] if per_sample_label else labels_now[-1]     # :395 uses the LAST sample's label (A-7)
+                ok = (lab == int(target[k])) if targeted else (lab != int(gt[k]))
+                if ok and iter_best_score[k] != -1:
+                    lower[k] = max(lower[k], scale_const[k])
+                    scale_const[k] = (lower[k] + upper[k]) * 0.5 if upper[k] < 1e9 else scale_const[k] * 2
+                else:
+                    upper[k] = min(upper[k], scale_const[k])
+                    if upper[k] < 1e9:
+                        scale_const[k] = (lower[k] + upper[k]) * 0.5
+        return best_attack, target, (np.array(best_loss) < 1e10), best_step, all_loss

@@ -396,7 +396,80 @@ def gen_dgcnn():
     print("dgcnn.npz:", len(fx), "arrays")
 
 
-SECTIONS = {"dgcnn": gen_dgcnn, "metrics": gen_metrics, "pointnet": gen_pointnet, "cw": gen_cw, "pointnet2": gen_pointnet2, "knn": gen_knn}
+def gen_geoa3():
+    """The REAL reference geoA3_attack on a seeded PointNet victim (B=1). Importing attack.GeoA3.* needs modules this
+    container lacks (open3d, torchvision, seaborn) and two removed torch APIs; empty stand-in modules satisfy the
+    imports — none of them is called on the attack path. The transfer models are dummy modules, which
+    avoids the reference's post-loop crash on real ones (it feeds them [B,N,3], SURVEY A-6)."""
+    install_cpu_shim()
+    import contextlib
+    import io
+    import types
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from oracle.ref_torch import seeded_state_dict
+    for name in ("open3d", "torchvision", "torchvision.transforms", "seaborn"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["seaborn"].set = lambda *a, **k: None
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    import importlib
+    importlib.import_module("torch.autograd.gradcheck")
+    sys.modules["torch.autograd.gradcheck"].zero_gradients = lambda *a, **k: None
+    torch.symeig = lambda L, eigenvectors=True: torch.linalg.eigh(L)
+    os.popen = lambda *a, **k: io.StringIO("24 80")
+    sys.path.insert(0, os.path.join(REF, "attack", "GeoA3"))
+    from model.pointnet import PointNetCls
+    from attack.GeoA3 import GeoA3_attack as ga
+    from attack.GeoA3 import loss_utils as lu
+    from attack.GeoA3.utility import estimate_normal
+
+    class Dummy(torch.nn.Module):
+        def forward(self, x):
+            z = torch.zeros(x.shape[0], 40)
+            return z, z, z
+
+    net = PointNetCls(k=40, feature_transform=False)
+    net.load_state_dict(seeded_state_dict(net, 0))
+    net.eval()
+    rng = np.random.default_rng(8642)
+    fx = {}
+    base = dict(attack_method='untarget', curv_loss_weight=1.0, curv_loss_knn=16, initial_const=10, iter_max_steps=12,
+                binary_max_steps=2, is_partial_var=False, optim='adam', lr=0.01, npoint=256, is_subsample_opt=False,
+                eval_num=1, is_pre_jitter_input=False, cls_loss_type='CE', classes=40, confidence=0, dis_loss_type='CD',
+                is_cd_single_side=False, dis_loss_weight=1.0, hd_loss_weight=0.1, uniform_loss_weight=0.0,
+                is_use_lr_scheduler=False, is_debug=False, is_pro_grad=False, cc_linf=0.0, binary_step=2, num_iter=12,
+                is_real_offset=False, knn_range=3)
+    cases = {"ce_cd_hd_curv": {}, "margin_l2": dict(cls_loss_type='Margin', confidence=5., dis_loss_type='L2', hd_loss_weight=0,
+                                                    curv_loss_weight=0)}
+    fx["names"] = np.array(sorted(cases))
+    for nm in sorted(cases):
+        cfg = types.SimpleNamespace(**{**base, **cases[nm]})
+        pc = unit_cloud(rng, 256)[None]
+        with torch.no_grad():
+            clean = int(torch.argmax(net(torch.from_numpy(pc).transpose(1, 2).contiguous())[0], dim=1))
+        torch.manual_seed(77)
+        np.random.seed(77)
+        with contextlib.redirect_stdout(io.StringIO()):
+            best, tgt, mask, steps, losses = ga.geoA3_attack(net, Dummy(), Dummy(), Dummy(), Dummy(), Dummy(),
+                                                             torch.from_numpy(pc), torch.tensor([clean]), cfg, 0, 1)
+        fx[f"{nm}_pc"], fx[f"{nm}_label"] = pc, np.array([clean])
+        fx[f"{nm}_best"], fx[f"{nm}_mask"] = best.detach().numpy(), np.asarray(mask)
+        fx[f"{nm}_steps"], fx[f"{nm}_losses"] = np.array(steps), np.array(losses, dtype=np.float64)
+    # one _forward_step worth of loss terms + the normal estimate, for unit-level checks
+    pc = torch.from_numpy(unit_cloud(rng, 300)[None]).transpose(1, 2).contiguous()
+    adv = pc + 0.01 * torch.randn(pc.shape, generator=torch.Generator().manual_seed(5))
+    normal = estimate_normal(pc, k=3)
+    fx["unit_pc"], fx["unit_adv"], fx["unit_normal"] = pc.numpy(), adv.numpy(), normal.numpy()
+    kappa_ori = lu._get_kappa_ori(pc, normal, 16)
+    ak, nrm = lu._get_kappa_adv(adv, pc, normal, 16)
+    fx["unit_kappa_ori"], fx["unit_kappa_adv"] = kappa_ori.numpy(), ak.numpy()
+    fx["unit_terms"] = np.array([float(lu.chamfer_loss(adv, pc)), float(lu.pseudo_chamfer_loss(adv, pc)),
+                                 float(lu.hausdorff_loss(adv, pc)), float(lu.curvature_loss(adv, pc, ak, kappa_ori)),
+                                 float(lu.kNN_smoothing_loss(adv, 5, 1.1)), float(lu.norm_l2_loss(adv, pc))])
+    np.savez_compressed(os.path.join(OUT, "geoa3.npz"), **fx)
+    print("geoa3.npz:", len(fx), "arrays")
+
+
+SECTIONS = {"geoa3": gen_geoa3, "dgcnn": gen_dgcnn, "metrics": gen_metrics, "pointnet": gen_pointnet, "cw": gen_cw, "pointnet2": gen_pointnet2, "knn": gen_knn}
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(SECTIONS)

@@ -187,3 +187,50 @@ def test_oracle_dgcnn_matches_reference():
     assert np.array_equal(ort.dgcnn_knn(torch.from_numpy(fx["feat"]), 20).numpy(), fx["feat_knn"])
     np.testing.assert_array_equal(ort.get_graph_feature(torch.from_numpy(fx["x"][:, :, :64].copy()), k=8).numpy(),
                                   fx["graph_feature"])
+
+
+def _geo_cfg(**over):
+    import types
+    base = dict(attack_method='untarget', curv_loss_weight=1.0, curv_loss_knn=16, initial_const=10, iter_max_steps=12,
+                binary_max_steps=2, is_partial_var=False, optim='adam', lr=0.01, npoint=256, is_subsample_opt=False,
+                eval_num=1, is_pre_jitter_input=False, cls_loss_type='CE', classes=40, confidence=0, dis_loss_type='CD',
+                is_cd_single_side=False, dis_loss_weight=1.0, hd_loss_weight=0.1, uniform_loss_weight=0.0,
+                is_use_lr_scheduler=False, is_debug=False, is_pro_grad=False, cc_linf=0.0, binary_step=2, num_iter=12,
+                is_real_offset=False, knn_range=3, calculate_project_jitter_noise_iter=50, jitter_k=16,
+                jitter_sigma=0.01, jitter_clip=0.05)
+    base.update(over)
+    return types.SimpleNamespace(**base)
+
+
+GEO_CASES = {"ce_cd_hd_curv": {}, "margin_l2": dict(cls_loss_type='Margin', confidence=5., dis_loss_type='L2',
+                                                    hd_loss_weight=0, curv_loss_weight=0)}
+
+
+def test_oracle_geoa3_matches_reference():
+    fx = np.load(os.path.join(GOLDEN, "geoa3.npz"))
+    net, _ = _oracle_pointnet(0)
+    orc_g = ort.GeoA3Oracle(as_written=True)
+    # unit level: normals, kappas, loss terms
+    pc, adv = torch.from_numpy(fx["unit_pc"]), torch.from_numpy(fx["unit_adv"])
+    normal = orc_g.estimate_normal(pc, 3)
+    agree = np.isclose(np.abs((normal.numpy() * fx["unit_normal"]).sum(1)), 1.0, atol=1e-3)
+    assert agree.mean() > 0.97        # eigenvector of a (near-)degenerate 3-point covariance may differ
+    nr = torch.from_numpy(fx["unit_normal"])
+    ko = orc_g._kappa(pc, nr, 16)
+    np.testing.assert_allclose(ko.numpy(), fx["unit_kappa_ori"], rtol=1e-4, atol=1e-6)
+    ak, _ = orc_g.kappa_adv(adv, pc, nr, 16)
+    np.testing.assert_allclose(ak.numpy(), fx["unit_kappa_adv"], rtol=1e-4, atol=1e-6)
+    terms = [float(orc_g.chamfer_loss(adv, pc)), float(orc_g.pseudo_chamfer_loss(adv, pc)), float(orc_g.hausdorff_loss(adv, pc)),
+             float(orc_g.curvature_loss(adv, pc, ak, ko))]
+    np.testing.assert_allclose(terms, fx["unit_terms"][:4], rtol=1e-4)
+    # full loop
+    for nm in fx["names"]:
+        cfg = _geo_cfg(**GEO_CASES[str(nm)])
+        torch.manual_seed(77)
+        np.random.seed(77)
+        best, tgt, mask, steps, losses = orc_g.attack(net, torch.from_numpy(fx[f"{nm}_pc"]), torch.from_numpy(fx[f"{nm}_label"]), cfg)
+        assert np.array_equal(mask, fx[f"{nm}_mask"]), nm
+        np.testing.assert_allclose(np.array(losses), fx[f"{nm}_losses"], rtol=2e-3, atol=1e-4, err_msg=str(nm))
+        if mask.any():
+            assert steps == fx[f"{nm}_steps"].tolist()
+            np.testing.assert_allclose(best.numpy(), fx[f"{nm}_best"], atol=1e-4)
