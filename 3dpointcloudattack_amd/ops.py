@@ -596,3 +596,16 @@ def gather_max(P, idx):
     """out[b,i,c] = max_j P[b, idx[b,i,j], c]; differentiable in P (gradient to the arg-max neighbour)."""
     _check(P, "P")
     return _GatherMaxFn.apply(P, idx.contiguous())
+
+
+# ------------------------------------------------------------------------------------------------------
+# K12: AOF spectral front-end
+# ------------------------------------------------------------------------------------------------------
+def graph_laplacian(xyz, k=30, cf=True):
+    """Dense L = D - A [B,N,N] of the symmetrised kNN-k Gaussian graph of xyz ([B,3,N] with cf, else [B,N,3])."""
+    p, bs, ps, cs, B, N = _pts(xyz, cf, "xyz")
+    _, idx = knn_raw(xyz, xyz, min(k, N), q_cf=cf, r_cf=cf)
+    L = torch.empty((B, N, N), dtype=torch.float32, device=xyz.device)
+    with torch.cuda.device(xyz.device):
+        _lib.call("pc3d_graph_laplacian_f32", p, bs, ps, cs, idx.data_ptr(), B, N, idx.shape[2], L.data_ptr(), _stream())
+    return L

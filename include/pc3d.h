@@ -262,6 +262,12 @@ int pc3d_gather_max_f32(const float* P, const int32_t* idx, const float* sign, i
                         float* out, int32_t* arg, void* stream);
 int pc3d_gather_max_bwd_f32(const float* g, const int32_t* arg, int B, int N, int C, float* gP, void* stream);
 
+/* K12  dense graph Laplacian L = D - A of the symmetrised kNN graph with Gaussian weights A_ij = exp(-|pi-pj|^2)
+ * (attack/AOF/TAOF_attack.py:31-52, attack/AOF/Eval_AOF.py:72-93). idx [B,N,K] from pc3d_knn_f32 (self included, as
+ * in the reference's topk); L [B,N,N] f32 is overwritten. Only the N*K graph edges are evaluated. */
+int pc3d_graph_laplacian_f32(const float* xyz, int64_t x_bs, int64_t x_ps, int64_t x_cs,
+                             const int32_t* idx, int B, int N, int K, float* L, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

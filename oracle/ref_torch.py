@@ -843,3 +843,82 @@ class GeoA3Oracle:
                     if upper[k] < 1e9:
                         scale_const[k] = (lower[k] + upper[k]) * 0.5
         return best_attack, target, (np.array(best_loss) < 1e10), best_step, all_loss
+
+
+# ----------------------------------------------------------------------------------------------------------
+# AOF / TAOF (attack/AOF/TAOF_attack.py)
+# ----------------------------------------------------------------------------------------------------------
+def aof_knn(x, k):
+    """TAOF_attack.py:13-28."""
+    inner = -2 * torch.matmul(x.transpose(2, 1), x)
+    xx = torch.sum(x ** 2, dim=1, keepdim=True)
+    return (-xx - inner - xx.transpose(2, 1)).topk(k=k, dim=-1)[1]
+
+
+def get_Laplace_from_pc(ori_pc, k=30):
+    """:31-52."""
+    pc = ori_pc.detach().clone()
+    with torch.no_grad():
+        idx = aof_knn(pc, k)
+        pc = pc.transpose(2, 1).contiguous()
+        point_mat = pc.unsqueeze(2) - pc.unsqueeze(1)
+        A = torch.exp(-torch.sum(point_mat.square(), dim=3))
+        mask = torch.zeros_like(A)
+        mask.scatter_(2, idx, 1)
+        mask = mask + mask.transpose(2, 1)
+        mask[mask > 1] = 1
+        A = A * mask
+        L = torch.diag_embed(torch.sum(A, dim=2)) - A
+        e, v = torch.linalg.eigh(L)
+    return e, v, L
+
+
+def taof_attack(model, data, target, y_truth, adv_func, clip_func, attack_lr=1e-2, binary_step=2, num_iter=200,
+                GAMMA=0.5, low_pass=100):
+    """:83-244. Returns (o_bestdist [B] f64, adv [B,K,3] numpy, success_num)."""
+    B, K = data.shape[:2]
+    data = data.float().transpose(1, 2).contiguous()
+    ori = data.clone().detach()
+    target, y_truth = target.long().view(-1), y_truth.long().view(-1)
+    label_val, y_val = target.numpy(), y_truth.numpy()
+    o_bestdist = np.array([1e10] * B)
+    o_bestscore = np.array([-1] * B)
+    o_bestattack = np.zeros((B, 3, K))
+    for p in model.parameters():
+        p.requires_grad = False
+    model(ori)
+    input_val = None
+    for bstep in range(binary_step):
+        adv = ori.clone().detach() + torch.randn((B, 3, K)) * 1e-7
+        _, V, _ = get_Laplace_from_pc(adv)
+        projs = torch.bmm(adv, V)
+        hfc = torch.bmm(projs[..., low_pass:], V[..., low_pass:].transpose(2, 1)).detach().clone()
+        lfc = torch.bmm(projs[..., :low_pass], V[..., :low_pass].transpose(2, 1)).detach().clone()
+        lfc.requires_grad_()
+        opt = torch.optim.Adam([lfc], lr=attack_lr, weight_decay=0.)
+        for it in range(num_iter):
+            adv = lfc + hfc
+            adv_loss = (1 - GAMMA) * adv_func(model(adv)[0], target).mean()
+            opt.zero_grad()
+            adv_loss.backward()
+            (GAMMA * adv_func(model(lfc)[0], target).mean()).backward()
+            opt.step()
+            with torch.no_grad():
+                adv = lfc + hfc
+                adv.data = clip_func(adv.detach().clone(), ori)
+                coeff = torch.bmm(adv, V)
+                hfc.data = torch.bmm(coeff[..., low_pass:], V[..., low_pass:].transpose(2, 1))
+                lfc.data = torch.bmm(coeff[..., :low_pass], V[..., :low_pass].transpose(2, 1))
+                pred = torch.argmax(model(adv)[0], dim=1).numpy()
+                lfc_pred = torch.argmax(model(lfc)[0], dim=1).numpy()
+            dist_val = torch.sqrt(torch.sum((adv - ori) ** 2, dim=[1, 2])).detach().numpy()
+            input_val = adv.detach().numpy().copy()
+            for e in range(B):
+                if dist_val[e] < o_bestdist[e] and pred[e] == label_val[e] and lfc_pred[e] != y_val[e]:
+                    o_bestdist[e], o_bestscore[e] = dist_val[e], pred[e]
+                    o_bestattack[e] = input_val[e]
+    fail = o_bestscore < 0
+    o_bestattack[fail] = input_val[fail]
+    adv_pc = torch.tensor(o_bestattack).float()
+    preds = torch.argmax(model(adv_pc)[0], dim=-1)
+    return o_bestdist, adv_pc.numpy().transpose((0, 2, 1)), int((preds == target).sum())

@@ -469,7 +469,46 @@ def gen_geoa3():
     print("geoa3.npz:", len(fx), "arrays")
 
 
-SECTIONS = {"geoa3": gen_geoa3, "dgcnn": gen_dgcnn, "metrics": gen_metrics, "pointnet": gen_pointnet, "cw": gen_cw, "pointnet2": gen_pointnet2, "knn": gen_knn}
+def gen_aof():
+    """REAL reference AOF pieces: the graph Laplacian (+ its spectrum) and a short CWTAOF.attack run."""
+    install_cpu_shim()
+    import contextlib
+    import io
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from oracle.ref_torch import seeded_state_dict
+    torch.symeig = lambda L, eigenvectors=True: torch.linalg.eigh(L)
+    from model.pointnet import PointNetCls
+    from attack.AOF import TAOF_attack as ta
+    from attack.CW.CW_utils.adv_utils import LogitsAdvLoss
+    from attack.CW.CW_utils.dist_utils import L2Dist
+    from attack.CW.CW_utils.clip_utils import ClipPointsLinf
+    rng = np.random.default_rng(97531)
+    fx = {}
+    pc = np.stack([unit_cloud(rng, 200) for _ in range(2)]).transpose(0, 2, 1).copy()
+    e, v = ta.get_Laplace_from_pc(torch.from_numpy(pc))
+    fx["lap_pc"], fx["lap_eig"] = pc, e.numpy()
+    fx["lap_knn"] = ta.knn(torch.from_numpy(pc), 30).numpy()
+    net = PointNetCls(k=40, feature_transform=False)
+    net.load_state_dict(seeded_state_dict(net, 0))
+    net.eval()
+    cloud = unit_cloud(rng, 256)[None]
+    with torch.no_grad():
+        lp = net(torch.from_numpy(cloud).transpose(1, 2).contiguous())[0]
+    y_truth = int(lp.argmax(1))
+    tgt = int(lp.topk(2)[1][0, 1])
+    atk = ta.CWTAOF(net, LogitsAdvLoss(kappa=0.), L2Dist(), attack_lr=1e-2, binary_step=2, num_iter=10, GAMMA=0.5,
+                    low_pass=40, clip_func=ClipPointsLinf(budget=0.18))
+    torch.manual_seed(31)
+    np.random.seed(31)
+    with contextlib.redirect_stdout(io.StringIO()):
+        bd, adv, sn = atk.attack(torch.from_numpy(cloud), torch.tensor([tgt]), torch.tensor([y_truth]))
+    fx["atk_pc"], fx["atk_target"], fx["atk_ytruth"] = cloud, np.array([tgt]), np.array([y_truth])
+    fx["atk_bestdist"], fx["atk_adv"], fx["atk_success"] = bd, adv.astype(np.float32), np.array(sn)
+    np.savez_compressed(os.path.join(OUT, "aof.npz"), **fx)
+    print("aof.npz:", len(fx), "arrays")
+
+
+SECTIONS = {"aof": gen_aof, "geoa3": gen_geoa3, "dgcnn": gen_dgcnn, "metrics": gen_metrics, "pointnet": gen_pointnet, "cw": gen_cw, "pointnet2": gen_pointnet2, "knn": gen_knn}
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(SECTIONS)

@@ -234,3 +234,18 @@ def test_oracle_geoa3_matches_reference():
         if mask.any():
             assert steps == fx[f"{nm}_steps"].tolist()
             np.testing.assert_allclose(best.numpy(), fx[f"{nm}_best"], atol=1e-4)
+
+
+def test_oracle_aof_matches_reference():
+    fx = np.load(os.path.join(GOLDEN, "aof.npz"))
+    e, v, L = ort.get_Laplace_from_pc(torch.from_numpy(fx["lap_pc"]))
+    np.testing.assert_allclose(e.numpy(), fx["lap_eig"], rtol=1e-4, atol=1e-5)
+    assert np.array_equal(ort.aof_knn(torch.from_numpy(fx["lap_pc"]), 30).numpy(), fx["lap_knn"])
+    net, _ = _oracle_pointnet(0)
+    torch.manual_seed(31)
+    bd, adv, sn = ort.taof_attack(net, torch.from_numpy(fx["atk_pc"]), torch.from_numpy(fx["atk_target"]),
+                                  torch.from_numpy(fx["atk_ytruth"]), ort.LogitsAdvLoss(0.), ort.ClipPointsLinf(0.18),
+                                  binary_step=2, num_iter=10, low_pass=40)
+    np.testing.assert_allclose(bd, fx["atk_bestdist"], rtol=1e-4)
+    np.testing.assert_allclose(adv, fx["atk_adv"], atol=1e-5)
+    assert sn == int(fx["atk_success"])
