@@ -1,0 +1,50 @@
+"""CurveNet classifier — MI355X mirror of model/curvenet.py:11-73 (same module tree / state_dict keys; returns RAW
+logits three times like the reference)."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .curvenet_util import CIC, LPFA
+from .pointnet import _FrozenFusedMixin
+
+curve_config = {
+    'default': [[100, 5], [100, 5], None, None],
+    'long': [[10, 30], None, None, None]
+}
+
+
+class CurveNet(_FrozenFusedMixin, nn.Module):
+    def __init__(self, num_classes=40, k=20, setting='default'):
+        super(CurveNet, self).__init__()
+        assert setting in curve_config
+        additional_channel = 32
+        self.lpfa = LPFA(9, additional_channel, k=k, mlp_num=1, initial=True)
+        cfg = curve_config[setting]
+        # encoder
+        self.cic11 = CIC(npoint=1024, radius=0.05, k=k, in_channels=additional_channel, output_channels=64, bottleneck_ratio=2, mlp_num=1, curve_config=cfg[0])
+        self.cic12 = CIC(npoint=1024, radius=0.05, k=k, in_channels=64, output_channels=64, bottleneck_ratio=4, mlp_num=1, curve_config=cfg[0])
+        self.cic21 = CIC(npoint=1024, radius=0.05, k=k, in_channels=64, output_channels=128, bottleneck_ratio=2, mlp_num=1, curve_config=cfg[1])
+        self.cic22 = CIC(npoint=1024, radius=0.1, k=k, in_channels=128, output_channels=128, bottleneck_ratio=4, mlp_num=1, curve_config=cfg[1])
+        self.cic31 = CIC(npoint=256, radius=0.1, k=k, in_channels=128, output_channels=256, bottleneck_ratio=2, mlp_num=1, curve_config=cfg[2])
+        self.cic32 = CIC(npoint=256, radius=0.2, k=k, in_channels=256, output_channels=256, bottleneck_ratio=4, mlp_num=1, curve_config=cfg[2])
+        self.cic41 = CIC(npoint=64, radius=0.2, k=k, in_channels=256, output_channels=512, bottleneck_ratio=2, mlp_num=1, curve_config=cfg[3])
+        self.cic42 = CIC(npoint=64, radius=0.4, k=k, in_channels=512, output_channels=512, bottleneck_ratio=4, mlp_num=1, curve_config=cfg[3])
+        self.conv0 = nn.Sequential(nn.Conv1d(512, 1024, kernel_size=1, bias=False), nn.BatchNorm1d(1024), nn.ReLU(inplace=True))
+        self.conv1 = nn.Linear(1024 * 2, 512, bias=False)
+        self.conv2 = nn.Linear(512, num_classes)
+        self.bn1 = nn.BatchNorm1d(512)
+        self.dp1 = nn.Dropout(p=0.5)
+        self._folded_cache = None
+
+    def forward(self, xyz):
+        self._require_fused(xyz)
+        xyz = xyz.float()
+        feats = self.lpfa(xyz, xyz)
+        pos = xyz
+        for blk in (self.cic11, self.cic12, self.cic21, self.cic22, self.cic31, self.cic32, self.cic41, self.cic42):
+            pos, feats = blk(pos, feats)
+        x = self.conv0(feats)
+        x = torch.cat((F.adaptive_max_pool1d(x, 1), F.adaptive_avg_pool1d(x, 1)), dim=1).squeeze(-1)
+        x = F.relu(self.bn1(self.conv1(x).unsqueeze(-1)), inplace=True).squeeze(-1)
+        x = self.conv2(self.dp1(x))
+        return x, x, x

@@ -1,0 +1,267 @@
+"""CurveNet building blocks — MI355X mirror of model/curvenet_util.py (same class names, constructor arguments,
+sub-module names / ``state_dict`` keys). Neighbour search, farthest-point sampling (start index 0, :81), ball query and
+every gather run on the HIP kernels (pc3d_knn_f32 / pc3d_fps_f32 / pc3d_ball_query_f32 / pc3d_group_gather_f32); the
+reference materialises [B,N,N] distance matrices for each of them (nine kNNs per forward) and hard-codes
+torch.device('cuda').
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from .pointnet import _FrozenFusedMixin
+from .walk import Walk
+
+
+def _cl(x):
+    """[B,C,N] -> contiguous [B,N,C]."""
+    return x.transpose(2, 1).contiguous().float()
+
+
+def knn(x, k):
+    """curvenet_util.py:10-17 — k+1 nearest (self first) of xyz [B,3,N] -> [B,N,k+1] int64."""
+    xt = _cl(x)
+    return ops.knn_raw(xt, xt, k + 1)[1].long()
+
+
+def normal_knn(x, k):
+    """:20-26."""
+    xt = _cl(x)
+    return ops.knn_raw(xt, xt, k)[1].long()
+
+
+def pc_normalize(pc):
+    centroid = np.mean(pc, axis=0)
+    pc = pc - centroid
+    return pc / np.max(np.sqrt(np.sum(pc ** 2, axis=1)))
+
+
+def square_distance(src, dst):
+    """:38-47 (dense; direct-difference form)."""
+    return ops.pairwise(src.float(), dst.float())
+
+
+def index_points(points, idx):
+    """:50-66."""
+    idx32 = idx.to(torch.int32)
+    if idx.dim() == 2:
+        B, S = idx.shape
+        return ops.group_gather(None, points.float(), idx32.reshape(B, S, 1).contiguous()).view(B, S, -1)
+    return ops.group_gather(None, points.float(), idx32.contiguous())
+
+
+def farthest_point_sample(xyz, npoint):
+    """:69-90 — deterministic: starts at index 0 (:81)."""
+    return ops.fps(xyz.float(), npoint, None).long()
+
+
+def query_ball_point(radius, nsample, xyz, new_xyz):
+    """:93-113."""
+    return ops.ball_query(radius, nsample, xyz.float(), new_xyz.float()).long()
+
+
+def sample_and_group(npoint, radius, nsample, xyz, points, returnfps=False):
+    """:116-140 — new_xyz [B,npoint,3], new_points [B,npoint,nsample,D] (features only, not centred)."""
+    xyz = xyz.float()
+    fps_idx = ops.fps(xyz, npoint, None)
+    B = xyz.shape[0]
+    new_xyz = ops.group_gather(xyz, None, fps_idx.view(B, npoint, 1)).view(B, npoint, 3)
+    idx = ops.ball_query(radius, nsample, xyz, new_xyz)
+    new_points = ops.group_gather(None, points.float(), idx)
+    if returnfps:
+        return new_xyz, new_points, idx.long()
+    return new_xyz, new_points
+
+
+class Attention_block(nn.Module):
+    """:143-170 (attention U-Net gate; segmentation only)."""
+
+    def __init__(self, F_g, F_l, F_int):
+        super(Attention_block, self).__init__()
+        self.W_g = nn.Sequential(nn.Conv1d(F_g, F_int, kernel_size=1, stride=1, padding=0, bias=True), nn.BatchNorm1d(F_int))
+        self.W_x = nn.Sequential(nn.Conv1d(F_l, F_int, kernel_size=1, stride=1, padding=0, bias=True), nn.BatchNorm1d(F_int))
+        self.psi = nn.Sequential(nn.Conv1d(F_int, 1, kernel_size=1, stride=1, padding=0, bias=True), nn.BatchNorm1d(1),
+                                 nn.Sigmoid())
+
+    def forward(self, g, x):
+        psi = self.psi(F.leaky_relu(self.W_g(g) + self.W_x(x), negative_slope=0.2))
+        return psi, 1. - psi
+
+
+class LPFA(nn.Module):
+    """Local point-feature aggregation (:175-236)."""
+
+    def __init__(self, in_channel, out_channel, k, mlp_num=2, initial=False):
+        super(LPFA, self).__init__()
+        self.k = k
+        self.initial = initial
+        if not initial:
+            self.xyz2feature = nn.Sequential(nn.Conv2d(9, in_channel, kernel_size=1, bias=False), nn.BatchNorm2d(in_channel))
+        layers = []
+        for _ in range(mlp_num):
+            layers.append(nn.Sequential(nn.Conv2d(in_channel, out_channel, 1, bias=False), nn.BatchNorm2d(out_channel),
+                                        nn.LeakyReLU(0.2)))
+            in_channel = out_channel
+        self.mlp = nn.Sequential(*layers)
+
+    def forward(self, x, xyz, idx=None):
+        x = self.mlp(self.group_feature(x, xyz, idx))
+        return x.max(dim=-1, keepdim=False)[0] if self.initial else x.mean(dim=-1, keepdim=False)
+
+    def group_feature(self, x, xyz, idx):
+        """[B,9,N,k] = [p_i, p_j, p_j - p_i] (initial) or leaky((x_j - x_i) + xyz2feature(that)) [B,C,N,k]."""
+        B, C, N = x.size()
+        if idx is None:
+            idx = knn(xyz, k=self.k)[:, :, :self.k]
+        idx32 = idx.to(torch.int32).contiguous()
+        pts = _cl(xyz)                                             # [B,N,3]
+        nbr = ops.group_gather(pts, None, idx32)                   # [B,N,k,3] (differentiable in the points)
+        ctr = pts.view(B, N, 1, 3).expand(-1, -1, self.k, -1)
+        geo = torch.cat((ctr, nbr, nbr - ctr), dim=3).permute(0, 3, 1, 2).contiguous()   # [B,9,N,k]
+        if self.initial:
+            return geo
+        feats = _cl(x)                                             # [B,N,C]
+        rel = ops.group_gather(None, feats, idx32) - feats.view(B, N, 1, C)              # x_j - x_i
+        return F.leaky_relu(rel.permute(0, 3, 1, 2) + self.xyz2feature(geo), 0.2)
+
+
+class PointNetFeaturePropagation(nn.Module):
+    """:239-299 (segmentation decoder; not used by the classifiers / attacks)."""
+
+    def __init__(self, in_channel, mlp, att=None):
+        super(PointNetFeaturePropagation, self).__init__()
+        self.mlp_convs = nn.ModuleList()
+        self.mlp_bns = nn.ModuleList()
+        last_channel = in_channel
+        self.att = None
+        if att is not None:
+            self.att = Attention_block(F_g=att[0], F_l=att[1], F_int=att[2])
+        for out_channel in mlp:
+            self.mlp_convs.append(nn.Conv1d(last_channel, out_channel, 1))
+            self.mlp_bns.append(nn.BatchNorm1d(out_channel))
+            last_channel = out_channel
+
+    def forward(self, xyz1, xyz2, points1, points2):
+        x1, x2, p2 = _cl(xyz1), _cl(xyz2), _cl(points2)
+        B, N, _ = x1.shape
+        if x2.shape[1] == 1:
+            interpolated = p2.repeat(1, N, 1)
+        else:
+            dists, idx = ops.knn(x1, x2, 3)
+            recip = 1.0 / (dists + 1e-8)
+            weight = recip / torch.sum(recip, dim=2, keepdim=True)
+            interpolated = torch.sum(ops.group_gather(None, p2, idx) * weight.view(B, N, 3, 1), dim=2)
+        if self.att is not None:
+            psix, _ = self.att(interpolated.permute(0, 2, 1), points1)
+            points1 = points1 * psix
+        new_points = interpolated if points1 is None else torch.cat([points1.permute(0, 2, 1), interpolated], dim=-1)
+        new_points = new_points.permute(0, 2, 1)
+        for conv, bn in zip(self.mlp_convs, self.mlp_bns):
+            new_points = F.leaky_relu(bn(conv(new_points)), 0.2)
+        return new_points
+
+
+class CIC(nn.Module):
+    """Curve intervention convolution block (:302-376)."""
+
+    def __init__(self, npoint, radius, k, in_channels, output_channels, bottleneck_ratio=2, mlp_num=2, curve_config=None):
+        super(CIC, self).__init__()
+        self.in_channels = in_channels
+        self.output_channels = output_channels
+        self.bottleneck_ratio = bottleneck_ratio
+        self.radius = radius
+        self.k = k
+        self.npoint = npoint
+        planes = in_channels // bottleneck_ratio
+        self.use_curve = curve_config is not None
+        if self.use_curve:
+            self.curveaggregation = CurveAggregation(planes)
+            self.curvegrouping = CurveGrouping(planes, k, curve_config[0], curve_config[1])
+        self.conv1 = nn.Sequential(nn.Conv1d(in_channels, planes, kernel_size=1, bias=False),
+                                   nn.BatchNorm1d(in_channels // bottleneck_ratio),
+                                   nn.LeakyReLU(negative_slope=0.2, inplace=True))
+        self.conv2 = nn.Sequential(nn.Conv1d(planes, output_channels, kernel_size=1, bias=False),
+                                   nn.BatchNorm1d(output_channels))
+        if in_channels != output_channels:
+            self.shortcut = nn.Sequential(nn.Conv1d(in_channels, output_channels, kernel_size=1, bias=False),
+                                          nn.BatchNorm1d(output_channels))
+        self.relu = nn.LeakyReLU(negative_slope=0.2, inplace=True)
+        self.maxpool = MaskedMaxPool(npoint, radius, k)
+        self.lpfa = LPFA(planes, planes, k, mlp_num=mlp_num, initial=False)
+
+    def forward(self, xyz, x):
+        if xyz.size(-1) != self.npoint:                            # FPS + ball-query max-pool down-sampling
+            xyz, x = self.maxpool(xyz.transpose(1, 2).contiguous(), x)
+            xyz = xyz.transpose(1, 2)
+        shortcut = x
+        x = self.conv1(x)
+        idx = knn(xyz, self.k)                                     # [B,N,k+1], self first
+        if self.use_curve:
+            curves = self.curvegrouping(x, xyz, idx[:, :, 1:])     # avoid self-loops
+            x = self.curveaggregation(x, curves)
+        x = self.conv2(self.lpfa(x, xyz, idx=idx[:, :, :self.k]))
+        if self.in_channels != self.output_channels:
+            shortcut = self.shortcut(shortcut)
+        return xyz, self.relu(x + shortcut)
+
+
+class CurveAggregation(nn.Module):
+    """:379-437 — fuse curve features back into the point features by inter- / intra-curve attention."""
+
+    def __init__(self, in_channel):
+        super(CurveAggregation, self).__init__()
+        self.in_channel = in_channel
+        mid_feature = in_channel // 2
+        self.conva = nn.Conv1d(in_channel, mid_feature, kernel_size=1, bias=False)
+        self.convb = nn.Conv1d(in_channel, mid_feature, kernel_size=1, bias=False)
+        self.convc = nn.Conv1d(in_channel, mid_feature, kernel_size=1, bias=False)
+        self.convn = nn.Conv1d(mid_feature, mid_feature, kernel_size=1, bias=False)
+        self.convl = nn.Conv1d(mid_feature, mid_feature, kernel_size=1, bias=False)
+        self.convd = nn.Sequential(nn.Conv1d(mid_feature * 2, in_channel, kernel_size=1, bias=False), nn.BatchNorm1d(in_channel))
+        self.line_conv_att = nn.Conv2d(in_channel, 1, kernel_size=1, bias=False)
+
+    def forward(self, x, curves):
+        att = self.line_conv_att(curves)                                          # [B,1,cn,cl]
+        inter = self.conva(torch.sum(curves * F.softmax(att, dim=-1), dim=-1))    # [B,mid,cn]
+        intra = self.convb(torch.sum(curves * F.softmax(att, dim=-2), dim=-2))    # [B,mid,cl]
+        q = self.convc(x).transpose(1, 2).contiguous()                            # [B,N,mid]
+        w_inter = F.softmax(torch.bmm(q, inter), dim=-1)                          # [B,N,cn]
+        w_intra = F.softmax(torch.bmm(q, intra), dim=-1)                          # [B,N,cl]
+        f_inter = torch.bmm(w_inter, self.convn(inter).transpose(1, 2).contiguous())
+        f_intra = torch.bmm(w_intra, self.convl(intra).transpose(1, 2).contiguous())
+        fused = torch.cat((f_inter, f_intra), dim=-1).transpose(1, 2).contiguous()
+        return F.leaky_relu(x + self.convd(fused), negative_slope=0.2)
+
+
+class CurveGrouping(nn.Module):
+    """:440-466 — pick curve_num start points by self-attention score, then walk."""
+
+    def __init__(self, in_channel, k, curve_num, curve_length):
+        super(CurveGrouping, self).__init__()
+        self.curve_num = curve_num
+        self.curve_length = curve_length
+        self.in_channel = in_channel
+        self.k = k
+        self.att = nn.Conv1d(in_channel, 1, kernel_size=1, bias=False)
+        self.walk = Walk(in_channel, k, curve_num, curve_length)
+
+    def forward(self, x, xyz, idx):
+        x_att = torch.sigmoid(self.att(x))
+        x = x * x_att
+        _, start_index = torch.topk(x_att, self.curve_num, dim=2, sorted=False)
+        return self.walk(xyz, x, idx, start_index.squeeze(1).unsqueeze(2))       # [B,C,cn,cl]
+
+
+class MaskedMaxPool(nn.Module):
+    """:469-484."""
+
+    def __init__(self, npoint, radius, k):
+        super(MaskedMaxPool, self).__init__()
+        self.npoint = npoint
+        self.radius = radius
+        self.k = k
+
+    def forward(self, xyz, features):
+        sub_xyz, nbr = sample_and_group(self.npoint, self.radius, self.k, xyz, features.transpose(1, 2).contiguous())
+        return sub_xyz, nbr.max(dim=2)[0].transpose(1, 2).contiguous()           # [B,S,3], [B,C,S]

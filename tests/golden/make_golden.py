@@ -508,7 +508,31 @@ def gen_aof():
     print("aof.npz:", len(fx), "arrays")
 
 
-SECTIONS = {"aof": gen_aof, "geoa3": gen_geoa3, "dgcnn": gen_dgcnn, "metrics": gen_metrics, "pointnet": gen_pointnet, "cw": gen_cw, "pointnet2": gen_pointnet2, "knn": gen_knn}
+def gen_curvenet():
+    """Reference CurveNet (model/curvenet.py) on seeded weights: logits and input gradient at N=1024 and N=2048 (the
+    latter exercises the FPS + ball-query max-pool of the first block)."""
+    install_cpu_shim()
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from oracle.ref_torch import seeded_state_dict, state_sha256
+    from model.curvenet import CurveNet
+    rng = np.random.default_rng(86420)
+    m = CurveNet(num_classes=40)
+    sd = seeded_state_dict(m, 9, gain=1.0)
+    m.load_state_dict(sd)
+    m.eval()
+    fx = {"sha256": np.array(state_sha256(sd))}
+    for nm, (B, N) in {"n1024": (2, 1024), "n2048": (1, 2048)}.items():
+        x = np.stack([unit_cloud(rng, N) for _ in range(B)]).transpose(0, 2, 1).copy()
+        tx = torch.from_numpy(x).requires_grad_()
+        out = m(tx)[0]
+        w = torch.from_numpy(rng.standard_normal(out.shape).astype(np.float32))
+        (out * w).sum().backward()
+        fx[f"{nm}_x"], fx[f"{nm}_logits"], fx[f"{nm}_w"], fx[f"{nm}_gx"] = x, out.detach().numpy(), w.numpy(), tx.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "curvenet.npz"), **fx)
+    print("curvenet.npz:", len(fx), "arrays")
+
+
+SECTIONS = {"curvenet": gen_curvenet, "aof": gen_aof, "geoa3": gen_geoa3, "dgcnn": gen_dgcnn, "metrics": gen_metrics, "pointnet": gen_pointnet, "cw": gen_cw, "pointnet2": gen_pointnet2, "knn": gen_knn}
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(SECTIONS)
