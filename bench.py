@@ -108,7 +108,7 @@ def main():
         raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist_on = world > 1
+    dist_on = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)   # launched by torch.distributed.run
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
