@@ -181,6 +181,19 @@ class CW:
             # launch-minimal pass: victim fwd/bwd (fused heads), bookkeeping, [NN search], one update launch
             with torch.no_grad():
                 cur = adv_data.detach()
+                if hasattr(self.model, "fused_attack_grad"):
+                    # 17 launches: the classifier tail writes pred + advances the step word, one update launch
+                    _, _, gx_model = self.model.fused_attack_grad(cur, st["target"], *fml, pred_out=st["pred"],
+                                                                  step=st["step"])
+                    nn_idx = None
+                    if dk == 2:
+                        _, nn_idx = ops.nn_raw(cur, ori_data, True, True)
+                    ops.cw_update(cur, ori_data, st["pred"], label, self.attack_method == 'untarget', st["bestdist"],
+                                  st["bestscore"], st["o_bestdist"], st["o_bestscore"], st["o_bestattack"], gx_model,
+                                  st["exp_avg"], st["exp_avg_sq"], st["step"], self.attack_lr, st["budget"],
+                                  input_val=st["input_val"], dist_val=st["dist_val"], dist_kind=dk, w=st["weights"],
+                                  nn_idx=nn_idx)
+                    return
                 _, pred, _, gx_model = self.model.fused_loss_and_grad(cur, st["target"], *fml)
                 ops.cw_bookkeep(cur, ori_data, pred, label, self.attack_method == 'untarget', st["bestdist"],
                                 st["bestscore"], st["o_bestdist"], st["o_bestscore"], st["o_bestattack"],

@@ -149,9 +149,189 @@ __global__ __launch_bounds__(256) void cw_step_kernel(StepArgs a) {
   pp[2 * a.p.cs] = oz + dz;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Bookkeeping + update merged: one workgroup per sample first reduces ||adv-ori||, updates the best-attack state
+// and copies the CURRENT iterate where required (exactly cw_bookkeep_kernel), then applies cw_step_kernel's
+// gradient-assembly + Adam + clip to its own points. The step word is only READ here (the classifier-tail launch
+// advances it earlier in the iteration), so no workgroup can observe a half-updated counter.
+// ---------------------------------------------------------------------------------------------------------
+struct UpdateArgs {
+  BookArgs bk;
+  StepArgs st;
+};
+
+// PER points per thread, all operands fetched up front (one memory round trip), then reduce -> decide -> update.
+template <int PER>
+__global__ __launch_bounds__(1024) void cw_update_kernel(UpdateArgs u) {
+  __shared__ float part[16];
+  __shared__ int s_copy;
+  __shared__ float s_dist;
+  const BookArgs& a = u.bk;
+  const StepArgs& s = u.st;
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x;
+  float px[PER], py[PER], pz[PER], ox[PER], oy[PER], oz[PER], gx[PER], gy[PER], gz[PER];
+  float m_[PER][3], v_[PER][3], qx[PER], qy[PER], qz[PER];
+  int nj[PER];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int k = tid + i * 1024;
+    nj[i] = (s.dist_kind == 2 && k < a.K) ? s.nn_idx[(int64_t)b * s.K + k] : 0;
+  }
+  const int t = s.step_dev ? s.step_dev[0] : s.step_host;
+  const int64_t pr = a.pred[b], lb = a.label[b];
+  const float bd = a.bestdist[b], obd = a.o_bestdist[b];
+  const float wb = s.w ? s.w[b] : 0.f;
+  float acc = 0.f;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int k = tid + i * 1024;
+    if (k < a.K) {
+      const float* p = s.p.p + (int64_t)b * s.p.bs + (int64_t)k * s.p.ps;
+      const float* o = s.ori.p + (int64_t)b * s.ori.bs + (int64_t)k * s.ori.ps;
+      const float* gp = s.g.p + (int64_t)b * s.g.bs + (int64_t)k * s.g.ps;
+      const float* mp = s.m.p + (int64_t)b * s.m.bs + (int64_t)k * s.m.ps;
+      const float* vp = s.v.p + (int64_t)b * s.v.bs + (int64_t)k * s.v.ps;
+      px[i] = p[0], py[i] = p[s.p.cs], pz[i] = p[2 * s.p.cs];
+      ox[i] = o[0], oy[i] = o[s.ori.cs], oz[i] = o[2 * s.ori.cs];
+      gx[i] = gp[0], gy[i] = gp[s.g.cs], gz[i] = gp[2 * s.g.cs];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) m_[i][c] = mp[c * s.m.cs], v_[i][c] = vp[c * s.v.cs];
+    } else {
+      px[i] = py[i] = pz[i] = ox[i] = oy[i] = oz[i] = gx[i] = gy[i] = gz[i] = 0.f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) m_[i][c] = v_[i][c] = 0.f;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const float* q = s.ori.p + (int64_t)b * s.ori.bs + (int64_t)nj[i] * s.ori.ps;
+    if (s.dist_kind == 2) qx[i] = q[0], qy[i] = q[s.ori.cs], qz[i] = q[2 * s.ori.cs];
+    else qx[i] = qy[i] = qz[i] = 0.f;
+  }
+  // the reduction tree differs from cw_bookkeep_kernel's (16 waves of 1024-strided partial sums instead of 4 waves of
+  // 256-strided ones), so ||adv-ori|| may differ from the two-launch path in the last ulp
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const float dx = px[i] - ox[i], dy = py[i] - oy[i], dz = pz[i] - oz[i];
+    acc += dx * dx + dy * dy + dz * dz;
+  }
+  acc = wave_sum(acc);
+  if ((tid & 63) == 0) part[tid >> 6] = acc;
+  __syncthreads();
+  if (tid == 0) {
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) tot += part[w];
+    const float dist = __builtin_sqrtf(tot);
+    s_dist = dist;
+    if (a.dist_val) a.dist_val[b] = dist;
+    const bool succ = a.untarget ? (pr != lb) : (pr == lb);
+    if (succ && dist < bd) {
+      a.bestdist[b] = dist;
+      a.bestscore[b] = pr;
+    }
+    int copy = 0;
+    if (succ && dist < obd) {
+      a.o_bestdist[b] = dist;
+      a.o_bestscore[b] = pr;
+      copy = 1;
+    }
+    s_copy = copy;
+  }
+  __syncthreads();
+  const bool copy = s_copy != 0;
+  const float l2n = s_dist;
+  const float omb1 = (float)(1.0 - s.b1), omb2 = (float)(1.0 - s.b2), fb2 = (float)s.b2;
+  const float step_size = (float)(s.lr / (1.0 - pow(s.b1, (double)t)));
+  const float bc2s = (float)sqrt(1.0 - pow(s.b2, (double)t));
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int k = tid + i * 1024;
+    if (k >= a.K) continue;
+    if (a.input_val.p) {
+      float* q = a.input_val.p + (int64_t)b * a.input_val.bs + (int64_t)k * a.input_val.ps;
+      q[0] = px[i], q[a.input_val.cs] = py[i], q[2 * a.input_val.cs] = pz[i];
+    }
+    if (copy) {
+      float* q = a.o_bestattack.p + (int64_t)b * a.o_bestattack.bs + (int64_t)k * a.o_bestattack.ps;
+      q[0] = px[i], q[a.o_bestattack.cs] = py[i], q[2 * a.o_bestattack.cs] = pz[i];
+    }
+    float g[3] = {gx[i], gy[i], gz[i]};
+    if (s.dist_kind == 1) {
+      const float c = wb / (float)s.B;
+      g[0] += c * ((px[i] - ox[i]) / l2n);
+      g[1] += c * ((py[i] - oy[i]) / l2n);
+      g[2] += c * ((pz[i] - oz[i]) / l2n);
+    } else if (s.dist_kind == 2) {
+      const float c = 2.f * (wb / (float)s.B) / (float)s.K;
+      g[0] += c * (px[i] - qx[i]);
+      g[1] += c * (py[i] - qy[i]);
+      g[2] += c * (pz[i] - qz[i]);
+    }
+    float* pp = s.p.p + (int64_t)b * s.p.bs + (int64_t)k * s.p.ps;
+    float* mp = s.m.p + (int64_t)b * s.m.bs + (int64_t)k * s.m.ps;
+    float* vp = s.v.p + (int64_t)b * s.v.bs + (int64_t)k * s.v.ps;
+    float np_[3];
+    const float pin[3] = {px[i], py[i], pz[i]};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float m = m_[i][c], v = v_[i][c];
+      m = m + (g[c] - m) * omb1;
+      v = v * fb2 + omb2 * g[c] * g[c];
+      mp[c * s.m.cs] = m;
+      vp[c * s.v.cs] = v;
+      const float denom = __builtin_sqrtf(v) / bc2s + s.eps;
+      np_[c] = pin[c] - step_size * (m / denom);
+    }
+    float dx = np_[0] - ox[i], dy = np_[1] - oy[i], dz = np_[2] - oz[i];
+    if (s.budget > 0.f) {
+      const float norm = __builtin_sqrtf(dx * dx + dy * dy + dz * dz);
+      const float sc = fminf(s.budget / (norm + 1e-9f), 1.f);
+      dx *= sc, dy *= sc, dz *= sc;
+    }
+    pp[0] = ox[i] + dx;
+    pp[s.p.cs] = oy[i] + dy;
+    pp[2 * s.p.cs] = oz[i] + dz;
+  }
+}
+
 }  // namespace pc3d
 
 using namespace pc3d;
+
+extern "C" int pc3d_cw_update_f32(float* adv, int64_t a_bs, int64_t a_ps, int64_t a_cs,
+                                  const float* ori, int64_t o_bs, int64_t o_ps, int64_t o_cs, int B, int K,
+                                  const int64_t* pred, const int64_t* label, int untarget,
+                                  float* bestdist, int64_t* bestscore, float* o_bestdist, int64_t* o_bestscore,
+                                  float* o_bestattack, float* input_val, float* dist_val,
+                                  const float* g, int64_t g_bs, int64_t g_ps, int64_t g_cs, float* m, float* v,
+                                  double lr, double beta1, double beta2, double eps, float budget,
+                                  const int32_t* step_dev, int step_host, int dist_kind, const float* w,
+                                  const int32_t* nn_idx, void* stream) {
+  PC3D_REQUIRE(B >= 0 && K >= 1 && K <= 8192, "pc3d_cw_update_f32: bad sizes B=%d K=%d (K <= 8192)", B, K);
+  PC3D_REQUIRE(step_dev != nullptr || step_host >= 1, "pc3d_cw_update_f32: step_host must be >= 1 without a device counter");
+  PC3D_REQUIRE(dist_kind >= 0 && dist_kind <= 2, "pc3d_cw_update_f32: dist_kind=%d not in {0,1,2}", dist_kind);
+  if (B == 0) return PC3D_OK;
+  PC3D_REQUIRE(adv && ori && pred && label && bestdist && bestscore && o_bestdist && o_bestscore && o_bestattack && g && m && v,
+               "pc3d_cw_update_f32: null pointer");
+  PC3D_REQUIRE(dist_kind == 0 || w != nullptr, "pc3d_cw_update_f32: distance term needs the weights w");
+  PC3D_REQUIRE(dist_kind != 2 || nn_idx != nullptr, "pc3d_cw_update_f32: Chamfer term needs nn_idx");
+  UpdateArgs u{};
+  // o_bestattack / input_val / m / v share adv's layout
+  u.bk = BookArgs{{adv, a_bs, a_ps, a_cs}, {ori, o_bs, o_ps, o_cs}, K, pred, label, untarget, bestdist, bestscore,
+                  o_bestdist, o_bestscore, {o_bestattack, a_bs, a_ps, a_cs}, {input_val, a_bs, a_ps, a_cs}, dist_val,
+                  nullptr};
+  u.st = StepArgs{{adv, a_bs, a_ps, a_cs}, {g, g_bs, g_ps, g_cs}, {m, a_bs, a_ps, a_cs}, {v, a_bs, a_ps, a_cs},
+                  {ori, o_bs, o_ps, o_cs}, K, B, lr, beta1, beta2, (float)eps, budget, step_dev, step_host, dist_kind, w,
+                  nullptr, nn_idx};
+  if (K <= 1024) hipLaunchKernelGGL(cw_update_kernel<1>, dim3(B), dim3(1024), 0, as_stream(stream), u);
+  else if (K <= 2048) hipLaunchKernelGGL(cw_update_kernel<2>, dim3(B), dim3(1024), 0, as_stream(stream), u);
+  else if (K <= 4096) hipLaunchKernelGGL(cw_update_kernel<4>, dim3(B), dim3(1024), 0, as_stream(stream), u);
+  else hipLaunchKernelGGL(cw_update_kernel<8>, dim3(B), dim3(1024), 0, as_stream(stream), u);
+  PC3D_LAUNCH_CHECK("pc3d_cw_update_f32");
+  return PC3D_OK;
+}
 
 extern "C" int pc3d_cw_bookkeep_f32(const float* adv, int64_t a_bs, int64_t a_ps, int64_t a_cs,
                                     const float* ori, int64_t o_bs, int64_t o_ps, int64_t o_cs, int B, int K,

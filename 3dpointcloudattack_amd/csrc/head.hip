@@ -45,7 +45,29 @@ __global__ __launch_bounds__(LN_T) void linear_kernel(LinArgs a) {
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
   // K is walked in chunks of 8 (4 per lane half); wave w takes chunks w, w+8, ...
   const int nchunk = a.K / 8;
-  if ((a.K & 7) == 0) {
+  if ((a.K & 7) == 0 && a.P == 1 && nchunk <= 16 * LN_W) {
+    // all operands of this wave's K range are fetched up front (<= 16 + 16 float4 per lane): one L2 round trip
+    // instead of one per 4 MFMAs — these launches are latency-, not throughput-bound
+    float4 xv[16], wv[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int c = wave + i * LN_W;
+      if (c < nchunk) {
+        xv[i] = *reinterpret_cast<const float4*>(xrow + 8 * c + 4 * h);
+        wv[i] = *reinterpret_cast<const float4*>(wrow + 8 * c + 4 * h);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int c = wave + i * LN_W;
+      if (c < nchunk) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[i].x, wv[i].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[i].y, wv[i].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[i].z, wv[i].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[i].w, wv[i].w, acc, 0, 0, 0);
+      }
+    }
+  } else if ((a.K & 7) == 0) {
     for (int c = wave; c < nchunk; c += LN_W) {
       const int k = 8 * c + 4 * h;
       float4 xv = *reinterpret_cast<const float4*>(xrow + k);
@@ -169,9 +191,150 @@ __global__ __launch_bounds__(64) void cls_loss_kernel(const float* logits, int l
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Classifier tail in ONE launch (one workgroup per 32 samples): logits = c2 W3^T + b3, log_softmax, prediction,
+// adversarial loss + its gradient on the logits, and g_c2 = (g_logits W3) * (c2 > 0) — i.e. fc3 forward, the loss
+// kernel above and fc3 backward (+ ReLU mask of fc2's activation) without three launches. Also advances the Adam
+// step word (it is the one single-workgroup launch of the iteration).  K2 = width of c2 (256), ncls <= 64.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int CT_T = 256;      // 4 waves = 4 samples per workgroup
+constexpr int CT_S = 4;
+constexpr int CT_MAXCLS = 64;
+constexpr int CT_K = 256;
+constexpr int CT_LD = CT_K + 4;  // 16-byte aligned rows; lane*260 mod 32 = 4*lane -> b128 reads are conflict-free
+
+struct ClsTailArgs {
+  const float* c2;      // [B,K2] post-ReLU activation of fc2
+  const float* W3;      // [ncls,K2]
+  const float* b3;      // [ncls]
+  const int64_t* target;
+  int B, K2, ncls, kind;
+  float kappa, scale;
+  float* logp;          // [B,ncls] or null
+  int64_t* pred;        // [B]
+  float* loss;          // [B]
+  float* g_c2;          // [B,K2]
+  int32_t* step;        // incremented by block 0 (may be null)
+};
+
+__global__ __launch_bounds__(CT_T) void cls_tail_kernel(ClsTailArgs a) {
+  __shared__ __attribute__((aligned(16))) float s_w[CT_MAXCLS * CT_LD];   // W3 (zero rows above ncls)
+  __shared__ __attribute__((aligned(16))) float s_c[CT_S * CT_LD];        // this block's rows of c2
+  __shared__ float s_g[CT_S][CT_MAXCLS];                                  // g_logits
+  const int b0 = blockIdx.x * CT_S;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kq = a.K2 >> 2;   // float4 per row
+  for (int i = tid; i < CT_MAXCLS * kq; i += CT_T) {
+    const int r = i / kq, k4 = i - r * kq;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < a.ncls) v = *reinterpret_cast<const float4*>(a.W3 + (int64_t)r * a.K2 + 4 * k4);
+    *reinterpret_cast<float4*>(&s_w[r * CT_LD + 4 * k4]) = v;
+  }
+  for (int i = tid; i < CT_S * kq; i += CT_T) {
+    const int r = i / kq, k4 = i - r * kq;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (b0 + r < a.B) v = *reinterpret_cast<const float4*>(a.c2 + (int64_t)(b0 + r) * a.K2 + 4 * k4);
+    *reinterpret_cast<float4*>(&s_c[r * CT_LD + 4 * k4]) = v;
+  }
+  const int b = b0 + wave;
+  const float bias = (lane < a.ncls) ? a.b3[lane] : 0.f;
+  const int t = (b < a.B) ? (int)a.target[b] : 0;
+  __syncthreads();
+  // logits of sample `wave`: lane = class, four interleaved fma chains over k (a re-association of the fp32 sum
+  // pc3d_linear_f32 forms; the tests bound the difference)
+  {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* wr = &s_w[lane * CT_LD];
+    const float* cr = &s_c[wave * CT_LD];
+#pragma unroll 4
+    for (int k = 0; k < a.K2; k += 4) {
+      const float4 w = *reinterpret_cast<const float4*>(wr + k);
+      const float4 c = *reinterpret_cast<const float4*>(cr + k);
+      acc[0] = __builtin_fmaf(c.x, w.x, acc[0]);
+      acc[1] = __builtin_fmaf(c.y, w.y, acc[1]);
+      acc[2] = __builtin_fmaf(c.z, w.z, acc[2]);
+      acc[3] = __builtin_fmaf(c.w, w.w, acc[3]);
+    }
+    const float zj = (lane < a.ncls) ? ((acc[0] + acc[1]) + (acc[2] + acc[3]) + bias) : -__builtin_inff();
+    float m = zj;
+    int am = lane;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(m, o, 64);
+      const int oi = __shfl_xor(am, o, 64);
+      if (ov > m || (ov == m && oi < am)) m = ov, am = oi;
+    }
+    const float ex = (lane < a.ncls) ? expf(zj - m) : 0.f;
+    const float lse = m + logf(wave_sum(ex));
+    const float lp = zj - lse;
+    float other = (lane < a.ncls) ? ((lane == t) ? -10000.f : lp) : -__builtin_inff();
+    int ao = lane;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(other, o, 64);
+      const int oi = __shfl_xor(ao, o, 64);
+      if (ov > other || (ov == other && oi < ao)) other = ov, ao = oi;
+    }
+    const float real = __shfl(lp, t, 64);
+    float lval = 0.f, gt = 0.f, go = 0.f;
+    if (a.kind == 0) {
+      const float mg = real - other + a.kappa;
+      lval = fmaxf(mg, 0.f);
+      if (mg > 0.f) gt = 1.f, go = -1.f;
+    } else if (a.kind == 1) {
+      const float mg = other - real + a.kappa;
+      lval = fmaxf(mg, 0.f);
+      if (mg > 0.f) gt = -1.f, go = 1.f;
+    } else {
+      lval = 0.f - real;
+      gt = -1.f;
+    }
+    const float gsum = gt + ((a.kind == 2) ? 0.f : go);
+    float g = (lane == t ? gt : 0.f) + ((a.kind != 2 && lane == ao) ? go : 0.f);
+    g -= expf(zj - lse) * gsum;
+    s_g[wave][lane] = (lane < a.ncls) ? g * a.scale : 0.f;
+    if (b < a.B) {
+      if (a.logp && lane < a.ncls) a.logp[(int64_t)b * a.ncls + lane] = lp;
+      if (lane == 0) {
+        a.pred[b] = am;
+        if (a.loss) a.loss[b] = lval;
+      }
+    }
+  }
+  __syncthreads();
+  // g_c2[b,k] = (sum_c g_logits[b,c] W3[c,k]) * (c2[b,k] > 0): thread = k, all CT_S samples at once
+  if (tid < a.K2) {
+    float acc[CT_S] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+    for (int c = 0; c < a.ncls; ++c) {
+      const float w = s_w[c * CT_LD + tid];
+#pragma unroll
+      for (int j = 0; j < CT_S; ++j) acc[j] = __builtin_fmaf(s_g[j][c], w, acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < CT_S; ++j)
+      if (b0 + j < a.B) a.g_c2[(int64_t)(b0 + j) * a.K2 + tid] = (s_c[j * CT_LD + tid] > 0.f) ? acc[j] : 0.f;
+  }
+  if (a.step && blockIdx.x == 0 && tid == 0) a.step[0] += 1;
+}
+
 }  // namespace pc3d
 
 using namespace pc3d;
+
+extern "C" int pc3d_cls_tail_f32(const float* c2, int B, int K2, const float* W3, const float* b3, int ncls,
+                                 const int64_t* target, int kind, float kappa, float scale, float* logp,
+                                 int64_t* pred, float* loss, float* g_c2, int32_t* step, void* stream) {
+  PC3D_REQUIRE(B >= 0 && K2 >= 4 && K2 <= CT_K && (K2 % 4) == 0 && ncls >= 2 && ncls <= CT_MAXCLS,
+               "pc3d_cls_tail_f32: unsupported sizes B=%d K2=%d ncls=%d (K2 <= 256, K2 %% 4 == 0, ncls <= 64)", B, K2, ncls);
+  PC3D_REQUIRE(kind >= 0 && kind <= 2, "pc3d_cls_tail_f32: kind=%d not in {0,1,2}", kind);
+  if (B == 0) return PC3D_OK;
+  PC3D_REQUIRE(c2 && W3 && b3 && target && pred && g_c2, "pc3d_cls_tail_f32: null pointer");
+  ClsTailArgs a{c2, W3, b3, target, B, K2, ncls, kind, kappa, scale, logp, pred, loss, g_c2, step};
+  hipLaunchKernelGGL(cls_tail_kernel, dim3(cdiv(B, CT_S)), dim3(CT_T), 0, as_stream(stream), a);
+  PC3D_LAUNCH_CHECK("pc3d_cls_tail_f32");
+  return PC3D_OK;
+}
 
 extern "C" int pc3d_linear_f32(const float* X, int ldx, int P, int B, int K, const float* W, const float* bias,
                                int O, int relu, const float* gate, int ldg, float* Y, int ldy, void* stream) {

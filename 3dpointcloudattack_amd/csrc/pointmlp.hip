@@ -14,6 +14,7 @@
 // Backward: max-pool routes each channel's gradient to ONE point, so dgrad of layer 3 is sparse:
 // workgroup = (b, tile of 64 points) gathers the channels whose argmax falls in its tile in ascending channel order
 // (deterministic, no atomics), recomputes h1/h2 masks for those 64 points and chains W2^T, W1^T on the VALU.
+#include <stdlib.h>
 #include "pc3d_common.h"
 
 namespace pc3d {
@@ -25,7 +26,7 @@ constexpr int PM_C2 = 128;
 constexpr int PM_TP = 128;           // forward: points per workgroup
 constexpr int PM_LD1 = PM_C1 + 4;    // LDS row strides (floats): +4 keeps ds_read_b128 conflict-free
 constexpr int PM_LD2 = PM_C2 + 4;
-constexpr int PM_BTP = 64;           // backward: points per workgroup
+constexpr int PM_BTP = 32;           // backward: points per workgroup
 constexpr int PM_MAXC3 = 1024;       // backward: widest pooled layer held in LDS
 
 struct PMFwdArgs {
@@ -255,70 +256,80 @@ struct PMBwdArgs {
   PtsViewMut gx;          // T == null: gradient wrt the tower input; T given: gradient wrt the RAW points x
   float* part_gT;         // [B, ntiles, 16] per-tile partial of d/dT (9 used) or null
   int accumulate;         // gx += instead of gx =
+  int stop;               // profiling aid (PC3D_BWD_STOP=n): return after phase n; 0 = run everything
 };
 
-// Workgroup = (batch b, 64 points), 4 waves.
+// Workgroup = (batch b, 32 points), 4 waves; <= 36 KiB LDS so four workgroups share a CU (the kernel is a chain of
+// dependent latencies, residency is what hides them).
 //  A. channels whose arg-max lies in the tile are compacted IN CHANNEL ORDER (block prefix sum) into two lists
-//     (points 0-31 / 32-63) and their rows g[c]*W3[c,:] are accumulated into g2s[pt][128] — ordered => deterministic;
-//  B. h1 = relu(W1 x + b1) is recomputed; the layer-2 pre-activation runs on MFMA (A = h1 from LDS, B = W2 rows from
-//     L2) and masks g2s in place;
-//  C. g1 = (g2 masked) . W2 runs on MFMA (A = g2s from LDS, B = W2T rows), is masked by h1 > 0 and overwrites h1s;
-//  D. gx' = g1 . W1 on the VALU.
+//     (points 0-15 / 16-31) and their rows g[c]*W3[c,:] are accumulated into g2s[pt][128] — ordered => deterministic;
+//  B. h1 = relu(W1 x + b1) is recomputed; the layer-2 pre-activation runs on MFMA (A = h1 from LDS, B = W2 rows
+//     prefetched at kernel entry) and masks g2s in place;
+//  C. g1 = (g2 masked) . W2 on MFMA with K = 128 split over wave pairs, masked by h1 > 0;
+//  D. g' = g1 . W1 on the VALU, then the x' = x @ T chain (dL/dx, per-tile partial of dL/dT).
 __global__ __launch_bounds__(256) void pointmlp3_max_bwd_kernel(PMBwdArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[PM_BTP * PM_LD2 + PM_BTP * PM_LD1 + 4 * PM_BTP + 4 * PM_MAXC3];
-  float* g2s = lds;                                   // [64][132]
-  float* h1s = g2s + PM_BTP * PM_LD2;                 // [64][68]   (later holds g1)
-  float* xs = h1s + PM_BTP * PM_LD1;                  // [3][64] (+64 spare: scan scratch)
-  int* s_scan = reinterpret_cast<int*>(xs + 3 * PM_BTP);   // [64] wave totals etc.
+  __shared__ __attribute__((aligned(16))) float lds[PM_BTP * PM_LD2 + PM_BTP * PM_LD1 + 4 * PM_BTP + PM_MAXC3 + (3 * PM_MAXC3) / 2];  // 36.4 KB
+  float* g2s = lds;                                   // [32][132]
+  float* h1s = g2s + PM_BTP * PM_LD2;                 // [32][68]   (later holds g1)
+  float* xs = h1s + PM_BTP * PM_LD1;                  // [3][32]
+  int* s_scan = reinterpret_cast<int*>(xs + 3 * PM_BTP);   // [32] wave totals
   float* s_g = xs + 4 * PM_BTP;                       // [C3]
-  int* s_n = reinterpret_cast<int*>(s_g + PM_MAXC3);  // [C3]
-  int* list0 = s_n + PM_MAXC3;                        // [C3] channels hitting points 0..31, ascending
-  int* list1 = list0 + PM_MAXC3;                      // [C3] channels hitting points 32..63
+  short* s_n = reinterpret_cast<short*>(s_g + PM_MAXC3);   // [C3] local point index or -1
+  short* list0 = s_n + PM_MAXC3;                      // [C3] channels hitting points 0..15, ascending
+  short* list1 = list0 + PM_MAXC3;                    // [C3] channels hitting points 16..31
   const int tile = blockIdx.x, b = blockIdx.y;
   const int n0 = tile * PM_BTP;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
 
+  // ---- A1. classify 4 consecutive channels per thread, block-wide ordered compaction.
+  // Issue the (tiny) arg-max / gradient loads FIRST: vector-memory results return in issue order, so anything issued
+  // behind the 64 KiB weight prefetch below would wait for all of it.
+  int ld_n[PM_MAXC3 / 256];
+  float ld_g[PM_MAXC3 / 256];
+#pragma unroll
+  for (int e = 0; e < PM_MAXC3 / 256; ++e) {
+    const int c = tid * (PM_MAXC3 / 256) + e;
+    ld_n[e] = (c < a.C3) ? a.argidx[(int64_t)b * a.C3 + c] : -1;
+    ld_g[e] = (c < a.C3) ? a.g[(int64_t)b * a.C3 + c] : 0.f;
+  }
+  float px = 0.f, py = 0.f, pz = 0.f;
+  if (tid < PM_BTP) load_point(a.x, a.T, b, n0 + tid, a.N, px, py, pz);
   // MFMA B operands of phases B and C depend on nothing: fetch them now so their L2 latency hides under phase A
-  float4 w2r[PM_C1 / 8], w2tr[PM_C2 / 8];
+  float4 w2r[PM_C1 / 8], w2tr[PM_C2 / 16];
   {
     const float* wrow = a.W2 + (32 * wave + r) * PM_C1 + 4 * h;
 #pragma unroll
     for (int t = 0; t < PM_C1 / 8; ++t) w2r[t] = *reinterpret_cast<const float4*>(wrow + 8 * t);
-    const float* wtrow = a.W2T + (32 * (wave >> 1) + r) * PM_C2 + 4 * h;
+    // phase C: wave = (j block wave&1, K half wave>>1): k in [64*(wave>>1), +64)
+    const float* wtrow = a.W2T + (32 * (wave & 1) + r) * PM_C2 + 64 * (wave >> 1) + 4 * h;
 #pragma unroll
-    for (int t = 0; t < PM_C2 / 8; ++t) w2tr[t] = *reinterpret_cast<const float4*>(wtrow + 8 * t);
+    for (int t = 0; t < PM_C2 / 16; ++t) w2tr[t] = *reinterpret_cast<const float4*>(wtrow + 8 * t);
   }
-
-  // ---- A1. classify 4 consecutive channels per thread, block-wide ordered compaction
   int cnt0 = 0, cnt1 = 0;
   int myn[PM_MAXC3 / 256];
 #pragma unroll
   for (int e = 0; e < PM_MAXC3 / 256; ++e) {
     const int c = tid * (PM_MAXC3 / 256) + e;
     int n = -1;
-    float gv = 0.f;
     if (c < a.C3) {
-      n = a.argidx[(int64_t)b * a.C3 + c] - n0;
-      gv = a.g[(int64_t)b * a.C3 + c];
+      n = ld_n[e] - n0;
+      const float gv = ld_g[e];
       if (n < 0 || n >= PM_BTP || gv == 0.f) n = -1;
       s_g[c] = gv;
-      s_n[c] = n;
+      s_n[c] = (short)n;
     }
     myn[e] = n;
-    cnt0 += (n >= 0 && n < 32) ? 1 : 0;
-    cnt1 += (n >= 32) ? 1 : 0;
+    cnt0 += (n >= 0 && n < 16) ? 1 : 0;
+    cnt1 += (n >= 16) ? 1 : 0;
   }
   if (tid < PM_BTP) {
-    float px, py, pz;
-    load_point(a.x, a.T, b, n0 + tid, a.N, px, py, pz);
     xs[tid] = px;
     xs[PM_BTP + tid] = py;
     xs[2 * PM_BTP + tid] = pz;
   }
   for (int i = tid; i < PM_BTP * PM_LD2; i += 256) g2s[i] = 0.f;
-  // inclusive scan of the packed counts inside the wave, then across the 4 waves
   int packed = cnt0 | (cnt1 << 16);
   int incl = packed;
 #pragma unroll
@@ -338,7 +349,7 @@ __global__ __launch_bounds__(256) void pointmlp3_max_bwd_kernel(PMBwdArgs a) {
   const int len0 = total & 0xffff, len1 = total >> 16;
   if (len0 + len1 == 0) {  // no critical point in this tile: gradient is exactly zero
     if (tid < 3 * PM_BTP && !a.accumulate) {
-      const int p = tid & (PM_BTP - 1), c = tid >> 6;
+      const int p = tid & (PM_BTP - 1), c = tid >> 5;
       if (n0 + p < a.N) a.gx.p[(int64_t)b * a.gx.bs + (int64_t)(n0 + p) * a.gx.ps + c * a.gx.cs] = 0.f;
     }
     if (a.part_gT && tid < 16) a.part_gT[((int64_t)b * gridDim.x + tile) * 16 + tid] = 0.f;
@@ -351,115 +362,132 @@ __global__ __launch_bounds__(256) void pointmlp3_max_bwd_kernel(PMBwdArgs a) {
     for (int e = 0; e < PM_MAXC3 / 256; ++e) {
       const int n = myn[e];
       const int c = tid * (PM_MAXC3 / 256) + e;
-      if (n >= 0 && n < 32) list0[o0++] = c;
-      if (n >= 32) list1[o1++] = c;
+      if (n >= 0 && n < 16) list0[o0++] = (short)c;
+      if (n >= 16) list1[o1++] = (short)c;
     }
   }
+  if (a.stop == 1) return;
   layer1_to_lds<PM_BTP, 256>(xs, h1s, a.W1, a.b1);
   __syncthreads();
+  if (a.stop == 2) return;
 
   // ---- A2. ordered accumulation: thread (k, half) walks its half's list; loads are independent -> pipelined
   {
     const int k = tid & (PM_C2 - 1), ph = tid >> 7;
-    const int* list = ph ? list1 : list0;
+    const short* list = ph ? list1 : list0;
     const int len = ph ? len1 : len0;
     int i = 0;
-    for (; i + 4 <= len; i += 4) {
-      int c[4];
-      float w[4];
+    for (; i + 8 <= len; i += 8) {  // 8 independent W3 loads in flight per round trip
+      int c[8];
+      float w[8];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
+      for (int e = 0; e < 8; ++e) {
         c[e] = list[i + e];
         w[e] = a.W3[(int64_t)c[e] * PM_C2 + k];
       }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float* dst = g2s + s_n[c[e]] * PM_LD2 + k;
+      for (int e = 0; e < 8; ++e) {
+        float* dst = g2s + (int)s_n[c[e]] * PM_LD2 + k;
         *dst = __builtin_fmaf(s_g[c[e]], w[e], *dst);
       }
     }
+    for (; i + 2 <= len; i += 2) {
+      const int c0 = list[i], c1 = list[i + 1];
+      const float w0 = a.W3[(int64_t)c0 * PM_C2 + k], w1 = a.W3[(int64_t)c1 * PM_C2 + k];
+      float* d0 = g2s + (int)s_n[c0] * PM_LD2 + k;
+      *d0 = __builtin_fmaf(s_g[c0], w0, *d0);
+      float* d1 = g2s + (int)s_n[c1] * PM_LD2 + k;
+      *d1 = __builtin_fmaf(s_g[c1], w1, *d1);
+    }
     for (; i < len; ++i) {
       const int c = list[i];
-      float* dst = g2s + s_n[c] * PM_LD2 + k;
+      float* dst = g2s + (int)s_n[c] * PM_LD2 + k;
       *dst = __builtin_fmaf(s_g[c], a.W3[(int64_t)c * PM_C2 + k], *dst);
     }
   }
   __syncthreads();
+  if (a.stop == 3) return;
 
-  // ---- B. layer-2 pre-activation on MFMA: D[pt][c2], wave owns c2 block [32*wave, +32), two point tiles; mask g2s
-  {
-    f32x16 acc[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-#pragma unroll
-    for (int t = 0; t < PM_C1 / 8; ++t) {
-      const float4 bw = w2r[t];
-      float4 av[2];
-#pragma unroll
-      for (int tl = 0; tl < 2; ++tl)
-        av[tl] = *reinterpret_cast<const float4*>(h1s + (tl * 32 + r) * PM_LD1 + 8 * t + 4 * h);
-#pragma unroll
-      for (int tl = 0; tl < 2; ++tl) {
-        acc[tl] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tl].x, bw.x, acc[tl], 0, 0, 0);
-        acc[tl] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tl].y, bw.y, acc[tl], 0, 0, 0);
-        acc[tl] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tl].z, bw.z, acc[tl], 0, 0, 0);
-        acc[tl] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tl].w, bw.w, acc[tl], 0, 0, 0);
-      }
-    }
-    const float bias = a.b2[32 * wave + r];
-#pragma unroll
-    for (int tl = 0; tl < 2; ++tl)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int pt = tl * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (!(acc[tl][e] + bias > 0.f)) g2s[pt * PM_LD2 + 32 * wave + r] = 0.f;
-      }
-  }
-  __syncthreads();
-
-  // ---- C. g1[pt][j] = sum_k2 g2[pt][k2] W2[k2][j] on MFMA: wave = (point tile wave&1, j block wave>>1), K = 128
+  // ---- B. layer-2 pre-activation on MFMA: D[pt][c2], wave owns c2 block [32*wave, +32); mask g2s
   {
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    const int tl = wave & 1, jb = wave >> 1;
 #pragma unroll
-    for (int t = 0; t < PM_C2 / 8; ++t) {
-      const float4 bw = w2tr[t];
-      const float4 av = *reinterpret_cast<const float4*>(g2s + (tl * 32 + r) * PM_LD2 + 8 * t + 4 * h);
+    for (int t = 0; t < PM_C1 / 8; ++t) {
+      const float4 bw = w2r[t];
+      const float4 av = *reinterpret_cast<const float4*>(h1s + r * PM_LD1 + 8 * t + 4 * h);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bw.x, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bw.y, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bw.z, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bw.w, acc, 0, 0, 0);
     }
-    // each (pt, j) of h1s is read (mask) and overwritten (g1) by exactly one lane: no barrier needed in between
+    const float bias = a.b2[32 * wave + r];
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const int pt = tl * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-      float* q = h1s + pt * PM_LD1 + 32 * jb + r;
-      *q = (*q > 0.f) ? acc[e] : 0.f;
+      const int pt = (e & 3) + 8 * (e >> 2) + 4 * h;
+      if (!(acc[e] + bias > 0.f)) g2s[pt * PM_LD2 + 32 * wave + r] = 0.f;
     }
   }
   __syncthreads();
+  if (a.stop == 4) return;
+
+  // ---- C. g1[pt][j] = sum_k2 g2[pt][k2] W2[k2][j] on MFMA: wave = (j block wave&1, K half wave>>1)
+  {
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    const int jb = wave & 1, kh = wave >> 1;
+#pragma unroll
+    for (int t = 0; t < PM_C2 / 16; ++t) {
+      const float4 bw = w2tr[t];
+      const float4 av = *reinterpret_cast<const float4*>(g2s + r * PM_LD2 + 64 * kh + 8 * t + 4 * h);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bw.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bw.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bw.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bw.w, acc, 0, 0, 0);
+    }
+    // the upper K half hands its partial tile to the lower one through LDS (fixed order: deterministic); g2s is dead
+    // once every wave has read its A operands, so it doubles as the exchange buffer (one [32][33] tile per j block)
+    __syncthreads();
+    float* cr = g2s + jb * (32 * 33);
+    if (kh == 1) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) cr[((e & 3) + 8 * (e >> 2) + 4 * h) * 33 + r] = acc[e];
+    }
+    __syncthreads();
+    if (kh == 0) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int pt = (e & 3) + 8 * (e >> 2) + 4 * h;
+        float* q = h1s + pt * PM_LD1 + 32 * jb + r;
+        *q = (*q > 0.f) ? (acc[e] + cr[pt * 33 + r]) : 0.f;
+      }
+    }
+  }
+  __syncthreads();
+  if (a.stop == 5) return;
 
   // ---- D. g'[p][c] = sum_j W1[j][c] g1[p][j]  (gradient wrt the tower input x' = x @ T)
-  float* gp = g2s;  // [3][64] scratch (g2s is dead)
-  if (tid < 3 * PM_BTP) {
-    const int p = tid & (PM_BTP - 1), c = tid >> 6;
+  float* gp = xs;  // [3][32] scratch (the staged coordinates are dead)
+  if (wave < 3 && lane < PM_BTP) {   // wave = coordinate c (uniform -> W1 comes through scalar loads), lane = point
+    const int p = lane, c = wave;
     float s0 = 0.f, s1 = 0.f;
-#pragma unroll 8
-    for (int j = 0; j < PM_C1; j += 2) {
-      s0 = __builtin_fmaf(a.W1[j * 3 + c], h1s[p * PM_LD1 + j], s0);
-      s1 = __builtin_fmaf(a.W1[(j + 1) * 3 + c], h1s[p * PM_LD1 + j + 1], s1);
+#pragma unroll
+    for (int j = 0; j < PM_C1; j += 4) {
+      const float4 hv = *reinterpret_cast<const float4*>(h1s + p * PM_LD1 + j);
+      s0 = __builtin_fmaf(a.W1[j * 3 + c], hv.x, s0);
+      s1 = __builtin_fmaf(a.W1[(j + 1) * 3 + c], hv.y, s1);
+      s0 = __builtin_fmaf(a.W1[(j + 2) * 3 + c], hv.z, s0);
+      s1 = __builtin_fmaf(a.W1[(j + 3) * 3 + c], hv.w, s1);
     }
     gp[c * PM_BTP + p] = s0 + s1;
   }
   __syncthreads();
-  if (tid < PM_BTP) {  // wave 0: lane = point
-    const int p = tid;
-    const float g0 = gp[p], g1v = gp[PM_BTP + p], g2v = gp[2 * PM_BTP + p];
+  if (wave == 0) {  // lanes 0..31 = the tile's points; lanes 32..63 contribute zeros to the reductions
+    const int p = lane & (PM_BTP - 1);
+    const bool live = lane < PM_BTP;
+    const float g0 = live ? gp[p] : 0.f, g1v = live ? gp[PM_BTP + p] : 0.f, g2v = live ? gp[2 * PM_BTP + p] : 0.f;
     float o0 = g0, o1 = g1v, o2 = g2v;
     if (a.T) {
       // x' = x @ T  =>  dL/dx[c] = sum_c' g'[c'] T[c][c'] ;  dL/dT[c][c'] = sum_p x[p][c] g'[p][c']
@@ -469,7 +497,7 @@ __global__ __launch_bounds__(256) void pointmlp3_max_bwd_kernel(PMBwdArgs a) {
       o2 = __builtin_fmaf(g2v, t[8], __builtin_fmaf(g1v, t[7], g0 * t[6]));
       if (a.part_gT) {
         float xr[3] = {0.f, 0.f, 0.f};
-        if (n0 + p < a.N) {
+        if (live && n0 + p < a.N) {
           const float* xp = a.x.p + (int64_t)b * a.x.bs + (int64_t)(n0 + p) * a.x.ps;
           xr[0] = xp[0], xr[1] = xp[a.x.cs], xr[2] = xp[2 * a.x.cs];
         }
@@ -479,12 +507,12 @@ __global__ __launch_bounds__(256) void pointmlp3_max_bwd_kernel(PMBwdArgs a) {
 #pragma unroll
           for (int d = 0; d < 3; ++d) {
             const float sum = wave_sum(xr[c] * gv[d]);
-            if (p == 0) a.part_gT[((int64_t)b * gridDim.x + tile) * 16 + c * 3 + d] = sum;
+            if (lane == 0) a.part_gT[((int64_t)b * gridDim.x + tile) * 16 + c * 3 + d] = sum;
           }
-        if (p >= 9 && p < 16) a.part_gT[((int64_t)b * gridDim.x + tile) * 16 + p] = 0.f;
+        if (lane >= 9 && lane < 16) a.part_gT[((int64_t)b * gridDim.x + tile) * 16 + lane] = 0.f;
       }
     }
-    if (n0 + p < a.N) {
+    if (live && n0 + p < a.N) {
       float* q = a.gx.p + (int64_t)b * a.gx.bs + (int64_t)(n0 + p) * a.gx.ps;
       if (a.accumulate) {
         q[0] += o0, q[a.gx.cs] += o1, q[2 * a.gx.cs] += o2;
@@ -543,7 +571,7 @@ extern "C" int pc3d_pointmlp3_max_bwd_f32(const float* x, int64_t x_bs, int64_t 
   PC3D_REQUIRE(x && W1 && b1 && W2 && b2 && W3 && W2T && argidx && g_pooled && grad_x,
                "pc3d_pointmlp3_max_bwd_f32: null pointer");
   PMBwdArgs a{{x, x_bs, x_ps, x_cs}, N, C3, T, W1, b1, W2, b2, W3, W2T, argidx, g_pooled, {grad_x, gx_bs, gx_ps, gx_cs},
-              part_gT, accumulate};
+              part_gT, accumulate, getenv("PC3D_BWD_STOP") ? atoi(getenv("PC3D_BWD_STOP")) : 0};
   hipLaunchKernelGGL(pointmlp3_max_bwd_kernel, dim3(cdiv(N, PM_BTP), B), dim3(256), 0, as_stream(stream), a);
   PC3D_LAUNCH_CHECK("pc3d_pointmlp3_max_bwd_f32");
   return PC3D_OK;

@@ -166,6 +166,15 @@ class PointNetCls(_FrozenFusedMixin, nn.Module):
         logp, pred, loss, g_logits = ops.cls_loss(logits, target, kind, kappa, scale=1.0 / x.shape[0])
         return logp, pred, loss, fused_input_grad(ctx, g_logits)
 
+    def fused_attack_grad(self, x, target, kind, kappa=0.0, pred_out=None, step=None):
+        """fused_loss_and_grad for the attack loops: the classifier tail (fc3, loss, fc3 backward) is one launch that
+        also writes the prediction into `pred_out` and advances the device step word. Returns (pred, loss, dL/dx)."""
+        _, ctx = fused_forward(self, x, tail=False)
+        c2, pk = ctx[-1], ctx[1]
+        _, pred, loss, g_c2 = ops.cls_tail(c2, pk["c"][4], pk["c"][5], target, kind, kappa, scale=1.0 / x.shape[0],
+                                           pred_out=pred_out, step=step, want_logp=False)
+        return pred, loss, fused_input_grad(ctx, None, g_c2=g_c2)
+
     def forward(self, x):
         self._require_fused(x)
         head = self.folded()
@@ -197,7 +206,7 @@ def _fused_pack(model):
                 s_t=(_t(w1s), _t(w2s), w3s_t.contiguous()), c_t=(_t(w1c), _t(w2c), _t(w3c)))
 
 
-def fused_forward(model, x):
+def fused_forward(model, x, tail=True):
     """Launch-minimal forward of PointNetCls: 2 tower launches (+2 folds) + 6 head launches, no autograd graph.
     Returns (logits [B,k] PRE-softmax, ctx) — ctx feeds fused_input_grad."""
     model._require_fused(x)
@@ -214,16 +223,17 @@ def fused_forward(model, x):
     pooled, idx = ops.pointmlp3_max_fwd_raw(x, pk["tower_c"], False, T=trans)
     c1 = ops.linear(pooled, w1c, b1c, relu=True)
     c2 = ops.linear(c1, w2c, b2c, relu=True)
-    logits = ops.linear(c2, w3c, b3c)
+    logits = ops.linear(c2, w3c, b3c) if tail else None
     return logits, (x, pk, pooled_s, idx_s, a1, a2, trans, idx, c1, c2)
 
 
-def fused_input_grad(ctx, g_logits, out=None):
+def fused_input_grad(ctx, g_logits, out=None, g_c2=None):
     """Backward-to-input of fused_forward for an upstream gradient on the logits: 6 head launches + 2 tower launches."""
     x, pk, pooled_s, idx_s, a1, a2, trans, idx, c1, c2 = ctx
     w1c_t, w2c_t, w3c_t = pk["c_t"]
     w1s_t, w2s_t, w3s_t = pk["s_t"]
-    g_c2 = ops.linear(g_logits, w3c_t, gate=c2)
+    if g_c2 is None:
+        g_c2 = ops.linear(g_logits, w3c_t, gate=c2)
     g_c1 = ops.linear(g_c2, w2c_t, gate=c1)
     g_pooled = ops.linear(g_c1, w1c_t)
     gx, part_gT = ops.pointmlp3_max_bwd_raw(x, pk["tower_c"], idx, g_pooled, T=trans, want_gT=True, out=out)

@@ -452,9 +452,51 @@ def cls_loss(logits, target, kind, kappa=0.0, scale=1.0, want_grad=True):
     return logp, pred, loss, g
 
 
+def cls_tail(c2, w3, b3, target, kind, kappa=0.0, scale=1.0, pred_out=None, step=None, want_logp=True):
+    """fc3 + cls_loss + fc3-backward in one launch (see pc3d_cls_tail_f32): (logp or None, pred, loss, g_c2).
+    pred_out: persistent int64 [B] to write the prediction into; step: int32 [1] device word to advance."""
+    _check(c2, "c2"), _check(w3, "w3"), _check(b3, "b3")
+    B, K2 = c2.shape
+    ncls = w3.shape[0]
+    dev = c2.device
+    if target.dtype != torch.int64 or not target.is_cuda:
+        raise TypeError("cls_tail: target must be an int64 GPU tensor")
+    logp = torch.empty((B, ncls), dtype=torch.float32, device=dev) if want_logp else None
+    pred = pred_out if pred_out is not None else torch.empty((B,), dtype=torch.int64, device=dev)
+    loss = torch.empty((B,), dtype=torch.float32, device=dev)
+    g_c2 = torch.empty((B, K2), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.call("pc3d_cls_tail_f32", c2.data_ptr(), B, K2, w3.data_ptr(), b3.data_ptr(), ncls, target.data_ptr(),
+                  LOSS_KINDS[kind] if isinstance(kind, str) else int(kind), float(kappa), float(scale), _ptr(logp),
+                  pred.data_ptr(), loss.data_ptr(), g_c2.data_ptr(), _ptr(step), _stream())
+    return logp, pred, loss, g_c2
+
+
 # ------------------------------------------------------------------------------------------------------
 # CW-family loop: bookkeeping + fused update
 # ------------------------------------------------------------------------------------------------------
+def cw_update(adv, ori, pred, label, untarget, bestdist, bestscore, o_bestdist, o_bestscore, o_bestattack, g, m, v,
+              step, lr, budget, input_val=None, dist_val=None, dist_kind=0, w=None, nn_idx=None,
+              betas=(0.9, 0.999), eps=1e-8, cf=True):
+    """cw_bookkeep + cw_step as one launch (see pc3d_cw_update_f32). `step` (int32 device word or int) is only READ."""
+    _, _, _, _, B, K = _pts(adv, cf, "adv")
+    for nm, t in (("o_bestattack", o_bestattack), ("m", m), ("v", v), ("input_val", input_val)):
+        if t is not None and (t.shape != adv.shape or t.stride() != adv.stride()):
+            raise ValueError(f"cw_update: {nm} must share adv's shape and strides")
+    if isinstance(step, torch.Tensor):
+        step_dev, step_host = step.data_ptr(), 0
+    else:
+        step_dev, step_host = 0, int(step)
+    with torch.cuda.device(adv.device):
+        _lib.call("pc3d_cw_update_f32", *_pv(adv, cf, "adv"), *_pv(ori, cf, "ori"), B, K, pred.data_ptr(),
+                  label.data_ptr(), 1 if untarget else 0, bestdist.data_ptr(), bestscore.data_ptr(),
+                  o_bestdist.data_ptr(), o_bestscore.data_ptr(), o_bestattack.data_ptr(), _ptr(input_val),
+                  _ptr(dist_val), *_pv(g, cf, "g"), m.data_ptr(), v.data_ptr(), float(lr), float(betas[0]),
+                  float(betas[1]), float(eps), float(budget), step_dev, step_host, int(dist_kind), _ptr(w),
+                  _ptr(nn_idx), _stream())
+    return adv
+
+
 def cw_bookkeep(adv, ori, pred, label, untarget, bestdist, bestscore, o_bestdist, o_bestscore, o_bestattack,
                 input_val=None, dist_val=None, step=None, cf=True):
     """In-place update of the best-attack state for one iteration (see pc3d_cw_bookkeep_f32)."""

@@ -268,6 +268,26 @@ int pc3d_gather_max_bwd_f32(const float* g, const int32_t* arg, int B, int N, in
 int pc3d_graph_laplacian_f32(const float* xyz, int64_t x_bs, int64_t x_ps, int64_t x_cs,
                              const int32_t* idx, int B, int N, int K, float* L, void* stream);
 
+/* Classifier tail in one launch: logits = c2 W3^T + b3 (fc3), log_softmax / pred / adversarial loss as
+ * pc3d_cls_loss_f32, and g_c2 = (g_logits W3) * (c2 > 0) (fc3 backward + ReLU mask of fc2's activation). K2 <= 256,
+ * ncls <= 64. *step (may be NULL) is incremented by one. */
+int pc3d_cls_tail_f32(const float* c2, int B, int K2, const float* W3, const float* b3, int ncls,
+                      const int64_t* target, int kind, float kappa, float scale, float* logp,
+                      int64_t* pred, float* loss, float* g_c2, int32_t* step, void* stream);
+
+/* pc3d_cw_bookkeep_f32 + pc3d_cw_step_f32 as ONE launch (one workgroup per sample): bookkeeping on the current
+ * iterate, then total gradient + Adam + clip on that sample's points. o_bestattack / input_val / m / v share adv's
+ * strides; input_val / dist_val may be NULL. The step number is READ from *step_dev (or step_host). */
+int pc3d_cw_update_f32(float* adv, int64_t a_bs, int64_t a_ps, int64_t a_cs,
+                       const float* ori, int64_t o_bs, int64_t o_ps, int64_t o_cs, int B, int K,
+                       const int64_t* pred, const int64_t* label, int untarget,
+                       float* bestdist, int64_t* bestscore, float* o_bestdist, int64_t* o_bestscore,
+                       float* o_bestattack, float* input_val, float* dist_val,
+                       const float* g, int64_t g_bs, int64_t g_ps, int64_t g_cs, float* m, float* v,
+                       double lr, double beta1, double beta2, double eps, float budget,
+                       const int32_t* step_dev, int step_host, int dist_kind, const float* w,
+                       const int32_t* nn_idx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

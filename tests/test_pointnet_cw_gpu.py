@@ -11,6 +11,7 @@ from helpers import hip_pointnet, oracle_pointnet, unit_cloud
 from oracle import ref_torch as ort
 
 pytestmark = pytest.mark.gpu
+ops = importlib.import_module("3dpointcloudattack_amd.ops")
 
 
 def _mods():
@@ -230,3 +231,62 @@ def test_launch_minimal_iteration_equals_generic_path(dev, dist_name):
     ok = bd0 < 1e9
     np.testing.assert_allclose(bd1[ok], bd0[ok], rtol=5e-3)
     assert (np.abs(ba1 - ba0) <= 1e-4).mean() > 0.95
+
+
+@pytest.mark.parametrize("kind,kappa", [("untargeted_logits", 5.0), ("logits", 0.0), ("cross_entropy", 0.0)])
+@pytest.mark.parametrize("B,ncls", [(5, 40), (37, 16)])
+def test_cls_tail_equals_three_launch_tail(dev, kind, kappa, B, ncls):
+    """pc3d_cls_tail_f32 = fc3 + cls_loss + fc3 backward (with fc2's ReLU mask), and it advances the step word."""
+    g = torch.Generator().manual_seed(B)
+    c2 = torch.relu(torch.randn(B, 256, generator=g)).to(dev)
+    w3, b3 = (torch.randn(ncls, 256, generator=g) * 0.2).to(dev), torch.randn(ncls, generator=g).to(dev)
+    tgt = torch.randint(0, ncls, (B,), generator=g).to(dev)
+    logits = ops.linear(c2, w3, b3)
+    logp, pred, loss, gl = ops.cls_loss(logits, tgt, kind, kappa, scale=1.0 / B)
+    g_ref = ops.linear(gl, w3.t().contiguous(), gate=c2)
+    step = torch.full((1,), 6, dtype=torch.int32, device=dev)
+    pred_out = torch.full((B,), -7, dtype=torch.int64, device=dev)
+    logp2, pred2, loss2, g_c2 = ops.cls_tail(c2, w3, b3, tgt, kind, kappa, scale=1.0 / B, pred_out=pred_out, step=step)
+    assert pred2 is pred_out and torch.equal(pred2, pred) and int(step) == 7
+    torch.testing.assert_close(logp2, logp, rtol=1e-5, atol=2e-5)
+    torch.testing.assert_close(loss2, loss, rtol=1e-5, atol=2e-5)
+    torch.testing.assert_close(g_c2, g_ref, rtol=1e-4, atol=1e-6)
+    assert torch.equal(g_c2 == 0, (g_ref == 0))
+
+
+@pytest.mark.parametrize("dk", [0, 1, 2])
+def test_cw_update_equals_bookkeep_plus_step(dev, dk):
+    """The merged launch equals pc3d_cw_bookkeep_f32 followed by pc3d_cw_step_f32 (the norm's reduction tree differs,
+    so float state agrees to the last ulps; integer state and the copies are exact)."""
+    B, K = 6, 333
+    g = torch.Generator().manual_seed(dk)
+    ori = torch.randn(B, 3, K, generator=g).to(dev)
+    adv0 = ori + 0.05 * torch.randn(B, 3, K, generator=g).to(dev)
+    grad = torch.randn(B, 3, K, generator=g).to(dev)
+    pred = torch.randint(0, 3, (B,), generator=g).to(dev)
+    label = torch.randint(0, 3, (B,), generator=g).to(dev)
+    w = torch.rand(B, generator=g).to(dev)
+    nn_idx = torch.randint(0, K, (B, K), generator=g).int().to(dev)
+
+    def state():
+        return dict(adv=adv0.clone(), bestdist=torch.full((B,), 1e10, device=dev), bestscore=torch.full((B,), -1, device=dev),
+                    o_bestdist=torch.tensor([1e10, 0.1, 1e10, 1e10, 0.0, 1e10], device=dev),
+                    o_bestscore=torch.full((B,), -1, device=dev), o_bestattack=torch.zeros(B, 3, K, device=dev),
+                    input_val=torch.zeros(B, 3, K, device=dev), dist_val=torch.zeros(B, device=dev),
+                    m=0.01 * grad.clone(), v=0.001 * grad.clone() ** 2)
+    a, b = state(), state()
+    step = torch.full((1,), 4, dtype=torch.int32, device=dev)
+    ops.cw_bookkeep(a["adv"], ori, pred, label, True, a["bestdist"], a["bestscore"], a["o_bestdist"], a["o_bestscore"],
+                    a["o_bestattack"], input_val=a["input_val"], dist_val=a["dist_val"], step=step)
+    assert int(step) == 5
+    ops.cw_step(a["adv"], grad, a["m"], a["v"], step, 0.01, ori, 0.18, dist_kind=dk, w=w, l2norm=a["dist_val"], nn_idx=nn_idx)
+    ops.cw_update(b["adv"], ori, pred, label, True, b["bestdist"], b["bestscore"], b["o_bestdist"], b["o_bestscore"],
+                  b["o_bestattack"], grad, b["m"], b["v"], step, 0.01, 0.18, input_val=b["input_val"],
+                  dist_val=b["dist_val"], dist_kind=dk, w=w, nn_idx=nn_idx)
+    assert int(step) == 5
+    for k in a:
+        if a[k].dtype == torch.float32 and k not in ("o_bestattack", "input_val"):
+            torch.testing.assert_close(a[k], b[k], rtol=2e-6, atol=1e-7, msg=k)
+        else:
+            assert torch.equal(a[k], b[k]), k
+    assert a["o_bestattack"].abs().sum() > 0 and not torch.equal(a["adv"], adv0)
