@@ -4,18 +4,12 @@
 //   K in {1,4,17}), attack/AOF/TAOF_attack.py:13-28 (k=30), model/dgcnn.py:194-200 on xyz (k=20),
 //   model/curvenet_util.py:10-17.
 //
-// Same skeleton as the NN kernel: workgroup = (batch, 64 queries), reference cloud staged through LDS as SoA,
-// the four waves scan one quarter of each LDS tile for the SAME 64 queries (one per lane). Each lane keeps a
-// sorted K-list in registers (compile-time KMAX in {8,16,32}); a candidate is inserted only when it beats the
-// lane's current K-th distance (wave-uniform skip otherwise). The four partial lists are merged through LDS.
-// Ties: the lower reference index comes first.
+// The reference cloud is staged through LDS as SoA (like the NN kernel); each wave serves 4 queries whose sorted
+// K-lists live across its lanes (details at knn_wave_kernel). K <= 64. Ties: the lower reference index comes first.
 #include "pc3d_common.h"
 
 namespace pc3d {
 
-constexpr int kKnnThreads = 256;
-constexpr int kKnnWaves = 4;
-constexpr int kKnnMaxTile = 4096;
 constexpr float kKnnFar = 1.0e18f;
 
 struct KnnArgs {
@@ -25,131 +19,179 @@ struct KnnArgs {
   int32_t* i;  // [B,N,K]
 };
 
-template <int KMAX>
-__device__ __forceinline__ void knn_insert(float (&bd)[KMAX], int (&bi)[KMAX], float d, int idx) {
-#pragma unroll
-  for (int j = KMAX - 1; j > 0; --j) {
-    const bool shift = d < bd[j - 1];
-    const bool here = d < bd[j];
-    bd[j] = shift ? bd[j - 1] : (here ? d : bd[j]);
-    bi[j] = shift ? bi[j - 1] : (here ? idx : bi[j]);
-  }
-  const bool first = d < bd[0];
-  bd[0] = first ? d : bd[0];
-  bi[0] = first ? idx : bi[0];
+// ---------------------------------------------------------------------------------------------------------
+// Wave-per-query search: the 64 lanes of a wave hold 64 CANDIDATES of one LDS step and test them against 4 queries
+// at once (wave-uniform thresholds), so a step costs ~10 VALU wave-instructions per query like the NN kernel, and a
+// candidate that beats a query's K-th distance is inserted into that query's sorted list, which lives ACROSS the
+// lanes (lane j = j-th nearest so far): ballot/popcount finds the slot, one DPP lane shift makes room.
+// (A list per lane — one query per lane — makes all 64 lanes pay for an insertion whenever ANY lane accepts, which
+// is almost every candidate: measured 3.3 ms at B=32, N=M=4096, K=21 against 0.56 ms for this layout.)
+// The first 64 candidates seed the list (bitonic sort, or K rounds of wave-min for small K). Ties: candidates are
+// visited in ascending index order and inserted AFTER equal distances, so the lower index comes first
+// (torch.topk / the reference's order).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kKwQPW = 4;          // queries scanned together by a wave
+constexpr int kKwTile = 2048;      // reference points per LDS tile (24 KiB SoA)
+
+__device__ __forceinline__ float readlane_f(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
 
-template <int KMAX>
-__global__ __launch_bounds__(kKnnThreads) void knn_kernel(KnnArgs a, int mt_cap) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int N = a.N, M = a.M, K = a.K;
-  const int q0 = blockIdx.x * kWave;
-  const int b = blockIdx.y;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int mt = M < mt_cap ? M : mt_cap;
-  const int slice = ((mt + kKnnWaves * 4 - 1) / (kKnnWaves * 4)) * 4;
-  const int mt_pad = slice * kKnnWaves;
-  float* sx = lds;
-  float* sy = lds + mt_pad;
-  float* sz = lds + 2 * mt_pad;
-
-  int qi = q0 + lane;
-  if (qi >= N) qi = N - 1;
-  const float* qp = a.q.p + (int64_t)b * a.q.bs + (int64_t)qi * a.q.ps;
-  const float qx = qp[0], qy = qp[a.q.cs], qz = qp[2 * a.q.cs];
-
-  float bd[KMAX];
-  int bi[KMAX];
+// lexicographic (d, idx) bitonic sort of one value per lane, ascending over lanes
+__device__ __forceinline__ void wave_sort_pairs(float& d, int& i, int lane) {
 #pragma unroll
-  for (int j = 0; j < KMAX; ++j) {
-    bd[j] = __builtin_inff();
-    bi[j] = 0x7fffffff;
+  for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const float od = __shfl_xor(d, j, 64);
+      const int oi = __shfl_xor(i, j, 64);
+      const bool keep_min = (((lane & j) == 0) == ((lane & k) == 0));
+      const bool other_less = (od < d) || (od == d && oi < i);
+      const bool other_more = (od > d) || (od == d && oi > i);
+      const bool take = keep_min ? other_less : other_more;
+      d = take ? od : d;
+      i = take ? oi : i;
+    }
   }
-  // only the first K slots matter: slots >= K would merely waste work, so the acceptance threshold is slot K-1
-  // (KMAX == K rounded up; unused tail slots just carry larger values)
+}
+
+// wave-wide minimum of one float per lane (DPP row shifts + row broadcasts; min is idempotent, so overlapping
+// contributions are harmless); the result is returned as a wave-uniform value
+__device__ __forceinline__ float wave_min_dpp(float v) {
+#define PC3D_DPP_MIN(ctrl)                                                                              \
+  v = fminf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v),        \
+                                                                     __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false)))
+  PC3D_DPP_MIN(0x111);  // row_shr:1
+  PC3D_DPP_MIN(0x112);  // row_shr:2
+  PC3D_DPP_MIN(0x114);  // row_shr:4
+  PC3D_DPP_MIN(0x118);  // row_shr:8  -> lane 15 of every row holds the row minimum
+  PC3D_DPP_MIN(0x142);  // row_bcast:15
+  PC3D_DPP_MIN(0x143);  // row_bcast:31 -> lane 63 holds the wave minimum
+#undef PC3D_DPP_MIN
+  return readlane_f(v, 63);
+}
+
+template <int kKwWaves>    // waves per workgroup: a workgroup serves 4 * kKwWaves queries from one staged copy of the cloud
+__global__ __launch_bounds__(kKwWaves * 64) void knn_wave_kernel(KnnArgs a) {
+  constexpr int kKwPasses = 1;
+  constexpr int kKwThreads = kKwWaves * 64;
+  __shared__ __attribute__((aligned(16))) float lds[3 * kKwTile];
+  const int N = a.N, M = a.M, K = a.K;
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: query loads / thresholds live in SGPRs
+  const int qbase = blockIdx.x * (kKwWaves * kKwPasses * kKwQPW) + wave * (kKwPasses * kKwQPW);
+  float* sx = lds;
+  float* sy = lds + kKwTile;
+  float* sz = lds + 2 * kKwTile;
+
+  // per-query state, statically indexed: [pass][u]
+  float ld[kKwPasses][kKwQPW], thr[kKwPasses][kKwQPW], qx[kKwPasses][kKwQPW], qy[kKwPasses][kKwQPW], qz[kKwPasses][kKwQPW];
+  int li[kKwPasses][kKwQPW];
+#pragma unroll
+  for (int p = 0; p < kKwPasses; ++p)
+#pragma unroll
+    for (int u = 0; u < kKwQPW; ++u) {
+      int qi = qbase + p * kKwQPW + u;
+      if (qi >= N) qi = N - 1;
+      const float* qp = a.q.p + (int64_t)b * a.q.bs + (int64_t)qi * a.q.ps;   // wave-uniform address
+      qx[p][u] = qp[0], qy[p][u] = qp[a.q.cs], qz[p][u] = qp[2 * a.q.cs];
+      ld[p][u] = __builtin_inff();
+      li[p][u] = 0x7fffffff;
+      thr[p][u] = __builtin_inff();
+    }
 
   const float* rb = a.r.p + (int64_t)b * a.r.bs;
-  for (int m0 = 0; m0 < M; m0 += mt) {
+  for (int m0 = 0; m0 < M; m0 += kKwTile) {
+    const int mt = (M - m0) < kKwTile ? (M - m0) : kKwTile;
     __syncthreads();
-    for (int j = threadIdx.x; j < mt_pad; j += kKnnThreads) {
-      const int m = m0 + j;
+    const int mt_pad = (mt + 63) & ~63;             // pad the last step with far sentinels (never the K nearest: K <= M)
+    for (int j = threadIdx.x; j < mt_pad; j += kKwThreads) {
       float x = kKnnFar, y = kKnnFar, z = kKnnFar;
-      if (j < mt && m < M) {
-        const float* rp = rb + (int64_t)m * a.r.ps;
+      if (j < mt) {
+        const float* rp = rb + (int64_t)(m0 + j) * a.r.ps;
         x = rp[0], y = rp[a.r.cs], z = rp[2 * a.r.cs];
       }
       sx[j] = x, sy[j] = y, sz[j] = z;
     }
     __syncthreads();
-    const int s0 = wave * slice;
-    for (int j = s0; j < s0 + slice; j += 4) {
-      const float4 rx = *reinterpret_cast<const float4*>(sx + j);
-      const float4 ry = *reinterpret_cast<const float4*>(sy + j);
-      const float4 rz = *reinterpret_cast<const float4*>(sz + j);
-      const float rxa[4] = {rx.x, rx.y, rx.z, rx.w};
-      const float rya[4] = {ry.x, ry.y, ry.z, ry.w};
-      const float rza[4] = {rz.x, rz.y, rz.z, rz.w};
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float dx = rxa[e] - qx, dy = rya[e] - qy, dz = rza[e] - qz;
-        float d = dx * dx;
-        d = __builtin_fmaf(dy, dy, d);
-        d = __builtin_fmaf(dz, dz, d);
-        const int m = m0 + j + e;
-        const bool valid = (j + e < mt) && (m < M);  // padding never enters a list
-        if (__builtin_amdgcn_ballot_w64(valid && d < bd[KMAX - 1]) != 0ull) {
-          if (valid) knn_insert<KMAX>(bd, bi, d, m);
+    for (int p = 0; p < kKwPasses; ++p) {
+      if (qbase + p * kKwQPW >= N) break;          // wave-uniform: no query left in this pass
+      for (int j0 = 0; j0 < mt; j0 += 64) {
+        const int j = j0 + lane;
+        const float cx = sx[j], cy = sy[j], cz = sz[j];
+        float d[kKwQPW];
+#pragma unroll
+        for (int u = 0; u < kKwQPW; ++u) {
+          const float dx = cx - qx[p][u], dy = cy - qy[p][u], dz = cz - qz[p][u];
+          float t = dx * dx;
+          t = __builtin_fmaf(dy, dy, t);
+          t = __builtin_fmaf(dz, dz, t);
+          d[u] = t;
+        }
+        if (m0 == 0 && j0 == 0) {
+          // seed: the K nearest of the first 64 candidates — K rounds of wave-min selection (ties: lowest lane) for small K
+          float rem[kKwQPW], m[kKwQPW];
+#pragma unroll
+          for (int u = 0; u < kKwQPW; ++u) rem[u] = (d[u] == d[u]) ? d[u] : __builtin_inff();   // NaN never a neighbour
+          if (K > 10) {                             // larger K: one bitonic sort per query is cheaper than K rounds
+#pragma unroll
+            for (int u = 0; u < kKwQPW; ++u) {
+              float sd = rem[u];
+              int si = lane;
+              wave_sort_pairs(sd, si, lane);
+              ld[p][u] = sd, li[p][u] = si;
+              thr[p][u] = readlane_f(sd, K - 1);
+            }
+            continue;
+          }
+          for (int t = 0; t < K; ++t) {
+#pragma unroll
+            for (int u = 0; u < kKwQPW; ++u) {      // four independent chains hide the DPP / readlane latencies
+              m[u] = wave_min_dpp(rem[u]);
+              const int c = __builtin_ctzll(__builtin_amdgcn_ballot_w64(rem[u] == m[u]) | (1ull << 63));
+              ld[p][u] = (lane == t) ? m[u] : ld[p][u];
+              li[p][u] = (lane == t) ? c : li[p][u];
+              rem[u] = (lane == c) ? __builtin_inff() : rem[u];
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < kKwQPW; ++u) thr[p][u] = m[u];
+          continue;
+        }
+#pragma unroll
+        for (int u = 0; u < kKwQPW; ++u) {
+          unsigned long long mask = __builtin_amdgcn_ballot_w64(d[u] < thr[p][u]);
+          while (mask) {
+            const int c = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            const float dc = readlane_f(d[u], c);
+            if (!(dc < thr[p][u])) continue;        // the threshold tightened since the ballot
+            const int ic = m0 + j0 + c;
+            const int pos = __builtin_popcountll(__builtin_amdgcn_ballot_w64(ld[p][u] <= dc));
+            // lane l <- lane l-1 (v_mov_b32_dpp wave_shr:1); lane 0 is never read when pos > 0, and is `pos` otherwise
+            const float sd = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+                0, __builtin_bit_cast(int, ld[p][u]), 0x138, 0xf, 0xf, false));
+            const int si = __builtin_amdgcn_update_dpp(0, li[p][u], 0x138, 0xf, 0xf, false);
+            ld[p][u] = lane < pos ? ld[p][u] : (lane == pos ? dc : sd);
+            li[p][u] = lane < pos ? li[p][u] : (lane == pos ? ic : si);
+            thr[p][u] = readlane_f(ld[p][u], K - 1);
+          }
         }
       }
     }
   }
-
-  // ---- merge the four waves' sorted lists: LDS layout [wave][k][lane] (conflict-free per k)
-  __syncthreads();
-  float* cd = lds;
-  int* ci = reinterpret_cast<int*>(lds + kKnnWaves * KMAX * kWave);
 #pragma unroll
-  for (int j = 0; j < KMAX; ++j) {
-    cd[(wave * KMAX + j) * kWave + lane] = bd[j];
-    ci[(wave * KMAX + j) * kWave + lane] = bi[j];
-  }
-  __syncthreads();
-  if (wave == 0) {
-    int pos[kKnnWaves] = {0, 0, 0, 0};
-    const int qo = q0 + lane;
-    for (int k = 0; k < K; ++k) {
-      float best = __builtin_inff();
-      int besti = 0x7fffffff, bw = 0;
+  for (int p = 0; p < kKwPasses; ++p)
 #pragma unroll
-      for (int w = 0; w < kKnnWaves; ++w) {
-        const int p = pos[w];
-        const float d = (p < KMAX) ? cd[(w * KMAX + p) * kWave + lane] : __builtin_inff();
-        const int i = (p < KMAX) ? ci[(w * KMAX + p) * kWave + lane] : 0x7fffffff;
-        if (d < best || (d == best && i < besti)) {
-          best = d, besti = i, bw = w;
-        }
-      }
-#pragma unroll
-      for (int w = 0; w < kKnnWaves; ++w) pos[w] += (w == bw) ? 1 : 0;
-      if (qo < N) {
-        // fewer than K reference points: pad with the last valid neighbour (M >= 1 guaranteed)
-        if (a.d) a.d[((int64_t)b * N + qo) * K + k] = best;
-        if (a.i) a.i[((int64_t)b * N + qo) * K + k] = besti;
+    for (int u = 0; u < kKwQPW; ++u) {
+      const int qi = qbase + p * kKwQPW + u;
+      if (qi < N && lane < K) {
+        if (a.d) a.d[((int64_t)b * N + qi) * K + lane] = ld[p][u];
+        if (a.i) a.i[((int64_t)b * N + qi) * K + lane] = li[p][u];
       }
     }
-  }
-}
-
-template <int KMAX>
-static int knn_launch(const KnnArgs& a, int B, hipStream_t st) {
-  const int mt = a.M < kKnnMaxTile ? a.M : kKnnMaxTile;
-  const int slice = ((mt + kKnnWaves * 4 - 1) / (kKnnWaves * 4)) * 4;
-  const size_t tile = (size_t)3 * slice * kKnnWaves * sizeof(float);
-  const size_t merge = (size_t)kKnnWaves * KMAX * kWave * 8;
-  const size_t lds = tile > merge ? tile : merge;
-  hipLaunchKernelGGL(knn_kernel<KMAX>, dim3(cdiv(a.N, kWave), B), dim3(kKnnThreads), lds, st, a, kKnnMaxTile);
-  PC3D_LAUNCH_CHECK("pc3d_knn_f32");
-  return PC3D_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -280,15 +322,15 @@ extern "C" int pc3d_knn_f32(const float* q, int64_t q_bs, int64_t q_ps, int64_t 
                             const float* r, int64_t r_bs, int64_t r_ps, int64_t r_cs,
                             int B, int N, int M, int K, float* dists, int32_t* idx, void* stream) {
   PC3D_REQUIRE(B >= 0 && N >= 0 && M >= 1, "pc3d_knn_f32: bad sizes B=%d N=%d M=%d", B, N, M);
-  PC3D_REQUIRE(K >= 1 && K <= 32, "pc3d_knn_f32: K=%d out of range [1,32]", K);
+  PC3D_REQUIRE(K >= 1 && K <= 64, "pc3d_knn_f32: K=%d out of range [1,64]", K);
   PC3D_REQUIRE(K <= M, "pc3d_knn_f32: K=%d exceeds the reference set size M=%d", K, M);
   PC3D_REQUIRE(B <= 65535, "pc3d_knn_f32: B=%d exceeds grid.y limit", B);
   if (B == 0 || N == 0) return PC3D_OK;
   PC3D_REQUIRE(q && r, "pc3d_knn_f32: null input pointer");
   KnnArgs a{{q, q_bs, q_ps, q_cs}, {r, r_bs, r_ps, r_cs}, N, M, K, dists, idx};
   hipStream_t st = as_stream(stream);
-  if (K <= 8) return knn_launch<8>(a, B, st);
-  if (K <= 16) return knn_launch<16>(a, B, st);
-  if (K <= 24) return knn_launch<24>(a, B, st);
-  return knn_launch<32>(a, B, st);
+  // 4 waves (16 queries) per workgroup: measured best of {2,4,8,16} — larger workgroups wait at the staging barriers
+  hipLaunchKernelGGL(knn_wave_kernel<4>, dim3(cdiv(N, 16), B), dim3(256), 0, st, a);
+  PC3D_LAUNCH_CHECK("pc3d_knn_f32");
+  return PC3D_OK;
 }

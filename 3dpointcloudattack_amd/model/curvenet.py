@@ -4,7 +4,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .curvenet_util import CIC, LPFA
+from .curvenet_util import CIC, LPFA, pw
 from .pointnet import _FrozenFusedMixin
 
 curve_config = {
@@ -43,8 +43,8 @@ class CurveNet(_FrozenFusedMixin, nn.Module):
         pos = xyz
         for blk in (self.cic11, self.cic12, self.cic21, self.cic22, self.cic31, self.cic32, self.cic41, self.cic42):
             pos, feats = blk(pos, feats)
-        x = self.conv0(feats)
+        x = pw(self.conv0, feats)
         x = torch.cat((F.adaptive_max_pool1d(x, 1), F.adaptive_avg_pool1d(x, 1)), dim=1).squeeze(-1)
-        x = F.relu(self.bn1(self.conv1(x).unsqueeze(-1)), inplace=True).squeeze(-1)
-        x = self.conv2(self.dp1(x))
+        x = F.relu(pw(self.conv1, x, bn=self.bn1))
+        x = pw(self.conv2, self.dp1(x))
         return x, x, x

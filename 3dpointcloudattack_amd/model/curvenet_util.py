@@ -14,6 +14,60 @@ from .pointnet import _FrozenFusedMixin
 from .walk import Walk
 
 
+def _fold_pointwise(conv, bn):
+    """(W [O,C], b [O] or None) of a kernel-size-1 Conv1d/Conv2d or a Linear followed by an eval-mode BatchNorm
+    (bn may be None), with DETACHED parameters: the attacks differentiate with respect to the points only."""
+    w = conv.weight.detach().float().reshape(conv.weight.shape[0], -1)
+    b = conv.bias.detach().float() if conv.bias is not None else None
+    if bn is not None:
+        sc = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+        w = w * sc[:, None]
+        b = (b if b is not None else 0.0) * sc + (bn.bias.detach().float() - bn.running_mean.detach().float() * sc)
+    return w.contiguous(), (b.contiguous() if b is not None else None)
+
+
+def pw(mod, x, bn=None):
+    """Frozen pointwise layer: `mod` is a 1x1 Conv1d / Conv2d / Linear or an nn.Sequential(conv[, bn][, activation]);
+    x is [B,C,L], [B,C,H,W] (conv) or [B,C] (Linear). One GEMM against folded weights (cached on the module and
+    re-folded whenever a parameter / buffer changes) instead of MIOpen convolution + batch-norm + weight-gradient
+    kernels (the reference leaves requires_grad on and pays for dL/dW in every attack step)."""
+    act = None
+    conv = mod
+    if isinstance(mod, nn.Sequential):
+        conv = mod[0]
+        for m in list(mod)[1:]:
+            if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d)):
+                bn = m
+            else:
+                act = m
+    if bn is not None and bn.training:
+        raise NotImplementedError("CurveNet: only the eval-mode (frozen-weight) attack path is implemented on MI355X")
+    ts = [conv.weight, conv.bias] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [])
+    key = tuple((t.data_ptr(), t._version) for t in ts if t is not None)
+    cache = getattr(conv, "_pw_cache", None)
+    if cache is None or cache[0] != key:
+        cache = (key,) + _fold_pointwise(conv, bn)
+        object.__setattr__(conv, "_pw_cache", cache)
+    _, w, b = cache
+    if x.dim() == 2:
+        y = F.linear(x, w, b)
+    else:
+        shp = x.shape
+        y = torch.matmul(w, x.reshape(shp[0], shp[1], -1))
+        if b is not None:
+            y = y + b[None, :, None]
+        y = y.view(shp[0], w.shape[0], *shp[2:])
+    if act is None:
+        return y
+    if isinstance(act, nn.LeakyReLU):
+        return F.leaky_relu(y, act.negative_slope)
+    if isinstance(act, nn.ReLU):
+        return F.relu(y)
+    if isinstance(act, nn.Sigmoid):
+        return torch.sigmoid(y)
+    raise NotImplementedError(f"pw: unsupported activation {type(act).__name__}")
+
+
 def _cl(x):
     """[B,C,N] -> contiguous [B,N,C]."""
     return x.transpose(2, 1).contiguous().float()
@@ -85,7 +139,7 @@ class Attention_block(nn.Module):
                                  nn.Sigmoid())
 
     def forward(self, g, x):
-        psi = self.psi(F.leaky_relu(self.W_g(g) + self.W_x(x), negative_slope=0.2))
+        psi = pw(self.psi, F.leaky_relu(pw(self.W_g, g) + pw(self.W_x, x), negative_slope=0.2))
         return psi, 1. - psi
 
 
@@ -106,7 +160,9 @@ class LPFA(nn.Module):
         self.mlp = nn.Sequential(*layers)
 
     def forward(self, x, xyz, idx=None):
-        x = self.mlp(self.group_feature(x, xyz, idx))
+        x = self.group_feature(x, xyz, idx)
+        for layer in self.mlp:
+            x = pw(layer, x)
         return x.max(dim=-1, keepdim=False)[0] if self.initial else x.mean(dim=-1, keepdim=False)
 
     def group_feature(self, x, xyz, idx):
@@ -123,7 +179,7 @@ class LPFA(nn.Module):
             return geo
         feats = _cl(x)                                             # [B,N,C]
         rel = ops.group_gather(None, feats, idx32) - feats.view(B, N, 1, C)              # x_j - x_i
-        return F.leaky_relu(rel.permute(0, 3, 1, 2) + self.xyz2feature(geo), 0.2)
+        return F.leaky_relu(rel.permute(0, 3, 1, 2) + pw(self.xyz2feature, geo), 0.2)
 
 
 class PointNetFeaturePropagation(nn.Module):
@@ -158,7 +214,7 @@ class PointNetFeaturePropagation(nn.Module):
         new_points = interpolated if points1 is None else torch.cat([points1.permute(0, 2, 1), interpolated], dim=-1)
         new_points = new_points.permute(0, 2, 1)
         for conv, bn in zip(self.mlp_convs, self.mlp_bns):
-            new_points = F.leaky_relu(bn(conv(new_points)), 0.2)
+            new_points = F.leaky_relu(pw(conv, new_points, bn=bn), 0.2)
         return new_points
 
 
@@ -195,14 +251,14 @@ class CIC(nn.Module):
             xyz, x = self.maxpool(xyz.transpose(1, 2).contiguous(), x)
             xyz = xyz.transpose(1, 2)
         shortcut = x
-        x = self.conv1(x)
+        x = pw(self.conv1, x)
         idx = knn(xyz, self.k)                                     # [B,N,k+1], self first
         if self.use_curve:
             curves = self.curvegrouping(x, xyz, idx[:, :, 1:])     # avoid self-loops
             x = self.curveaggregation(x, curves)
-        x = self.conv2(self.lpfa(x, xyz, idx=idx[:, :, :self.k]))
+        x = pw(self.conv2, self.lpfa(x, xyz, idx=idx[:, :, :self.k]))
         if self.in_channels != self.output_channels:
-            shortcut = self.shortcut(shortcut)
+            shortcut = pw(self.shortcut, shortcut)
         return xyz, self.relu(x + shortcut)
 
 
@@ -222,16 +278,16 @@ class CurveAggregation(nn.Module):
         self.line_conv_att = nn.Conv2d(in_channel, 1, kernel_size=1, bias=False)
 
     def forward(self, x, curves):
-        att = self.line_conv_att(curves)                                          # [B,1,cn,cl]
-        inter = self.conva(torch.sum(curves * F.softmax(att, dim=-1), dim=-1))    # [B,mid,cn]
-        intra = self.convb(torch.sum(curves * F.softmax(att, dim=-2), dim=-2))    # [B,mid,cl]
-        q = self.convc(x).transpose(1, 2).contiguous()                            # [B,N,mid]
+        att = pw(self.line_conv_att, curves)                                          # [B,1,cn,cl]
+        inter = pw(self.conva, torch.sum(curves * F.softmax(att, dim=-1), dim=-1))    # [B,mid,cn]
+        intra = pw(self.convb, torch.sum(curves * F.softmax(att, dim=-2), dim=-2))    # [B,mid,cl]
+        q = pw(self.convc, x).transpose(1, 2).contiguous()                            # [B,N,mid]
         w_inter = F.softmax(torch.bmm(q, inter), dim=-1)                          # [B,N,cn]
         w_intra = F.softmax(torch.bmm(q, intra), dim=-1)                          # [B,N,cl]
-        f_inter = torch.bmm(w_inter, self.convn(inter).transpose(1, 2).contiguous())
-        f_intra = torch.bmm(w_intra, self.convl(intra).transpose(1, 2).contiguous())
+        f_inter = torch.bmm(w_inter, pw(self.convn, inter).transpose(1, 2).contiguous())
+        f_intra = torch.bmm(w_intra, pw(self.convl, intra).transpose(1, 2).contiguous())
         fused = torch.cat((f_inter, f_intra), dim=-1).transpose(1, 2).contiguous()
-        return F.leaky_relu(x + self.convd(fused), negative_slope=0.2)
+        return F.leaky_relu(x + pw(self.convd, fused), negative_slope=0.2)
 
 
 class CurveGrouping(nn.Module):
@@ -247,7 +303,7 @@ class CurveGrouping(nn.Module):
         self.walk = Walk(in_channel, k, curve_num, curve_length)
 
     def forward(self, x, xyz, idx):
-        x_att = torch.sigmoid(self.att(x))
+        x_att = torch.sigmoid(pw(self.att, x))
         x = x * x_att
         _, start_index = torch.topk(x_att, self.curve_num, dim=2, sorted=False)
         return self.walk(xyz, x, idx, start_index.squeeze(1).unsqueeze(2))       # [B,C,cn,cl]

@@ -11,6 +11,12 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+
+def pw(mod, x):
+    from .curvenet_util import pw as _pw   # late import: curvenet_util imports this module
+    return _pw(mod, x)
+
+
 def batched_index_select(input, dim, index):
     """model/walk.py:7-14."""
     views = [input.shape[0]] + [1 if i != dim else -1 for i in range(1, len(input.shape))]
@@ -64,14 +70,14 @@ class Walk(nn.Module):
                 pre_feature = start.transpose(1, 2).unsqueeze(-1)                         # [B,C,cn,1]
             else:
                 both = torch.cat((cur_feature.squeeze(3), pre_feature.squeeze(3)), dim=1)  # [B,2C,cn]
-                mom = F.softmax(self.momentum_mlp(both), dim=1).view(B, 1, cn, 2)          # dynamic momentum
+                mom = F.softmax(pw(self.momentum_mlp, both), dim=1).view(B, 1, cn, 2)          # dynamic momentum
                 pre_feature = torch.sum(torch.cat((cur_feature, pre_feature), dim=-1) * mom, dim=-1, keepdim=True)
                 pre_flat = pre_feature.transpose(1, 2).contiguous().view(B * cn, C)
             nbr_idx = torch.gather(adj, 1, node.unsqueeze(-1).expand(-1, -1, k))           # [B,cn,k]
             nbr = torch.gather(feats, 1, nbr_idx.reshape(B, cn * k, 1).expand(-1, -1, C)).view(B, cn, k, C)
             nbr_flat = nbr.reshape(B * cn, k, C).transpose(1, 2).contiguous()              # [B*cn,C,k]
             nbr_c = nbr.permute(0, 3, 1, 2)                                                # [B,C,cn,k]
-            score = self.agent_mlp(torch.cat((nbr_c, pre_feature.expand_as(nbr_c)), dim=1))  # [B,1,cn,k]
+            score = pw(self.agent_mlp, torch.cat((nbr_c, pre_feature.expand_as(nbr_c)), dim=1))  # [B,1,cn,k]
             if step != 0:
                 d = self.crossover_suppression(cur_flat - pre_flat, nbr_flat - cur_flat.unsqueeze(-1), B, cn, k)
                 score = torch.mul(score, d.view(B, cn, k).unsqueeze(1))

@@ -359,8 +359,8 @@ def knn_raw(q, r, K, q_cf=False, r_cf=False):
     rp, rbs, rps, rcs, B2, M = _pts(r, r_cf, "r")
     if B != B2:
         raise ValueError("q and r must have the same batch dimension")
-    if not (1 <= K <= min(32, M)):
-        raise ValueError(f"K={K} out of range [1, min(32, M={M})]")
+    if not (1 <= K <= min(64, M)):
+        raise ValueError(f"K={K} out of range [1, min(64, M={M})]")
     if K == 1:  # the dedicated nearest-neighbour kernel (split-M, several queries per lane) is faster
         d1, i1 = nn_raw(q, r, q_cf, r_cf)
         return d1.unsqueeze(-1), i1.unsqueeze(-1)

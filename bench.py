@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sweep", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -226,6 +227,27 @@ def main():
                        "cloud_iters_per_s": iters_per_s * B},
             "roofline": roofline, "chamfer": chamfer,
         }
+        if not args.no_sweep and world == 1:
+            # north_star's other sizes / the reference's default regulariser, short runs of the same loop (N=1 only)
+            sweep = {}
+            for npts, dname in ((NPTS, "l2"), (2048, "chamfer"), (4096, "chamfer")):
+                rs = np.random.default_rng(4321 + npts)
+                d2 = torch.from_numpy(np.stack([unit_cloud(rs, npts) for _ in range(B)]))
+                with torch.no_grad():
+                    l2 = model(d2.transpose(1, 2).contiguous().to(dev))[0].argmax(1).cpu()
+                atk = CW(model, trans_model, adv_func=adv_utils.UntargetedLogitsAdvLoss(kappa=KAPPA),
+                         clip_func=clip_utils.ClipPointsLinf(budget=BUDGET),
+                         dist_func=dist_utils.L2Dist() if dname == "l2" else dist_utils.ChamferDist(),
+                         attack_lr=LR, binary_step=10, num_iter=500, device=dev)
+                torch.manual_seed(7)
+                s2 = atk._begin(d2, l2)
+                atk._begin_binary_step(s2)
+                r2 = atk._make_runner(s2)
+                for i in range(10):
+                    r2(i)
+                ms = ev_ms(lambda: r2(0), 60, stream)
+                sweep[f"cw_pointnet_{dname}_B{B}_N{npts}"] = {"iters_per_s": 1e3 / ms, "ms_per_step": ms}
+            out["sweep"] = sweep
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(pcs, labels)
         elif world == 1:

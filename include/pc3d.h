@@ -171,7 +171,7 @@ int pc3d_pairwise_f32(const float* x, int64_t x_bs, int64_t x_ps, int64_t x_cs,
 
 /* ---------------------------------------------------------------------------------------------------------
  * K2/K4  K nearest reference points (xyz, squared L2, direct-difference form) of every query, ascending;
- * ties put the lower reference index first. 1 <= K <= min(32, M). dists/idx: [B,N,K] f32 / i32 (either may be NULL).
+ * ties put the lower reference index first. 1 <= K <= min(64, M). dists/idx: [B,N,K] f32 / i32 (either may be NULL).
  * Replaces the [B,N,M] matrix + topk of attack/CW/CW_utils/dist_utils.py:133-144 (KNNDist),
  * attack/GeoA3/knn_utils.py:10-55 (knn_points), attack/AOF/TAOF_attack.py:13-28, model/dgcnn.py:194-200 on xyz,
  * model/curvenet_util.py:10-17. Self-kNN (q == r) returns the point itself first (distance 0), like the reference.

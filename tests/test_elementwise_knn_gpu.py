@@ -74,7 +74,8 @@ def test_pairwise_matches_oracle(ops, dev, metrics_fx):
 
 
 @pytest.mark.parametrize("B,N,M,K", [(2, 100, 100, 6), (1, 64, 300, 17), (2, 1024, 1024, 21), (1, 50, 40, 31),
-                                     (1, 5000, 70, 1), (2, 33, 4500, 4)])
+                                     (1, 5000, 70, 1), (2, 33, 4500, 4), (1, 70, 64, 64), (2, 130, 2113, 40),
+                                     (1, 20, 4100, 9)])
 def test_knn_matches_exact_topk(ops, dev, B, N, M, K):
     rng = np.random.default_rng(N + M + K)
     r = np.stack([unit_cloud(rng, M) for _ in range(B)])
@@ -90,6 +91,25 @@ def test_knn_matches_exact_topk(ops, dev, B, N, M, K):
         assert all(len(set(row)) == K for row in i[bb][:: max(1, N // 50)])
     if N == M:
         assert np.array_equal(i[:, :, 0], np.broadcast_to(np.arange(N), (B, N)))
+
+
+def test_knn_ties_prefer_lower_index(ops, dev):
+    """Duplicated reference points (equal distances): the lower index comes first, within a step, across steps and
+    across LDS tiles — the order torch.topk / the reference's sort gives on its distance matrix."""
+    rng = np.random.default_rng(5)
+    base = unit_cloud(rng, 700)
+    r = np.concatenate([base, base, base, base])[None]            # 2800 points: 4 copies, crosses the 2048-point tile
+    q = base[None, :90]
+    d, i = ops.knn_raw(torch.from_numpy(q).to(dev), torch.from_numpy(r).to(dev), 12)
+    i = i.cpu().numpy()[0]
+    D = ((q[0].astype(np.float64)[:, None] - r[0].astype(np.float64)[None]) ** 2).sum(-1)
+    ref = np.lexsort((np.broadcast_to(np.arange(2800), D.shape), D), axis=1)[:, :12]
+    # float32 distances of exact duplicates are bit-equal, so the groups of 4 must appear as j, j+700, j+1400, j+2100
+    assert np.array_equal(i[:, :4], np.arange(90)[:, None] + 700 * np.arange(4)[None])
+    assert np.array_equal(i % 700, ref % 700)
+    for row in i:
+        for g in range(3):
+            assert np.all(np.diff(row[4 * g:4 * g + 4]) == 700)
 
 
 @pytest.mark.parametrize("det", [False, True])
