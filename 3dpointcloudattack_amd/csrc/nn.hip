@@ -9,6 +9,9 @@
 //   * all four waves hold the SAME 64*Q queries in registers (Q per lane) and each scans one quarter of the
 //     LDS tile with broadcast ds_read_b128 (4 reference points per read) -> split-M across waves gives
 //     4x more waves per query tile, which is what fills 256 CUs at N=1024;
+//   * the running arg-min is kept per CHUNK of 8 reference points (6 VALU ops per pair for the distance + 0.5 for
+//     v_min3 + 3/8 for the compare/select = 6.9 instead of 9 with a per-pair compare/select); the position inside
+//     the winning chunk is recovered after the scan by recomputing its 8 distances;
 //   * distance is the direct-difference form (dx*dx + dy*dy + dz*dz with FMA) — the |a|^2+|b|^2-2ab expansion
 //     loses 1e-5 relative accuracy on near-coincident clouds;
 //   * per-wave (min,argmin) are merged through LDS in ascending reference order so ties resolve to the
@@ -32,6 +35,16 @@ constexpr int kNNWaves = kNNThreads / kWave;
 constexpr int kNNMaxTile = 4096;           // reference points per LDS tile (48 KiB SoA)
 constexpr float kFar = 1.0e18f;            // sentinel coordinate: (1e18)^2*3 < FLT_MAX, never the minimum
 
+constexpr int kNNChunk = 8;                // reference points per arg-min bookkeeping step
+
+// the one distance formula of this file (scan and index resolution must agree bit for bit)
+__device__ __forceinline__ float nn_dist(float rx, float ry, float rz, float qx, float qy, float qz) {
+  const float dx = rx - qx, dy = ry - qy, dz = rz - qz;
+  float d = dx * dx;
+  d = __builtin_fmaf(dy, dy, d);
+  return __builtin_fmaf(dz, dz, d);
+}
+
 template <int Q>
 __global__ __launch_bounds__(kNNThreads) void nn_kernel(NNArgs args, int mt_cap) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -43,9 +56,9 @@ __global__ __launch_bounds__(kNNThreads) void nn_kernel(NNArgs args, int mt_cap)
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
 
-  // tile geometry (uniform): mt = points staged per pass, slice = points scanned per wave, multiple of 4
+  // tile geometry (uniform): mt = points staged per pass, slice = points scanned per wave, multiple of the chunk
   const int mt = M < mt_cap ? M : mt_cap;
-  const int slice = ((mt + kNNWaves * 4 - 1) / (kNNWaves * 4)) * 4;
+  const int slice = ((mt + kNNWaves * kNNChunk - 1) / (kNNWaves * kNNChunk)) * kNNChunk;
   const int mt_pad = slice * kNNWaves;
   float* sx = lds;
   float* sy = lds + mt_pad;
@@ -85,27 +98,26 @@ __global__ __launch_bounds__(kNNThreads) void nn_kernel(NNArgs args, int mt_cap)
     __syncthreads();
 
     const int s0 = wave * slice;
-    for (int j = s0; j < s0 + slice; j += 4) {
-      const float4 rx = *reinterpret_cast<const float4*>(sx + j);
-      const float4 ry = *reinterpret_cast<const float4*>(sy + j);
-      const float4 rz = *reinterpret_cast<const float4*>(sz + j);
-      const float rxa[4] = {rx.x, rx.y, rx.z, rx.w};
-      const float rya[4] = {ry.x, ry.y, ry.z, ry.w};
-      const float rza[4] = {rz.x, rz.y, rz.z, rz.w};
+    for (int j = s0; j < s0 + slice; j += kNNChunk) {
+      const float4 rx0 = *reinterpret_cast<const float4*>(sx + j), rx1 = *reinterpret_cast<const float4*>(sx + j + 4);
+      const float4 ry0 = *reinterpret_cast<const float4*>(sy + j), ry1 = *reinterpret_cast<const float4*>(sy + j + 4);
+      const float4 rz0 = *reinterpret_cast<const float4*>(sz + j), rz1 = *reinterpret_cast<const float4*>(sz + j + 4);
+      const float rxa[kNNChunk] = {rx0.x, rx0.y, rx0.z, rx0.w, rx1.x, rx1.y, rx1.z, rx1.w};
+      const float rya[kNNChunk] = {ry0.x, ry0.y, ry0.z, ry0.w, ry1.x, ry1.y, ry1.z, ry1.w};
+      const float rza[kNNChunk] = {rz0.x, rz0.y, rz0.z, rz0.w, rz1.x, rz1.y, rz1.z, rz1.w};
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
+      for (int k = 0; k < Q; ++k) {
+        float d[kNNChunk];
 #pragma unroll
-        for (int k = 0; k < Q; ++k) {
-          const float dx = rxa[e] - qx[k];
-          const float dy = rya[e] - qy[k];
-          const float dz = rza[e] - qz[k];
-          float d = dx * dx;
-          d = __builtin_fmaf(dy, dy, d);
-          d = __builtin_fmaf(dz, dz, d);
-          if (d < best[k]) {
-            best[k] = d;
-            bidx[k] = m0 + j + e;
-          }
+        for (int e = 0; e < kNNChunk; ++e) d[e] = nn_dist(rxa[e], rya[e], rza[e], qx[k], qy[k], qz[k]);
+        // chunk minimum with v_min3 (0.5 op / pair); WHICH of the 8 it was is resolved once, after the scan
+        float m = __builtin_fminf(__builtin_fminf(d[0], d[1]), d[2]);
+        m = __builtin_fminf(__builtin_fminf(m, d[3]), d[4]);
+        m = __builtin_fminf(__builtin_fminf(m, d[5]), d[6]);
+        m = __builtin_fminf(m, d[7]);
+        if (m < best[k]) {     // strict: the EARLIEST chunk holding the minimum wins
+          best[k] = m;
+          bidx[k] = m0 + j;
         }
       }
     }
@@ -137,17 +149,33 @@ __global__ __launch_bounds__(kNNThreads) void nn_kernel(NNArgs args, int mt_cap)
     const int qi = q0 + t;
     if (qi < N) {
       if (D.d) D.d[(int64_t)b * N + qi] = bd;
-      if (D.i) D.i[(int64_t)b * N + qi] = bi;
+      if (D.i) {
+        // bi is the first index of the winning chunk: the arg-min is the first of its 8 points whose distance,
+        // recomputed with the same instructions, equals the minimum (ties -> lowest index, as torch.min)
+        const float* qp = qb + (int64_t)qi * D.q.ps;
+        const float x = qp[0], y = qp[D.q.cs], z = qp[2 * D.q.cs];
+        int arg = bi;
+#pragma unroll
+        for (int e = kNNChunk - 1; e >= 0; --e) {
+          const int m = bi + e;
+          if (m < M) {
+            const float* rp = rb + (int64_t)m * D.r.ps;
+            if (nn_dist(rp[0], rp[D.r.cs], rp[2 * D.r.cs], x, y, z) == bd) arg = m;
+          }
+        }
+        D.i[(int64_t)b * N + qi] = arg;
+      }
     }
   }
 }
 
 static size_t nn_lds_bytes(int M, int Q, int* mt_cap_out) {
-  const int mt = M < kNNMaxTile ? M : kNNMaxTile;
-  const int slice = ((mt + kNNWaves * 4 - 1) / (kNNWaves * 4)) * 4;
+  const int cap = kNNMaxTile;   // 1024 / 2048 / 4096 measured equal at B=32, N=4096
+  const int mt = M < cap ? M : cap;
+  const int slice = ((mt + kNNWaves * kNNChunk - 1) / (kNNWaves * kNNChunk)) * kNNChunk;
   const size_t tile = (size_t)3 * slice * kNNWaves * sizeof(float);
   const size_t merge = (size_t)kNNWaves * kWave * Q * 8;
-  *mt_cap_out = kNNMaxTile;
+  *mt_cap_out = cap;
   return tile > merge ? tile : merge;
 }
 

@@ -1,0 +1,54 @@
+"""Whole-attack wall time per iteration for BASELINE.json configs[2] (GeoA3 on DGCNN, B=32 N=1024) and configs[3]
+(KNN attack on PointNet++ SSG, B=64 N=2048), short runs; prints JSON."""
+import importlib, sys, os, json, time, types
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+from helpers import unit_cloud
+from oracle.ref_torch import seeded_state_dict
+from test_oracle_golden import _geo_cfg
+M = importlib.import_module
+dev = torch.device("cuda:0")
+def mk(modname, cls, seed=0, **kw):
+    m = getattr(M(f"3dpointcloudattack_amd.model.{modname}"), cls)(**kw)
+    m.load_state_dict(seeded_state_dict(m, seed)); return m.to(dev).eval()
+rng = np.random.default_rng(0)
+which = sys.argv[1:] or ["geoa3", "knn"]
+res = {}
+if "geoa3" in which:
+    B, N, IT = 32, 1024, 20
+    net = mk("dgcnn", "DGCNN", 0, args=types.SimpleNamespace(k=20, emb_dims=1024, dropout=0.5), output_channels=40)
+    pcs = torch.from_numpy(np.stack([unit_cloud(rng, N) for _ in range(B)]))
+    with torch.no_grad():
+        lab = net(pcs.transpose(1, 2).contiguous().to(dev))[0].argmax(1).cpu()
+    ga = M("3dpointcloudattack_amd.attack.GeoA3.GeoA3_attack")
+    for it in (4, 4, 4 + IT):
+        cfg = _geo_cfg(iter_max_steps=it, binary_max_steps=1, npoint=N, cls_loss_type='CE', hd_loss_weight=0.1, curv_loss_weight=1.0)
+        torch.manual_seed(0); np.random.seed(0)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        ga.geoA3_attack(net, None, None, None, None, None, pcs, lab, cfg, 0, 1)
+        torch.cuda.synchronize(); t = time.perf_counter() - t0
+        res.setdefault("geoa3_t", []).append(t)
+    res["geoa3_dgcnn_B32_N1024_ms_per_iter"] = (res["geoa3_t"][2] - res["geoa3_t"][1]) / IT * 1e3
+    print(res, flush=True)
+if "knn" in which:
+    B, N, IT = 64, 2048, 20
+    net = mk("pointnet2_SSG", "PointNet_Ssg", 0, num_classes=40)
+    pcs = torch.from_numpy(np.stack([unit_cloud(rng, N) for _ in range(B)]))
+    with torch.no_grad():
+        lab = net(pcs.transpose(1, 2).contiguous().to(dev))[0].argmax(1).cpu()
+    ka = M("3dpointcloudattack_amd.attack.KNN.KNN_attack")
+    adv = M("3dpointcloudattack_amd.attack.CW.CW_utils.adv_utils"); du = M("3dpointcloudattack_amd.attack.CW.CW_utils.dist_utils")
+    cu = M("3dpointcloudattack_amd.attack.CW.CW_utils.clip_utils")
+    ts = []
+    for it in (4, 4, 4 + IT):
+        atk = ka.CWKNN(net, None, None, None, None, None, adv.UntargetedLogitsAdvLoss(kappa=15.), du.ChamferkNNDist(chamfer_method='adv2ori', knn_k=5, knn_alpha=1.05, chamfer_weight=5., knn_weight=3.),
+                       cu.ProjectInnerClipLinf(budget=0.18), attack_lr=1e-2, num_iter=it)
+        torch.manual_seed(0); np.random.seed(0)
+        data = torch.cat([pcs, torch.nn.functional.normalize(pcs, dim=2)], dim=2)    # [B,N,6]: points + normals
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        atk.attack(data, lab)
+        torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+    res["knn_ssg_B64_N2048_ms_per_iter"] = (ts[2] - ts[1]) / IT * 1e3
+    print(res, flush=True)
+print(json.dumps(res))
