@@ -2,23 +2,27 @@
 //
 // (1) knn_feat: k nearest neighbours in C-dimensional FEATURE space (C in {64,64,128} after the first layer), self
 //     included, for channels-last features x [B,N,C]. The reference materialises -|xi-xj|^2 as a [B,N,N] matrix
-//     (GEMM + 2 broadcasts) and calls topk. Here a workgroup owns 32 queries: the 32 x N similarity strip is
-//     produced by v_mfma_f32_32x32x2_f32 (this IS a dense contraction over C) straight into LDS (<= 128 KiB, never
-//     HBM), then each wave extracts the top-k of 4 strips with k rounds of a wave-wide arg-max.
+//     (GEMM + 2 broadcasts) and calls topk. Here a workgroup owns 32 queries and walks the references in blocks of
+//     128: each wave forms one 32 x 32 tile with v_mfma_f32_32x32x2_f32 (this IS a dense contraction over C) into a
+//     double-buffered LDS block (never HBM), then scans the block against the K-lists of its 8 queries, which live
+//     across the lanes (knn_list.h: ballot/popcount + one DPP shift per insertion). Any N; K <= 64.
 // (2) gather_max: out[b,i,c] = max_{j in nbr(i)} P[b,idx[b,i,j],c] (and the arg-max for the backward), the
 //     neighbour reduction of an EdgeConv rewritten as two point-wise GEMMs:
 //         W [x_j - x_i ; x_i] = Wa x_j + (Wb - Wa) x_i = P_j + Q_i ,   W = [Wa | Wb]
 //     so  max_j leaky(bn(P_j + Q_i)) = leaky(bn(max_j P_j + Q_i))  for a positive BN scale (min_j for a negative one):
 //     the [B,2C,N,k] edge tensor (up to 671 MB at B=32) and the k-fold conv FLOPs disappear.
 #include "pc3d_common.h"
+#include "knn_list.h"
 
 namespace pc3d {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-constexpr int KF_T = 512;      // 8 waves
-constexpr int KF_Q = 32;       // queries per workgroup
-constexpr int KF_MAXN = 1024;  // reference points per strip (LDS: 32 x 1024 x 4 B = 128 KiB)
+constexpr int KF_T = 256;      // 4 waves
+constexpr int KF_Q = 32;       // queries per workgroup (the MFMA row block)
+constexpr int KF_BLK = 128;    // reference points per block: one 32-column MFMA tile per wave
+constexpr int KF_LD = KF_BLK + 4;
+constexpr int KF_QW = KF_Q / 4;   // queries whose K-lists a wave maintains
 
 struct KnnFeatArgs {
   const float* x;  // [B,N,C] channels-last
@@ -26,96 +30,129 @@ struct KnnFeatArgs {
   int32_t* idx;    // [B,N,K]
 };
 
+// Register diet on purpose (~80 VGPRs -> 4+ waves per SIMD): the insertions are chains of dependent VALU/SALU
+// hops, and only other resident waves hide them. So the A operand (the 32 query rows) sits in LDS, the B operand is
+// streamed from global memory a few float4 ahead, and nothing but the accumulator tile and the lists stays live.
+constexpr int KF_PF = 4;              // float4 of the B operand in flight per lane
+
 __global__ __launch_bounds__(KF_T) void knn_feat_kernel(KnnFeatArgs a) {
-  __shared__ float strip[KF_Q][KF_MAXN + 1];  // similarity -|qi - rj|^2 ; +1 breaks the power-of-two row stride
-  __shared__ float qn[KF_Q];
+  extern __shared__ __attribute__((aligned(16))) float kf_lds[];
+  const int ldq = a.C + 4;                                  // row stride of the query block (16-byte aligned rows)
+  float (*strip)[KF_LD] = reinterpret_cast<float (*)[KF_LD]>(kf_lds);          // [32][132] distance block
+  float* qs = kf_lds + KF_Q * KF_LD;                                             // [32][C+4] query rows
+  float* qn = qs + KF_Q * ldq;                                                   // [32] squared norms
   const int b = blockIdx.y, q0 = blockIdx.x * KF_Q;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 31, h = lane >> 5;
   const float* xb = a.x + (int64_t)b * a.N * a.C;
-  // A operand = query rows (fixed for the workgroup): lane (r,h) holds x[q0+r][8t+4h .. +3]
-  const int qrow = (q0 + r < a.N) ? q0 + r : a.N - 1;
-  const float* qp = xb + (int64_t)qrow * a.C + 4 * h;
   const int nt = a.C / 8;
-  float4 aq[16];  // C <= 128
-#pragma unroll
-  for (int t = 0; t < 16; ++t)
-    if (t < nt) aq[t] = *reinterpret_cast<const float4*>(qp + 8 * t);
-  // squared norms of the queries (lane pairs r / r+32 hold complementary halves of the row)
+  const int K = a.K;
+  // stage the query rows (clamped at the cloud's end) and their squared norms
   {
-    float s = 0.f;
-#pragma unroll
-    for (int t = 0; t < 16; ++t)
-      if (t < nt) s += aq[t].x * aq[t].x + aq[t].y * aq[t].y + aq[t].z * aq[t].z + aq[t].w * aq[t].w;
-    s += __shfl_xor(s, 32, 64);
-    if (wave == 0 && h == 0) qn[r] = s;
-  }
-  __syncthreads();
-  // each wave produces reference tiles wave, wave+8, ...
-  const int ntile = (a.N + 31) / 32;
-  for (int tile = wave; tile < ntile; tile += KF_T / 64) {
-    const int r0 = tile * 32;
-    const int rrow = (r0 + r < a.N) ? r0 + r : a.N - 1;
-    const float* rp = xb + (int64_t)rrow * a.C + 4 * h;
-    f32x16 acc;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    float rn = 0.f;
-#pragma unroll
-    for (int t = 0; t < 16; ++t)
-      if (t < nt) {
-        const float4 bv = *reinterpret_cast<const float4*>(rp + 8 * t);
-        rn += bv.x * bv.x + bv.y * bv.y + bv.z * bv.z + bv.w * bv.w;
-        // D[row = query][col = reference]
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[t].x, bv.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[t].y, bv.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[t].z, bv.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[t].w, bv.w, acc, 0, 0, 0);
+    const int cq = a.C / 4;   // float4 per row
+    for (int i = threadIdx.x; i < KF_Q * cq; i += KF_T) {
+      const int row = i / cq, c4 = i - row * cq;
+      const int qrow = (q0 + row < a.N) ? q0 + row : a.N - 1;
+      *reinterpret_cast<float4*>(qs + row * ldq + 4 * c4) = *reinterpret_cast<const float4*>(xb + (int64_t)qrow * a.C + 4 * c4);
+    }
+    __syncthreads();
+    if (wave == 0) {   // lane (r,h) sums the float4s 8t+4h of row r — the same partition and order as the reference rows below
+      float s = 0.f;
+      for (int t = 0; t < nt; ++t) {
+        const float4 v = *reinterpret_cast<const float4*>(qs + r * ldq + 8 * t + 4 * h);
+        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
       }
-    rn += __shfl_xor(rn, 32, 64);  // |r_j|^2 for column j = r
-    const bool valid = (r0 + r) < a.N;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int qi = (e & 3) + 8 * (e >> 2) + 4 * h;
-      // model/dgcnn.py:195-197: -xx - (-2 x.x) - xx^T  = 2 q.r - |q|^2 - |r|^2
-      strip[qi][r0 + r] = valid ? (2.f * acc[e] - qn[qi] - rn) : -__builtin_inff();
+      s += __shfl_xor(s, 32, 64);
+      if (h == 0) qn[r] = s;
     }
   }
-  __syncthreads();
-  // top-K per query strip: wave w handles queries w, w+8, ... ; lane holds N/64 strided candidates
-  constexpr int PER = KF_MAXN / 64;
-  for (int qi = wave; qi < KF_Q; qi += KF_T / 64) {
-    if (q0 + qi >= a.N) break;
-    float v[PER];
+  // K-lists of this wave's queries (8*wave .. +7), across the lanes
+  float ld[KF_QW], thr[KF_QW];
+  int li[KF_QW];
 #pragma unroll
-    for (int e = 0; e < PER; ++e) {
-      const int j = e * 64 + lane;
-      v[e] = (j < a.N) ? strip[qi][j] : -__builtin_inff();
-    }
-    int32_t* o = a.idx + ((int64_t)b * a.N + q0 + qi) * a.K;
-    for (int k = 0; k < a.K; ++k) {
-      float bv = -__builtin_inff();
-      int be = 0;
+  for (int u = 0; u < KF_QW; ++u) ld[u] = __builtin_inff(), li[u] = 0x7fffffff, thr[u] = __builtin_inff();
+
+  const int nblk = (a.N + KF_BLK - 1) / KF_BLK;
+  __syncthreads();   // qn visible
+  for (int blk = 0; blk < nblk; ++blk) {
+    float (*st)[KF_LD] = strip;
+    // ---- phase 1: this wave's 32 x 32 tile of the block on MFMA (this IS a dense contraction over C)
+    {
+      const int rrow0 = blk * KF_BLK + 32 * wave + r;
+      const int rrow = rrow0 < a.N ? rrow0 : a.N - 1;
+      const float* rp = xb + (int64_t)rrow * a.C + 4 * h;
+      f32x16 acc;
 #pragma unroll
-      for (int e = 0; e < PER; ++e)
-        if (v[e] > bv) bv = v[e], be = e;  // ascending index inside the lane: strict > keeps the lowest
-      int bj = be * 64 + lane;
-      float wv = bv;
-      int wj = bj;
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+      float rn = 0.f;
+      float4 bv[KF_PF];
 #pragma unroll
-      for (int o2 = 32; o2 > 0; o2 >>= 1) {
-        const float ov = __shfl_xor(wv, o2, 64);
-        const int oj = __shfl_xor(wj, o2, 64);
-        if (ov > wv || (ov == wv && oj < wj)) wv = ov, wj = oj;
+      for (int t = 0; t < KF_PF; ++t) bv[t] = (t < nt) ? *reinterpret_cast<const float4*>(rp + 8 * t) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int t0 = 0; t0 < nt; t0 += KF_PF) {
+#pragma unroll
+        for (int tt = 0; tt < KF_PF; ++tt) {
+          const int t = t0 + tt;
+          const float4 v = bv[tt];
+          if (t + KF_PF < nt) bv[tt] = *reinterpret_cast<const float4*>(rp + 8 * (t + KF_PF));
+          if (t < nt) {
+            const float4 q = *reinterpret_cast<const float4*>(qs + r * ldq + 8 * t + 4 * h);
+            rn += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q.x, v.x, acc, 0, 0, 0);   // D[row = query][col = reference]
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q.y, v.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q.z, v.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q.w, v.w, acc, 0, 0, 0);
+          }
+        }
       }
-      if (lane == 0) o[k] = wj;
-      // the owner retires the winner (static register indexing: predicated writes)
-      const bool mine = (wj & 63) == lane;
-      const int we = wj >> 6;
+      rn += __shfl_xor(rn, 32, 64);            // |r_j|^2 for column j = r
+      const bool valid = (blk * KF_BLK + 32 * wave + r) < a.N;
 #pragma unroll
-      for (int e = 0; e < PER; ++e)
-        if (mine && e == we) v[e] = -__builtin_inff();
+      for (int e = 0; e < 16; ++e) {
+        const int qi = (e & 3) + 8 * (e >> 2) + 4 * h;
+        // model/dgcnn.py:195-197 ranks by 2 q.r - |q|^2 - |r|^2 (largest first); its exact negation is stored, so
+        // "smallest first" here is the same order with the same ties
+        st[qi][32 * wave + r] = valid ? -(2.f * acc[e] - qn[qi] - rn) : __builtin_inff();
+      }
     }
+    __syncthreads();
+    // ---- phase 2: two steps of 64 candidates against this wave's 8 lists
+#pragma unroll
+    for (int s = 0; s < KF_BLK / 64; ++s) {
+      const int jbase = blk * KF_BLK + 64 * s;
+      float d[KF_QW];
+#pragma unroll
+      for (int u = 0; u < KF_QW; ++u) d[u] = st[KF_QW * wave + u][64 * s + lane];
+      if (blk == 0 && s == 0) {
+#pragma unroll
+        for (int u = 0; u < KF_QW; ++u) {      // seed: sort the first 64 candidates
+          float sd = (d[u] == d[u]) ? d[u] : __builtin_inff();
+          int si = lane;
+          wave_sort_pairs(sd, si, lane);
+          ld[u] = sd, li[u] = si;
+          thr[u] = readlane_f(sd, K - 1);
+        }
+        continue;
+      }
+#pragma unroll
+      for (int u = 0; u < KF_QW; ++u) {
+        unsigned long long mask = __builtin_amdgcn_ballot_w64(d[u] < thr[u]);
+        while (mask) {
+          const int c = __builtin_ctzll(mask);
+          mask &= mask - 1;
+          const float dc = readlane_f(d[u], c);
+          if (!(dc < thr[u])) continue;
+          knn_list_insert(ld[u], li[u], dc, jbase + c, lane);
+          thr[u] = readlane_f(ld[u], K - 1);
+        }
+      }
+    }
+    __syncthreads();   // the block is consumed before the next one overwrites it (single buffer: LDS buys residency)
+  }
+#pragma unroll
+  for (int u = 0; u < KF_QW; ++u) {
+    const int qi = q0 + KF_QW * wave + u;
+    if (qi < a.N && lane < K) a.idx[((int64_t)b * a.N + qi) * K + lane] = li[u];
   }
 }
 
@@ -167,14 +204,14 @@ __global__ __launch_bounds__(256) void gather_max_bwd_kernel(const float* g, con
 using namespace pc3d;
 
 extern "C" int pc3d_knn_feat_f32(const float* x, int B, int N, int C, int K, int32_t* idx, void* stream) {
-  PC3D_REQUIRE(B >= 0 && N >= 1 && K >= 1 && K <= N, "pc3d_knn_feat_f32: bad sizes B=%d N=%d K=%d", B, N, K);
+  PC3D_REQUIRE(B >= 0 && N >= 1 && K >= 1 && K <= N && K <= 64, "pc3d_knn_feat_f32: bad sizes B=%d N=%d K=%d (K <= 64)", B, N, K);
   PC3D_REQUIRE(C >= 8 && C <= 128 && C % 8 == 0, "pc3d_knn_feat_f32: C=%d must be a multiple of 8 in [8,128]", C);
-  PC3D_REQUIRE(N <= KF_MAXN, "pc3d_knn_feat_f32: N=%d exceeds %d", N, KF_MAXN);
   PC3D_REQUIRE(B <= 65535, "pc3d_knn_feat_f32: B=%d exceeds grid.y limit", B);
   if (B == 0) return PC3D_OK;
   PC3D_REQUIRE(x && idx, "pc3d_knn_feat_f32: null pointer");
   KnnFeatArgs a{x, N, C, K, idx};
-  hipLaunchKernelGGL(knn_feat_kernel, dim3(cdiv(N, KF_Q), B), dim3(KF_T), 0, as_stream(stream), a);
+  const size_t lds = (size_t)(KF_Q * KF_LD + KF_Q * (C + 4) + KF_Q) * sizeof(float);   // 25.7 KiB (C=64) / 33.9 KiB (C=128)
+  hipLaunchKernelGGL(knn_feat_kernel, dim3(cdiv(N, KF_Q), B), dim3(KF_T), lds, as_stream(stream), a);
   PC3D_LAUNCH_CHECK("pc3d_knn_feat_f32");
   return PC3D_OK;
 }

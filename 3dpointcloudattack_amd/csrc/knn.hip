@@ -7,6 +7,7 @@
 // The reference cloud is staged through LDS as SoA (like the NN kernel); each wave serves 4 queries whose sorted
 // K-lists live across its lanes (details at knn_wave_kernel). K <= 64. Ties: the lower reference index comes first.
 #include "pc3d_common.h"
+#include "knn_list.h"
 
 namespace pc3d {
 
@@ -32,44 +33,6 @@ struct KnnArgs {
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kKwQPW = 4;          // queries scanned together by a wave
 constexpr int kKwTile = 2048;      // reference points per LDS tile (24 KiB SoA)
-
-__device__ __forceinline__ float readlane_f(float v, int l) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
-}
-
-// lexicographic (d, idx) bitonic sort of one value per lane, ascending over lanes
-__device__ __forceinline__ void wave_sort_pairs(float& d, int& i, int lane) {
-#pragma unroll
-  for (int k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      const float od = __shfl_xor(d, j, 64);
-      const int oi = __shfl_xor(i, j, 64);
-      const bool keep_min = (((lane & j) == 0) == ((lane & k) == 0));
-      const bool other_less = (od < d) || (od == d && oi < i);
-      const bool other_more = (od > d) || (od == d && oi > i);
-      const bool take = keep_min ? other_less : other_more;
-      d = take ? od : d;
-      i = take ? oi : i;
-    }
-  }
-}
-
-// wave-wide minimum of one float per lane (DPP row shifts + row broadcasts; min is idempotent, so overlapping
-// contributions are harmless); the result is returned as a wave-uniform value
-__device__ __forceinline__ float wave_min_dpp(float v) {
-#define PC3D_DPP_MIN(ctrl)                                                                              \
-  v = fminf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v),        \
-                                                                     __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false)))
-  PC3D_DPP_MIN(0x111);  // row_shr:1
-  PC3D_DPP_MIN(0x112);  // row_shr:2
-  PC3D_DPP_MIN(0x114);  // row_shr:4
-  PC3D_DPP_MIN(0x118);  // row_shr:8  -> lane 15 of every row holds the row minimum
-  PC3D_DPP_MIN(0x142);  // row_bcast:15
-  PC3D_DPP_MIN(0x143);  // row_bcast:31 -> lane 63 holds the wave minimum
-#undef PC3D_DPP_MIN
-  return readlane_f(v, 63);
-}
 
 template <int kKwWaves>    // waves per workgroup: a workgroup serves 4 * kKwWaves queries from one staged copy of the cloud
 __global__ __launch_bounds__(kKwWaves * 64) void knn_wave_kernel(KnnArgs a) {
@@ -169,13 +132,7 @@ __global__ __launch_bounds__(kKwWaves * 64) void knn_wave_kernel(KnnArgs a) {
             const float dc = readlane_f(d[u], c);
             if (!(dc < thr[p][u])) continue;        // the threshold tightened since the ballot
             const int ic = m0 + j0 + c;
-            const int pos = __builtin_popcountll(__builtin_amdgcn_ballot_w64(ld[p][u] <= dc));
-            // lane l <- lane l-1 (v_mov_b32_dpp wave_shr:1); lane 0 is never read when pos > 0, and is `pos` otherwise
-            const float sd = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
-                0, __builtin_bit_cast(int, ld[p][u]), 0x138, 0xf, 0xf, false));
-            const int si = __builtin_amdgcn_update_dpp(0, li[p][u], 0x138, 0xf, 0xf, false);
-            ld[p][u] = lane < pos ? ld[p][u] : (lane == pos ? dc : sd);
-            li[p][u] = lane < pos ? li[p][u] : (lane == pos ? ic : si);
+            knn_list_insert(ld[p][u], li[p][u], dc, ic, lane);
             thr[p][u] = readlane_f(ld[p][u], K - 1);
           }
         }

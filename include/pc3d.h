@@ -250,9 +250,10 @@ int pc3d_group_gather_bwd_f32(const float* g_out, const int32_t* idx, const int3
 /* ---------------------------------------------------------------------------------------------------------
  * K3  DGCNN dynamic graph (model/dgcnn.py:194-227,299-313).
  * pc3d_knn_feat_f32: idx[b,i,:] = the K nearest points of i in C-dimensional feature space (self included, nearest
- * first, lowest index on ties) for channels-last features x [B,N,C]; C % 8 == 0, C <= 128, N <= 1024. The
- * similarity -|xi-xj|^2 = 2 xi.xj - |xi|^2 - |xj|^2 strip of 32 queries is formed by fp32 MFMA in LDS and reduced by
- * wave arg-max rounds; nothing of size N*N reaches HBM (the reference writes [B,N,N] and calls topk).
+ * first, lowest index on ties) for channels-last features x [B,N,C]; C % 8 == 0, C <= 128, K <= 64, any N. The
+ * distances |xi-xj|^2 = |xi|^2 + |xj|^2 - 2 xi.xj of 32 queries x 128 references at a time are formed by fp32 MFMA in
+ * LDS and scanned against K-lists held across the lanes; nothing of size N*N reaches HBM (the reference writes
+ * [B,N,N] and calls topk).
  * pc3d_gather_max_f32: out[b,i,c] = max (sign[c] < 0: min; sign NULL: max) over j in idx[b,i,:] of P[b,j,c], with
  * the winning j in arg (may be NULL) — the neighbour reduction of an EdgeConv expressed as W[xj-xi; xi] = P_j + Q_i.
  * pc3d_gather_max_bwd_f32: gP[b,arg,c] += g (gP overwritten; float atomics).

@@ -52,12 +52,12 @@ def test_knn_feat_matches_reference_topk(ops, dev, fx):
     np.testing.assert_allclose(picked, np.sort(D, axis=2)[:, :, :20], rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("B,N,C,K", [(1, 40, 8, 5), (2, 1024, 128, 20), (3, 333, 64, 20), (1, 20, 64, 20)])
+@pytest.mark.parametrize("B,N,C,K", [(1, 40, 8, 5), (2, 1024, 128, 20), (3, 333, 64, 20), (1, 20, 64, 20), (1, 2500, 64, 20), (1, 200, 72, 64)])
 def test_knn_feat_sizes(ops, dev, B, N, C, K):
     torch.manual_seed(N + C)
     x = torch.randn(B, N, C)
     idx = ops.knn_feat(x.to(dev), K).cpu().numpy()
-    D = ((x.double()[:, :, None, :] - x.double()[:, None, :, :]) ** 2).sum(-1).numpy()
+    D = (torch.cdist(x.double(), x.double(), compute_mode='donot_use_mm_for_euclid_dist') ** 2).numpy()
     picked = np.take_along_axis(D, idx.astype(np.int64), axis=2)
     np.testing.assert_allclose(picked, np.sort(D, axis=2)[:, :, :K], rtol=1e-4, atol=1e-3)
     assert all(len(set(r)) == K for r in idx.reshape(-1, K))
