@@ -5,7 +5,7 @@ root=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
 out=$root/gpurun_out/prof_$tag
 mkdir -p $out
-rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 $root/bench.py --steps 100 --warmup 10 > $out/bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 $root/bench.py --steps 100 --warmup 10 --no-sweep --no-cpu-baseline > $out/bench.log 2>&1
 f=$(ls $out/*/*kernel_stats.csv | head -1)
 cp $f $out/kernel_stats.csv
 python3 - "$f" <<'PY'
