@@ -18,7 +18,7 @@ from ._lib import LIB_PATH, Pc3dError, load  # noqa: F401
 
 __version__ = "0.1.0"
 
-_MIRRORS = ("attack", "model", "utils")
+_MIRRORS = ("attack", "model", "utils", "dataset")
 
 
 class _MirrorFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):

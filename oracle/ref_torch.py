@@ -922,3 +922,108 @@ def taof_attack(model, data, target, y_truth, adv_func, clip_func, attack_lr=1e-
     adv_pc = torch.tensor(o_bestattack).float()
     preds = torch.argmax(model(adv_pc)[0], dim=-1)
     return o_bestdist, adv_pc.numpy().transpose((0, 2, 1)), int((preds == target).sum())
+
+
+# ---------------------------------------------------------------------------------------------------------
+# attack/additional_exp/CW_attack.py: CW with the binary-searched point-set distance, z-only
+# perturbation in a +-0.4 box, renormalisation in the loop, expectation over 10 small rotations (+ resampling).
+# Restated for B = 1 semantics generalised per sample (the reference's prints/zip force B = 1, :80-84,:158-182).
+# ---------------------------------------------------------------------------------------------------------
+def _renorm_cf(x):
+    """attack/additional_exp/CW_attack.py:107-115."""
+    p = x.permute(0, 2, 1)
+    p = p - torch.mean(p, dim=1).unsqueeze(1)
+    var = torch.max(torch.sqrt(torch.sum(p ** 2, dim=2)), dim=1, keepdim=True)[0]
+    return (p / var.unsqueeze(1)).permute(0, 2, 1)
+
+
+def cw_additional_attack(model, data, target, origin_label, adv_func, dist_func, attack_lr=1e-2, init_weight=10.,
+                         max_weight=80., binary_step=10, num_iter=500, whether_target=True, whether_1d=True,
+                         whether_renormalization=False, whether_3Dtransform=False, whether_resample=False):
+    """adv_func(logits, label, whether_target=...), dist_func(adv[B,K,3], ori[B,K,3], weights[B]) -> scalar or [B].
+    Returns (o_bestdist [B] f64, o_bestattack [B,K,3] f64, success_num). Random streams as the reference: torch CPU
+    generator for the start noise and the angles (:88,:196), Python `random` for the axis choice / resampling (:211,:238)."""
+    import random
+    if data.shape[2] == 3:
+        data = data.transpose(1, 2).contiguous()
+    B, _, K = data.shape
+    data = data.float().detach()
+    ori = data.clone().detach()
+    target = target.long().view(-1)
+    origin_label = origin_label.long().view(-1)
+    goal = (target if whether_target else origin_label).numpy()
+    goal_t = target if whether_target else origin_label
+    lower, upper, cur_w = np.zeros((B,)), np.ones((B,)) * max_weight, np.ones((B,)) * init_weight
+    o_bestdist = np.array([1e10] * B)
+    o_bestscore = np.array([-1] * B)
+    o_bestattack = np.zeros((B, 3, K))
+    model(ori)                                                                    # :75 clean forward
+    adv = ori.clone().detach() + torch.randn((B, 3, K)) * 1e-7                    # :88 — ONE start for the whole search
+    input_val = None
+    box = 0.4
+    for bstep in range(binary_step):
+        adv.requires_grad_()
+        bestdist = np.array([1e10] * B)
+        bestscore = np.array([-1] * B)
+        opt = torch.optim.Adam([adv], lr=attack_lr, weight_decay=0.)              # :96
+        for it in range(num_iter):
+            logits = model(_renorm_cf(adv) if whether_renormalization else adv)[0]   # :105-117
+            pred = torch.argmax(logits, dim=1)
+            dist_loss = dist_func(adv.permute(0, 2, 1), ori.permute(0, 2, 1), torch.from_numpy(cur_w))   # :151-153
+            dist_val = np.broadcast_to(dist_loss.detach().double().numpy().reshape(-1), (B,))
+            pred_val = pred.detach().numpy()
+            input_val = adv.detach().numpy().copy()
+            dist_loss = dist_loss.mean()
+            for e in range(B):                                                    # :160-182
+                ok = (pred_val[e] == goal[e]) if whether_target else (pred_val[e] != goal[e])
+                if dist_val[e] < bestdist[e] and ok:
+                    bestdist[e], bestscore[e] = dist_val[e], pred_val[e]
+                if dist_val[e] < o_bestdist[e] and ok:
+                    o_bestdist[e], o_bestscore[e] = dist_val[e], pred_val[e]
+                    o_bestattack[e] = input_val[e]
+            wt = 1 if whether_target else 0
+            if whether_3Dtransform:                                               # :191-251
+                diff = adv - ori.detach()
+                losses = []
+                for _ in range(10):
+                    theta = torch.randn(1) * 1e-2
+                    c, s_ = float(torch.cos(theta)), float(torch.sin(theta))
+                    r = random.random()
+                    if r < 0.2:
+                        m = [[c, s_, 0], [-s_, c, 0], [0, 0, 1]]
+                    elif r < 0.4:
+                        m = [[1, 0, 0], [0, c, s_], [0, -s_, c]]
+                    elif r < 0.6:
+                        m = [[c, 0, s_], [0, 1, 0], [-s_, 0, c]]
+                    else:
+                        m = [[1, 0, 0], [0, 1, 0], [0, 0, 1]]
+                    Tr = torch.tensor(m, dtype=torch.float32).unsqueeze(0).expand(B, -1, -1)
+                    x = torch.bmm(Tr, ori.detach()) + diff
+                    if whether_renormalization:
+                        x = _renorm_cf(x)
+                    if whether_resample:
+                        idx = random.sample(range(1, K * 2), K)                   # :238 (4000 of 8000 there)
+                        x = torch.index_select(torch.cat((x, x), 2), 2, torch.LongTensor(idx))
+                    losses.append(adv_func(model(x)[0], goal_t, whether_target=wt).mean())
+                adv_loss = torch.mean(torch.stack(losses))
+            else:
+                adv_loss = adv_func(logits, goal_t, whether_target=wt).mean()     # :254-260
+            loss = adv_loss + dist_loss
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            if whether_1d:                                                        # :266-275
+                with torch.no_grad():
+                    adv[:, 0] = ori[:, 0]
+                    adv[:, 1] = ori[:, 1]
+                    adv[:, 2] = torch.max(torch.min(adv[:, 2], ori[:, 2] + box), ori[:, 2] - box)
+        for e in range(B):                                                        # :283-303
+            hit = (bestscore[e] == goal[e]) if whether_target else (bestscore[e] != goal[e])
+            if hit and bestscore[e] != -1 and bestdist[e] <= o_bestdist[e]:
+                lower[e] = max(lower[e], cur_w[e])
+            else:
+                upper[e] = min(upper[e], cur_w[e])
+            cur_w[e] = (lower[e] + upper[e]) / 2.
+    fail_idx = (lower == 0.)                                                      # :309-310
+    o_bestattack[fail_idx] = input_val[fail_idx]
+    return o_bestdist, o_bestattack.transpose((0, 2, 1)), int((lower > 0.).sum())

@@ -532,7 +532,98 @@ def gen_curvenet():
     print("curvenet.npz:", len(fx), "arrays")
 
 
-SECTIONS = {"curvenet": gen_curvenet, "aof": gen_aof, "geoa3": gen_geoa3, "dgcnn": gen_dgcnn, "metrics": gen_metrics, "pointnet": gen_pointnet, "cw": gen_cw, "pointnet2": gen_pointnet2, "knn": gen_knn}
+def gen_cw_additional():
+    """Short runs of the REAL attack/additional_exp/CW_attack.py (B=1) on seeded PointNet weights. No functor of the
+    reference accepts the `whether_target` keyword this attack passes (:245-259), so the adversarial functors are
+    wrapped; the distance functors are the reference's own, called with [B,K,3] as that file does (:151-153)."""
+    install_cpu_shim()
+    import contextlib
+    import io
+    import random
+    from model.pointnet import PointNetCls
+    from attack.additional_exp.CW_attack import CW
+    from attack.CW.CW_utils.adv_utils import UntargetedLogitsAdvLoss, LogitsAdvLoss
+    from attack.CW.CW_utils.dist_utils import L2Dist, ChamferDist, ChamferkNNDist
+
+    class Adv:
+        def __init__(self, kappa):
+            self.t, self.u = LogitsAdvLoss(kappa=kappa), UntargetedLogitsAdvLoss(kappa=kappa)
+
+        def __call__(self, logits, label, whether_target=1):
+            return (self.t if whether_target else self.u)(logits, label)
+
+    class Recorder(torch.nn.Module):
+        def __init__(self, inner, per_sample):
+            super().__init__()
+            self.inner, self.per_sample, self.log = inner, per_sample, []
+
+        def forward(self, adv, ori, weights=None):
+            self.log.append(adv.detach().numpy().copy())
+            return self.inner(adv, ori, weights, batch_avg=not self.per_sample)
+
+    rng = np.random.default_rng(2024)
+    model, sha = _seeded_pointnet(PointNetCls, 40, 0)
+    fx = {"sha256": np.array(sha)}
+    cases = {
+        "z_chamfer_target": dict(dist="chamfer", target=True, d1=True, renorm=False, eot=False, resample=False, N=200, steps=2, iters=12, kappa=0.),
+        "eot_renorm_chamferknn_target": dict(dist="chamferknn", target=True, d1=True, renorm=True, eot=True, resample=False, N=160, steps=2, iters=6, kappa=0.),
+        "free_l2_untarget": dict(dist="l2", target=False, d1=False, renorm=False, eot=False, resample=False, N=256, steps=3, iters=10, kappa=5.),
+        "resample_chamfer_target": dict(dist="chamfer", target=True, d1=True, renorm=False, eot=True, resample=True, N=4000, steps=1, iters=2, kappa=0.),
+    }
+    fx["names"] = np.array(sorted(cases))
+    for nm in sorted(cases):
+        c = cases[nm]
+        pc = unit_cloud(rng, c["N"])[None]
+        with torch.no_grad():
+            lg = model(torch.from_numpy(pc).transpose(1, 2).contiguous())[0]
+        clean, runner_up = int(torch.argmax(lg, dim=1)), int(torch.topk(lg, 2)[1][0, 1])
+        inner = {"chamfer": ChamferDist(), "chamferknn": ChamferkNNDist(), "l2": L2Dist()}[c["dist"]]
+        # L2Dist takes channel-first clouds but is rotation-agnostic here (it only sums squares); the untargeted
+        # branch iterates over dist_val (:172-174), so it needs the per-sample [B] form
+        rec = Recorder(inner, per_sample=not c["target"])
+        atk = CW(model, Adv(c["kappa"]), rec, attack_lr=1e-2, init_weight=10., max_weight=80., binary_step=c["steps"],
+                 num_iter=c["iters"], whether_target=c["target"], whether_1d=c["d1"], whether_renormalization=c["renorm"],
+                 whether_3Dtransform=c["eot"], whether_resample=c["resample"])
+        torch.manual_seed(2000)
+        random.seed(2000)
+        np.random.seed(2000)
+        with contextlib.redirect_stdout(io.StringIO()):
+            bd, ba, sn = atk.attack(torch.from_numpy(pc), torch.tensor([runner_up]), torch.tensor([clean]))
+        fx[f"{nm}_pc"], fx[f"{nm}_target"], fx[f"{nm}_origin"] = pc, np.array([runner_up]), np.array([clean])
+        fx[f"{nm}_bestdist"], fx[f"{nm}_bestattack"], fx[f"{nm}_success"] = np.asarray(bd), ba.astype(np.float32), np.array(int(sn))
+        traj = np.stack(rec.log).astype(np.float32)[:, 0]                      # [steps*iters, K, 3]
+        fx[f"{nm}_traj"] = traj if c["N"] <= 512 else traj[:, ::16]
+    np.savez_compressed(os.path.join(OUT, "cw_additional.npz"), **fx)
+    print("cw_additional.npz:", len(fx), "arrays")
+
+
+def gen_formats():
+    """On-disk formats through the reference's own dataset code, on two data files the reference
+    ships (copied to tests/golden/data/ as plain data): Bosphorus_Dataset.__getitem__'s csv-text branch
+    (dataset/bosphorus_dataset.py:59-84) and AdvData_dataset.read_PC (:21-38). open3d (absent) is stubbed as an
+    empty module and `np.float` (removed from numpy) restored for the import, as SURVEY §8(c) describes."""
+    import types
+    import pandas as pd
+    sys.modules.setdefault("open3d", types.ModuleType("open3d"))
+    if not hasattr(np, "float"):
+        np.float = float
+    sys.path.insert(0, os.path.join(os.environ.get("PC3D_REFERENCE", "/root/reference"), "utils"))   # `from readbnt import ...`
+    from dataset.bosphorus_dataset import Bosphorus_Dataset
+    from dataset.AdvData_dataset import read_PC
+    ref = os.environ.get("PC3D_REFERENCE", "/root/reference")
+    fx = {}
+    ds = object.__new__(Bosphorus_Dataset)                   # skip __init__ (needs the private csv index)
+    ds.df = pd.DataFrame([[os.path.join(ref, "AddData", "face0424.txt"), 105]])
+    np.random.seed(4242)
+    pc, cls = ds[0]
+    fx["bosphorus_pc"], fx["bosphorus_cls"] = pc.numpy(), cls.numpy()
+    A, ori, tar = read_PC(0, os.path.join(ref, "attack", "CW", "AdvData", "PointNet"))
+    fx["advdata_A"], fx["advdata_ori_tar"] = A, np.array([ori, tar])
+    np.savez_compressed(os.path.join(OUT, "formats.npz"), **fx)
+    print("formats.npz:", len(fx), "arrays")
+
+
+SECTIONS = {"formats": gen_formats, "cw_additional": gen_cw_additional, "curvenet": gen_curvenet, "aof": gen_aof, "geoa3": gen_geoa3, "dgcnn": gen_dgcnn, "metrics": gen_metrics, "pointnet": gen_pointnet, "cw": gen_cw, "pointnet2": gen_pointnet2, "knn": gen_knn}
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(SECTIONS)

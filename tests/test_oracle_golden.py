@@ -249,3 +249,53 @@ def test_oracle_aof_matches_reference():
     np.testing.assert_allclose(bd, fx["atk_bestdist"], rtol=1e-4)
     np.testing.assert_allclose(adv, fx["atk_adv"], atol=1e-5)
     assert sn == int(fx["atk_success"])
+
+
+ADDL_CASES = {
+    "z_chamfer_target": dict(dist="chamfer", target=True, d1=True, renorm=False, eot=False, resample=False, steps=2, iters=12, kappa=0.),
+    "eot_renorm_chamferknn_target": dict(dist="chamferknn", target=True, d1=True, renorm=True, eot=True, resample=False, steps=2, iters=6, kappa=0.),
+    "free_l2_untarget": dict(dist="l2", target=False, d1=False, renorm=False, eot=False, resample=False, steps=3, iters=10, kappa=5.),
+    "resample_chamfer_target": dict(dist="chamfer", target=True, d1=True, renorm=False, eot=True, resample=True, steps=1, iters=2, kappa=0.),
+}
+
+
+class _AddlAdv:
+    """adv_func(logits, label, whether_target=...) over the oracle's functors (additional_exp/CW_attack.py:245-259)."""
+
+    def __init__(self, mod, kappa):
+        self.t, self.u = mod.LogitsAdvLoss(kappa), mod.UntargetedLogitsAdvLoss(kappa)
+
+    def __call__(self, logits, label, whether_target=1):
+        return (self.t if whether_target else self.u)(logits, label)
+
+
+def test_oracle_cw_additional_matches_reference():
+    """oracle.cw_additional_attack vs the real attack/additional_exp/CW_attack.py (fixtures: make_golden.py
+    cw_additional): same arithmetic on the same CPU backend, same random streams -> same iterates."""
+    import random
+    fx = np.load(os.path.join(GOLDEN, "cw_additional.npz"))
+    net, _ = _oracle_pointnet(0)
+    assert sorted(ADDL_CASES) == sorted(str(n) for n in fx["names"])
+    for nm, c in ADDL_CASES.items():
+        inner = {"chamfer": ort.ChamferDist(), "chamferknn": ort.ChamferkNNDist(), "l2": ort.L2Dist()}[c["dist"]]
+        log = []
+
+        def dist(adv, ori, w, inner=inner, per_sample=not c["target"], log=log):
+            log.append(adv.detach().numpy().copy())
+            return inner(adv, ori, w, batch_avg=not per_sample)
+        torch.manual_seed(2000)
+        random.seed(2000)
+        np.random.seed(2000)
+        bd, ba, sn = ort.cw_additional_attack(
+            net, torch.from_numpy(fx[f"{nm}_pc"]), torch.from_numpy(fx[f"{nm}_target"]), torch.from_numpy(fx[f"{nm}_origin"]),
+            _AddlAdv(ort, c["kappa"]), dist, attack_lr=1e-2, binary_step=c["steps"], num_iter=c["iters"],
+            whether_target=c["target"], whether_1d=c["d1"], whether_renormalization=c["renorm"],
+            whether_3Dtransform=c["eot"], whether_resample=c["resample"])
+        traj = np.stack(log)[:, 0]
+        if traj.shape[1] > 512:
+            traj = traj[:, ::16]
+        np.testing.assert_allclose(traj, fx[f"{nm}_traj"], atol=2e-5, err_msg=nm)
+        assert sn == int(fx[f"{nm}_success"]), nm
+        np.testing.assert_allclose(bd, fx[f"{nm}_bestdist"], rtol=1e-3, err_msg=nm)
+        if sn:
+            np.testing.assert_allclose(ba, fx[f"{nm}_bestattack"], atol=2e-5, err_msg=nm)
