@@ -189,6 +189,37 @@ __global__ __launch_bounds__(256) void gather_max_kernel(GMaxArgs a) {
   }
 }
 
+// C % 4 == 0: a lane owns 4 consecutive channels (one 16-byte load per neighbour), C/4 lanes per point and
+// 256 / (C/4) points per workgroup; the K neighbour rows are independent loads, so they pipeline.
+__global__ __launch_bounds__(256) void gather_max4_kernel(GMaxArgs a, int lpp) {   // lpp = C / 4 lanes per point
+  const int b = blockIdx.y;
+  const int ppw = 256 / lpp;                       // points per workgroup
+  const int i = blockIdx.x * ppw + threadIdx.x / lpp;
+  const int l = threadIdx.x % lpp;
+  if (threadIdx.x >= ppw * lpp || i >= a.N) return;
+  const int32_t* nb = a.idx + ((int64_t)b * a.N + i) * a.K;
+  const float* Pb = a.P + (int64_t)b * a.N * a.C + 4 * l;
+  bool mx[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) mx[e] = (a.sign == nullptr) || (a.sign[4 * l + e] >= 0.f);
+  float best[4];
+  int bj[4];
+  const int j0 = nb[0];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) best[e] = mx[e] ? -__builtin_inff() : __builtin_inff(), bj[e] = j0;
+  for (int k = 0; k < a.K; ++k) {
+    const int j = nb[k];
+    const float4 v4 = *reinterpret_cast<const float4*>(Pb + (int64_t)j * a.C);
+    const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (mx[e] ? (v[e] > best[e]) : (v[e] < best[e])) best[e] = v[e], bj[e] = j;
+  }
+  const int64_t o = ((int64_t)b * a.N + i) * a.C + 4 * l;
+  *reinterpret_cast<float4*>(a.out + o) = make_float4(best[0], best[1], best[2], best[3]);
+  if (a.arg) *reinterpret_cast<int4*>(a.arg + o) = make_int4(bj[0], bj[1], bj[2], bj[3]);
+}
+
 // backward: gP[b, arg[b,i,c], c] += g[b,i,c]   (gP zero-filled first)
 __global__ __launch_bounds__(256) void gather_max_bwd_kernel(const float* g, const int32_t* arg, int N, int C, float* gP) {
   const int b = blockIdx.y;
@@ -223,7 +254,12 @@ extern "C" int pc3d_gather_max_f32(const float* P, const int32_t* idx, const flo
   if (B == 0) return PC3D_OK;
   PC3D_REQUIRE(P && idx && out, "pc3d_gather_max_f32: null pointer");
   GMaxArgs a{P, idx, sign, N, C, K, out, arg};
-  hipLaunchKernelGGL(gather_max_kernel, dim3(cdiv(N, 4), B), dim3(256), 0, as_stream(stream), a);
+  if (C % 4 == 0 && C <= 1024) {
+    const int lpp = C / 4, ppw = 256 / lpp;
+    hipLaunchKernelGGL(gather_max4_kernel, dim3(cdiv(N, ppw), B), dim3(256), 0, as_stream(stream), a, lpp);
+  } else {
+    hipLaunchKernelGGL(gather_max_kernel, dim3(cdiv(N, 4), B), dim3(256), 0, as_stream(stream), a);
+  }
   PC3D_LAUNCH_CHECK("pc3d_gather_max_f32");
   return PC3D_OK;
 }

@@ -63,9 +63,10 @@ def test_knn_feat_sizes(ops, dev, B, N, C, K):
     assert all(len(set(r)) == K for r in idx.reshape(-1, K))
 
 
-def test_gather_max_fwd_bwd_vs_torch(ops, dev):
+@pytest.mark.parametrize("C", [96, 64, 30, 256])      # 16-byte lanes (C % 4 == 0) and the scalar kernel
+def test_gather_max_fwd_bwd_vs_torch(ops, dev, C):
     torch.manual_seed(1)
-    B, N, C, K = 2, 70, 96, 9
+    B, N, K = 2, 70, 9
     P = torch.randn(B, N, C, device=dev, requires_grad=True)
     idx = torch.randint(0, N, (B, N, K), device=dev, dtype=torch.int32)
     out = ops.gather_max(P, idx)
