@@ -273,7 +273,8 @@ class CW:
         with torch.cuda.graph(g):
             self._iterate(st)
         st["graph"] = g
-        st["graph_run"] = lambda i=None: g.replay()
+        # the captured launches hold raw pointers into st's tensors: the runner keeps st alive for as long as it lives
+        st["graph_run"] = lambda i=None, _keep=st: g.replay()
         return st["graph_run"]
 
     def _end_binary_step(self, st):

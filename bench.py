@@ -107,13 +107,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world == 1:
         raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if os.environ.get("PC3D_BENCH_REHEARSAL"):      # rehearsal on a one-GPU box: every rank on cuda:0, gloo collectives
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist_on = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)   # launched by torch.distributed.run
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if os.environ.get("PC3D_BENCH_REHEARSAL"):
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # RCCL over xGMI
 
     pc3d = importlib.import_module("3dpointcloudattack_amd")
     pc3d.load()  # fail loudly if the HIP library is missing
