@@ -66,11 +66,12 @@ __global__ __launch_bounds__(FPS_T) void fps_kernel(FpsArgs a) {
         bi = e * FPS_T + tid;
       }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float ov = __shfl_xor(bv, o, 64);
-      const int oi = __shfl_xor(bi, o, 64);
-      if (ov > bv || (ov == bv && oi < bi)) bv = ov, bi = oi;
+    // wave arg-max on DPP (the shuffle version cost ~800 cycles of LDS-crossbar latency per step): the maximum
+    // first, then the lowest index among the lanes that hold it (= the reference's first-index tie rule)
+    {
+      const float wv = wave_max_dpp(bv);
+      bi = wave_min_dpp_i32(bv == wv ? bi : 0x7fffffff);
+      bv = wv;
     }
     const int buf = s & 1;  // double-buffered exchange: one barrier per step
     if (lane == 0) red_v[buf][wave] = bv, red_i[buf][wave] = bi;

@@ -54,4 +54,31 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+
+// Low-latency wave reductions on DPP row shifts / row broadcasts (VALU only, no LDS crossbar round trips): for
+// idempotent operators (max, min) overlapping contributions are harmless. The result is wave-uniform.
+#define PC3D_DPP_STEP_F(op, v, ctrl)                                                                     \
+  v = op(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v),            \
+                                                                  __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false)))
+#define PC3D_DPP_STEP_I(op, v, ctrl) v = op(v, __builtin_amdgcn_update_dpp(v, v, ctrl, 0xf, 0xf, false))
+__device__ __forceinline__ float wave_max_dpp(float v) {
+  PC3D_DPP_STEP_F(fmaxf, v, 0x111);  // row_shr:1
+  PC3D_DPP_STEP_F(fmaxf, v, 0x112);  // row_shr:2
+  PC3D_DPP_STEP_F(fmaxf, v, 0x114);  // row_shr:4
+  PC3D_DPP_STEP_F(fmaxf, v, 0x118);  // row_shr:8   -> lane 15 of every row holds the row maximum
+  PC3D_DPP_STEP_F(fmaxf, v, 0x142);  // row_bcast:15
+  PC3D_DPP_STEP_F(fmaxf, v, 0x143);  // row_bcast:31 -> lane 63 holds the wave maximum
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ int imin_(int a, int b) { return a < b ? a : b; }
+__device__ __forceinline__ int wave_min_dpp_i32(int v) {
+  PC3D_DPP_STEP_I(imin_, v, 0x111);
+  PC3D_DPP_STEP_I(imin_, v, 0x112);
+  PC3D_DPP_STEP_I(imin_, v, 0x114);
+  PC3D_DPP_STEP_I(imin_, v, 0x118);
+  PC3D_DPP_STEP_I(imin_, v, 0x142);
+  PC3D_DPP_STEP_I(imin_, v, 0x143);
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
 }  // namespace pc3d
