@@ -17,6 +17,30 @@ from .. import ops
 from .pointnet import _FrozenFusedMixin
 
 
+
+class _LinearReLUFn(torch.autograd.Function):
+    """relu(x @ w.T + b) as ONE GEMM with a bias+ReLU epilogue (hipBLASLt via torch._addmm_activation, which has no
+    autograd formula of its own). Frozen weights: only dL/dx is produced."""
+
+    @staticmethod
+    def forward(ctx, x2d, w, b):
+        y = torch._addmm_activation(b, x2d, w.t(), use_gelu=False)
+        ctx.save_for_backward(y, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        y, w = ctx.saved_tensors
+        return torch.ops.aten.threshold_backward(gy.contiguous(), y, 0).mm(w), None, None
+
+
+def _linear_relu(x, w, b):
+    """relu(x @ w.T + b) over the last dimension; bit-identical to F.relu(F.linear(...)), measured 1.4-1.8x faster on
+    the SA-layer shapes because the activation is not re-read and re-written by a separate elementwise pass."""
+    shp = x.shape
+    y = _LinearReLUFn.apply(x.reshape(-1, shp[-1]), w, b)
+    return y.view(*shp[:-1], w.shape[0])
+
 def pc_normalize(pc):
     """model/pointnet2_utils.py:11-17."""
     centroid = np.mean(pc, axis=0)
@@ -143,7 +167,7 @@ class PointNetSetAbstraction(_FrozenFusedMixin, nn.Module):
         else:
             new_xyz, new_points, _, _ = _sample_and_group_i32(self.npoint, self.radius, self.nsample, xyz_t, pts)
         for w, b in self.folded():                 # channels-last 1x1 convs: one GEMM each, no permutes
-            new_points = F.relu(F.linear(new_points, w, b))
+            new_points = _linear_relu(new_points, w, b)
         new_points = torch.max(new_points, 2)[0]   # [B,S,D']
         return new_xyz.permute(0, 2, 1), new_points.permute(0, 2, 1)
 
@@ -198,7 +222,7 @@ class PointNetSetAbstractionMsg(_FrozenFusedMixin, nn.Module):
             idx = ops.ball_query(radius, self.nsample_list[i], xyz_t, new_xyz)
             g = ops.group_gather(xyz_t, pts, idx, centers=new_xyz.detach(), center_idx=fps_idx)
             for w, b in self.folded()[i]:
-                g = F.relu(F.linear(g, w, b))
+                g = _linear_relu(g, w, b)
             outs.append(torch.max(g, 2)[0])
         return new_xyz.permute(0, 2, 1), torch.cat(outs, dim=-1).permute(0, 2, 1)
 
@@ -239,5 +263,5 @@ class PointNetFeaturePropagation(_FrozenFusedMixin, nn.Module):
             interpolated = torch.sum(ops.group_gather(None, p2, idx) * weight.view(B, N, 3, 1), dim=2)
         new_points = interpolated if points1 is None else torch.cat([_cl(points1), interpolated], dim=-1)
         for w, b in self.folded():
-            new_points = F.relu(F.linear(new_points, w, b))
+            new_points = _linear_relu(new_points, w, b)
         return new_points.permute(0, 2, 1)
