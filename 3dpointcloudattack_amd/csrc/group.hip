@@ -200,7 +200,75 @@ __global__ __launch_bounds__(256) void group_gather_bwd_kernel(GatherBwdArgs a) 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Backward of  out[g,c] = max_r relu(x[g,r,:] . W[c,:] + b[c])  (the last 1x1 conv + ReLU + max over the group of a
+// PointNet++ set-abstraction layer, model/pointnet2_utils.py:190-197) to x. `max` hands each channel's gradient to ONE
+// row of its group, so dL/dx[g,r,:] = sum_{c: arg[g,c]==r, out[g,c]>0} gout[g,c] W[c,:] is a sparse row accumulation
+// (C3 rows of W per group) instead of the dense [ns x C3] x [C3 x C2] product autograd runs on a tensor that is zero
+// except for one entry per (group, channel). Workgroup = (group, block of 128 input channels); thread (k, half) owns
+// column k of the rows of its parity and walks the channels in ascending order => deterministic, no atomics.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int GMB_T = 256;
+constexpr int GMB_KB = 128;      // input-channel block
+constexpr int GMB_MAXNS = 128;   // rows per group (LDS: 128 x 129 floats)
+
+struct GroupMaxBwdArgs {
+  const float* gout;    // [G,C3]
+  const float* out;     // [G,C3] forward result (post-ReLU max): gradient flows where it is > 0
+  const int64_t* arg;   // [G,C3] winning row inside the group (torch.max indices)
+  const float* W;       // [C3,C2]
+  int ns, C2, C3;
+  float* gx;            // [G,ns,C2]
+};
+
+__global__ __launch_bounds__(GMB_T) void group_max_linear_bwd_kernel(GroupMaxBwdArgs a) {
+  extern __shared__ float gmb_lds[];
+  float* acc = gmb_lds;                                      // [ns][GMB_KB + 1]
+  float* s_g = acc + a.ns * (GMB_KB + 1);                    // [C3] masked upstream gradient
+  int* s_r = reinterpret_cast<int*>(s_g + a.C3);             // [C3] winning row
+  const int g = blockIdx.x, kb = blockIdx.y * GMB_KB;
+  const int tid = threadIdx.x, k = tid & (GMB_KB - 1), half = tid >> 7;
+  for (int i = tid; i < a.ns * (GMB_KB + 1); i += GMB_T) acc[i] = 0.f;
+  for (int c = tid; c < a.C3; c += GMB_T) {
+    const int64_t e = (int64_t)g * a.C3 + c;
+    s_g[c] = (a.out[e] > 0.f) ? a.gout[e] : 0.f;
+    s_r[c] = (int)a.arg[e];
+  }
+  __syncthreads();
+  if (kb + k < a.C2) {
+    const float* wcol = a.W + kb + k;
+    int c = 0;
+    for (; c + 4 <= a.C3; c += 4) {                          // 4 independent weight loads in flight
+      float w[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w[e] = wcol[(int64_t)(c + e) * a.C2];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = s_r[c + e];
+        if ((r & 1) == half) {
+          float* d = acc + r * (GMB_KB + 1) + k;
+          *d = __builtin_fmaf(s_g[c + e], w[e], *d);
+        }
+      }
+    }
+    for (; c < a.C3; ++c) {
+      const int r = s_r[c];
+      if ((r & 1) == half) {
+        float* d = acc + r * (GMB_KB + 1) + k;
+        *d = __builtin_fmaf(s_g[c], wcol[(int64_t)c * a.C2], *d);
+      }
+    }
+  }
+  __syncthreads();
+  const int kw = (a.C2 - kb) < GMB_KB ? (a.C2 - kb) : GMB_KB;
+  for (int i = tid; i < a.ns * kw; i += GMB_T) {
+    const int r = i / kw, kk = i - r * kw;
+    a.gx[((int64_t)g * a.ns + r) * a.C2 + kb + kk] = acc[r * (GMB_KB + 1) + kk];
+  }
+}
+
 }  // namespace pc3d
+
 
 using namespace pc3d;
 
@@ -271,5 +339,18 @@ extern "C" int pc3d_group_gather_bwd_f32(const float* g_out, const int32_t* idx,
   GatherBwdArgs a{g_out, idx, center_idx, N, S, ns, D, (has_xyz ? 3 : 0) + D, has_xyz, grad_xyz, grad_feat};
   hipLaunchKernelGGL(group_gather_bwd_kernel, dim3(cdiv(S * ns, 4), B), dim3(256), 0, st, a);
   PC3D_LAUNCH_CHECK("pc3d_group_gather_bwd_f32");
+  return PC3D_OK;
+}
+
+extern "C" int pc3d_group_max_linear_bwd_f32(const float* gout, const float* out, const int64_t* arg, const float* W,
+                                             int G, int ns, int C2, int C3, float* gx, void* stream) {
+  PC3D_REQUIRE(G >= 0 && ns >= 1 && ns <= GMB_MAXNS && C2 >= 1 && C3 >= 1 && C3 <= 4096,
+               "pc3d_group_max_linear_bwd_f32: bad sizes G=%d ns=%d C2=%d C3=%d (ns <= 128, C3 <= 4096)", G, ns, C2, C3);
+  if (G == 0) return PC3D_OK;
+  PC3D_REQUIRE(gout && out && arg && W && gx, "pc3d_group_max_linear_bwd_f32: null pointer");
+  GroupMaxBwdArgs a{gout, out, arg, W, ns, C2, C3, gx};
+  const size_t lds = ((size_t)ns * (GMB_KB + 1) + 2 * (size_t)C3) * sizeof(float);
+  hipLaunchKernelGGL(group_max_linear_bwd_kernel, dim3(G, cdiv(C2, GMB_KB)), dim3(GMB_T), lds, as_stream(stream), a);
+  PC3D_LAUNCH_CHECK("pc3d_group_max_linear_bwd_f32");
   return PC3D_OK;
 }

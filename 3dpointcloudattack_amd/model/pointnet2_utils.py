@@ -34,6 +34,17 @@ class _LinearReLUFn(torch.autograd.Function):
         return torch.ops.aten.threshold_backward(gy.contiguous(), y, 0).mm(w), None, None
 
 
+def _mlp_max(x, layers):
+    """[B,S,ns,C0] -> [B,S,C_last]: the shared MLP of a set-abstraction layer and the max over the group; the last
+    layer + max use the sparse-backward operator when the group fits it."""
+    for w, b in layers[:-1]:
+        x = _linear_relu(x, w, b)
+    w, b = layers[-1]
+    if x.shape[2] <= ops.GROUP_MAX_NS and x.is_cuda:
+        return ops.linear_relu_max(x, w, b)
+    return torch.max(_linear_relu(x, w, b), 2)[0]
+
+
 def _linear_relu(x, w, b):
     """relu(x @ w.T + b) over the last dimension; bit-identical to F.relu(F.linear(...)), measured 1.4-1.8x faster on
     the SA-layer shapes because the activation is not re-read and re-written by a separate elementwise pass."""
@@ -166,9 +177,7 @@ class PointNetSetAbstraction(_FrozenFusedMixin, nn.Module):
             new_xyz, new_points = sample_and_group_all(xyz_t, pts)
         else:
             new_xyz, new_points, _, _ = _sample_and_group_i32(self.npoint, self.radius, self.nsample, xyz_t, pts)
-        for w, b in self.folded():                 # channels-last 1x1 convs: one GEMM each, no permutes
-            new_points = _linear_relu(new_points, w, b)
-        new_points = torch.max(new_points, 2)[0]   # [B,S,D']
+        new_points = _mlp_max(new_points, self.folded())   # [B,S,D'] channels-last 1x1 convs: one GEMM each, no permutes
         return new_xyz.permute(0, 2, 1), new_points.permute(0, 2, 1)
 
 
@@ -221,9 +230,7 @@ class PointNetSetAbstractionMsg(_FrozenFusedMixin, nn.Module):
         for i, radius in enumerate(self.radius_list):
             idx = ops.ball_query(radius, self.nsample_list[i], xyz_t, new_xyz)
             g = ops.group_gather(xyz_t, pts, idx, centers=new_xyz.detach(), center_idx=fps_idx)
-            for w, b in self.folded()[i]:
-                g = _linear_relu(g, w, b)
-            outs.append(torch.max(g, 2)[0])
+            outs.append(_mlp_max(g, self.folded()[i]))
         return new_xyz.permute(0, 2, 1), torch.cat(outs, dim=-1).permute(0, 2, 1)
 
 

@@ -651,3 +651,43 @@ def graph_laplacian(xyz, k=30, cf=True):
     with torch.cuda.device(xyz.device):
         _lib.call("pc3d_graph_laplacian_f32", p, bs, ps, cs, idx.data_ptr(), B, N, idx.shape[2], L.data_ptr(), _stream())
     return L
+
+
+# ------------------------------------------------------------------------------------------------------
+# Last 1x1 conv + ReLU + max over the group of a set-abstraction layer, with the sparse backward
+# ------------------------------------------------------------------------------------------------------
+GROUP_MAX_NS = 128
+
+
+class _LinearReLUMaxFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        # x [G,ns,C2] -> out [G,C3]; GEMM with bias+ReLU epilogue, then torch's max (values + winning row)
+        G, ns, C2 = x.shape
+        y = torch._addmm_activation(b, x.reshape(G * ns, C2), w.t(), use_gelu=False).view(G, ns, -1)
+        out, arg = y.max(dim=1)
+        ctx.save_for_backward(out, arg, w)
+        ctx.shape = (G, ns, C2)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        out, arg, w = ctx.saved_tensors
+        G, ns, C2 = ctx.shape
+        g = g.contiguous()
+        gx = torch.empty((G, ns, C2), dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            _lib.call("pc3d_group_max_linear_bwd_f32", g.data_ptr(), out.data_ptr(), arg.data_ptr(), w.data_ptr(),
+                      G, ns, C2, w.shape[0], gx.data_ptr(), _stream())
+        return gx, None, None
+
+
+def linear_relu_max(x, w, b):
+    """max over dim -2 of relu(x @ w.T + b) for x [..., ns, C2] with frozen (w [C3,C2], b): [..., C3]. The backward
+    routes each channel's gradient to its winning row only (pc3d_group_max_linear_bwd_f32)."""
+    _check(x, "x"), _check(w, "w"), _check(b, "b")
+    lead, ns, C2 = x.shape[:-2], x.shape[-2], x.shape[-1]
+    if ns > GROUP_MAX_NS:
+        raise ValueError(f"linear_relu_max: group size {ns} exceeds {GROUP_MAX_NS}")
+    out = _LinearReLUMaxFn.apply(x.reshape(-1, ns, C2).contiguous(), w.contiguous(), b.contiguous())
+    return out.view(*lead, w.shape[0])

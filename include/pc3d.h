@@ -247,6 +247,13 @@ int pc3d_group_gather_f32(const float* xyz, int64_t x_bs, int64_t x_ps, int64_t 
 int pc3d_group_gather_bwd_f32(const float* g_out, const int32_t* idx, const int32_t* center_idx, int B, int N, int S,
                               int ns, int D, int has_xyz, float* grad_xyz, float* grad_feat, void* stream);
 
+/* Backward to x of out[g,c] = max_r relu(x[g,r,:] . W[c,:] + b[c]) — the last 1x1 conv + ReLU + max over the group of
+ * a set-abstraction layer (model/pointnet2_utils.py:190-197, :243-257). gout/out [G,C3], arg [G,C3] int64 = winning row
+ * inside the group (torch.max indices), W [C3,C2]; gx [G,ns,C2] overwritten. Sparse row accumulation in ascending
+ * channel order (deterministic) instead of autograd's dense product on a one-nonzero-per-channel tensor. ns <= 128. */
+int pc3d_group_max_linear_bwd_f32(const float* gout, const float* out, const int64_t* arg, const float* W,
+                                  int G, int ns, int C2, int C3, float* gx, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * K3  DGCNN dynamic graph (model/dgcnn.py:194-227,299-313).
  * pc3d_knn_feat_f32: idx[b,i,:] = the K nearest points of i in C-dimensional feature space (self included, nearest

@@ -153,3 +153,26 @@ def test_classifier_logits_and_input_grad_vs_reference(dev, fx, name):
     close = np.isclose(got, go, rtol=5e-3, atol=2e-5 * np.abs(go).max())
     assert close.mean() > 0.97       # max-pool arg-max near-ties move single contributions (9 max-pools in MSG)
     assert np.linalg.norm(got - go) / np.linalg.norm(go) < 1e-2
+
+
+@pytest.mark.parametrize("G,ns,C2,C3", [(7, 32, 64, 128), (3, 128, 512, 1024), (5, 16, 33, 40), (2, 1, 8, 8)])
+def test_linear_relu_max_fwd_bwd_vs_autograd(dev, G, ns, C2, C3):
+    """ops.linear_relu_max (GEMM epilogue + sparse backward through the max) vs relu(linear).max with autograd."""
+    ops = importlib.import_module("3dpointcloudattack_amd.ops")
+    g = torch.Generator().manual_seed(G * ns + C3)
+    x = torch.randn(G, ns, C2, generator=g).to(dev).requires_grad_()
+    w = (torch.randn(C3, C2, generator=g) / C2 ** 0.5).to(dev)
+    b = torch.randn(C3, generator=g).to(dev)
+    up = torch.randn(G, C3, generator=g).to(dev)
+    out = ops.linear_relu_max(x, w, b)
+    (out * up).sum().backward()
+    g1 = x.grad.clone()
+    x.grad = None
+    ref = torch.relu(torch.nn.functional.linear(x, w, b)).max(dim=1)[0]
+    (ref * up).sum().backward()
+    torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(g1, x.grad, rtol=1e-4, atol=1e-6)
+    # deterministic: same bits on a second call
+    x.grad = None
+    (ops.linear_relu_max(x, w, b) * up).sum().backward()
+    assert torch.equal(x.grad, g1)
