@@ -198,18 +198,9 @@ def geoA3_attack(net, pt_model, ptm_model, pts_model, dgcnn_model, cur_model, pc
             else:
                 input_curr_iter = input_all
 
-            with torch.no_grad():
-                if input_curr_iter.size(2) < input_all.size(2):
-                    votes = torch.zeros(b, device=dev)
-                    for _ in range(cfg.eval_num):
-                        lab = torch.max(_logits_of(net(farthest_points_sample(input_all, cfg.npoint))), 1)[1]
-                        votes += _compare(lab, target, gt_target, targeted).float()
-                        output_label = lab
-                    attack_success = votes > 0.5 * cfg.eval_num
-                else:
-                    output_label = torch.argmax(_logits_of(net(input_curr_iter)), dim=1)
-                    attack_success = _compare(output_label, target, gt_target, targeted)
-                metric = constrain_loss.detach()
+            def record(output_label, attack_success, metric):
+                """:321-330, vectorised over the batch (device-side selects, no host round trip)."""
+                nonlocal best_loss, best_attack, best_attack_BS_idx, best_attack_step, iter_best_loss, iter_best_score
                 upd = attack_success & (metric < best_loss)
                 best_loss = torch.where(upd, metric, best_loss)
                 best_attack = torch.where(upd[:, None, None], input_all.detach(), best_attack)
@@ -219,6 +210,26 @@ def geoA3_attack(net, pt_model, ptm_model, pts_model, dgcnn_model, cur_model, pc
                 iter_best_loss = torch.where(upd_i, metric, iter_best_loss)
                 iter_best_score = torch.where(upd_i, output_label, iter_best_score)
 
+            # The reference evaluates the iterate with one forward (:307-319) and then runs the SAME input through the
+            # victim again inside _forward_step (:335). For a victim whose forward is a pure function of its input
+            # (`deterministic_forward`; PointNet++ is not: it draws FPS start points) the second forward's logits
+            # serve both, which saves one of the two victim forwards per iteration.
+            share_forward = (getattr(net, "deterministic_forward", False) and not cfg.is_pre_jitter_input
+                             and input_curr_iter.size(2) == input_all.size(2))
+            if not share_forward:
+                with torch.no_grad():
+                    if input_curr_iter.size(2) < input_all.size(2):
+                        votes = torch.zeros(b, device=dev)
+                        for _ in range(cfg.eval_num):
+                            lab = torch.max(_logits_of(net(farthest_points_sample(input_all, cfg.npoint))), 1)[1]
+                            votes += _compare(lab, target, gt_target, targeted).float()
+                            output_label = lab
+                        attack_success = votes > 0.5 * cfg.eval_num
+                    else:
+                        output_label = torch.argmax(_logits_of(net(input_curr_iter)), dim=1)
+                        attack_success = _compare(output_label, target, gt_target, targeted)
+                    record(output_label, attack_success, constrain_loss.detach())
+
             if cfg.is_pre_jitter_input:
                 if step % cfg.calculate_project_jitter_noise_iter == 0:
                     project_jitter_noise = estimate_perpendicular(input_curr_iter, cfg.jitter_k, sigma=cfg.jitter_sigma,
@@ -227,8 +238,13 @@ def geoA3_attack(net, pt_model, ptm_model, pts_model, dgcnn_model, cur_model, pc
                     project_jitter_noise = project_jitter_noise.clone()
                 input_curr_iter.data = input_curr_iter.data + project_jitter_noise
 
-            _, normal_curr_iter, loss, loss_n, cls_loss, dis_loss, hd_loss, nor_loss, constrain_loss, info = \
+            prev_constrain = constrain_loss
+            logits_curr, normal_curr_iter, loss, loss_n, cls_loss, dis_loss, hd_loss, nor_loss, constrain_loss, info = \
                 _forward_step(net, pc_ori, input_curr_iter, normal_ori, kappa_ori, target, scale_const, cfg, targeted)
+            if share_forward:
+                with torch.no_grad():   # input_all still holds this iteration's iterate: the optimiser steps below
+                    output_label = torch.argmax(logits_curr.detach(), dim=1)
+                    record(output_label, _compare(output_label, target, gt_target, targeted), prev_constrain.detach())
             loss_curves.append(loss_n.detach())
 
             optimizer.zero_grad()

@@ -14,6 +14,8 @@ curve_config = {
 
 
 class CurveNet(_FrozenFusedMixin, nn.Module):
+    deterministic_forward = True   # forward is a pure function of its input (no RNG): attack loops may share it
+
     def __init__(self, num_classes=40, k=20, setting='default'):
         super(CurveNet, self).__init__()
         assert setting in curve_config

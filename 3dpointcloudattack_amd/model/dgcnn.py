@@ -48,6 +48,7 @@ def _fold_edge(conv, bn):
 
 class DGCNN(_FrozenFusedMixin, nn.Module):
     """model/dgcnn.py:262-328. ``args`` needs ``k``, ``emb_dims``, ``dropout``."""
+    deterministic_forward = True   # forward is a pure function of its input (no RNG): attack loops may share it
 
     def __init__(self, args, output_channels=105 + 1):
         super(DGCNN, self).__init__()

@@ -137,6 +137,7 @@ class PointNetfeat(_FrozenFusedMixin, nn.Module):
 
 class PointNetCls(_FrozenFusedMixin, nn.Module):
     """model/pointnet.py:130-148 — returns (log_softmax logits [B,k], trans [B,3,3], trans_feat None)."""
+    deterministic_forward = True   # forward is a pure function of its input (no RNG): attack loops may share it
 
     def __init__(self, k=2, feature_transform=False):
         super(PointNetCls, self).__init__()
