@@ -208,20 +208,23 @@ def main():
                     "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS,
                     "traffic": traffic, "launch_us": k_ms * 1e3, "launches_per_step": 2}
         # ---- the Chamfer kernel at N=4096 (north_star's second figure): VALU-bound, HBM share reported too
-        Nc = 4096
-        a = torch.randn(B, Nc, 3, device=dev)
-        b = a + 0.01 * torch.randn_like(a)
-        for _ in range(3):
-            ops.nn_bidir_raw(a, b)
-        c_ms = ev_ms(lambda: ops.nn_bidir_raw(a, b), 20, stream)
-        alg_bytes = B * (2 * Nc * 12 + 2 * Nc * 8)          # 40*N bytes per cloud pair
-        alg_ops = 10.0 * B * Nc * Nc                         # 8 (shared distance) + 2 (running mins) per pair
-        issued_ops = 2.0 * B * Nc * Nc * 6.875               # what the kernel issues: 6 + 0.5 + 3/8 per pair and direction
-        chamfer = {"kernel": "nn_kernel", "config": f"B={B} N=M={Nc} bidirectional", "launch_us": c_ms * 1e3,
-                   "hbm_alg_GBps": alg_bytes / (c_ms * 1e-3) / 1e9,
-                   "hbm_frac": alg_bytes / (c_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                   "valu_frac": alg_ops / (c_ms * 1e-3) / VALU_LANE_OPS_PEAK,
-                   "valu_issue_frac": issued_ops / (c_ms * 1e-3) / VALU_LANE_OPS_PEAK, "bound": "valu"}
+        def chamfer_point(Nc):
+            a = torch.randn(B, Nc, 3, device=dev)
+            b = a + 0.01 * torch.randn_like(a)
+            for _ in range(3):
+                ops.nn_bidir_raw(a, b)
+            c_ms = ev_ms(lambda: ops.nn_bidir_raw(a, b), 20, stream)
+            alg_bytes = B * (2 * Nc * 12 + 2 * Nc * 8)          # 40*N bytes per cloud pair
+            alg_ops = 10.0 * B * Nc * Nc                         # 8 (shared distance) + 2 (running mins) per pair
+            issued_ops = 2.0 * B * Nc * Nc * 6.875               # what the kernel issues: 6 + 0.5 + 3/8 per pair and direction
+            return {"kernel": "nn_kernel", "config": f"B={B} N=M={Nc} bidirectional", "launch_us": c_ms * 1e3,
+                    "hbm_alg_GBps": alg_bytes / (c_ms * 1e-3) / 1e9,
+                    "hbm_frac": alg_bytes / (c_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "valu_frac": alg_ops / (c_ms * 1e-3) / VALU_LANE_OPS_PEAK,
+                    "valu_issue_frac": issued_ops / (c_ms * 1e-3) / VALU_LANE_OPS_PEAK, "bound": "valu"}
+        chamfer = chamfer_point(4096)
+        chamfer["other_sizes"] = {f"N{n}": {k: v for k, v in chamfer_point(n).items() if k in ("launch_us", "hbm_alg_GBps", "valu_frac", "valu_issue_frac")}
+                                  for n in (1024, 2048)}
         out = {
             "metric": "attack iters/s (B=32, N=1024, PointNet) + Chamfer HBM GB/s vs peak",
             "value": iters_per_s, "unit": "iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
