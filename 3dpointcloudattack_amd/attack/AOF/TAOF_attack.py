@@ -41,7 +41,7 @@ class CWTAOF:
     """Class for CW attack."""
 
     def __init__(self, model, adv_func, dist_func, attack_lr=1e-2, binary_step=2, num_iter=200, GAMMA=0.5,
-                 low_pass=100, clip_func=None, device=None, verbose=False, fused=True):
+                 low_pass=100, clip_func=None, device=None, verbose=False, fused=True, graph=True):
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.model = model.to(self.device)
         self.model.eval()
@@ -55,6 +55,7 @@ class CWTAOF:
         self.clip_func = clip_func
         self.verbose = verbose
         self.fused = fused
+        self.graph = graph          # capture the fused iteration into a hipGraph (own functors only)
 
     def _fused_kind(self):
         if not self.fused or not hasattr(self.model, "fused_loss_and_grad"):
@@ -90,7 +91,9 @@ class CWTAOF:
         fk = self._fused_kind()
         lp = self.low_pass
         adv_data = ori_data
-        for binary_step in range(self.binary_step):
+        if fk is not None:
+            o_bestdist, o_bestscore, o_bestattack, adv_data = self._attack_fused(ori_data, target, y_truth, fk, lp)
+        for binary_step in range(self.binary_step if fk is None else 0):
             adv_data = ori_data.clone().detach() + torch.randn((B, 3, K)).to(dev) * 1e-7
             Evs, V = get_Laplace_from_pc(adv_data)
             V_lo, V_hi = V[..., :lp].contiguous(), V[..., lp:].contiguous()
@@ -98,27 +101,16 @@ class CWTAOF:
             hfc = torch.bmm(projs[..., lp:], V_hi.transpose(2, 1)).detach().clone()
             lfc = torch.bmm(projs[..., :lp], V_lo.transpose(2, 1)).detach().clone()
             lfc.requires_grad_()
-            if fk is None:
-                opt = optim.Adam([lfc], lr=self.attack_lr, weight_decay=0.)
-            else:
-                exp_avg, exp_avg_sq = torch.zeros_like(lfc), torch.zeros_like(lfc)
+            opt = optim.Adam([lfc], lr=self.attack_lr, weight_decay=0.)
 
             for iteration in range(self.num_iter):
-                if fk is None:
-                    adv_data = lfc + hfc
-                    adv_loss = (1 - self.GAMMA) * self.adv_func(_logits_of(self.model(adv_data)), target).mean()
-                    opt.zero_grad()
-                    adv_loss.backward()
-                    lfc_adv_loss = self.GAMMA * self.adv_func(_logits_of(self.model(lfc)), target).mean()
-                    lfc_adv_loss.backward()
-                    opt.step()
-                else:
-                    with torch.no_grad():
-                        l0 = lfc.detach()
-                        g1 = self.model.fused_loss_and_grad(l0 + hfc, target, *fk)[3]
-                        g2 = self.model.fused_loss_and_grad(l0, target, *fk)[3]
-                        g = (1 - self.GAMMA) * g1 + self.GAMMA * g2
-                        ops.adam_clip_step(lfc.data, g, exp_avg, exp_avg_sq, iteration + 1, self.attack_lr)
+                adv_data = lfc + hfc
+                adv_loss = (1 - self.GAMMA) * self.adv_func(_logits_of(self.model(adv_data)), target).mean()
+                opt.zero_grad()
+                adv_loss.backward()
+                lfc_adv_loss = self.GAMMA * self.adv_func(_logits_of(self.model(lfc)), target).mean()
+                lfc_adv_loss.backward()
+                opt.step()
 
                 with torch.no_grad():
                     adv_data = lfc.detach() + hfc
@@ -127,13 +119,8 @@ class CWTAOF:
                     coeff = torch.bmm(adv_data, V)
                     hfc = torch.bmm(coeff[..., lp:], V_hi.transpose(2, 1))
                     lfc.data = torch.bmm(coeff[..., :lp], V_lo.transpose(2, 1))
-                    if fk is None:
-                        pred = torch.argmax(_logits_of(self.model(adv_data)), dim=1)
-                        lfc_pred = torch.argmax(_logits_of(self.model(lfc)), dim=1)
-                    else:
-                        ffw = importlib_fused_forward()
-                        pred = torch.argmax(ffw(self.model, adv_data)[0], dim=1)
-                        lfc_pred = torch.argmax(ffw(self.model, lfc.detach().contiguous())[0], dim=1)
+                    pred = torch.argmax(_logits_of(self.model(adv_data)), dim=1)
+                    lfc_pred = torch.argmax(_logits_of(self.model(lfc)), dim=1)
                     dist_val = torch.sqrt(torch.sum((adv_data - ori_data) ** 2, dim=[1, 2]))
                     upd = (dist_val < o_bestdist) & (pred == target) & (lfc_pred != y_truth)
                     o_bestdist = torch.where(upd, dist_val, o_bestdist)
@@ -149,6 +136,84 @@ class CWTAOF:
         if self.verbose:
             print('Successfully attack {}/{}'.format(success_num, B))
         return (o_bestdist.double().cpu().numpy(), o_bestattack.detach().cpu().numpy().transpose((0, 2, 1)), success_num)
+
+
+    # ---- launch-minimal path (PointNet victim + this package's adversarial functor): no autograd, every buffer
+    # updated IN PLACE so the iteration can be captured once into a hipGraph and replayed (:105-210) -------------------
+    def _capturable(self):
+        from ..CW.CW_utils import clip_utils as _clip_utils
+        return self.graph and (self.clip_func is None or type(self.clip_func) in (
+            _clip_utils.ClipPointsLinf, _clip_utils.ClipPointsL2, _clip_utils.ProjectInnerPoints, _clip_utils.ProjectInnerClipLinf))
+
+    def _attack_fused(self, ori_data, target, y_truth, fk, lp):
+        dev = self.device
+        B, _, K = ori_data.shape
+        ffw = importlib_fused_forward()
+        st = dict(
+            V=torch.empty((B, K, K), device=dev), V_lo_t=torch.empty((B, lp, K), device=dev),
+            V_hi_t=torch.empty((B, K - lp, K), device=dev), lfc=torch.empty((B, 3, K), device=dev),
+            hfc=torch.empty((B, 3, K), device=dev), adv=torch.empty((B, 3, K), device=dev),
+            m=torch.zeros((B, 3, K), device=dev), v=torch.zeros((B, 3, K), device=dev),
+            step=torch.zeros((1,), dtype=torch.int32, device=dev),
+            o_bestdist=torch.full((B,), 1e10, dtype=torch.float32, device=dev),
+            o_bestscore=torch.full((B,), -1, dtype=torch.long, device=dev),
+            o_bestattack=torch.zeros((B, 3, K), dtype=torch.float32, device=dev))
+
+        def begin_step(adv0):
+            _, V = get_Laplace_from_pc(adv0)
+            st["V"].copy_(V)
+            st["V_lo_t"].copy_(V[..., :lp].transpose(2, 1))
+            st["V_hi_t"].copy_(V[..., lp:].transpose(2, 1))
+            projs = torch.bmm(adv0, V)
+            st["hfc"].copy_(torch.bmm(projs[..., lp:], st["V_hi_t"]))
+            st["lfc"].copy_(torch.bmm(projs[..., :lp], st["V_lo_t"]))
+            st["m"].zero_(), st["v"].zero_(), st["step"].zero_()
+
+        def iterate():
+            with torch.no_grad():
+                lfc, hfc = st["lfc"], st["hfc"]
+                ops.i32_add(st["step"], 1)
+                g1 = self.model.fused_loss_and_grad(lfc + hfc, target, *fk)[3]
+                g2 = self.model.fused_loss_and_grad(lfc, target, *fk)[3]
+                g = (1 - self.GAMMA) * g1 + self.GAMMA * g2
+                ops.adam_clip_step(lfc, g, st["m"], st["v"], st["step"], self.attack_lr)
+                adv = lfc + hfc
+                if self.clip_func is not None:
+                    adv = self.clip_func(adv, ori_data)
+                coeff = torch.bmm(adv, st["V"])
+                hfc.copy_(torch.bmm(coeff[..., lp:], st["V_hi_t"]))
+                lfc.copy_(torch.bmm(coeff[..., :lp], st["V_lo_t"]))
+                pred = torch.argmax(ffw(self.model, adv)[0], dim=1)
+                lfc_pred = torch.argmax(ffw(self.model, lfc)[0], dim=1)
+                dist_val = torch.sqrt(torch.sum((adv - ori_data) ** 2, dim=[1, 2]))
+                upd = (dist_val < st["o_bestdist"]) & (pred == target) & (lfc_pred != y_truth)
+                st["o_bestdist"].copy_(torch.where(upd, dist_val, st["o_bestdist"]))
+                st["o_bestscore"].copy_(torch.where(upd, pred, st["o_bestscore"]))
+                st["o_bestattack"].copy_(torch.where(upd[:, None, None], adv, st["o_bestattack"]))
+                st["adv"].copy_(adv)
+
+        run = iterate
+        for binary_step in range(self.binary_step):
+            adv0 = ori_data.clone().detach() + torch.randn((B, 3, K)).to(dev) * 1e-7
+            begin_step(adv0)
+            if binary_step == 0 and self._capturable() and self.num_iter > 0:
+                # capture once (after eager warm-up passes on a side stream, as torch requires), then rewind the state
+                side = torch.cuda.Stream(device=dev)
+                side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side):
+                    for _ in range(2):
+                        iterate()
+                torch.cuda.current_stream(dev).wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    iterate()
+                run = g.replay
+                st["o_bestdist"].fill_(1e10), st["o_bestscore"].fill_(-1), st["o_bestattack"].zero_()
+                begin_step(adv0)
+            for _ in range(self.num_iter):
+                run()
+        adv_last = st["adv"] if self.num_iter > 0 else ori_data
+        return st["o_bestdist"], st["o_bestscore"], st["o_bestattack"], adv_last
 
 
 def importlib_fused_forward():

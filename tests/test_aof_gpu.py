@@ -73,3 +73,22 @@ def test_taof_batched(dev):
     torch.manual_seed(2)
     bd, out, sn = atk.attack(pcs, tgt, y)
     assert out.shape == (3, 128, 3) and np.isfinite(out).all() and 0 <= sn <= 3
+
+
+def test_taof_graph_replay_equals_eager(dev):
+    """The hipGraph-captured TAOF iteration reproduces the eager fused path bit for bit (same launches, same order)."""
+    ta, adv, dist, clip = _mods()
+    net, _ = hip_pointnet(0, dev)
+    rng = np.random.default_rng(15)
+    pcs = torch.from_numpy(np.stack([unit_cloud(rng, 160) for _ in range(3)]))
+    with torch.no_grad():
+        lp = net(pcs.transpose(1, 2).contiguous().to(dev))[0]
+    y, tgt = lp.argmax(1).cpu(), lp.topk(2)[1][:, 1].cpu()
+    outs = []
+    for graph in (False, True):
+        atk = ta.CWTAOF(net, adv.LogitsAdvLoss(0.), dist.L2Dist(), binary_step=2, num_iter=8, low_pass=30,
+                        clip_func=clip.ClipPointsLinf(0.18), graph=graph)
+        assert atk._capturable() == graph
+        torch.manual_seed(4)
+        outs.append(atk.attack(pcs, tgt, y))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]) and outs[0][2] == outs[1][2]
