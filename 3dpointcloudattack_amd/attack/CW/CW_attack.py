@@ -35,6 +35,27 @@ def _logits_of(out):
     return out[0] if isinstance(out, tuple) else out
 
 
+class _GraphRunner:
+    """Replays captured iterations; batches calls into the unrolled graph. The captured launches hold raw pointers
+    into the state dict's tensors, so the runner keeps that dict alive for as long as it lives."""
+
+    def __init__(self, st, g1, gu, unroll):
+        self._keep, self.g1, self.gu, self.unroll, self.pending = st, g1, gu, unroll, 0
+
+    def __call__(self, i=None):
+        self.pending += 1
+        if self.gu is not None and self.pending == self.unroll:
+            self.gu.replay()
+            self.pending = 0
+        elif self.gu is None:
+            self.flush()
+
+    def flush(self):
+        while self.pending:
+            self.g1.replay()
+            self.pending -= 1
+
+
 class CW:
     """Class for CW attack."""
 
@@ -251,13 +272,16 @@ class CW:
             ops.adam_clip_step(adv_data.data, adv_data.grad, st["exp_avg"], st["exp_avg_sq"], st["step"],
                                self.attack_lr, ori=ori_data, budget=st["budget"])
 
-    def _make_runner(self, st, warmup=3):
-        """Capture one iteration into a hipGraph (after `warmup` eager passes on a side stream, as torch requires)
-        and return a callable that replays it. Only the fused path (recognised clip functor) is captured; the
-        generic path with arbitrary user callables returns an eager runner. Replays are bit-identical to eager
-        passes: same kernels, same order, same buffers."""
+    def _make_runner(self, st, warmup=3, unroll=4):
+        """Capture the iteration into hipGraphs (after `warmup` eager passes on a side stream, as torch requires) and
+        return a callable that replays it. Only the fused path (recognised clip functor) is captured; the generic
+        path with arbitrary user callables returns an eager runner. Replays are bit-identical to eager passes: same
+        kernels, same order, same buffers. Two graphs are kept: one iteration, and `unroll` iterations back to back —
+        the runner batches calls into the unrolled graph (one graph launch per `unroll` iterations instead of one
+        each) and `flush()` runs whatever is still pending; callers flush before they read results or stop a clock."""
         if not self._capturable():
-            return lambda i=None: self._iterate(st, i)
+            run = lambda i=None: self._iterate(st, i)    # noqa: E731
+            return run
         if st["graph"] is not None:
             return st["graph_run"]
         side = torch.cuda.Stream(device=self.device)
@@ -268,13 +292,18 @@ class CW:
         torch.cuda.current_stream(self.device).wait_stream(side)
         # warm-up passes are real iterations; account for them by NOT rolling anything back: callers start counting
         # after _make_runner (bench) or use _begin_binary_step to reset the state (attack()).
-        g = torch.cuda.CUDAGraph()
         st["adv"].grad = None
-        with torch.cuda.graph(g):
+        g1 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1):
             self._iterate(st)
-        st["graph"] = g
-        # the captured launches hold raw pointers into st's tensors: the runner keeps st alive for as long as it lives
-        st["graph_run"] = lambda i=None, _keep=st: g.replay()
+        gu = None
+        if unroll > 1:
+            gu = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gu):
+                for _ in range(unroll):
+                    self._iterate(st)
+        st["graph"] = g1
+        st["graph_run"] = _GraphRunner(st, g1, gu, unroll)
         return st["graph_run"]
 
     def _end_binary_step(self, st):
@@ -330,6 +359,8 @@ class CW:
                     run()
                 else:
                     self._iterate(st, iteration)
+            if hasattr(run, "flush"):
+                run.flush()
             self._end_binary_step(st)
 
         pred = st["pred"] if self.num_iter > 0 and self.binary_step > 0 else None

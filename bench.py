@@ -46,11 +46,17 @@ def seeded_state(model, seed):
 
 
 def ev_ms(fn, iters, stream):
-    """Average ms per call of fn() over `iters` back-to-back calls, HIP events on `stream`."""
+    """Average ms per call of fn() over `iters` back-to-back calls, HIP events on `stream`. A runner that batches
+    calls (CW's graph runner) is flushed inside the timed region, so exactly `iters` calls are measured."""
+    flush = getattr(fn, "flush", None)
+    if flush is not None:
+        flush()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(stream)
     for _ in range(iters):
         fn()
+    if flush is not None:
+        flush()
     e1.record(stream)
     e1.synchronize()
     return e0.elapsed_time(e1) / iters
@@ -166,6 +172,8 @@ def main():
     for _ in range(args.warmup):
         step(it)
         it += 1
+    if hasattr(run, "flush"):
+        run.flush()        # warm-up iterations all executed before the clock starts
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
@@ -173,6 +181,8 @@ def main():
     for _ in range(args.steps):
         step(it)
         it += 1
+    if hasattr(run, "flush"):
+        run.flush()        # EXACTLY `steps` iterations are inside the timed region
     torch.cuda.synchronize()
     if dist_on:
         dist.barrier()
@@ -255,7 +265,7 @@ def main():
                 r2 = atk._make_runner(s2)
                 for i in range(10):
                     r2(i)
-                ms = ev_ms(lambda: r2(0), 60, stream)
+                ms = ev_ms(r2, 60, stream)
                 sweep[f"cw_pointnet_{dname}_B{B}_N{npts}"] = {"iters_per_s": 1e3 / ms, "ms_per_step": ms}
             out["sweep"] = sweep
         if not args.no_cpu_baseline and world == 1:
