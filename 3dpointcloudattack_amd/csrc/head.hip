@@ -118,6 +118,72 @@ __global__ __launch_bounds__(LN_T) void linear_kernel(LinArgs a) {
   }
 }
 
+// 32 rows x 16 outputs per workgroup on v_mfma_f32_16x16x4_f32: twice the workgroups (CUs) of the 32 x 32 tiling for
+// the same layer, half the MFMA time and half the weight bytes per workgroup — these launches are latency-bound and
+// use at most O/32 of the 256 CUs. Operand mapping: lane (r = lane & 15, q = lane >> 4) holds the float4 at
+// k = 16c + 4q of row r; MFMA call e consumes element e of every lane's float4, so its four k-slices are
+// k = 16c + 4q + e — the same permutation on both operands, i.e. an exact fp32 sum in a permuted k order.
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+__global__ __launch_bounds__(LN_T) void linear16_kernel(LinArgs a) {
+  __shared__ float red[LN_W][32][17];
+  const int o0 = blockIdx.x * 16, b0 = blockIdx.y * 32;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int xb0 = (b0 + r < a.B) ? b0 + r : a.B - 1;
+  const int xb1 = (b0 + 16 + r < a.B) ? b0 + 16 + r : a.B - 1;
+  const int wo = (o0 + r < a.O) ? o0 + r : a.O - 1;
+  const float* x0 = a.X + (int64_t)xb0 * a.ldx + 4 * q;
+  const float* x1 = a.X + (int64_t)xb1 * a.ldx + 4 * q;
+  const float* wr = a.W + (int64_t)wo * a.K + 4 * q;
+  const int nchunk = a.K / 16;          // chunks of 16 k; wave w takes chunks w, w+8, ... (<= 8 per wave)
+  float4 xv0[8], xv1[8], wv[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = wave + i * LN_W;
+    if (c < nchunk) {
+      xv0[i] = *reinterpret_cast<const float4*>(x0 + 16 * c);
+      xv1[i] = *reinterpret_cast<const float4*>(x1 + 16 * c);
+      wv[i] = *reinterpret_cast<const float4*>(wr + 16 * c);
+    }
+  }
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = wave + i * LN_W;
+    if (c < nchunk) {   // D[row = sample][col = output]; two independent accumulators cover the 40-cycle MFMA latency
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv0[i].x, wv[i].x, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv1[i].x, wv[i].x, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv0[i].y, wv[i].y, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv1[i].y, wv[i].y, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv0[i].z, wv[i].z, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv1[i].z, wv[i].z, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv0[i].w, wv[i].w, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv1[i].w, wv[i].w, acc1, 0, 0, 0);
+    }
+  }
+  // 16x16x4 result layout: lane holds column r, rows 4*q + e
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    red[wave][4 * q + e][r] = acc0[e];
+    red[wave][16 + 4 * q + e][r] = acc1[e];
+  }
+  __syncthreads();
+  {
+    const int row = threadIdx.x >> 4, col = threadIdx.x & 15;   // 512 threads = 32 x 16 outputs
+    float s = red[0][row][col];
+#pragma unroll
+    for (int w = 1; w < LN_W; ++w) s += red[w][row][col];
+    const int b = b0 + row, o = o0 + col;
+    if (b < a.B && o < a.O) {
+      if (a.bias) s += a.bias[o];
+      if (a.relu) s = fmaxf(s, 0.f);
+      if (a.gate && !(a.gate[(int64_t)b * a.ldg + o] > 0.f)) s = 0.f;
+      a.Y[(int64_t)b * a.ldy + o] = s;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // log_softmax + prediction + adversarial loss and its gradient w.r.t. the LOGITS (pre-softmax), one wave per sample.
 //   kind 0: UntargetedLogitsAdvLoss  mean_b max(real - other + kappa, 0)     (adv_utils.py:64-80)
@@ -345,7 +411,10 @@ extern "C" int pc3d_linear_f32(const float* X, int ldx, int P, int B, int K, con
   PC3D_REQUIRE(X && W && Y, "pc3d_linear_f32: null pointer");
   PC3D_REQUIRE(gate == nullptr || ldg >= O, "pc3d_linear_f32: ldg=%d too small", ldg);
   LinArgs a{X, ldx, P, W, bias, gate, ldg, Y, ldy, B, K, O, relu};
-  hipLaunchKernelGGL(linear_kernel, dim3(cdiv(O, 32), cdiv(B, 32)), dim3(LN_T), 0, as_stream(stream), a);
+  if ((K & 15) == 0 && P == 1 && K / 16 <= 8 * LN_W && O >= 64)
+    hipLaunchKernelGGL(linear16_kernel, dim3(cdiv(O, 16), cdiv(B, 32)), dim3(LN_T), 0, as_stream(stream), a);
+  else
+    hipLaunchKernelGGL(linear_kernel, dim3(cdiv(O, 32), cdiv(B, 32)), dim3(LN_T), 0, as_stream(stream), a);
   PC3D_LAUNCH_CHECK("pc3d_linear_f32");
   return PC3D_OK;
 }
