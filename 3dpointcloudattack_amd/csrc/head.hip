@@ -68,18 +68,30 @@ __global__ __launch_bounds__(LN_T) void linear_kernel(LinArgs a) {
       }
     }
   } else if ((a.K & 7) == 0) {
-    for (int c = wave; c < nchunk; c += LN_W) {
-      const int k = 8 * c + 4 * h;
-      float4 xv = *reinterpret_cast<const float4*>(xrow + k);
-      for (int p = 1; p < a.P; ++p) {
-        const float4 t = *reinterpret_cast<const float4*>(xrow + (int64_t)p * a.K + k);
-        xv.x += t.x, xv.y += t.y, xv.z += t.z, xv.w += t.w;
+    // P partial slabs: sum_p (x_p . W) = (sum_p x_p) . W, so every (slab, chunk) pair is an independent work item
+    // spread over the waves (the tower backward hands over one dL/dT partial per 32-point tile: P = N / 32)
+    const int items = nchunk * a.P;
+    for (int it0 = wave; it0 < items; it0 += 4 * LN_W) {
+      float4 xv[4], wv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {          // four items' operands in flight
+        const int it = it0 + u * LN_W;
+        if (it < items) {
+          const int p = it / nchunk, c = it - p * nchunk;
+          const int k = 8 * c + 4 * h;
+          xv[u] = *reinterpret_cast<const float4*>(xrow + (int64_t)p * a.K + k);
+          wv[u] = *reinterpret_cast<const float4*>(wrow + k);
+        }
       }
-      const float4 wv = *reinterpret_cast<const float4*>(wrow + k);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv.x, wv.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv.y, wv.y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv.z, wv.z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv.w, wv.w, acc, 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (it0 + u * LN_W < items) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[u].x, wv[u].x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[u].y, wv[u].y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[u].z, wv[u].z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[u].w, wv[u].w, acc, 0, 0, 0);
+        }
+      }
     }
   } else {  // ragged K (e.g. the 9 entries of the STN transform): scalar loads with zero fill
     for (int c = wave; c * 8 < a.K; c += LN_W) {
