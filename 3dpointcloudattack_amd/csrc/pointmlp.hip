@@ -12,8 +12,9 @@
 // kernel folds the tiles. The [B,C3,N] activation is never written.
 //
 // Backward: max-pool routes each channel's gradient to ONE point, so dgrad of layer 3 is sparse:
-// workgroup = (b, tile of 64 points) gathers the channels whose argmax falls in its tile in ascending channel order
-// (deterministic, no atomics), recomputes h1/h2 masks for those 64 points and chains W2^T, W1^T on the VALU.
+// workgroup = (b, tile of 32 points) gathers the channels whose argmax falls in its tile in ascending channel order
+// (deterministic, no atomics), applies the ReLU decisions of layers 1-2 that the FORWARD launch recorded as per-point
+// bit masks (24 B per point — nothing is recomputed) and chains W2^T on MFMA and W1^T on the VALU.
 #include <stdlib.h>
 #include "pc3d_common.h"
 
@@ -36,6 +37,8 @@ struct PMFwdArgs {
   const float *W1, *b1, *W2, *b2, *W3, *b3;
   float* part_val;    // [B, ntiles, C3]
   int32_t* part_idx;  // [B, ntiles, C3]
+  uint64_t* mask1;    // [B,N]    bit c  = (layer-1 output c of the point > 0), or null
+  uint32_t* mask2;    // [B,N,4]  word j bit r = (layer-2 output 32j+r of the point > 0), or null
 };
 
 __device__ __forceinline__ void load_point(const PtsView& x, const float* T, int b, int n, int N, float& px,
@@ -56,18 +59,26 @@ __device__ __forceinline__ void load_point(const PtsView& x, const float* T, int
 }
 
 // h1[p][c] = relu(W1[c,:].x_p + b1[c]) for `npts` points whose coordinates sit in xs[3][npts]; lanes run over c.
+// m1 (may be null) receives, for point p, the 64-bit mask of its positive channels: the wave's lanes ARE the 64
+// channels, so the mask is one ballot; lane i keeps point i's mask and the wave stores `per` consecutive words.
 template <int NPTS, int NTHREADS>
-__device__ __forceinline__ void layer1_to_lds(const float* xs, float* h1, const float* W1, const float* b1) {
+__device__ __forceinline__ void layer1_to_lds(const float* xs, float* h1, const float* W1, const float* b1,
+                                              uint64_t* m1 = nullptr, int nvalid = NPTS) {
   const int c = threadIdx.x & (PM_C1 - 1);
   const int grp = threadIdx.x >> 6;
   constexpr int per = NPTS / (NTHREADS / 64);
+  static_assert(per <= 64, "one mask word per lane");
   const float w0 = W1[c * 3 + 0], w1 = W1[c * 3 + 1], w2 = W1[c * 3 + 2], bb = b1[c];
+  unsigned long long mine = 0ull;
 #pragma unroll 4
   for (int i = 0; i < per; ++i) {
     const int p = grp * per + i;
     float v = __builtin_fmaf(w2, xs[2 * NPTS + p], __builtin_fmaf(w1, xs[NPTS + p], __builtin_fmaf(w0, xs[p], bb)));
     h1[p * PM_LD1 + c] = fmaxf(v, 0.f);
+    const unsigned long long bal = __builtin_amdgcn_ballot_w64(v > 0.f);
+    if (c == i) mine = bal;
   }
+  if (m1 != nullptr && c < per && grp * per + c < nvalid) m1[grp * per + c] = mine;
 }
 
 constexpr int PM_MAXC3F = 1024;      // forward: widest layer 3 (cross-wave max scratch aliases the h2 tile)
@@ -92,7 +103,7 @@ __global__ __launch_bounds__(PM_FT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     xs[2 * PM_TP + threadIdx.x] = pz;
   }
   __syncthreads();
-  layer1_to_lds<PM_TP, PM_FT>(xs, h1, a.W1, a.b1);
+  layer1_to_lds<PM_TP, PM_FT>(xs, h1, a.W1, a.b1, a.mask1 ? a.mask1 + (int64_t)b * a.N + n0 : nullptr, a.N - n0);
   __syncthreads();
 
   // ---- layer 2 on MFMA: D[pt][c2] = sum_k h1[pt][k] W2[c2][k]; wave owns c2 block (wave&3) and 2 of the 4 point tiles
@@ -121,13 +132,24 @@ __global__ __launch_bounds__(PM_FT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     }
     __syncthreads();  // every wave is done reading h1
     const float bias = a.b2[32 * c2b + r];
+    unsigned long long mine = 0ull;   // lane 16*tl + e keeps the ballot of (tl, e): points pt(e,0) [low word], pt(e,1) [high]
 #pragma unroll
     for (int tl = 0; tl < 2; ++tl)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int pt = (tl0 + tl) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        h2[pt * PM_LD2 + 32 * c2b + r] = fmaxf(acc[tl][e] + bias, 0.f);
+        const float v = acc[tl][e] + bias;
+        h2[pt * PM_LD2 + 32 * c2b + r] = fmaxf(v, 0.f);
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(v > 0.f);
+        if (lane == 16 * tl + e) mine = bal;
       }
+    if (a.mask2 != nullptr && lane < 32) {   // the backward's layer-2 ReLU mask: exactly the decisions taken here
+      const int tl = lane >> 4, e = lane & 15;
+      const int pt0 = n0 + (tl0 + tl) * 32 + (e & 3) + 8 * (e >> 2);
+      uint32_t* m2 = a.mask2 + ((int64_t)b * a.N) * 4 + c2b;
+      if (pt0 < a.N) m2[(int64_t)pt0 * 4] = (uint32_t)mine;
+      if (pt0 + 4 < a.N) m2[(int64_t)(pt0 + 4) * 4] = (uint32_t)(mine >> 32);
+    }
   }
   __syncthreads();
 
@@ -252,31 +274,35 @@ struct PMBwdArgs {
   const float* T;
   const float *W1, *b1, *W2, *b2, *W3, *W2T;  // W2T = W2 transposed, [64][128] row-major
   const int32_t* argidx;  // [B,C3]
+  const uint64_t* mask1;  // [B,N]   layer-1 ReLU decisions of the forward launch (bit c)
+  const uint32_t* mask2;  // [B,N,4] layer-2 ReLU decisions (word j, bit r = channel 32j+r)
   const float* g;         // [B,C3] upstream gradient on pooled (already masked for relu_last by the caller)
   PtsViewMut gx;          // T == null: gradient wrt the tower input; T given: gradient wrt the RAW points x
   float* part_gT;         // [B, ntiles, 16] per-tile partial of d/dT (9 used) or null
   int accumulate;         // gx += instead of gx =
-  int stop;               // profiling aid (PC3D_BWD_STOP=n): return after phase n; 0 = run everything
+  int stop;               // profiling aid (PC3D_BWD_STOP=3|5): return after phase A / C; 0 = run everything
 };
 
 // Workgroup = (batch b, 32 points), 4 waves; <= 36 KiB LDS so four workgroups share a CU (the kernel is a chain of
 // dependent latencies, residency is what hides them).
 //  A. channels whose arg-max lies in the tile are compacted IN CHANNEL ORDER (block prefix sum) into two lists
 //     (points 0-15 / 16-31) and their rows g[c]*W3[c,:] are accumulated into g2s[pt][128] — ordered => deterministic;
-//  B. h1 = relu(W1 x + b1) is recomputed; the layer-2 pre-activation runs on MFMA (A = h1 from LDS, B = W2 rows
-//     prefetched at kernel entry) and masks g2s in place;
-//  C. g1 = (g2 masked) . W2 on MFMA with K = 128 split over wave pairs, masked by h1 > 0;
+//     each thread then clears the entries of its own column whose layer-2 ReLU was off in the FORWARD launch (the
+//     forward kernel hands over its decisions as bit masks: nothing is recomputed, and no decision can differ);
+//  C. g1 = (g2 masked) . W2 on MFMA with K = 128 split over wave pairs, masked by the forward's layer-1 bits;
 //  D. g' = g1 . W1 on the VALU, then the x' = x @ T chain (dL/dx, per-tile partial of dL/dT).
 __global__ __launch_bounds__(256) void pointmlp3_max_bwd_kernel(PMBwdArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[PM_BTP * PM_LD2 + PM_BTP * PM_LD1 + 4 * PM_BTP + PM_MAXC3 + (3 * PM_MAXC3) / 2];  // 36.4 KB
   float* g2s = lds;                                   // [32][132]
-  float* h1s = g2s + PM_BTP * PM_LD2;                 // [32][68]   (later holds g1)
-  float* xs = h1s + PM_BTP * PM_LD1;                  // [3][32]
+  float* h1s = g2s + PM_BTP * PM_LD2;                 // [32][68]   g1
+  float* xs = h1s + PM_BTP * PM_LD1;                  // [3][32]    scratch of phase D
   int* s_scan = reinterpret_cast<int*>(xs + 3 * PM_BTP);   // [32] wave totals
   float* s_g = xs + 4 * PM_BTP;                       // [C3]
   short* s_n = reinterpret_cast<short*>(s_g + PM_MAXC3);   // [C3] local point index or -1
   short* list0 = s_n + PM_MAXC3;                      // [C3] channels hitting points 0..15, ascending
   short* list1 = list0 + PM_MAXC3;                    // [C3] channels hitting points 16..31
+  __shared__ uint32_t s_m2[PM_BTP][4];
+  __shared__ uint64_t s_m1[PM_BTP];
   const int tile = blockIdx.x, b = blockIdx.y;
   const int n0 = tile * PM_BTP;
   const int tid = threadIdx.x;
@@ -284,8 +310,8 @@ __global__ __launch_bounds__(256) void pointmlp3_max_bwd_kernel(PMBwdArgs a) {
   const int r = lane & 31, h = lane >> 5;
 
   // ---- A1. classify 4 consecutive channels per thread, block-wide ordered compaction.
-  // Issue the (tiny) arg-max / gradient loads FIRST: vector-memory results return in issue order, so anything issued
-  // behind the 64 KiB weight prefetch below would wait for all of it.
+  // Issue the (tiny) arg-max / gradient / mask loads FIRST: vector-memory results return in issue order, so anything
+  // issued behind the 32 KiB weight prefetch below would wait for all of it.
   int ld_n[PM_MAXC3 / 256];
   float ld_g[PM_MAXC3 / 256];
 #pragma unroll
@@ -294,14 +320,13 @@ __global__ __launch_bounds__(256) void pointmlp3_max_bwd_kernel(PMBwdArgs a) {
     ld_n[e] = (c < a.C3) ? a.argidx[(int64_t)b * a.C3 + c] : -1;
     ld_g[e] = (c < a.C3) ? a.g[(int64_t)b * a.C3 + c] : 0.f;
   }
-  float px = 0.f, py = 0.f, pz = 0.f;
-  if (tid < PM_BTP) load_point(a.x, a.T, b, n0 + tid, a.N, px, py, pz);
-  // MFMA B operands of phases B and C depend on nothing: fetch them now so their L2 latency hides under phase A
-  float4 w2r[PM_C1 / 8], w2tr[PM_C2 / 16];
+  uint32_t ld_m2 = 0u;
+  uint64_t ld_m1 = 0ull;
+  if (tid < PM_BTP * 4 && n0 + (tid >> 2) < a.N) ld_m2 = a.mask2[((int64_t)b * a.N + n0) * 4 + tid];
+  if (tid < PM_BTP && n0 + tid < a.N) ld_m1 = a.mask1[(int64_t)b * a.N + n0 + tid];
+  // MFMA B operand of phase C depends on nothing: fetch it now so its L2 latency hides under phase A
+  float4 w2tr[PM_C2 / 16];
   {
-    const float* wrow = a.W2 + (32 * wave + r) * PM_C1 + 4 * h;
-#pragma unroll
-    for (int t = 0; t < PM_C1 / 8; ++t) w2r[t] = *reinterpret_cast<const float4*>(wrow + 8 * t);
     // phase C: wave = (j block wave&1, K half wave>>1): k in [64*(wave>>1), +64)
     const float* wtrow = a.W2T + (32 * (wave & 1) + r) * PM_C2 + 64 * (wave >> 1) + 4 * h;
 #pragma unroll
@@ -324,11 +349,8 @@ __global__ __launch_bounds__(256) void pointmlp3_max_bwd_kernel(PMBwdArgs a) {
     cnt0 += (n >= 0 && n < 16) ? 1 : 0;
     cnt1 += (n >= 16) ? 1 : 0;
   }
-  if (tid < PM_BTP) {
-    xs[tid] = px;
-    xs[PM_BTP + tid] = py;
-    xs[2 * PM_BTP + tid] = pz;
-  }
+  if (tid < PM_BTP * 4) s_m2[tid >> 2][tid & 3] = ld_m2;
+  if (tid < PM_BTP) s_m1[tid] = ld_m1;
   for (int i = tid; i < PM_BTP * PM_LD2; i += 256) g2s[i] = 0.f;
   int packed = cnt0 | (cnt1 << 16);
   int incl = packed;
@@ -366,10 +388,7 @@ __global__ __launch_bounds__(256) void pointmlp3_max_bwd_kernel(PMBwdArgs a) {
       if (n >= 16) list1[o1++] = (short)c;
     }
   }
-  if (a.stop == 1) return;
-  layer1_to_lds<PM_BTP, 256>(xs, h1s, a.W1, a.b1);
   __syncthreads();
-  if (a.stop == 2) return;
 
   // ---- A2. ordered accumulation: thread (k, half) walks its half's list; loads are independent -> pipelined
   {
@@ -404,33 +423,16 @@ __global__ __launch_bounds__(256) void pointmlp3_max_bwd_kernel(PMBwdArgs a) {
       float* dst = g2s + (int)s_n[c] * PM_LD2 + k;
       *dst = __builtin_fmaf(s_g[c], a.W3[(int64_t)c * PM_C2 + k], *dst);
     }
+    // layer-2 ReLU of the forward pass: this thread is the only writer of column k for its half's 16 points, so it
+    // applies the mask to them without a barrier (bit k&31 of word k>>5 of the point's mask2)
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+      const int pt = 16 * ph + p;
+      if (!((s_m2[pt][k >> 5] >> (k & 31)) & 1u)) g2s[pt * PM_LD2 + k] = 0.f;
+    }
   }
   __syncthreads();
   if (a.stop == 3) return;
-
-  // ---- B. layer-2 pre-activation on MFMA: D[pt][c2], wave owns c2 block [32*wave, +32); mask g2s
-  {
-    f32x16 acc;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-#pragma unroll
-    for (int t = 0; t < PM_C1 / 8; ++t) {
-      const float4 bw = w2r[t];
-      const float4 av = *reinterpret_cast<const float4*>(h1s + r * PM_LD1 + 8 * t + 4 * h);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bw.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bw.y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bw.z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bw.w, acc, 0, 0, 0);
-    }
-    const float bias = a.b2[32 * wave + r];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int pt = (e & 3) + 8 * (e >> 2) + 4 * h;
-      if (!(acc[e] + bias > 0.f)) g2s[pt * PM_LD2 + 32 * wave + r] = 0.f;
-    }
-  }
-  __syncthreads();
-  if (a.stop == 4) return;
 
   // ---- C. g1[pt][j] = sum_k2 g2[pt][k2] W2[k2][j] on MFMA: wave = (j block wave&1, K half wave>>1)
   {
@@ -460,8 +462,8 @@ __global__ __launch_bounds__(256) void pointmlp3_max_bwd_kernel(PMBwdArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int pt = (e & 3) + 8 * (e >> 2) + 4 * h;
-        float* q = h1s + pt * PM_LD1 + 32 * jb + r;
-        *q = (*q > 0.f) ? (acc[e] + cr[pt * 33 + r]) : 0.f;
+        const bool on = (s_m1[pt] >> (32 * jb + r)) & 1ull;          // layer-1 ReLU of the forward pass
+        h1s[pt * PM_LD1 + 32 * jb + r] = on ? (acc[e] + cr[pt * 33 + r]) : 0.f;
       }
     }
   }
@@ -469,7 +471,7 @@ __global__ __launch_bounds__(256) void pointmlp3_max_bwd_kernel(PMBwdArgs a) {
   if (a.stop == 5) return;
 
   // ---- D. g'[p][c] = sum_j W1[j][c] g1[p][j]  (gradient wrt the tower input x' = x @ T)
-  float* gp = xs;  // [3][32] scratch (the staged coordinates are dead)
+  float* gp = xs;  // [3][32] scratch
   if (wave < 3 && lane < PM_BTP) {   // wave = coordinate c (uniform -> W1 comes through scalar loads), lane = point
     const int p = lane, c = wave;
     float s0 = 0.f, s1 = 0.f;
@@ -534,7 +536,8 @@ extern "C" int pc3d_pointmlp3_max_fwd_f32(const float* x, int64_t x_bs, int64_t 
                                           const float* T, const float* W1, const float* b1, const float* W2,
                                           const float* b2, const float* W3, const float* b3, int C1, int C2,
                                           int C3, int relu_last, float* part_val, int32_t* part_idx,
-                                          float* pooled, int32_t* argidx, void* stream) {
+                                          float* pooled, int32_t* argidx, uint64_t* mask1, uint32_t* mask2,
+                                          void* stream) {
   PC3D_REQUIRE(B >= 0 && N >= 1, "pc3d_pointmlp3_max_fwd_f32: bad sizes B=%d N=%d", B, N);
   PC3D_REQUIRE(C1 == PM_C1 && C2 == PM_C2 && C3 >= 32 && C3 % 32 == 0 && C3 <= PM_MAXC3F,
                "pc3d_pointmlp3_max_fwd_f32: unsupported widths %d/%d/%d (need 64/128/multiple of 32 <= 1024)", C1, C2, C3);
@@ -544,8 +547,10 @@ extern "C" int pc3d_pointmlp3_max_fwd_f32(const float* x, int64_t x_bs, int64_t 
                "pc3d_pointmlp3_max_fwd_f32: null pointer");
   PC3D_REQUIRE((pooled == nullptr) == (argidx == nullptr),
                "pc3d_pointmlp3_max_fwd_f32: pooled and argidx must both be given or both be NULL");
+  PC3D_REQUIRE((mask1 == nullptr) == (mask2 == nullptr),
+               "pc3d_pointmlp3_max_fwd_f32: mask1 and mask2 must both be given or both be NULL");
   const int ntiles = cdiv(N, PM_TP);
-  PMFwdArgs a{{x, x_bs, x_ps, x_cs}, N, C3, ntiles, T, W1, b1, W2, b2, W3, b3, part_val, part_idx};
+  PMFwdArgs a{{x, x_bs, x_ps, x_cs}, N, C3, ntiles, T, W1, b1, W2, b2, W3, b3, part_val, part_idx, mask1, mask2};
   hipStream_t st = as_stream(stream);
   hipLaunchKernelGGL(pointmlp3_max_fwd_kernel, dim3(ntiles, B), dim3(PM_FT), 0, st, a);
   PC3D_LAUNCH_CHECK("pc3d_pointmlp3_max_fwd_f32");
@@ -560,7 +565,8 @@ extern "C" int pc3d_pointmlp3_max_fwd_f32(const float* x, int64_t x_bs, int64_t 
 extern "C" int pc3d_pointmlp3_max_bwd_f32(const float* x, int64_t x_bs, int64_t x_ps, int64_t x_cs, int B, int N,
                                           const float* T, const float* W1, const float* b1, const float* W2,
                                           const float* b2, const float* W3, const float* W2T, int C1, int C2,
-                                          int C3, const int32_t* argidx, const float* g_pooled, float* grad_x,
+                                          int C3, const int32_t* argidx, const uint64_t* mask1,
+                                          const uint32_t* mask2, const float* g_pooled, float* grad_x,
                                           int64_t gx_bs, int64_t gx_ps, int64_t gx_cs, float* part_gT,
                                           int accumulate, void* stream) {
   PC3D_REQUIRE(B >= 0 && N >= 1, "pc3d_pointmlp3_max_bwd_f32: bad sizes B=%d N=%d", B, N);
@@ -568,9 +574,9 @@ extern "C" int pc3d_pointmlp3_max_bwd_f32(const float* x, int64_t x_bs, int64_t 
                "pc3d_pointmlp3_max_bwd_f32: unsupported widths %d/%d/%d", C1, C2, C3);
   PC3D_REQUIRE(B <= 65535, "pc3d_pointmlp3_max_bwd_f32: B=%d exceeds grid.y limit", B);
   if (B == 0) return PC3D_OK;
-  PC3D_REQUIRE(x && W1 && b1 && W2 && b2 && W3 && W2T && argidx && g_pooled && grad_x,
+  PC3D_REQUIRE(x && W1 && b1 && W2 && b2 && W3 && W2T && argidx && mask1 && mask2 && g_pooled && grad_x,
                "pc3d_pointmlp3_max_bwd_f32: null pointer");
-  PMBwdArgs a{{x, x_bs, x_ps, x_cs}, N, C3, T, W1, b1, W2, b2, W3, W2T, argidx, g_pooled, {grad_x, gx_bs, gx_ps, gx_cs},
+  PMBwdArgs a{{x, x_bs, x_ps, x_cs}, N, C3, T, W1, b1, W2, b2, W3, W2T, argidx, mask1, mask2, g_pooled, {grad_x, gx_bs, gx_ps, gx_cs},
               part_gT, accumulate, getenv("PC3D_BWD_STOP") ? atoi(getenv("PC3D_BWD_STOP")) : 0};
   hipLaunchKernelGGL(pointmlp3_max_bwd_kernel, dim3(cdiv(N, PM_BTP), B), dim3(256), 0, as_stream(stream), a);
   PC3D_LAUNCH_CHECK("pc3d_pointmlp3_max_bwd_f32");

@@ -171,7 +171,7 @@ class PointNetCls(_FrozenFusedMixin, nn.Module):
         """fused_loss_and_grad for the attack loops: the classifier tail (fc3, loss, fc3 backward) is one launch that
         also writes the prediction into `pred_out` and advances the device step word. Returns (pred, loss, dL/dx)."""
         _, ctx = fused_forward(self, x, tail=False)
-        c2, pk = ctx[-1], ctx[1]
+        c2, pk = ctx[9], ctx[1]
         _, pred, loss, g_c2 = ops.cls_tail(c2, pk["c"][4], pk["c"][5], target, kind, kappa, scale=1.0 / x.shape[0],
                                            pred_out=pred_out, step=step, want_logp=False)
         return pred, loss, fused_input_grad(ctx, None, g_c2=g_c2)
@@ -217,31 +217,31 @@ def fused_forward(model, x, tail=True):
         object.__setattr__(model, "_fused_cache", pk)
     w1s, b1s, w2s, b2s, w3s, b3s = pk["s"]
     w1c, b1c, w2c, b2c, w3c, b3c = pk["c"]
-    pooled_s, idx_s = ops.pointmlp3_max_fwd_raw(x, pk["tower_s"], True)
+    pooled_s, idx_s, masks_s = ops.pointmlp3_max_fwd_raw(x, pk["tower_s"], True, want_masks=True)
     a1 = ops.linear(pooled_s, w1s, b1s, relu=True)
     a2 = ops.linear(a1, w2s, b2s, relu=True)
     trans = ops.linear(a2, w3s, b3s)                                   # [B,9] incl. the identity
-    pooled, idx = ops.pointmlp3_max_fwd_raw(x, pk["tower_c"], False, T=trans)
+    pooled, idx, masks = ops.pointmlp3_max_fwd_raw(x, pk["tower_c"], False, T=trans, want_masks=True)
     c1 = ops.linear(pooled, w1c, b1c, relu=True)
     c2 = ops.linear(c1, w2c, b2c, relu=True)
     logits = ops.linear(c2, w3c, b3c) if tail else None
-    return logits, (x, pk, pooled_s, idx_s, a1, a2, trans, idx, c1, c2)
+    return logits, (x, pk, pooled_s, idx_s, a1, a2, trans, idx, c1, c2, masks_s, masks)
 
 
 def fused_input_grad(ctx, g_logits, out=None, g_c2=None):
     """Backward-to-input of fused_forward for an upstream gradient on the logits: 6 head launches + 2 tower launches."""
-    x, pk, pooled_s, idx_s, a1, a2, trans, idx, c1, c2 = ctx
+    x, pk, pooled_s, idx_s, a1, a2, trans, idx, c1, c2, masks_s, masks = ctx
     w1c_t, w2c_t, w3c_t = pk["c_t"]
     w1s_t, w2s_t, w3s_t = pk["s_t"]
     if g_c2 is None:
         g_c2 = ops.linear(g_logits, w3c_t, gate=c2)
     g_c1 = ops.linear(g_c2, w2c_t, gate=c1)
     g_pooled = ops.linear(g_c1, w1c_t)
-    gx, part_gT = ops.pointmlp3_max_bwd_raw(x, pk["tower_c"], idx, g_pooled, T=trans, want_gT=True, out=out)
+    gx, part_gT = ops.pointmlp3_max_bwd_raw(x, pk["tower_c"], idx, g_pooled, masks, T=trans, want_gT=True, out=out)
     g_a2 = ops.linear(part_gT, w3s_t, gate=a2, parts=part_gT.shape[1])  # sums the per-tile dL/dT partials on load
     g_a1 = ops.linear(g_a2, w2s_t, gate=a1)
     g_pooled_s = ops.linear(g_a1, w1s_t, gate=pooled_s)                 # ReLU after the STN max-pool
-    ops.pointmlp3_max_bwd_raw(x, pk["tower_s"], idx_s, g_pooled_s, out=gx, accumulate=True)
+    ops.pointmlp3_max_bwd_raw(x, pk["tower_s"], idx_s, g_pooled_s, masks_s, out=gx, accumulate=True)
     return gx
 
 

@@ -210,9 +210,10 @@ def _pm_tile():
     return _PM_TILE
 
 
-def pointmlp3_max_fwd_raw(x, weights, relu_last, T=None, x_cf=True, fold=True):
+def pointmlp3_max_fwd_raw(x, weights, relu_last, T=None, x_cf=True, fold=True, want_masks=False):
     """x [B,3,N] (x_cf) or [B,N,3]; weights = (W1[64,3], b1, W2[128,64], b2, W3[C3,128], b3) with eval-BN folded.
-    Returns (pooled [B,C3] f32, argidx [B,C3] i32)."""
+    Returns (pooled [B,C3] f32, argidx [B,C3] i32) and, with want_masks, a third item (mask1 [B,N] i64, mask2 [B,N,4]
+    i32): the per-point ReLU decisions of layers 1 and 2 as bit masks, which pointmlp3_max_bwd_raw consumes."""
     xp, xbs, xps, xcs, B, N = _pts(x, x_cf, "x")
     W1, b1, W2, b2, W3, b3 = weights[:6]
     for w in weights:
@@ -229,26 +230,35 @@ def pointmlp3_max_fwd_raw(x, weights, relu_last, T=None, x_cf=True, fold=True):
     part_idx = torch.empty((B, ntiles, C3), dtype=torch.int32, device=dev)
     pooled = torch.empty((B, C3), dtype=torch.float32, device=dev)
     argidx = torch.empty((B, C3), dtype=torch.int32, device=dev)
+    masks = None
+    if want_masks:
+        masks = (torch.empty((B, N), dtype=torch.int64, device=dev), torch.empty((B, N, 4), dtype=torch.int32, device=dev))
     with torch.cuda.device(dev):
         _lib.call("pc3d_pointmlp3_max_fwd_f32", xp, xbs, xps, xcs, B, N, _ptr(T),
                   W1.data_ptr(), b1.data_ptr(), W2.data_ptr(), b2.data_ptr(), W3.data_ptr(), b3.data_ptr(),
                   C1, C2, C3, 1 if relu_last else 0, part_val.data_ptr(), part_idx.data_ptr(),
-                  pooled.data_ptr() if fold else 0, argidx.data_ptr() if fold else 0, _stream())
+                  pooled.data_ptr() if fold else 0, argidx.data_ptr() if fold else 0,
+                  masks[0].data_ptr() if masks else 0, masks[1].data_ptr() if masks else 0, _stream())
     if not fold:
         return part_val, part_idx
-    return pooled, argidx
+    return (pooled, argidx, masks) if want_masks else (pooled, argidx)
 
 
-def pointmlp3_max_bwd_raw(x, weights, argidx, g_pooled, T=None, x_cf=True, out=None, accumulate=False,
+def pointmlp3_max_bwd_raw(x, weights, argidx, g_pooled, masks, T=None, x_cf=True, out=None, accumulate=False,
                           want_gT=False):
     """Gradient w.r.t. the tower input (T None) or w.r.t. the raw points through x' = x @ T (T given); same layout
-    as x. want_gT: also return the per-tile partials [B, ntiles, 16] of dL/dT. out/accumulate: add into `out`."""
+    as x. masks: the (mask1, mask2) pair of the forward launch on the same x/T (want_masks=True).
+    want_gT: also return the per-tile partials [B, ntiles, 16] of dL/dT. out/accumulate: add into `out`."""
     xp, xbs, xps, xcs, B, N = _pts(x, x_cf, "x")
     W1, b1, W2, b2, W3, b3 = weights[:6]
     W2T = weights[6] if len(weights) > 6 else W2.t().contiguous()
     C1, C2, C3 = W1.shape[0], W2.shape[0], W3.shape[0]
     _check(g_pooled, "g_pooled")
     g_pooled = g_pooled.contiguous()
+    m1, m2 = masks
+    if m1.shape != (B, N) or m1.dtype != torch.int64 or m2.shape != (B, N, 4) or m2.dtype != torch.int32 \
+            or not (m1.is_contiguous() and m2.is_contiguous()):
+        raise ValueError("pointmlp3_max_bwd_raw: masks must be the (int64 [B,N], int32 [B,N,4]) pair of the forward launch")
     gx = out if out is not None else torch.empty((B, 3, N) if x_cf else (B, N, 3), dtype=torch.float32,
                                                  device=x.device)
     gp, gbs, gps, gcs, _, _ = _pts(gx, x_cf, "grad_x")
@@ -259,7 +269,8 @@ def pointmlp3_max_bwd_raw(x, weights, argidx, g_pooled, T=None, x_cf=True, out=N
     with torch.cuda.device(x.device):
         _lib.call("pc3d_pointmlp3_max_bwd_f32", xp, xbs, xps, xcs, B, N, _ptr(T),
                   W1.data_ptr(), b1.data_ptr(), W2.data_ptr(), b2.data_ptr(), W3.data_ptr(), W2T.data_ptr(),
-                  C1, C2, C3, argidx.data_ptr(), g_pooled.data_ptr(), gp, gbs, gps, gcs, _ptr(part_gT),
+                  C1, C2, C3, argidx.data_ptr(), m1.data_ptr(), m2.data_ptr(), g_pooled.data_ptr(), gp, gbs, gps, gcs,
+                  _ptr(part_gT),
                   1 if accumulate else 0, _stream())
     return (gx, part_gT) if want_gT else gx
 
@@ -270,17 +281,17 @@ class _PointMLP3MaxFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, relu_last, W1, b1, W2, b2, W3, b3, W2T):
         weights = (W1, b1, W2, b2, W3, b3, W2T)
-        pooled, argidx = pointmlp3_max_fwd_raw(x, weights, relu_last)
-        ctx.save_for_backward(x, argidx, pooled, *weights)
+        pooled, argidx, masks = pointmlp3_max_fwd_raw(x, weights, relu_last, want_masks=True)
+        ctx.save_for_backward(x, argidx, pooled, masks[0], masks[1], *weights)
         ctx.relu_last = relu_last
         return pooled
 
     @staticmethod
     def backward(ctx, g):
-        x, argidx, pooled, *weights = ctx.saved_tensors
+        x, argidx, pooled, m1, m2, *weights = ctx.saved_tensors
         if ctx.relu_last:
             g = g * (pooled > 0)
-        gx = pointmlp3_max_bwd_raw(x, tuple(weights), argidx, g)
+        gx = pointmlp3_max_bwd_raw(x, tuple(weights), argidx, g, (m1, m2))
         return (gx,) + (None,) * 8
 
 

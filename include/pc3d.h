@@ -88,6 +88,9 @@ int pc3d_nn_bwd_f32(const float* a, int64_t a_bs, int64_t a_ps, int64_t a_cs,
  *   part_val/part_idx  caller workspace [B, ceil(N / pc3d_pointmlp3_tile_points()), C3] f32 / i32
  *   pooled [B,C3] f32 (after the optional ReLU), argidx [B,C3] i32 = lowest point index attaining the max;
  *          pass both NULL to keep only the per-tile partials (no fold launch)
+ *   mask1 [B,N] u64, mask2 [B,N,4] u32 (both or neither)  the ReLU decisions of layers 1 and 2 per point (bit c of
+ *          mask1 = channel c of layer 1 is positive; word j bit r of mask2 = channel 32j+r of layer 2 is positive),
+ *          which the backward launch consumes instead of recomputing the two layers
  * fp32 throughout: layer 2/3 run on v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains).
  * ------------------------------------------------------------------------------------------------------- */
 int pc3d_pointmlp3_tile_points(void);
@@ -96,7 +99,7 @@ int pc3d_pointmlp3_max_fwd_f32(const float* x, int64_t x_bs, int64_t x_ps, int64
                                const float* T, const float* W1, const float* b1, const float* W2,
                                const float* b2, const float* W3, const float* b3, int C1, int C2, int C3,
                                int relu_last, float* part_val, int32_t* part_idx,
-                               float* pooled, int32_t* argidx, void* stream);
+                               float* pooled, int32_t* argidx, uint64_t* mask1, uint32_t* mask2, void* stream);
 
 /* Backward-to-input of the above (weights are frozen during an attack: no weight gradients, SURVEY A-14).
  * g_pooled [B,C3] is the upstream gradient on `pooled`; with relu_last the caller zeroes it where pooled <= 0.
@@ -106,11 +109,13 @@ int pc3d_pointmlp3_max_fwd_f32(const float* x, int64_t x_bs, int64_t x_ps, int64
  * their sum over tiles is the gradient that flows on into the STN head. accumulate != 0: grad_x += (used to add the
  * STN tower's contribution on top of the trunk's).
  * W2T is W2 transposed ([64,128] row-major; lets the W2^T product read its operand rows contiguously).
+ * mask1 / mask2 are the forward launch's outputs of those names (required).
  * The max-pool routes each channel to one point, so the layer-3 dgrad is a sparse ordered gather: deterministic. */
 int pc3d_pointmlp3_max_bwd_f32(const float* x, int64_t x_bs, int64_t x_ps, int64_t x_cs, int B, int N,
                                const float* T, const float* W1, const float* b1, const float* W2,
                                const float* b2, const float* W3, const float* W2T, int C1, int C2, int C3,
-                               const int32_t* argidx, const float* g_pooled,
+                               const int32_t* argidx, const uint64_t* mask1, const uint32_t* mask2,
+                               const float* g_pooled,
                                float* grad_x, int64_t gx_bs, int64_t gx_ps, int64_t gx_cs,
                                float* part_gT, int accumulate, void* stream);
 

@@ -79,8 +79,8 @@ def test_backward_is_deterministic(ops, dev):
     torch.manual_seed(5)
     x = torch.randn(3, 3, 512, device=dev)
     w = _weights(dev, 1024, 4)
-    pooled, idx = ops.pointmlp3_max_fwd_raw(x, w, False)
+    pooled, idx, masks = ops.pointmlp3_max_fwd_raw(x, w, False, want_masks=True)
     g = torch.randn_like(pooled)
-    a = ops.pointmlp3_max_bwd_raw(x, w, idx, g)
-    b = ops.pointmlp3_max_bwd_raw(x, w, idx, g)
+    a = ops.pointmlp3_max_bwd_raw(x, w, idx, g, masks)
+    b = ops.pointmlp3_max_bwd_raw(x, w, idx, g, masks)
     assert torch.equal(a, b)
