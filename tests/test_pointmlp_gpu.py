@@ -84,3 +84,26 @@ def test_backward_is_deterministic(ops, dev):
     a = ops.pointmlp3_max_bwd_raw(x, w, idx, g, masks)
     b = ops.pointmlp3_max_bwd_raw(x, w, idx, g, masks)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("B,N", [(2, 128), (3, 333), (1, 1), (2, 1024)])
+def test_forward_relu_masks_match_torch(ops, dev, B, N):
+    """mask1 / mask2 of pc3d_pointmlp3_max_fwd_f32 are the layer-1 / layer-2 ReLU decisions per point (the backward
+    launch consumes them instead of recomputing): compare with torch's activations, allowing a pre-activation within
+    fp32 rounding of zero to fall on either side."""
+    torch.manual_seed(N)
+    x = torch.randn(B, 3, N, device=dev) * 0.5
+    w = _weights(dev, 256, 3)
+    T = torch.randn(B, 3, 3, device=dev) * 0.5 if N > 1 else None
+    _, _, (m1, m2) = ops.pointmlp3_max_fwd_raw(x, w, False, T=T, want_masks=True)
+    assert m1.shape == (B, N) and m1.dtype == torch.int64 and m2.shape == (B, N, 4) and m2.dtype == torch.int32
+    xt = x if T is None else torch.bmm(x.transpose(1, 2), T).transpose(1, 2)
+    z1 = F.conv1d(xt.double(), w[0].double()[:, :, None], w[1].double())             # [B,64,N]
+    z2 = F.conv1d(F.relu(z1), w[2].double()[:, :, None], w[3].double())               # [B,128,N]
+    bits1 = ((m1.unsqueeze(-1) >> torch.arange(64, device=dev)) & 1).bool()           # [B,N,64]
+    bits2 = ((m2.unsqueeze(-1) >> torch.arange(32, device=dev)) & 1).bool().reshape(B, N, 128)
+    for bits, z in ((bits1, z1), (bits2, z2)):
+        zt = z.transpose(1, 2)
+        sure = zt.abs() > 1e-5
+        assert torch.equal(bits[sure], (zt > 0)[sure])
+        assert sure.float().mean() > 0.999
