@@ -1,7 +1,8 @@
 // K11 + K10/K9 fused for the CW-family loops: the per-iteration bookkeeping of the reference
 // (attack/CW/CW_attack.py:121-153 — argmax already done by the loss kernel; per-sample L2 perturbation norm,
 // best-distance / best-attack selection, the D2H copy of the whole cloud and the Python loop over samples) and the
-// optimiser update (loss.backward() of the distance term + Adam + clip, :160-174) as TWO launches.
+// optimiser update (loss.backward() of the distance term + Adam + clip, :160-174) as TWO launches
+// (cw_bookkeep_kernel + cw_step_kernel) or as ONE (cw_update_kernel, what the captured CW iteration uses).
 #include "pc3d_common.h"
 
 namespace pc3d {

@@ -4,10 +4,10 @@
 // Replaces: model/pointnet.py:34-37 (STN3d tower) and :110-123 (PointNetfeat trunk): three Conv1d+BN(+ReLU) and
 // torch.max over N, which materialise [B,64,N], [B,128,N] and [B,1024,N] activations (134 MB at B=32,N=1024).
 //
-// Forward: workgroup = (batch b, tile of 128 points), 4 waves. Layers 1-2 are computed once per tile into LDS
-// (h2 tile [128 pts][128 ch], 66 KiB); layer 3 runs on v_mfma_f32_32x32x2_f32 with POINTS on the MFMA row index
+// Forward: workgroup = (batch b, tile of 128 points), 8 waves. Layers 1-2 are computed once per tile into LDS
+// (h2 tile [128 pts][128 ch], 66 KiB) and their ReLU decisions leave as per-point bit masks; layer 3 runs on v_mfma_f32_32x32x2_f32 with POINTS on the MFMA row index
 // and CHANNELS on the column (lane) index, so the max over a tile's points is an in-register reduction
-// (64 accumulator values per lane) + one cross-half shuffle; W3 rows stream from L2 as float4 per lane with a
+// (16 accumulator values per lane and channel block) + one cross-half shuffle; W3 rows stream from L2 as float4 per lane with a
 // permuted-k order shared by both operands. Only (max, argmax) per (b, tile, channel) leaves the CU; a tiny second
 // kernel folds the tiles. The [B,C3,N] activation is never written.
 //

@@ -162,7 +162,7 @@ class PointNetCls(_FrozenFusedMixin, nn.Module):
 
     def fused_loss_and_grad(self, x, target, kind, kappa=0.0):
         """Attack fast path (no autograd): (logp [B,k], pred [B], per-sample adv loss [B], d mean(loss)/dx).
-        kind in ops.LOSS_KINDS. Numerically the same computation as forward() + autograd, in ~22 launches."""
+        kind in ops.LOSS_KINDS. Numerically the same computation as forward() + autograd, in ~20 launches."""
         logits, ctx = fused_forward(self, x)
         logp, pred, loss, g_logits = ops.cls_loss(logits, target, kind, kappa, scale=1.0 / x.shape[0])
         return logp, pred, loss, fused_input_grad(ctx, g_logits)
