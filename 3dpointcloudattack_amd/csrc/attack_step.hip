@@ -166,7 +166,7 @@ template <int PER>
 __global__ __launch_bounds__(1024) void cw_update_kernel(UpdateArgs u) {
   __shared__ float part[16];
   __shared__ int s_copy;
-  __shared__ float s_dist;
+  __shared__ float s_dist, s_step_size, s_bc2s;
   const BookArgs& a = u.bk;
   const StepArgs& s = u.st;
   const int b = blockIdx.x;
@@ -239,13 +239,15 @@ __global__ __launch_bounds__(1024) void cw_update_kernel(UpdateArgs u) {
       copy = 1;
     }
     s_copy = copy;
+    // Adam bias corrections in double (as torch): evaluated once per workgroup, not by all 1024 threads
+    s_step_size = (float)(s.lr / (1.0 - pow(s.b1, (double)t)));
+    s_bc2s = (float)sqrt(1.0 - pow(s.b2, (double)t));
   }
   __syncthreads();
   const bool copy = s_copy != 0;
   const float l2n = s_dist;
   const float omb1 = (float)(1.0 - s.b1), omb2 = (float)(1.0 - s.b2), fb2 = (float)s.b2;
-  const float step_size = (float)(s.lr / (1.0 - pow(s.b1, (double)t)));
-  const float bc2s = (float)sqrt(1.0 - pow(s.b2, (double)t));
+  const float step_size = s_step_size, bc2s = s_bc2s;
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
     const int k = tid + i * 1024;
