@@ -202,7 +202,7 @@ class CW:
             # launch-minimal pass: victim fwd/bwd (fused heads), bookkeeping, [NN search], one update launch
             with torch.no_grad():
                 cur = adv_data.detach()
-                if hasattr(self.model, "fused_attack_grad"):
+                if hasattr(self.model, "fused_attack_grad") and st["K"] <= ops.CW_UPDATE_MAX_POINTS:
                     # 17 launches: the classifier tail writes pred + advances the step word, one update launch
                     _, _, gx_model = self.model.fused_attack_grad(cur, st["target"], *fml, pred_out=st["pred"],
                                                                   step=st["step"])

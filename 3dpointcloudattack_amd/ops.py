@@ -486,6 +486,9 @@ def cls_tail(c2, w3, b3, target, kind, kappa=0.0, scale=1.0, pred_out=None, step
 # ------------------------------------------------------------------------------------------------------
 # CW-family loop: bookkeeping + fused update
 # ------------------------------------------------------------------------------------------------------
+CW_UPDATE_MAX_POINTS = 8192     # pc3d_cw_update_f32 keeps a sample's points in registers (8 per thread x 1024 threads)
+
+
 def cw_update(adv, ori, pred, label, untarget, bestdist, bestscore, o_bestdist, o_bestscore, o_bestattack, g, m, v,
               step, lr, budget, input_val=None, dist_val=None, dist_kind=0, w=None, nn_idx=None,
               betas=(0.9, 0.999), eps=1e-8, cf=True):

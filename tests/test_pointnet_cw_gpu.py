@@ -294,3 +294,21 @@ def test_cw_update_equals_bookkeep_plus_step(dev, dk):
         else:
             assert torch.equal(a[k], b[k]), k
     assert a["o_bestattack"].abs().sum() > 0 and not torch.equal(a["adv"], adv0)
+
+
+def test_cw_large_cloud_uses_two_launch_update(dev):
+    """K > 8192 points per cloud: the merged update launch does not apply (register-resident per sample); the loop
+    falls back to bookkeeping + step launches and still runs captured."""
+    cwm, adv, dist, clip = _mods()
+    model, _ = hip_pointnet(0, dev)
+    trans_model, _ = hip_pointnet(1, dev)
+    rng = np.random.default_rng(2)
+    pcs = torch.from_numpy(np.stack([unit_cloud(rng, 9000) for _ in range(2)]))
+    with torch.no_grad():
+        labels = model(pcs.transpose(1, 2).contiguous().to(dev))[0].argmax(1).cpu()
+    atk = cwm.CW(model, trans_model, adv_func=adv.UntargetedLogitsAdvLoss(5.), clip_func=clip.ClipPointsLinf(0.18),
+                 dist_func=dist.ChamferDist(), binary_step=1, num_iter=10)
+    torch.manual_seed(3)
+    bd, ba, sn = atk.attack(pcs, labels)
+    assert ba.shape == (2, 9000, 3) and np.isfinite(ba).all() and 0 <= sn <= 2
+    assert np.max(np.linalg.norm(ba - pcs.numpy(), axis=2)) <= 0.18 + 1e-5
