@@ -230,6 +230,67 @@ __global__ __launch_bounds__(256) void gather_max_bwd_kernel(const float* g, con
   atomicAdd(gP + ((int64_t)b * N + j) * C + c, g[(int64_t)b * N * C + e]);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// EdgeConv epilogue in one launch: PQ[b,i,:] = [P_i | Q_i] (one GEMM against [U;V] with bias [0;t]),
+//   out[b,i,c] = leaky(max_{j in nbr(i)} P[b,j,c] + Q[b,i,c])        (model/dgcnn.py:299-313 per layer)
+// and its backward: g_pre = g * (out > 0 ? 1 : slope); dQ[b,i,c] = g_pre; dP[b,arg,c] += g_pre.
+// Same lane layout as gather_max4_kernel (a lane owns 4 consecutive channels); C % 4 == 0.
+// ---------------------------------------------------------------------------------------------------------
+struct EdgeMaxArgs {
+  const float* PQ;      // [B,N,2C]
+  const int32_t* idx;   // [B,N,K]
+  int N, C, K;
+  float slope;
+  float* out;           // [B,N,C]
+  int32_t* arg;         // [B,N,C]
+};
+
+__global__ __launch_bounds__(256) void edge_max_kernel(EdgeMaxArgs a, int lpp) {
+  const int b = blockIdx.y;
+  const int ppw = 256 / lpp;
+  const int i = blockIdx.x * ppw + threadIdx.x / lpp;
+  const int l = threadIdx.x % lpp;
+  if (threadIdx.x >= ppw * lpp || i >= a.N) return;
+  const int32_t* nb = a.idx + ((int64_t)b * a.N + i) * a.K;
+  const float* Pb = a.PQ + (int64_t)b * a.N * 2 * a.C + 4 * l;
+  const float4 q = *reinterpret_cast<const float4*>(Pb + (int64_t)i * 2 * a.C + a.C);
+  float best[4] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+  const int j0 = nb[0];
+  int bj[4] = {j0, j0, j0, j0};
+  for (int k = 0; k < a.K; ++k) {
+    const int j = nb[k];
+    const float4 v4 = *reinterpret_cast<const float4*>(Pb + (int64_t)j * 2 * a.C);
+    const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (v[e] > best[e]) best[e] = v[e], bj[e] = j;
+  }
+  const float qq[4] = {q.x, q.y, q.z, q.w};
+  float o[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float z = best[e] + qq[e];
+    o[e] = z > 0.f ? z : z * a.slope;
+  }
+  const int64_t off = ((int64_t)b * a.N + i) * a.C + 4 * l;
+  *reinterpret_cast<float4*>(a.out + off) = make_float4(o[0], o[1], o[2], o[3]);
+  *reinterpret_cast<int4*>(a.arg + off) = make_int4(bj[0], bj[1], bj[2], bj[3]);
+}
+
+// backward: one thread per (b, i, c): dQ written, dP scattered with float atomics into the zero-filled P half
+__global__ __launch_bounds__(256) void edge_max_bwd_kernel(const float* g, const float* out, const int32_t* arg, int N,
+                                                           int C, float slope, float* gPQ) {
+  const int b = blockIdx.y;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)N * C) return;
+  const int i = (int)(e / C), c = (int)(e - (int64_t)i * C);
+  const int64_t o = (int64_t)b * N * C + e;
+  const float gp = g[o] * (out[o] > 0.f ? 1.f : slope);
+  float* base = gPQ + (int64_t)b * N * 2 * C;
+  base[(int64_t)i * 2 * C + C + c] = gp;
+  atomicAdd(base + (int64_t)arg[o] * 2 * C + c, gp);
+}
+
 }  // namespace pc3d
 
 using namespace pc3d;
@@ -279,5 +340,36 @@ extern "C" int pc3d_gather_max_bwd_f32(const float* g, const int32_t* arg, int B
   hipLaunchKernelGGL(gather_max_bwd_kernel, dim3((unsigned)(((int64_t)N * C + 255) / 256), B), dim3(256), 0, st, g, arg,
                      N, C, gP);
   PC3D_LAUNCH_CHECK("pc3d_gather_max_bwd_f32");
+  return PC3D_OK;
+}
+
+extern "C" int pc3d_edge_max_f32(const float* PQ, const int32_t* idx, int B, int N, int C, int K, float slope,
+                                 float* out, int32_t* arg, void* stream) {
+  PC3D_REQUIRE(B >= 0 && N >= 1 && C >= 4 && C % 4 == 0 && C <= 1024 && K >= 1, "pc3d_edge_max_f32: bad sizes (C %% 4 == 0, C <= 1024)");
+  PC3D_REQUIRE(B <= 65535, "pc3d_edge_max_f32: B=%d exceeds grid.y limit", B);
+  if (B == 0) return PC3D_OK;
+  PC3D_REQUIRE(PQ && idx && out && arg, "pc3d_edge_max_f32: null pointer");
+  EdgeMaxArgs a{PQ, idx, N, C, K, slope, out, arg};
+  const int lpp = C / 4, ppw = 256 / lpp;
+  hipLaunchKernelGGL(edge_max_kernel, dim3(cdiv(N, ppw), B), dim3(256), 0, as_stream(stream), a, lpp);
+  PC3D_LAUNCH_CHECK("pc3d_edge_max_f32");
+  return PC3D_OK;
+}
+
+extern "C" int pc3d_edge_max_bwd_f32(const float* g, const float* out, const int32_t* arg, int B, int N, int C,
+                                     float slope, float* gPQ, void* stream) {
+  PC3D_REQUIRE(B >= 0 && N >= 1 && C >= 1, "pc3d_edge_max_bwd_f32: bad sizes");
+  PC3D_REQUIRE(B <= 65535, "pc3d_edge_max_bwd_f32: B=%d exceeds grid.y limit", B);
+  if (B == 0) return PC3D_OK;
+  PC3D_REQUIRE(g && out && arg && gPQ, "pc3d_edge_max_bwd_f32: null pointer");
+  hipStream_t st = as_stream(stream);
+  hipError_t e = hipMemsetAsync(gPQ, 0, (size_t)B * N * 2 * C * sizeof(float), st);
+  if (e != hipSuccess) {
+    set_error("pc3d_edge_max_bwd_f32: memset failed: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  hipLaunchKernelGGL(edge_max_bwd_kernel, dim3((unsigned)(((int64_t)N * C + 255) / 256), B), dim3(256), 0, st, g, out,
+                     arg, N, C, slope, gPQ);
+  PC3D_LAUNCH_CHECK("pc3d_edge_max_bwd_f32");
   return PC3D_OK;
 }

@@ -5,8 +5,9 @@ EdgeConv is evaluated without the [B,2C,N,k] edge tensor: with W = [Wa | Wb] (1x
     W [x_j - x_i ; x_i] = Wa x_j + (Wb - Wa) x_i = P_j + Q_i ,
 and because eval-BatchNorm (folded into Wa, Wb) and LeakyReLU are monotone per channel once the BN scale is folded,
     max_j leaky(bn(W e_ij)) = leaky(max_j P_j + Q_i + t).
-So an EdgeConv layer = two point-wise GEMMs + one neighbour gather-max launch (pc3d_gather_max_f32); the dynamic graph
-comes from pc3d_knn_f32 (xyz) / pc3d_knn_feat_f32 (fp32 MFMA, LDS-resident similarity strips). The reference builds
+So an EdgeConv layer = ONE point-wise GEMM against [Wa ; Wb - Wa] (rows [P | Q]) + one launch that gathers, takes the
+neighbour max, adds Q and applies the LeakyReLU (pc3d_edge_max_f32); the dynamic graph comes from pc3d_knn_f32 (xyz) /
+pc3d_knn_feat_f32 (fp32 MFMA distance blocks in LDS, K-lists across the lanes). The reference builds
 335-671 MB edge tensors per layer at B=32.
 """
 import torch
@@ -37,13 +38,15 @@ def get_graph_feature(x, k=20, idx=None):
 
 
 def _fold_edge(conv, bn):
-    """Conv2d(2C -> C', bias=False) + BatchNorm2d -> (U [C',C], V [C',C], t [C']) with y_ij = U x_j + V x_i + t."""
+    """Conv2d(2C -> C', bias=False) + BatchNorm2d -> (UV [2C',C], bias [2C']) with y_ij = U x_j + V x_i + t."""
     w = conv.weight.detach().reshape(conv.weight.shape[0], -1).float()
     C = w.shape[1] // 2
     s = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
     t = bn.bias.detach().float() - bn.running_mean.detach().float() * s
     wa, wb = w[:, :C], w[:, C:]
-    return (wa * s[:, None]).contiguous(), ((wb - wa) * s[:, None]).contiguous(), t.contiguous()
+    U, V = wa * s[:, None], (wb - wa) * s[:, None]
+    # one GEMM per layer: rows [U; V] with bias [0; t] give [P | Q] side by side (ops.edge_max consumes that layout)
+    return torch.cat((U, V), 0).contiguous(), torch.cat((torch.zeros_like(t), t)).contiguous()
 
 
 class DGCNN(_FrozenFusedMixin, nn.Module):
@@ -91,13 +94,12 @@ class DGCNN(_FrozenFusedMixin, nn.Module):
         B = x.size(0)
         f = x.transpose(2, 1).contiguous().float()          # [B,N,3] channels-last from here on
         feats = []
-        for li, (U, V, t) in enumerate(edges):
+        for li, (UV, tb) in enumerate(edges):
             with torch.no_grad():                           # graph indices are constants for autograd (topk indices)
                 fd = f.detach()
                 idx = ops.knn_raw(fd, fd, self.k)[1] if li == 0 else ops.knn_feat(fd, self.k)
-            P = F.linear(f, U)                              # U x_j
-            Q = F.linear(f, V, t)                           # V x_i + t
-            f = F.leaky_relu(ops.gather_max(P, idx) + Q, negative_slope=0.2)   # == max_j leaky(bn(conv(e_ij)))
+            PQ = F.linear(f, UV, tb)                        # [U x | V x + t] in one GEMM
+            f = ops.edge_max(PQ, idx, 0.2)                  # leaky(max_j P_j + Q_i) == max_j leaky(bn(conv(e_ij)))
             feats.append(f)
         g = torch.cat(feats, dim=2)                         # [B,N,512]
         g = F.leaky_relu(F.linear(g, *c5), negative_slope=0.2)

@@ -654,6 +654,41 @@ def gather_max(P, idx):
     return _GatherMaxFn.apply(P, idx.contiguous())
 
 
+class _EdgeMaxFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, PQ, idx, slope):
+        B, N, C2 = PQ.shape
+        C = C2 // 2
+        out = torch.empty((B, N, C), dtype=torch.float32, device=PQ.device)
+        arg = torch.empty((B, N, C), dtype=torch.int32, device=PQ.device)
+        with torch.cuda.device(PQ.device):
+            _lib.call("pc3d_edge_max_f32", PQ.data_ptr(), idx.data_ptr(), B, N, C, idx.shape[2], float(slope),
+                      out.data_ptr(), arg.data_ptr(), _stream())
+        ctx.save_for_backward(out, arg)
+        ctx.slope = float(slope)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        out, arg = ctx.saved_tensors
+        B, N, C = out.shape
+        g = g.contiguous()
+        gPQ = torch.empty((B, N, 2 * C), dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            _lib.call("pc3d_edge_max_bwd_f32", g.data_ptr(), out.data_ptr(), arg.data_ptr(), B, N, C, ctx.slope,
+                      gPQ.data_ptr(), _stream())
+        return gPQ, None, None
+
+
+def edge_max(PQ, idx, slope=0.2):
+    """out[b,i,c] = leaky(max_j P[b,idx[b,i,j],c] + Q[b,i,c]) for PQ [B,N,2C] = [P | Q] (C % 4 == 0): the neighbour
+    reduction, the centre term and the activation of an EdgeConv layer in one launch; differentiable in PQ."""
+    _check(PQ, "PQ")
+    if PQ.shape[2] % 8:
+        raise ValueError("edge_max: PQ must be [B,N,2C] with C % 4 == 0")
+    return _EdgeMaxFn.apply(PQ.contiguous(), idx.contiguous(), slope)
+
+
 # ------------------------------------------------------------------------------------------------------
 # K12: AOF spectral front-end
 # ------------------------------------------------------------------------------------------------------

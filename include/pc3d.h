@@ -274,6 +274,13 @@ int pc3d_knn_feat_f32(const float* x, int B, int N, int C, int K, int32_t* idx, 
 int pc3d_gather_max_f32(const float* P, const int32_t* idx, const float* sign, int B, int N, int C, int K,
                         float* out, int32_t* arg, void* stream);
 int pc3d_gather_max_bwd_f32(const float* g, const int32_t* arg, int B, int N, int C, float* gP, void* stream);
+/* One EdgeConv layer's epilogue (model/dgcnn.py:299-313): PQ [B,N,2C] = [P | Q] from ONE GEMM against [U;V];
+ * out[b,i,c] = leaky_slope(max_j P[b,idx[b,i,j],c] + Q[b,i,c]), arg = the winning j. C % 4 == 0.
+ * Backward: gPQ [B,N,2C] overwritten: dQ = g * leaky'(out), dP scattered to arg (float atomics). */
+int pc3d_edge_max_f32(const float* PQ, const int32_t* idx, int B, int N, int C, int K, float slope,
+                      float* out, int32_t* arg, void* stream);
+int pc3d_edge_max_bwd_f32(const float* g, const float* out, const int32_t* arg, int B, int N, int C, float slope,
+                          float* gPQ, void* stream);
 
 /* K12  dense graph Laplacian L = D - A of the symmetrised kNN graph with Gaussian weights A_ij = exp(-|pi-pj|^2)
  * (attack/AOF/TAOF_attack.py:31-52, attack/AOF/Eval_AOF.py:72-93). idx [B,N,K] from pc3d_knn_f32 (self included, as

@@ -110,3 +110,23 @@ def test_dgcnn_logits_and_input_grad_vs_reference(dev, fx):
     idx = dg.knn(torch.from_numpy(fx["x"]).to(dev), 20).cpu().numpy()
     assert idx.dtype == np.int64
     assert _knn_sets_ok(fx["x"], idx, fx["xyz_knn"], 20) <= 0.01 * idx.shape[0] * idx.shape[1]
+
+
+@pytest.mark.parametrize("C", [64, 256, 12])
+def test_edge_max_fwd_bwd_vs_torch(ops, dev, C):
+    """ops.edge_max = leaky(max_j P_j + Q_i) on [P | Q] rows, forward and backward, vs torch gather/max/leaky."""
+    torch.manual_seed(C)
+    B, N, K = 2, 90, 7
+    PQ = torch.randn(B, N, 2 * C, device=dev, requires_grad=True)
+    idx = torch.randint(0, N, (B, N, K), device=dev, dtype=torch.int32)
+    out = ops.edge_max(PQ, idx, 0.2)
+    w = torch.randn_like(out)
+    (out * w).sum().backward()
+    g1 = PQ.grad.clone()
+    PQ.grad = None
+    P, Q = PQ[..., :C], PQ[..., C:]
+    nb = torch.gather(P.unsqueeze(1).expand(-1, N, -1, -1), 2, idx.long()[..., None].expand(-1, -1, -1, C))
+    ref = torch.nn.functional.leaky_relu(nb.max(dim=2)[0] + Q, 0.2)
+    torch.testing.assert_close(out, ref.detach())
+    (ref * w).sum().backward()
+    torch.testing.assert_close(g1, PQ.grad, rtol=1e-5, atol=1e-6)
