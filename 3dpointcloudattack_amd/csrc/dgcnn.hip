@@ -291,6 +291,69 @@ __global__ __launch_bounds__(256) void edge_max_bwd_kernel(const float* g, const
   atomicAdd(base + (int64_t)arg[o] * 2 * C + c, gp);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Global pooling head of DGCNN / CurveNet (model/dgcnn.py:317-320, model/curvenet.py:64-67):
+//   z = leaky_slope(Y) (slope 0 = ReLU); out[b, c] = max_i z[b,i,c]; out[b, C + c] = mean_i z[b,i,c]
+// in ONE pass over Y [B,N,C] (the reference: activation pass + two reductions + cat), and the backward
+//   gY[b,i,c] = leaky'(Y[b,i,c]) * (gmax[b,c] * [i == arg[b,c]] + gmean[b,c] / N)
+// in one pass as well (autograd: scatter into zeros + expand + add + activation backward).
+// Workgroup = (64 channels, cloud b); 4 row groups x 64 channels, fixed-order LDS combine => deterministic.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void act_pool_fwd_kernel(const float* Y, int N, int C, float slope, float* out,
+                                                           int32_t* arg) {
+  __shared__ float s_mx[4][64], s_sm[4][64];
+  __shared__ int s_ai[4][64];
+  const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+  const bool live = c < C;
+  const int rows = (N + 3) / 4, r0 = rg * rows, r1 = (r0 + rows < N) ? r0 + rows : N;
+  float mx = -__builtin_inff(), sm = 0.f;
+  int ai = r0 < N ? r0 : 0;
+  if (live) {
+    const float* col = Y + (int64_t)b * N * C + c;
+    for (int i = r0; i < r1; ++i) {
+      const float y = col[(int64_t)i * C];
+      const float z = y > 0.f ? y : y * slope;
+      sm += z;
+      if (z > mx) mx = z, ai = i;       // strict: lowest row wins ties (torch.max)
+    }
+  }
+  s_mx[rg][threadIdx.x & 63] = mx, s_sm[rg][threadIdx.x & 63] = sm, s_ai[rg][threadIdx.x & 63] = ai;
+  __syncthreads();
+  if (rg == 0 && live) {
+    const int l = threadIdx.x & 63;
+    float m = s_mx[0][l], t = s_sm[0][l];
+    int a = s_ai[0][l];
+#pragma unroll
+    for (int g = 1; g < 4; ++g) {
+      t += s_sm[g][l];
+      if (s_mx[g][l] > m) m = s_mx[g][l], a = s_ai[g][l];
+    }
+    out[(int64_t)b * 2 * C + c] = m;
+    out[(int64_t)b * 2 * C + C + c] = t / (float)N;
+    arg[(int64_t)b * C + c] = a;
+  }
+}
+
+__global__ __launch_bounds__(256) void act_pool_bwd_kernel(const float* Y, const float* gout, const int32_t* arg, int N,
+                                                           int C, float slope, float* gY) {
+  const int b = blockIdx.y;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;     // over N * C / 4 (float4 of channels)
+  const int c4 = C / 4;
+  if (e >= (int64_t)N * c4) return;
+  const int i = (int)(e / c4), c = 4 * (int)(e - (int64_t)i * c4);
+  const float4 y = *reinterpret_cast<const float4*>(Y + ((int64_t)b * N + i) * C + c);
+  const float4 gm = *reinterpret_cast<const float4*>(gout + (int64_t)b * 2 * C + c);
+  const float4 ga = *reinterpret_cast<const float4*>(gout + (int64_t)b * 2 * C + C + c);
+  const int4 a = *reinterpret_cast<const int4*>(arg + (int64_t)b * C + c);
+  const float inv = 1.f / (float)N;
+  float4 g;
+  g.x = (y.x > 0.f ? 1.f : slope) * ((a.x == i ? gm.x : 0.f) + ga.x * inv);
+  g.y = (y.y > 0.f ? 1.f : slope) * ((a.y == i ? gm.y : 0.f) + ga.y * inv);
+  g.z = (y.z > 0.f ? 1.f : slope) * ((a.z == i ? gm.z : 0.f) + ga.z * inv);
+  g.w = (y.w > 0.f ? 1.f : slope) * ((a.w == i ? gm.w : 0.f) + ga.w * inv);
+  *reinterpret_cast<float4*>(gY + ((int64_t)b * N + i) * C + c) = g;
+}
+
 }  // namespace pc3d
 
 using namespace pc3d;
@@ -371,5 +434,28 @@ extern "C" int pc3d_edge_max_bwd_f32(const float* g, const float* out, const int
   hipLaunchKernelGGL(edge_max_bwd_kernel, dim3((unsigned)(((int64_t)N * C + 255) / 256), B), dim3(256), 0, st, g, out,
                      arg, N, C, slope, gPQ);
   PC3D_LAUNCH_CHECK("pc3d_edge_max_bwd_f32");
+  return PC3D_OK;
+}
+
+extern "C" int pc3d_act_pool_f32(const float* Y, int B, int N, int C, float slope, float* out, int32_t* arg,
+                                 void* stream) {
+  PC3D_REQUIRE(B >= 0 && N >= 1 && C >= 4 && C % 4 == 0, "pc3d_act_pool_f32: bad sizes B=%d N=%d C=%d (C %% 4 == 0)", B, N, C);
+  PC3D_REQUIRE(B <= 65535, "pc3d_act_pool_f32: B=%d exceeds grid.y limit", B);
+  if (B == 0) return PC3D_OK;
+  PC3D_REQUIRE(Y && out && arg, "pc3d_act_pool_f32: null pointer");
+  hipLaunchKernelGGL(act_pool_fwd_kernel, dim3(cdiv(C, 64), B), dim3(256), 0, as_stream(stream), Y, N, C, slope, out, arg);
+  PC3D_LAUNCH_CHECK("pc3d_act_pool_f32");
+  return PC3D_OK;
+}
+
+extern "C" int pc3d_act_pool_bwd_f32(const float* Y, const float* gout, const int32_t* arg, int B, int N, int C,
+                                     float slope, float* gY, void* stream) {
+  PC3D_REQUIRE(B >= 0 && N >= 1 && C >= 4 && C % 4 == 0, "pc3d_act_pool_bwd_f32: bad sizes");
+  PC3D_REQUIRE(B <= 65535, "pc3d_act_pool_bwd_f32: B=%d exceeds grid.y limit", B);
+  if (B == 0) return PC3D_OK;
+  PC3D_REQUIRE(Y && gout && arg && gY, "pc3d_act_pool_bwd_f32: null pointer");
+  hipLaunchKernelGGL(act_pool_bwd_kernel, dim3((unsigned)(((int64_t)N * (C / 4) + 255) / 256), B), dim3(256), 0,
+                     as_stream(stream), Y, gout, arg, N, C, slope, gY);
+  PC3D_LAUNCH_CHECK("pc3d_act_pool_bwd_f32");
   return PC3D_OK;
 }

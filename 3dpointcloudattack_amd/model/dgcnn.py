@@ -102,8 +102,7 @@ class DGCNN(_FrozenFusedMixin, nn.Module):
             f = ops.edge_max(PQ, idx, 0.2)                  # leaky(max_j P_j + Q_i) == max_j leaky(bn(conv(e_ij)))
             feats.append(f)
         g = torch.cat(feats, dim=2)                         # [B,N,512]
-        g = F.leaky_relu(F.linear(g, *c5), negative_slope=0.2)
-        g = torch.cat((g.max(dim=1)[0], g.mean(dim=1)), 1)  # adaptive max / avg pool over N
+        g = ops.act_maxmean_pool(F.linear(g, *c5), 0.2)     # leaky + adaptive max / avg pool over N in one pass
         g = F.leaky_relu(F.linear(g, *head[0]), negative_slope=0.2)
         g = F.leaky_relu(F.linear(g, *head[1]), negative_slope=0.2)
         g = F.linear(g, *head[2])

@@ -654,6 +654,38 @@ def gather_max(P, idx):
     return _GatherMaxFn.apply(P, idx.contiguous())
 
 
+class _ActPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, Y, slope):
+        B, N, C = Y.shape
+        out = torch.empty((B, 2 * C), dtype=torch.float32, device=Y.device)
+        arg = torch.empty((B, C), dtype=torch.int32, device=Y.device)
+        with torch.cuda.device(Y.device):
+            _lib.call("pc3d_act_pool_f32", Y.data_ptr(), B, N, C, float(slope), out.data_ptr(), arg.data_ptr(), _stream())
+        ctx.save_for_backward(Y, arg)
+        ctx.slope = float(slope)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        Y, arg = ctx.saved_tensors
+        B, N, C = Y.shape
+        g = g.contiguous()
+        gY = torch.empty_like(Y)
+        with torch.cuda.device(g.device):
+            _lib.call("pc3d_act_pool_bwd_f32", Y.data_ptr(), g.data_ptr(), arg.data_ptr(), B, N, C, ctx.slope,
+                      gY.data_ptr(), _stream())
+        return gY, None
+
+
+def act_maxmean_pool(Y, slope):
+    """[max_i z | mean_i z] over dim 1 of z = leaky_relu(Y, slope) (slope 0: ReLU) for Y [B,N,C], C % 4 == 0 -> [B,2C]."""
+    _check(Y, "Y")
+    if Y.dim() != 3 or Y.shape[2] % 4:
+        raise ValueError("act_maxmean_pool: Y must be [B,N,C] with C % 4 == 0")
+    return _ActPoolFn.apply(Y.contiguous(), slope)
+
+
 class _EdgeMaxFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, PQ, idx, slope):

@@ -279,6 +279,12 @@ int pc3d_gather_max_bwd_f32(const float* g, const int32_t* arg, int B, int N, in
  * Backward: gPQ [B,N,2C] overwritten: dQ = g * leaky'(out), dP scattered to arg (float atomics). */
 int pc3d_edge_max_f32(const float* PQ, const int32_t* idx, int B, int N, int C, int K, float slope,
                       float* out, int32_t* arg, void* stream);
+/* Global pooling head (model/dgcnn.py:317-320, model/curvenet.py:64-67): z = leaky_slope(Y) (slope 0: ReLU),
+ * out[b, 0:C] = max_i z[b,i,:], out[b, C:2C] = mean_i z[b,i,:], arg [B,C] = lowest arg-max row; one pass over
+ * Y [B,N,C]. Backward: gY overwritten in one pass from gout [B,2C]. C % 4 == 0. Deterministic. */
+int pc3d_act_pool_f32(const float* Y, int B, int N, int C, float slope, float* out, int32_t* arg, void* stream);
+int pc3d_act_pool_bwd_f32(const float* Y, const float* gout, const int32_t* arg, int B, int N, int C, float slope,
+                          float* gY, void* stream);
 int pc3d_edge_max_bwd_f32(const float* g, const float* out, const int32_t* arg, int B, int N, int C, float slope,
                           float* gPQ, void* stream);
 

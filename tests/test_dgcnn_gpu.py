@@ -130,3 +130,20 @@ def test_edge_max_fwd_bwd_vs_torch(ops, dev, C):
     torch.testing.assert_close(out, ref.detach())
     (ref * w).sum().backward()
     torch.testing.assert_close(g1, PQ.grad, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("B,N,C,slope", [(2, 100, 64, 0.2), (3, 1024, 1024, 0.2), (1, 3, 8, 0.0), (2, 257, 132, 0.0)])
+def test_act_maxmean_pool_fwd_bwd_vs_torch(ops, dev, B, N, C, slope):
+    torch.manual_seed(N + C)
+    Y = torch.randn(B, N, C, device=dev, requires_grad=True)
+    out = ops.act_maxmean_pool(Y, slope)
+    w = torch.randn_like(out)
+    (out * w).sum().backward()
+    g1 = Y.grad.clone()
+    Y.grad = None
+    z = torch.nn.functional.leaky_relu(Y, slope)
+    ref = torch.cat((z.max(dim=1)[0], z.mean(dim=1)), 1)
+    torch.testing.assert_close(out, ref.detach(), rtol=1e-5, atol=1e-6)
+    (ref * w).sum().backward()
+    torch.testing.assert_close(g1, Y.grad, rtol=1e-5, atol=1e-7)
+    assert torch.equal(ops.act_maxmean_pool(Y, slope), out)          # deterministic
