@@ -205,12 +205,10 @@ __global__ __launch_bounds__(256) void group_gather_bwd_kernel(GatherBwdArgs a) 
 // PointNet++ set-abstraction layer, model/pointnet2_utils.py:190-197) to x. `max` hands each channel's gradient to ONE
 // row of its group, so dL/dx[g,r,:] = sum_{c: arg[g,c]==r, out[g,c]>0} gout[g,c] W[c,:] is a sparse row accumulation
 // (C3 rows of W per group) instead of the dense [ns x C3] x [C3 x C2] product autograd runs on a tensor that is zero
-// except for one entry per (group, channel). Workgroup = (group, block of 128 input channels); thread (k, half) owns
-// column k of the rows of its parity and walks the channels in ascending order => deterministic, no atomics.
+// except for one entry per (group, channel). Workgroup = (group, block of 128 input channels).
 // ---------------------------------------------------------------------------------------------------------
-constexpr int GMB_T = 256;
-constexpr int GMB_KB = 128;      // input-channel block
-constexpr int GMB_MAXNS = 128;   // rows per group (LDS: 128 x 129 floats)
+constexpr int GMB_T = 128;       // threads = input-channel columns handled by a workgroup
+constexpr int GMB_MAXNS = 128;   // rows per group
 
 struct GroupMaxBwdArgs {
   const float* gout;    // [G,C3]
@@ -221,49 +219,70 @@ struct GroupMaxBwdArgs {
   float* gx;            // [G,ns,C2]
 };
 
+// Thread = one input channel k of one group; its NS row accumulators live in REGISTERS and are addressed with the
+// winning row of each channel, which is the same for every thread (a scalar load of arg[g,c]) — so the compiler indexes
+// the register file through M0 (v_movrel), and a channel costs one coalesced weight load + one FMA: no LDS, no
+// barrier, no atomics; channels are walked in ascending order => deterministic.
+using gmb_f32x32 = __attribute__((ext_vector_type(32))) float;
+using gmb_f32x16 = __attribute__((ext_vector_type(16))) float;
+
+template <int NS>
 __global__ __launch_bounds__(GMB_T) void group_max_linear_bwd_kernel(GroupMaxBwdArgs a) {
+  constexpr int NV = (NS + 31) / 32;          // accumulators as 32-wide register vectors: a uniform dynamic index into
+  const int g = blockIdx.x;                    // one of those lowers to M0-relative register addressing (v_movrel)
+  const int k = blockIdx.y * blockDim.x + threadIdx.x;
+  const bool live = k < a.C2;
+  const float* wcol = a.W + (live ? k : 0);
+  const int64_t base = (int64_t)g * a.C3;
+  gmb_f32x32 acc[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v)
+#pragma unroll
+    for (int e = 0; e < 32; ++e) acc[v][e] = 0.f;
+  // the group's (row, masked gradient) pairs: one coalesced round trip into LDS, then read 8 channels ahead so the LDS
+  // latency of the register index is paid once per 8 channels, not per channel
   extern __shared__ float gmb_lds[];
-  float* acc = gmb_lds;                                      // [ns][GMB_KB + 1]
-  float* s_g = acc + a.ns * (GMB_KB + 1);                    // [C3] masked upstream gradient
-  int* s_r = reinterpret_cast<int*>(s_g + a.C3);             // [C3] winning row
-  const int g = blockIdx.x, kb = blockIdx.y * GMB_KB;
-  const int tid = threadIdx.x, k = tid & (GMB_KB - 1), half = tid >> 7;
-  for (int i = tid; i < a.ns * (GMB_KB + 1); i += GMB_T) acc[i] = 0.f;
-  for (int c = tid; c < a.C3; c += GMB_T) {
-    const int64_t e = (int64_t)g * a.C3 + c;
-    s_g[c] = (a.out[e] > 0.f) ? a.gout[e] : 0.f;
-    s_r[c] = (int)a.arg[e];
+  float* s_g = gmb_lds;                                 // [C3]
+  int* s_r = reinterpret_cast<int*>(gmb_lds + a.C3);    // [C3]
+  for (int c = threadIdx.x; c < a.C3; c += blockDim.x) {
+    s_g[c] = (a.out[base + c] > 0.f) ? a.gout[base + c] : 0.f;
+    s_r[c] = (int)a.arg[base + c];
   }
   __syncthreads();
-  if (kb + k < a.C2) {
-    const float* wcol = a.W + kb + k;
-    int c = 0;
-    for (; c + 4 <= a.C3; c += 4) {                          // 4 independent weight loads in flight
-      float w[4];
+  int c = 0;
+  for (; c + 8 <= a.C3; c += 8) {
+    int rr[8];
+    float gg[8], ww[8];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) w[e] = wcol[(int64_t)(c + e) * a.C2];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int r = s_r[c + e];
-        if ((r & 1) == half) {
-          float* d = acc + r * (GMB_KB + 1) + k;
-          *d = __builtin_fmaf(s_g[c + e], w[e], *d);
-        }
-      }
+    for (int e = 0; e < 8; ++e) {
+      rr[e] = s_r[c + e];
+      gg[e] = s_g[c + e];
+      ww[e] = wcol[(int64_t)(c + e) * a.C2];
     }
-    for (; c < a.C3; ++c) {
-      const int r = s_r[c];
-      if ((r & 1) == half) {
-        float* d = acc + r * (GMB_KB + 1) + k;
-        *d = __builtin_fmaf(s_g[c], wcol[(int64_t)c * a.C2], *d);
-      }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int r = __builtin_amdgcn_readfirstlane(rr[e]);
+      const int hi = r >> 5, lo = r & 31;
+#pragma unroll
+      for (int v = 0; v < NV; ++v)
+        if (hi == v) acc[v][lo] = __builtin_fmaf(gg[e], ww[e], acc[v][lo]);
     }
   }
-  __syncthreads();
-  const int kw = (a.C2 - kb) < GMB_KB ? (a.C2 - kb) : GMB_KB;
-  for (int i = tid; i < a.ns * kw; i += GMB_T) {
-    const int r = i / kw, kk = i - r * kw;
-    a.gx[((int64_t)g * a.ns + r) * a.C2 + kb + kk] = acc[r * (GMB_KB + 1) + kk];
+  for (; c < a.C3; ++c) {
+    const int r = __builtin_amdgcn_readfirstlane(s_r[c]);
+    const float gv = s_g[c], w = wcol[(int64_t)c * a.C2];
+    const int hi = r >> 5, lo = r & 31;
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+      if (hi == v) acc[v][lo] = __builtin_fmaf(gv, w, acc[v][lo]);
+  }
+  if (live) {
+    float* o = a.gx + (int64_t)g * a.ns * a.C2 + k;
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+      for (int e = 0; e < 32; ++e)
+        if (32 * v + e < a.ns) o[(int64_t)(32 * v + e) * a.C2] = acc[v][e];
   }
 }
 
@@ -349,8 +368,13 @@ extern "C" int pc3d_group_max_linear_bwd_f32(const float* gout, const float* out
   if (G == 0) return PC3D_OK;
   PC3D_REQUIRE(gout && out && arg && W && gx, "pc3d_group_max_linear_bwd_f32: null pointer");
   GroupMaxBwdArgs a{gout, out, arg, W, ns, C2, C3, gx};
-  const size_t lds = ((size_t)ns * (GMB_KB + 1) + 2 * (size_t)C3) * sizeof(float);
-  hipLaunchKernelGGL(group_max_linear_bwd_kernel, dim3(G, cdiv(C2, GMB_KB)), dim3(GMB_T), lds, as_stream(stream), a);
+  const int bt = C2 <= 64 ? 64 : GMB_T;          // one wave per group when the layer is narrow
+  const dim3 grid(G, cdiv(C2, bt)), block(bt);
+  hipStream_t st = as_stream(stream);
+  const size_t lds = 2 * (size_t)C3 * sizeof(float);
+  if (ns <= 32) hipLaunchKernelGGL(group_max_linear_bwd_kernel<32>, grid, block, lds, st, a);
+  else if (ns <= 64) hipLaunchKernelGGL(group_max_linear_bwd_kernel<64>, grid, block, lds, st, a);
+  else hipLaunchKernelGGL(group_max_linear_bwd_kernel<128>, grid, block, lds, st, a);
   PC3D_LAUNCH_CHECK("pc3d_group_max_linear_bwd_f32");
   return PC3D_OK;
 }
