@@ -44,6 +44,7 @@ SIGNATURES = {
     "pc3d_clip_f32": _PTS + _PTS + _PTS + [_I, _I, _I, _F] + _PTS + [_P],
     "pc3d_adam_clip_step_f32": _PTS + _PTS + [_P, _P] + _PTS + _PTS + [_I, _I, _D, _D, _D, _D, _F, _P, _I, _P],
     "pc3d_i32_add": [_P, _I, _P],
+    "pc3d_group_linear_max_f32": [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
     "pc3d_act_pool_f32": [_P, _I, _I, _I, _F, _P, _P, _P],
     "pc3d_act_pool_bwd_f32": [_P, _P, _P, _I, _I, _I, _F, _P, _P],
     "pc3d_edge_max_f32": [_P, _P, _I, _I, _I, _I, _F, _P, _P, _P],

@@ -286,6 +286,94 @@ __global__ __launch_bounds__(GMB_T) void group_max_linear_bwd_kernel(GroupMaxBwd
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Forward of the same operator: out[g,c] = max_r relu(x[g,r,:] . W[c,:] + b[c]), arg[g,c] = winning row — the last
+// 1x1 conv + ReLU + max over the group of a set-abstraction layer (model/pointnet2_utils.py:190-197) WITHOUT writing
+// the [G*ns, C3] activation (537 MB per layer at SSG's B=64, N=2048) and reading it back for the max.
+// Workgroup = group g; wave w owns rows 32w..32w+31 of it: its A operands (32 rows x C2) are loaded once into
+// registers and every 32-column block of W streams past them on v_mfma_f32_32x32x2_f32 (rows on the MFMA row index, so
+// the max over the wave's rows is an in-register reduction + one cross-half shuffle, like the PointNet tower);
+// several waves (ns > 32) combine through LDS in ascending row order (lowest row wins ties, as torch.max).
+// ---------------------------------------------------------------------------------------------------------
+using glm_f32x16 = __attribute__((ext_vector_type(16))) float;
+
+struct GroupLinMaxArgs {
+  const float* x;      // [G,ns,C2]
+  const float* W;      // [C3,C2]
+  const float* b;      // [C3]
+  int ns, C2, C3;
+  float* out;          // [G,C3]
+  int64_t* arg;        // [G,C3]
+};
+
+template <int NT>     // float4 per lane along K: C2 <= 8 * NT
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void group_linear_max_kernel(GroupLinMaxArgs a) {
+  extern __shared__ float glm_lds[];           // [nw][C3] values + [nw][C3] rows (only when more than one wave)
+  const int g = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int nt = a.C2 / 8;
+  const int r0 = 32 * wave;
+  const int row = (r0 + r < a.ns) ? r0 + r : a.ns - 1;              // clamped: masked out of the max below
+  const float* xr = a.x + ((int64_t)g * a.ns + row) * a.C2 + 4 * h;
+  float4 av[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) av[t] = (t < nt) ? *reinterpret_cast<const float4*>(xr + 8 * t) : make_float4(0.f, 0.f, 0.f, 0.f);
+  // W streams from L2 one float4 per lane per 4 MFMAs; nothing of it is kept: the small register footprint (about 4
+  // waves per SIMD) is what hides the load latency here (double-buffering whole blocks in registers measured slower)
+  const int ncb = a.C3 / 32;
+  for (int cb = 0; cb < ncb; ++cb) {
+    const float* wr = a.W + (int64_t)(cb * 32 + r) * a.C2 + 4 * h;
+    glm_f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if (t < nt) {   // D[row = group row][col = output channel]
+        const float4 bw = *reinterpret_cast<const float4*>(wr + 8 * t);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].x, bw.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].y, bw.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].z, bw.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].w, bw.w, acc, 0, 0, 0);
+      }
+    }
+    float best = -__builtin_inff();
+    int bi = r0;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int rr = r0 + (e & 3) + 8 * (e >> 2) + 4 * h;          // ascending in e for fixed h
+      if (rr < a.ns && acc[e] > best) best = acc[e], bi = rr;
+    }
+    const float ov = __shfl_xor(best, 32, 64);
+    const int oi = __shfl_xor(bi, 32, 64);
+    if (ov > best || (ov == best && oi < bi)) best = ov, bi = oi;
+    const int ch = cb * 32 + r;
+    if (nw == 1) {
+      if (h == 0) {
+        a.out[(int64_t)g * a.C3 + ch] = fmaxf(best + a.b[ch], 0.f);
+        a.arg[(int64_t)g * a.C3 + ch] = bi;
+      }
+    } else if (h == 0) {
+      glm_lds[wave * a.C3 + ch] = best;
+      reinterpret_cast<int*>(glm_lds + nw * a.C3)[wave * a.C3 + ch] = bi;
+    }
+  }
+  if (nw > 1) {
+    __syncthreads();
+    const int* pi = reinterpret_cast<const int*>(glm_lds + nw * a.C3);
+    for (int ch = threadIdx.x; ch < a.C3; ch += blockDim.x) {
+      float best = glm_lds[ch];
+      int bi = pi[ch];
+      for (int w = 1; w < nw; ++w) {
+        const float v = glm_lds[w * a.C3 + ch];
+        if (v > best) best = v, bi = pi[w * a.C3 + ch];           // ascending wave = ascending rows: strict >
+      }
+      a.out[(int64_t)g * a.C3 + ch] = fmaxf(best + a.b[ch], 0.f);
+      a.arg[(int64_t)g * a.C3 + ch] = bi;
+    }
+  }
+}
+
 }  // namespace pc3d
 
 
@@ -376,5 +464,22 @@ extern "C" int pc3d_group_max_linear_bwd_f32(const float* gout, const float* out
   else if (ns <= 64) hipLaunchKernelGGL(group_max_linear_bwd_kernel<64>, grid, block, lds, st, a);
   else hipLaunchKernelGGL(group_max_linear_bwd_kernel<128>, grid, block, lds, st, a);
   PC3D_LAUNCH_CHECK("pc3d_group_max_linear_bwd_f32");
+  return PC3D_OK;
+}
+
+extern "C" int pc3d_group_linear_max_f32(const float* x, const float* W, const float* b, int G, int ns, int C2, int C3,
+                                         float* out, int64_t* arg, void* stream) {
+  PC3D_REQUIRE(G >= 0 && ns >= 1 && ns <= 128 && C2 >= 8 && C2 <= 128 && C2 % 8 == 0 && C3 >= 32 && C3 % 32 == 0 && C3 <= 4096,
+               "pc3d_group_linear_max_f32: unsupported sizes ns=%d C2=%d C3=%d (ns <= 128, C2 %% 8 == 0 <= 128, C3 %% 32 == 0)",
+               ns, C2, C3);
+  if (G == 0) return PC3D_OK;
+  PC3D_REQUIRE(x && W && b && out && arg, "pc3d_group_linear_max_f32: null pointer");
+  GroupLinMaxArgs a{x, W, b, ns, C2, C3, out, arg};
+  const int nw = cdiv(ns, 32);
+  const size_t lds = nw > 1 ? (size_t)2 * nw * C3 * sizeof(float) : 0;
+  hipStream_t st = as_stream(stream);
+  if (C2 <= 64) hipLaunchKernelGGL(group_linear_max_kernel<8>, dim3(G), dim3(64 * nw), lds, st, a);
+  else hipLaunchKernelGGL(group_linear_max_kernel<16>, dim3(G), dim3(64 * nw), lds, st, a);
+  PC3D_LAUNCH_CHECK("pc3d_group_linear_max_f32");
   return PC3D_OK;
 }

@@ -745,8 +745,17 @@ class _LinearReLUMaxFn(torch.autograd.Function):
     def forward(ctx, x, w, b):
         # x [G,ns,C2] -> out [G,C3]; GEMM with bias+ReLU epilogue, then torch's max (values + winning row)
         G, ns, C2 = x.shape
-        y = torch._addmm_activation(b, x.reshape(G * ns, C2), w.t(), use_gelu=False).view(G, ns, -1)
-        out, arg = y.max(dim=1)
+        C3 = w.shape[0]
+        if C2 % 8 == 0 and C2 <= 128 and C3 % 32 == 0 and C3 <= 4096:
+            # fused fp32-MFMA kernel: the [G*ns, C3] activation is never written
+            out = torch.empty((G, C3), dtype=torch.float32, device=x.device)
+            arg = torch.empty((G, C3), dtype=torch.int64, device=x.device)
+            with torch.cuda.device(x.device):
+                _lib.call("pc3d_group_linear_max_f32", x.data_ptr(), w.data_ptr(), b.data_ptr(), G, ns, C2, C3,
+                          out.data_ptr(), arg.data_ptr(), _stream())
+        else:
+            y = torch._addmm_activation(b, x.reshape(G * ns, C2), w.t(), use_gelu=False).view(G, ns, -1)
+            out, arg = y.max(dim=1)
         ctx.save_for_backward(out, arg, w)
         ctx.shape = (G, ns, C2)
         return out

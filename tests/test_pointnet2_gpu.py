@@ -192,7 +192,8 @@ def test_classifier_logits_and_input_grad_vs_reference(dev, fx, name):
     assert np.linalg.norm(got - go) / np.linalg.norm(go) < 1e-2
 
 
-@pytest.mark.parametrize("G,ns,C2,C3", [(7, 32, 64, 128), (3, 128, 512, 1024), (5, 16, 33, 40), (2, 1, 8, 8)])
+@pytest.mark.parametrize("G,ns,C2,C3", [(7, 32, 64, 128), (3, 128, 512, 1024), (5, 16, 33, 40), (2, 1, 8, 8), (9, 64, 128, 256),
+                                        (4, 128, 96, 128), (6, 16, 32, 64), (3, 50, 72, 96), (2, 1, 8, 32), (300, 32, 64, 128)])
 def test_linear_relu_max_fwd_bwd_vs_autograd(dev, G, ns, C2, C3):
     """ops.linear_relu_max (GEMM epilogue + sparse backward through the max) vs relu(linear).max with autograd."""
     ops = importlib.import_module("3dpointcloudattack_amd.ops")
