@@ -177,26 +177,64 @@ struct GatherBwdArgs {
   float* gf;               // [B,N,D] contiguous or null
 };
 
+// Workgroup = one group (b, s), its rows spread over the 4 waves. Ball query pads a group by repeating its FIRST index
+// (56-65 % of all entries at SSG's sizes), and those repeats all land on one point: their rows are summed in registers
+// (+ one LDS combine across the waves) and sent as ONE atomic per channel instead of one per row; the centre term
+// (-sum over the whole group on xyz) is folded the same way.
+constexpr int GGB_MAXC = 1024;   // channels whose padded-tail sum fits the LDS combine buffer
+
 __global__ __launch_bounds__(256) void group_gather_bwd_kernel(GatherBwdArgs a) {
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  const int b = blockIdx.y;
-  if (row >= (int64_t)a.S * a.ns) return;
-  const int s = (int)(row / a.ns);
-  const int i = a.idx[((int64_t)b * a.S) * a.ns + row];
-  const float* g = a.g + (((int64_t)b * a.S) * a.ns + row) * a.C;
-  int c0 = 0;
-  if (a.has_x) {
-    if (a.gx && lane < 3) {
-      const float v = g[lane];
-      atomicAdd(a.gx + ((int64_t)b * a.N + i) * 3 + lane, v);
-      if (a.cidx) atomicAdd(a.gx + ((int64_t)b * a.N + a.cidx[(int64_t)b * a.S + s]) * 3 + lane, -v);
+  __shared__ float s_tail[4][GGB_MAXC];
+  __shared__ float s_ctr[4][4];
+  const int s = blockIdx.x, b = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int32_t* idx = a.idx + ((int64_t)b * a.S + s) * a.ns;
+  const float* gbase = a.g + (((int64_t)b * a.S + s) * a.ns) * a.C;
+  const int i0 = idx[0];
+  const int c0 = a.has_x ? 3 : 0;
+  const bool merge = a.C <= GGB_MAXC;
+  // per-lane partial sums over this wave's padded rows, channel chunks of 64
+  float tail[GGB_MAXC / 64];
+#pragma unroll
+  for (int q = 0; q < GGB_MAXC / 64; ++q) tail[q] = 0.f;
+  float csum = 0.f;                                       // lane < 3: sum of g[..., lane] over this wave's rows
+  for (int j = wave; j < a.ns; j += 4) {
+    const int i = idx[j];
+    const float* g = gbase + (int64_t)j * a.C;
+    if (a.has_x && a.gx && lane < 3) csum += g[lane];
+    if (merge && j > 0 && i == i0) {                      // a repeat of the first index: accumulate, no atomics
+#pragma unroll
+      for (int q = 0; q < GGB_MAXC / 64; ++q)
+        if (64 * q + lane < a.C) tail[q] += g[64 * q + lane];
+      continue;
     }
-    c0 = 3;
+    if (a.has_x && a.gx && lane < 3) atomicAdd(a.gx + ((int64_t)b * a.N + i) * 3 + lane, g[lane]);
+    if (a.gf) {
+      float* f = a.gf + ((int64_t)b * a.N + i) * a.D;
+      for (int d = lane; d < a.D; d += 64) atomicAdd(f + d, g[c0 + d]);
+    }
   }
-  if (a.gf) {
-    float* f = a.gf + ((int64_t)b * a.N + i) * a.D;
-    for (int d = lane; d < a.D; d += 64) atomicAdd(f + d, g[c0 + d]);
+  if (merge) {
+#pragma unroll
+    for (int q = 0; q < GGB_MAXC / 64; ++q)
+      if (64 * q + lane < a.C) s_tail[wave][64 * q + lane] = tail[q];
+  }
+  if (lane < 3) s_ctr[wave][lane] = csum;
+  __syncthreads();
+  if (merge) {
+    for (int c = threadIdx.x; c < a.C; c += 256) {
+      const float v = (s_tail[0][c] + s_tail[1][c]) + (s_tail[2][c] + s_tail[3][c]);
+      if (v == 0.f) continue;
+      if (c < c0) {
+        if (a.gx) atomicAdd(a.gx + ((int64_t)b * a.N + i0) * 3 + c, v);
+      } else if (a.gf) {
+        atomicAdd(a.gf + ((int64_t)b * a.N + i0) * a.D + (c - c0), v);
+      }
+    }
+  }
+  if (a.has_x && a.gx && a.cidx && threadIdx.x < 3) {
+    const float v = (s_ctr[0][threadIdx.x] + s_ctr[1][threadIdx.x]) + (s_ctr[2][threadIdx.x] + s_ctr[3][threadIdx.x]);
+    atomicAdd(a.gx + ((int64_t)b * a.N + a.cidx[(int64_t)b * a.S + s]) * 3 + threadIdx.x, -v);
   }
 }
 
@@ -444,7 +482,7 @@ extern "C" int pc3d_group_gather_bwd_f32(const float* g_out, const int32_t* idx,
     return (int)e;
   }
   GatherBwdArgs a{g_out, idx, center_idx, N, S, ns, D, (has_xyz ? 3 : 0) + D, has_xyz, grad_xyz, grad_feat};
-  hipLaunchKernelGGL(group_gather_bwd_kernel, dim3(cdiv(S * ns, 4), B), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(group_gather_bwd_kernel, dim3(S, B), dim3(256), 0, st, a);
   PC3D_LAUNCH_CHECK("pc3d_group_gather_bwd_f32");
   return PC3D_OK;
 }
