@@ -255,6 +255,8 @@ struct GroupMaxBwdArgs {
   const float* W;       // [C3,C2]
   int ns, C2, C3;
   float* gx;            // [G,ns,C2]
+  const float* xin;     // [G,ns,C2] or null: the operator's input when it is itself a ReLU output — gx is then
+                        // zeroed where xin <= 0, i.e. the previous layer's ReLU backward is applied on the way out
 };
 
 // Thread = one input channel k of one group; its NS row accumulators live in REGISTERS and are addressed with the
@@ -316,11 +318,18 @@ __global__ __launch_bounds__(GMB_T) void group_max_linear_bwd_kernel(GroupMaxBwd
   }
   if (live) {
     float* o = a.gx + (int64_t)g * a.ns * a.C2 + k;
+    const float* xi = a.xin ? a.xin + (int64_t)g * a.ns * a.C2 + k : nullptr;
 #pragma unroll
-    for (int v = 0; v < NV; ++v)
+    for (int v = 0; v < NV; ++v) {
+      float m[32];
+      if (xi) {   // all 32 mask loads of this register vector in flight before the first store
+#pragma unroll
+        for (int e = 0; e < 32; ++e) m[e] = (32 * v + e < a.ns) ? xi[(int64_t)(32 * v + e) * a.C2] : 0.f;
+      }
 #pragma unroll
       for (int e = 0; e < 32; ++e)
-        if (32 * v + e < a.ns) o[(int64_t)(32 * v + e) * a.C2] = acc[v][e];
+        if (32 * v + e < a.ns) o[(int64_t)(32 * v + e) * a.C2] = (xi && !(m[e] > 0.f)) ? 0.f : acc[v][e];
+    }
   }
 }
 
@@ -488,12 +497,12 @@ extern "C" int pc3d_group_gather_bwd_f32(const float* g_out, const int32_t* idx,
 }
 
 extern "C" int pc3d_group_max_linear_bwd_f32(const float* gout, const float* out, const int64_t* arg, const float* W,
-                                             int G, int ns, int C2, int C3, float* gx, void* stream) {
+                                             int G, int ns, int C2, int C3, const float* xin, float* gx, void* stream) {
   PC3D_REQUIRE(G >= 0 && ns >= 1 && ns <= GMB_MAXNS && C2 >= 1 && C3 >= 1 && C3 <= 4096,
                "pc3d_group_max_linear_bwd_f32: bad sizes G=%d ns=%d C2=%d C3=%d (ns <= 128, C3 <= 4096)", G, ns, C2, C3);
   if (G == 0) return PC3D_OK;
   PC3D_REQUIRE(gout && out && arg && W && gx, "pc3d_group_max_linear_bwd_f32: null pointer");
-  GroupMaxBwdArgs a{gout, out, arg, W, ns, C2, C3, gx};
+  GroupMaxBwdArgs a{gout, out, arg, W, ns, C2, C3, gx, xin};
   const int bt = C2 <= 64 ? 64 : GMB_T;          // one wave per group when the layer is narrow
   const dim3 grid(G, cdiv(C2, bt)), block(bt);
   hipStream_t st = as_stream(stream);

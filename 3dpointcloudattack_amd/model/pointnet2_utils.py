@@ -37,12 +37,11 @@ class _LinearReLUFn(torch.autograd.Function):
 def _mlp_max(x, layers):
     """[B,S,ns,C0] -> [B,S,C_last]: the shared MLP of a set-abstraction layer and the max over the group; the last
     layer + max use the sparse-backward operator when the group fits it."""
-    for w, b in layers[:-1]:
-        x = _linear_relu(x, w, b)
-    w, b = layers[-1]
     if x.shape[2] <= ops.GROUP_MAX_NS and x.is_cuda:
-        return ops.linear_relu_max(x, w, b)
-    return torch.max(_linear_relu(x, w, b), 2)[0]
+        return ops.mlp_relu_max(x, layers)
+    for w, b in layers:
+        x = _linear_relu(x, w, b)
+    return torch.max(x, 2)[0]
 
 
 def _linear_relu(x, w, b):

@@ -745,17 +745,7 @@ class _LinearReLUMaxFn(torch.autograd.Function):
     def forward(ctx, x, w, b):
         # x [G,ns,C2] -> out [G,C3]; GEMM with bias+ReLU epilogue, then torch's max (values + winning row)
         G, ns, C2 = x.shape
-        C3 = w.shape[0]
-        if C2 % 8 == 0 and C2 <= 128 and C3 % 32 == 0 and C3 <= 4096:
-            # fused fp32-MFMA kernel: the [G*ns, C3] activation is never written
-            out = torch.empty((G, C3), dtype=torch.float32, device=x.device)
-            arg = torch.empty((G, C3), dtype=torch.int64, device=x.device)
-            with torch.cuda.device(x.device):
-                _lib.call("pc3d_group_linear_max_f32", x.data_ptr(), w.data_ptr(), b.data_ptr(), G, ns, C2, C3,
-                          out.data_ptr(), arg.data_ptr(), _stream())
-        else:
-            y = torch._addmm_activation(b, x.reshape(G * ns, C2), w.t(), use_gelu=False).view(G, ns, -1)
-            out, arg = y.max(dim=1)
+        out, arg = _group_linear_max_fwd(x, w, b)      # fused fp32-MFMA kernel: no [G*ns, C3] activation
         ctx.save_for_backward(out, arg, w)
         ctx.shape = (G, ns, C2)
         return out
@@ -768,8 +758,72 @@ class _LinearReLUMaxFn(torch.autograd.Function):
         gx = torch.empty((G, ns, C2), dtype=torch.float32, device=g.device)
         with torch.cuda.device(g.device):
             _lib.call("pc3d_group_max_linear_bwd_f32", g.data_ptr(), out.data_ptr(), arg.data_ptr(), w.data_ptr(),
-                      G, ns, C2, w.shape[0], gx.data_ptr(), _stream())
+                      G, ns, C2, w.shape[0], 0, gx.data_ptr(), _stream())
         return gx, None, None
+
+
+def _group_linear_max_fwd(x, w, b):
+    """(out [G,C3], arg [G,C3] int64) of max_r relu(x[g,r,:] @ w.T + b): fused MFMA kernel when the shape fits it."""
+    G, ns, C2 = x.shape
+    C3 = w.shape[0]
+    if C2 % 8 == 0 and C2 <= 128 and C3 % 32 == 0 and C3 <= 4096:
+        out = torch.empty((G, C3), dtype=torch.float32, device=x.device)
+        arg = torch.empty((G, C3), dtype=torch.int64, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.call("pc3d_group_linear_max_f32", x.data_ptr(), w.data_ptr(), b.data_ptr(), G, ns, C2, C3,
+                      out.data_ptr(), arg.data_ptr(), _stream())
+        return out, arg
+    y = torch._addmm_activation(b, x.reshape(G * ns, C2), w.t(), use_gelu=False).view(G, ns, -1)
+    return y.max(dim=1)
+
+
+class _MLPReLUMaxFn(torch.autograd.Function):
+    """The whole shared MLP of a set-abstraction layer + the max over the group, x [G,ns,C0] -> [G,C_last], with a
+    hand-written backward: hidden layers are GEMMs with a bias+ReLU epilogue; the last layer + max is the fused MFMA
+    launch; backward = sparse row accumulation through the max (which also applies the last hidden ReLU's mask), then
+    per hidden layer one GEMM and — except for the first — one mask pass. Frozen weights: only dL/dx."""
+
+    @staticmethod
+    def forward(ctx, x, *wb):
+        G, ns, C0 = x.shape
+        ws, bs = wb[0::2], wb[1::2]
+        acts = [x.reshape(G * ns, C0)]
+        for w, b in zip(ws[:-1], bs[:-1]):
+            acts.append(torch._addmm_activation(b, acts[-1], w.t(), use_gelu=False))
+        out, arg = _group_linear_max_fwd(acts[-1].view(G, ns, -1), ws[-1], bs[-1])
+        ctx.save_for_backward(out, arg, *acts[1:], *ws)
+        ctx.meta = (G, ns, C0, len(ws))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        G, ns, C0, nl = ctx.meta
+        saved = ctx.saved_tensors
+        out, arg = saved[0], saved[1]
+        acts, ws = saved[2:2 + nl - 1], saved[2 + nl - 1:]
+        g = g.contiguous()
+        C2 = ws[-1].shape[1]
+        gx = torch.empty((G * ns, C2), dtype=torch.float32, device=g.device)
+        last_hidden = acts[-1] if nl > 1 else None                     # ReLU output feeding the last layer (or raw x)
+        with torch.cuda.device(g.device):
+            _lib.call("pc3d_group_max_linear_bwd_f32", g.data_ptr(), out.data_ptr(), arg.data_ptr(), ws[-1].data_ptr(),
+                      G, ns, C2, ws[-1].shape[0], _ptr(last_hidden), gx.data_ptr(), _stream())
+        for li in range(nl - 2, -1, -1):                                # hidden layers, last to first
+            gx = gx.mm(ws[li])                                          # gradient wrt that layer's input
+            if li > 0:
+                gx = torch.ops.aten.threshold_backward(gx, acts[li - 1], 0)
+        return (gx.view(G, ns, C0),) + (None,) * (2 * nl)
+
+
+def mlp_relu_max(x, layers):
+    """x [..., ns, C0], layers [(w, b), ...] frozen -> max over dim -2 of the ReLU MLP's output: [..., C_last]."""
+    _check(x, "x")
+    lead, ns, C0 = x.shape[:-2], x.shape[-2], x.shape[-1]
+    if ns > GROUP_MAX_NS:
+        raise ValueError(f"mlp_relu_max: group size {ns} exceeds {GROUP_MAX_NS}")
+    flat = [t.contiguous() for wb in layers for t in wb]
+    out = _MLPReLUMaxFn.apply(x.reshape(-1, ns, C0).contiguous(), *flat)
+    return out.view(*lead, layers[-1][0].shape[0])
 
 
 def linear_relu_max(x, w, b):

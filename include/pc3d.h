@@ -255,14 +255,16 @@ int pc3d_group_gather_bwd_f32(const float* g_out, const int32_t* idx, const int3
 /* Backward to x of out[g,c] = max_r relu(x[g,r,:] . W[c,:] + b[c]) — the last 1x1 conv + ReLU + max over the group of
  * a set-abstraction layer (model/pointnet2_utils.py:190-197, :243-257). gout/out [G,C3], arg [G,C3] int64 = winning row
  * inside the group (torch.max indices), W [C3,C2]; gx [G,ns,C2] overwritten. Sparse row accumulation in ascending
- * channel order (deterministic) instead of autograd's dense product on a one-nonzero-per-channel tensor. ns <= 128. */
+ * channel order (deterministic) instead of autograd's dense product on a one-nonzero-per-channel tensor. ns <= 128.
+ * xin (may be NULL): x itself when x is the ReLU output of the previous layer — gx is zeroed where xin <= 0, which folds
+ * that layer's ReLU backward into this launch. */
 /* Forward of that operator without the [G*ns, C3] activation: out[g,c] = max_r relu(x[g,r,:] . W[c,:] + b[c]),
  * arg[g,c] = the winning row (int64, lowest on ties; unspecified where out == 0). x [G,ns,C2], ns <= 128,
  * C2 % 8 == 0 and <= 128, C3 % 32 == 0. fp32 MFMA. */
 int pc3d_group_linear_max_f32(const float* x, const float* W, const float* b, int G, int ns, int C2, int C3,
                               float* out, int64_t* arg, void* stream);
 int pc3d_group_max_linear_bwd_f32(const float* gout, const float* out, const int64_t* arg, const float* W,
-                                  int G, int ns, int C2, int C3, float* gx, void* stream);
+                                  int G, int ns, int C2, int C3, const float* xin, float* gx, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * K3  DGCNN dynamic graph (model/dgcnn.py:194-227,299-313).

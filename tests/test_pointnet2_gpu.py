@@ -214,3 +214,26 @@ def test_linear_relu_max_fwd_bwd_vs_autograd(dev, G, ns, C2, C3):
     x.grad = None
     (ops.linear_relu_max(x, w, b) * up).sum().backward()
     assert torch.equal(x.grad, g1)
+
+
+@pytest.mark.parametrize("G,ns,dims", [(6, 32, (3, 64, 64, 128)), (4, 64, (131, 128, 128, 256)), (2, 128, (259, 256, 512, 1024)),
+                                       (5, 16, (6, 32, 32, 64)), (3, 20, (9, 40))])
+def test_mlp_relu_max_fwd_bwd_vs_autograd(dev, G, ns, dims):
+    """ops.mlp_relu_max (GEMM epilogues + fused last layer/max + hand-written backward) vs the plain torch chain."""
+    ops = importlib.import_module("3dpointcloudattack_amd.ops")
+    g = torch.Generator().manual_seed(G * ns + len(dims))
+    x = torch.randn(G, ns, dims[0], generator=g).to(dev).requires_grad_()
+    layers = [((torch.randn(co, ci, generator=g) / ci ** 0.5).to(dev), (0.3 * torch.randn(co, generator=g)).to(dev))
+              for ci, co in zip(dims[:-1], dims[1:])]
+    out = ops.mlp_relu_max(x, layers)
+    up = torch.randn(out.shape, generator=g).to(dev)
+    (out * up).sum().backward()
+    g1 = x.grad.clone()
+    x.grad = None
+    h = x.double()
+    for w, b in layers:
+        h = torch.relu(torch.nn.functional.linear(h, w.double(), b.double()))
+    ref = h.max(dim=1)[0]
+    torch.testing.assert_close(out.double(), ref.detach(), rtol=2e-5, atol=2e-5)
+    (ref * up.double()).sum().backward()
+    torch.testing.assert_close(g1.double(), x.grad.double(), rtol=2e-3, atol=2e-4)
