@@ -297,24 +297,38 @@ __global__ __launch_bounds__(256) void edge_max_bwd_kernel(const float* g, const
 // in ONE pass over Y [B,N,C] (the reference: activation pass + two reductions + cat), and the backward
 //   gY[b,i,c] = leaky'(Y[b,i,c]) * (gmax[b,c] * [i == arg[b,c]] + gmean[b,c] / N)
 // in one pass as well (autograd: scatter into zeros + expand + add + activation backward).
-// Workgroup = (64 channels, cloud b); 4 row groups x 64 channels, fixed-order LDS combine => deterministic.
+// Workgroup = (64 channels, cloud b); 16 row groups x 64 channels, fixed-order LDS combine => deterministic.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void act_pool_fwd_kernel(const float* Y, int N, int C, float slope, float* out,
-                                                           int32_t* arg) {
-  __shared__ float s_mx[4][64], s_sm[4][64];
-  __shared__ int s_ai[4][64];
+constexpr int AP_RG = 16;   // row groups (waves) per workgroup
+
+__global__ __launch_bounds__(64 * AP_RG) void act_pool_fwd_kernel(const float* Y, int N, int C, float slope, float* out,
+                                                                  int32_t* arg) {
+  __shared__ float s_mx[AP_RG][64], s_sm[AP_RG][64];
+  __shared__ int s_ai[AP_RG][64];
   const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
   const bool live = c < C;
-  const int rows = (N + 3) / 4, r0 = rg * rows, r1 = (r0 + rows < N) ? r0 + rows : N;
+  const int rows = (N + AP_RG - 1) / AP_RG, r0 = rg * rows, r1 = (r0 + rows < N) ? r0 + rows : N;
   float mx = -__builtin_inff(), sm = 0.f;
   int ai = r0 < N ? r0 : 0;
   if (live) {
     const float* col = Y + (int64_t)b * N * C + c;
-    for (int i = r0; i < r1; ++i) {
+    int i = r0;
+    for (; i + 8 <= r1; i += 8) {       // 8 independent row loads in flight
+      float y[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) y[e] = col[(int64_t)(i + e) * C];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float z = y[e] > 0.f ? y[e] : y[e] * slope;
+        sm += z;
+        if (z > mx) mx = z, ai = i + e;   // strict: lowest row wins ties (torch.max)
+      }
+    }
+    for (; i < r1; ++i) {
       const float y = col[(int64_t)i * C];
       const float z = y > 0.f ? y : y * slope;
       sm += z;
-      if (z > mx) mx = z, ai = i;       // strict: lowest row wins ties (torch.max)
+      if (z > mx) mx = z, ai = i;
     }
   }
   s_mx[rg][threadIdx.x & 63] = mx, s_sm[rg][threadIdx.x & 63] = sm, s_ai[rg][threadIdx.x & 63] = ai;
@@ -324,7 +338,7 @@ __global__ __launch_bounds__(256) void act_pool_fwd_kernel(const float* Y, int N
     float m = s_mx[0][l], t = s_sm[0][l];
     int a = s_ai[0][l];
 #pragma unroll
-    for (int g = 1; g < 4; ++g) {
+    for (int g = 1; g < AP_RG; ++g) {
       t += s_sm[g][l];
       if (s_mx[g][l] > m) m = s_mx[g][l], a = s_ai[g][l];
     }
@@ -443,7 +457,7 @@ extern "C" int pc3d_act_pool_f32(const float* Y, int B, int N, int C, float slop
   PC3D_REQUIRE(B <= 65535, "pc3d_act_pool_f32: B=%d exceeds grid.y limit", B);
   if (B == 0) return PC3D_OK;
   PC3D_REQUIRE(Y && out && arg, "pc3d_act_pool_f32: null pointer");
-  hipLaunchKernelGGL(act_pool_fwd_kernel, dim3(cdiv(C, 64), B), dim3(256), 0, as_stream(stream), Y, N, C, slope, out, arg);
+  hipLaunchKernelGGL(act_pool_fwd_kernel, dim3(cdiv(C, 64), B), dim3(64 * AP_RG), 0, as_stream(stream), Y, N, C, slope, out, arg);
   PC3D_LAUNCH_CHECK("pc3d_act_pool_f32");
   return PC3D_OK;
 }
