@@ -1,0 +1,309 @@
+// K16: the guided curve walk of CurveNet (model/walk.py:74-153) as ONE forward and ONE backward launch.
+//
+// The reference (and the step-by-step torch formulation) spends ~30 launches per walk step on tensors of
+// curve_num x k x C elements (100 x 20 x 16..32): 1.5 ms forward / 3.3 ms forward+backward per CIC block at B=32, four
+// blocks per CurveNet forward. Here one workgroup walks all curves of one cloud; a wavefront takes one curve at a
+// time: lane j holds candidate neighbour j's feature row (C registers), the curve state (descriptor `pre`, current
+// feature `cur`) lives in LDS and is read as broadcasts, the softmax / arg-max over the k candidates are wave
+// reductions. The forward stores, per step, the node whose neighbours were scored, the picked slot, `pre` and the
+// curve's momentum softmax; the backward walks the steps in reverse, recomputing scores from those.
+//
+// Why a workgroup per cloud and not a wave per curve: the reference reshapes the momentum softmax [B,2,cn] with
+// .view(B,1,cn,2) (walk.py:104-105), i.e. curve c blends with elements 2c and 2c+1 of the FLATTENED [2,cn] array —
+// softmax values of other curves. That reinterpretation is part of the function being mirrored, so the curves of a
+// cloud exchange their momentum values (and, backwards, the gradients with respect to them) through LDS once per step.
+//
+// Gradient scatter: d(loss)/d(feats[row]) receives (a) G_cur on the picked row, (b) gscore_j * w_nbr on each of the k
+// candidate rows — a rank-1 term with the SAME vector w_nbr for every candidate, so the kernel accumulates only the
+// scalar coefficient per row (coef[b,row], one atomic instead of C) and the host adds coef (x) w_nbr in one pass —
+// and (c) G_pre on the start row.
+#include "pc3d_common.h"
+
+namespace pc3d {
+
+struct WalkArgs {
+  const float* feats;  // [B,N,C]
+  const int* adj;      // [B,N,k]
+  const int* start;    // [B,cn]
+  const float* aw;     // [2C] agent weights: [0,C) neighbour part, [C,2C) descriptor part (BatchNorm folded)
+  const float* ab;     // [1]
+  const float* mw;     // [2,2C] momentum weights: columns [0,C) current feature, [C,2C) descriptor
+  const float* mb;     // [2]
+  int B, N, k, cn, L;
+  float* curves;       // [B,cn,L,C]
+  int* nodes;          // [B,cn,L]
+  int* pick;           // [B,cn,L]
+  float* pre;          // [B,cn,L,C]
+  float* mom;          // [B,cn,L,2]  the curve's OWN momentum softmax entering step s (unused at s = 0)
+  // backward only
+  const float* gcurves;  // [B,cn,L,C]
+  float* gfeats;         // [B,N,C] (accumulated)
+  float* coef;           // [B,N]   (accumulated)
+};
+
+__device__ __forceinline__ float readlane_f32(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+// Orders LDS traffic between the lanes of ONE wavefront (LDS operations of a wave complete in issue order; this only
+// stops the compiler from moving them across).
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int C>
+__device__ __forceinline__ void load_row(const float* __restrict__ p, float (&r)[C]) {
+#pragma unroll
+  for (int c = 0; c < C; c += 4) {
+    const float4 v = *reinterpret_cast<const float4*>(p + c);
+    r[c] = v.x, r[c + 1] = v.y, r[c + 2] = v.z, r[c + 3] = v.w;
+  }
+}
+template <int C>
+__device__ __forceinline__ void store_row(float* __restrict__ p, const float (&r)[C]) {
+#pragma unroll
+  for (int c = 0; c < C; c += 4) *reinterpret_cast<float4*>(p + c) = make_float4(r[c], r[c + 1], r[c + 2], r[c + 3]);
+}
+
+// score of candidate row nb given descriptor pre (agent_mlp, walk.py:128-131) and, from the second step on, the
+// crossover-suppression factor d (walk.py:55-72, :133-137). pre / cur are wave-uniform rows (LDS or global).
+// Returns score * d; *d_out = d.
+template <int C>
+__device__ __forceinline__ float walk_score(const WalkArgs& a, const float (&nb)[C], const float* pre,
+                                            const float* cur, bool first, float* d_out) {
+  float sn = 0.f, sp = 0.f;
+#pragma unroll
+  for (int c = 0; c < C; ++c) sn += a.aw[c] * nb[c], sp += a.aw[C + c] * pre[c];
+  float sc = sn + sp + a.ab[0];
+  float d = 1.f;
+  if (!first) {
+    float dot = 0.f, nu = 0.f, nv = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float cc = cur[c], u = cc - pre[c], v = nb[c] - cc;
+      dot += u * v, nu += u * u, nv += v * v;
+    }
+    const float div = fmaxf(sqrtf(nu) * sqrtf(nv), 1e-8f);
+    d = fminf(fmaxf(1.f + dot / div, 0.f), 1.f);
+    sc *= d;
+  }
+  *d_out = d;
+  return sc;
+}
+
+// workgroup size: 16 waves (128 VGPRs each) hold a C <= 32 row per lane; C = 64 needs the 256-VGPR budget of 8 waves
+template <int C>
+constexpr int kWalkThreads = C <= 32 ? 1024 : 512;
+
+// LDS (floats): pre [cn][C] | cur [cn][C] | M [2 parities][2][cn]
+static size_t walk_fwd_lds(int cn, int C) { return sizeof(float) * ((size_t)2 * cn * C + 4 * cn); }
+// LDS (floats): Gc [cn][C] | Gp [cn][C] | gM [2 parities][2 cn]
+static size_t walk_bwd_lds(int cn, int C) { return sizeof(float) * ((size_t)2 * cn * C + 4 * cn); }
+
+template <int C>
+__global__ __launch_bounds__(kWalkThreads<C>) void curve_walk_fwd_kernel(WalkArgs a) {
+  extern __shared__ float4 walk_sm4[];
+  float* const s_pre = reinterpret_cast<float*>(walk_sm4);
+  float* const s_cur = s_pre + a.cn * C;
+  float* const s_M = s_cur + a.cn * C;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+  const int b = blockIdx.x, cn = a.cn;
+  const float* __restrict__ F = a.feats + (long)b * a.N * C;
+  const int* __restrict__ adj = a.adj + (long)b * a.N * a.k;
+  const bool act = lane < a.k;
+  // walk.py:96-99: the start point's feature is the first descriptor
+  for (int c = wave; c < cn; c += nw) {
+    const long o = ((long)b * cn + c) * a.L;
+    const int node = min(max(a.start[(long)b * cn + c], 0), a.N - 1);  // indices are clamped: a bad graph must not
+    if (lane < C) s_pre[c * C + lane] = F[(long)node * C + lane];      // become a wild read
+    if (lane == 0) a.nodes[o] = node;
+  }
+  __syncthreads();
+  for (int s = 0; s < a.L; ++s) {
+    const float* Mr = s_M + (s & 1) * 2 * cn;
+    float* Mw = s_M + ((s + 1) & 1) * 2 * cn;
+    for (int c = wave; c < cn; c += nw) {
+      float* pre = s_pre + c * C;
+      float* cur = s_cur + c * C;
+      const long o = ((long)b * cn + c) * a.L + s;
+      if (s > 0) {  // dynamic momentum (walk.py:104-108): entries 2c, 2c+1 of the flattened [2,cn] softmax array
+        const float m0 = Mr[2 * c], m1 = Mr[2 * c + 1];
+        if (lane < C) pre[lane] = cur[lane] * m0 + pre[lane] * m1;
+        wave_lds_sync();
+      }
+      if (lane < C) a.pre[o * C + lane] = pre[lane];
+      const int node = a.nodes[o];
+      const int idx = act ? min(max(adj[(long)node * a.k + lane], 0), a.N - 1) : node;
+      float nb[C];
+      load_row<C>(F + (long)idx * C, nb);
+      float d;
+      float sc = walk_score<C>(a, nb, pre, cur, s == 0, &d);
+      sc = act ? sc : -INFINITY;
+      const float mx = wave_max(sc);
+      const float e = act ? expf(sc - mx) : 0.f;
+      const float y = e / wave_sum(e);
+      const float ymax = wave_max(y);
+      const unsigned long long bal = __ballot(act && y == ymax);
+      const int jstar = bal ? __builtin_amdgcn_readfirstlane(__ffsll((long long)bal) - 1) : 0;  // lowest slot on ties
+      const int next = __builtin_amdgcn_readlane(idx, jstar);
+      wave_lds_sync();  // every lane has read cur / pre before cur is replaced
+      if (lane == jstar) {  // straight-through hard pick: the new current feature is the chosen neighbour's row
+        store_row<C>(a.curves + o * C, nb);
+        store_row<C>(cur, nb);
+      }
+      if (lane == 0) {
+        a.pick[o] = jstar;
+        if (s + 1 < a.L) a.nodes[o + 1] = next;
+        if (s == 0) a.mom[o * 2] = 0.f, a.mom[o * 2 + 1] = 0.f;
+      }
+      if (s + 1 < a.L) {  // this curve's momentum softmax for the next step (walk.py:102-105)
+        wave_lds_sync();
+        float p0 = 0.f, p1 = 0.f;
+        if (lane < C) {
+          const float cv = cur[lane], pv = pre[lane];
+          p0 = a.mw[lane] * cv + a.mw[C + lane] * pv;
+          p1 = a.mw[2 * C + lane] * cv + a.mw[3 * C + lane] * pv;
+        }
+        const float z0 = wave_sum(p0) + a.mb[0], z1 = wave_sum(p1) + a.mb[1];
+        const float zm = fmaxf(z0, z1), e0 = expf(z0 - zm), e1 = expf(z1 - zm), es = e0 + e1;
+        if (lane == 0) {
+          Mw[c] = e0 / es, Mw[cn + c] = e1 / es;
+          a.mom[(o + 1) * 2] = e0 / es, a.mom[(o + 1) * 2 + 1] = e1 / es;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int C>
+__global__ __launch_bounds__(kWalkThreads<C>) void curve_walk_bwd_kernel(WalkArgs a) {
+  extern __shared__ float4 walk_sm4[];
+  float* const s_Gc = reinterpret_cast<float*>(walk_sm4);
+  float* const s_Gp = s_Gc + a.cn * C;
+  float* const s_gM = s_Gp + a.cn * C;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+  const int b = blockIdx.x, cn = a.cn;
+  const float* __restrict__ F = a.feats + (long)b * a.N * C;
+  const int* __restrict__ adj = a.adj + (long)b * a.N * a.k;
+  float* __restrict__ gF = a.gfeats + (long)b * a.N * C;
+  float* __restrict__ coef = a.coef + (long)b * a.N;
+  const bool act = lane < a.k;
+  for (int i = threadIdx.x; i < 2 * cn * C; i += blockDim.x) s_Gc[i] = 0.f;  // Gc and Gp are adjacent
+  __syncthreads();
+  for (int s = a.L - 1; s >= 0; --s) {
+    float* gMw = s_gM + (s & 1) * 2 * cn;
+    for (int c = wave; c < cn; c += nw) {
+      float* Gc = s_Gc + c * C;
+      float* Gp = s_Gp + c * C;
+      const long o = ((long)b * cn + c) * a.L + s;
+      if (lane < C) Gc[lane] += a.gcurves[o * C + lane];
+      wave_lds_sync();
+      const int node = min(max(a.nodes[o], 0), a.N - 1), jstar = a.pick[o] & 63;
+      const int idx = act ? min(max(adj[(long)node * a.k + lane], 0), a.N - 1) : node;
+      float nb[C];
+      load_row<C>(F + (long)idx * C, nb);
+      const float* pre = a.pre + o * C;             // wave-uniform rows: scalar loads
+      const float* curp = a.curves + (o - 1) * C;   // only dereferenced when s > 0
+      float d;
+      float sc = walk_score<C>(a, nb, pre, curp, s == 0, &d);
+      sc = act ? sc : -INFINITY;
+      const float mx = wave_max(sc);
+      const float e = act ? expf(sc - mx) : 0.f;
+      const float y = e / wave_sum(e);
+      // cur = sum_j nb_j * (hard_j + y_j - stopgrad(y_j)):  d/d nb_j = hard_j,  d/d y_j = nb_j
+      float gy = 0.f;
+#pragma unroll
+      for (int ch = 0; ch < C; ++ch) gy += Gc[ch] * nb[ch];
+      const float t = wave_sum(act ? y * gy : 0.f);
+      const float gsc = act ? y * (gy - t) * d : 0.f;  // softmax backward, then through the (constant) factor d
+      if (act) atomicAdd(coef + idx, gsc);
+      const int prow = __builtin_amdgcn_readlane(idx, jstar);
+      if (lane < C) atomicAdd(gF + (long)prow * C + lane, Gc[lane]);
+      const float S = wave_sum(gsc);
+      float gp = 0.f;
+      if (lane < C) gp = Gp[lane] + S * a.aw[C + lane];  // total gradient with respect to pre_s
+      if (s > 0) {
+        // pre_s = cur_{s-1} m0 + pre_{s-1} m1 with (m0, m1) = entries 2c, 2c+1 of the flattened [2,cn] softmax array
+        const float* pp = a.pre + (o - 1) * C;
+        const float g0 = wave_sum(lane < C ? gp * curp[lane] : 0.f), g1 = wave_sum(lane < C ? gp * pp[lane] : 0.f);
+        const int f0 = 2 * c, f1 = 2 * c + 1;
+        const float m0 = a.mom[(((long)b * cn + f0 % cn) * a.L + s) * 2 + f0 / cn];
+        const float m1 = a.mom[(((long)b * cn + f1 % cn) * a.L + s) * 2 + f1 / cn];
+        if (lane == 0) gMw[f0] = g0, gMw[f1] = g1;
+        wave_lds_sync();  // Gc was read (scatter) before it is replaced
+        if (lane < C) Gc[lane] = gp * m0, Gp[lane] = gp * m1;  // direct terms of d pre_s / d cur_{s-1}, d pre_{s-1}
+      } else if (lane < C) {
+        atomicAdd(gF + (long)node * C + lane, gp);  // pre_0 is the start row
+      }
+    }
+    __syncthreads();
+    if (s > 0) {  // through the momentum softmax of curve c: rows (0,c) and (1,c) of the [2,cn] array
+      for (int c = wave; c < cn; c += nw) {
+        const long o = ((long)b * cn + c) * a.L + s;
+        const float M0 = a.mom[o * 2], M1 = a.mom[o * 2 + 1];
+        const float gM0 = gMw[c], gM1 = gMw[cn + c];
+        const float tt = M0 * gM0 + M1 * gM1, gz0 = M0 * (gM0 - tt), gz1 = M1 * (gM1 - tt);
+        if (lane < C) {
+          s_Gc[c * C + lane] += a.mw[lane] * gz0 + a.mw[2 * C + lane] * gz1;
+          s_Gp[c * C + lane] += a.mw[C + lane] * gz0 + a.mw[3 * C + lane] * gz1;
+        }
+      }
+      // no barrier: the next step's first phase touches only this wave's own curves and the other gM parity
+    }
+  }
+}
+
+template <int C>
+static int launch_walk(bool bwd, const WalkArgs& a, hipStream_t st) {
+  const int waves = a.cn < kWalkThreads<C> / kWave ? a.cn : kWalkThreads<C> / kWave;
+  const dim3 grid((unsigned)a.B), block(waves * kWave);
+  const size_t lds = bwd ? walk_bwd_lds(a.cn, C) : walk_fwd_lds(a.cn, C);
+  PC3D_REQUIRE(lds <= 64 * 1024, "pc3d_curve_walk: curve_num * C = %d * %d does not fit the 64 KB LDS window", a.cn, C);
+  if (bwd)
+    hipLaunchKernelGGL(curve_walk_bwd_kernel<C>, grid, block, lds, st, a);
+  else
+    hipLaunchKernelGGL(curve_walk_fwd_kernel<C>, grid, block, lds, st, a);
+  PC3D_LAUNCH_CHECK(bwd ? "pc3d_curve_walk_bwd_f32" : "pc3d_curve_walk_fwd_f32");
+  return PC3D_OK;
+}
+
+static int walk_dispatch(bool bwd, const WalkArgs& a, int C, void* stream) {
+  const char* nm = bwd ? "pc3d_curve_walk_bwd_f32" : "pc3d_curve_walk_fwd_f32";
+  PC3D_REQUIRE(a.B > 0 && a.N > 0 && a.cn > 0 && a.L > 0, "%s: empty problem", nm);
+  PC3D_REQUIRE(a.k >= 1 && a.k <= 64, "%s: k=%d (supported: 1..64, one lane per candidate)", nm, a.k);
+  PC3D_REQUIRE(a.feats && a.adj && a.aw && a.ab && a.mw && a.mb && a.curves && a.nodes && a.pick && a.pre && a.mom,
+               "%s: null pointer", nm);
+  switch (C) {
+    case 8: return launch_walk<8>(bwd, a, as_stream(stream));
+    case 16: return launch_walk<16>(bwd, a, as_stream(stream));
+    case 32: return launch_walk<32>(bwd, a, as_stream(stream));
+    case 64: return launch_walk<64>(bwd, a, as_stream(stream));
+    default: PC3D_REQUIRE(false, "%s: C=%d (supported: 8, 16, 32, 64)", nm, C);
+  }
+}
+
+}  // namespace pc3d
+
+extern "C" int pc3d_curve_walk_fwd_f32(const float* feats, const int32_t* adj, const int32_t* start,
+                                       const float* agent_w, const float* agent_b, const float* mom_w,
+                                       const float* mom_b, int B, int N, int C, int k, int cn, int L, float* curves,
+                                       int32_t* nodes, int32_t* pick, float* pre, float* mom, void* stream) {
+  PC3D_REQUIRE(start != nullptr, "pc3d_curve_walk_fwd_f32: null start");
+  pc3d::WalkArgs a{feats, adj, start, agent_w, agent_b, mom_w, mom_b, B, N, k, cn, L, curves, nodes, pick, pre, mom,
+                   nullptr, nullptr, nullptr};
+  return pc3d::walk_dispatch(false, a, C, stream);
+}
+
+extern "C" int pc3d_curve_walk_bwd_f32(const float* gcurves, const float* feats, const int32_t* adj,
+                                       const float* agent_w, const float* agent_b, const float* mom_w,
+                                       const float* mom_b, int B, int N, int C, int k, int cn, int L,
+                                       const float* curves, const int32_t* nodes, const int32_t* pick,
+                                       const float* pre, const float* mom, float* gfeats, float* coef, void* stream) {
+  PC3D_REQUIRE(gcurves && gfeats && coef, "pc3d_curve_walk_bwd_f32: null gradient pointer");
+  pc3d::WalkArgs a{feats, adj, nullptr, agent_w, agent_b, mom_w, mom_b, B, N, k, cn, L,
+                   const_cast<float*>(curves), const_cast<int32_t*>(nodes), const_cast<int32_t*>(pick),
+                   const_cast<float*>(pre), const_cast<float*>(mom), gcurves, gfeats, coef};
+  return pc3d::walk_dispatch(true, a, C, stream);
+}

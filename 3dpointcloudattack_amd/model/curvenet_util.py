@@ -26,11 +26,10 @@ def _fold_pointwise(conv, bn):
     return w.contiguous(), (b.contiguous() if b is not None else None)
 
 
-def pw(mod, x, bn=None):
-    """Frozen pointwise layer: `mod` is a 1x1 Conv1d / Conv2d / Linear or an nn.Sequential(conv[, bn][, activation]);
-    x is [B,C,L], [B,C,H,W] (conv) or [B,C] (Linear). One GEMM against folded weights (cached on the module and
-    re-folded whenever a parameter / buffer changes) instead of MIOpen convolution + batch-norm + weight-gradient
-    kernels (the reference leaves requires_grad on and pays for dL/dW in every attack step)."""
+def folded_pw(mod, bn=None):
+    """(conv, activation, W, b) of a frozen pointwise layer: `mod` is a 1x1 Conv1d / Conv2d / Linear or an
+    nn.Sequential(conv[, bn][, activation]). Folded weights are cached on the module and re-folded whenever a
+    parameter / buffer changes."""
     act = None
     conv = mod
     if isinstance(mod, nn.Sequential):
@@ -48,7 +47,14 @@ def pw(mod, x, bn=None):
     if cache is None or cache[0] != key:
         cache = (key,) + _fold_pointwise(conv, bn)
         object.__setattr__(conv, "_pw_cache", cache)
-    _, w, b = cache
+    return conv, act, cache[1], cache[2]
+
+
+def pw(mod, x, bn=None):
+    """Frozen pointwise layer: `mod` as in folded_pw; x is [B,C,L], [B,C,H,W] (conv) or [B,C] (Linear). One GEMM
+    against folded weights instead of MIOpen convolution + batch-norm + weight-gradient kernels (the reference leaves
+    requires_grad on and pays for dL/dW in every attack step)."""
+    _, act, w, b = folded_pw(mod, bn)
     if x.dim() == 2:
         y = F.linear(x, w, b)
     else:

@@ -10,6 +10,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import ops
 
 
 def pw(mod, x):
@@ -43,6 +44,7 @@ class Walk(nn.Module):
         self.k = k
         self.agent_mlp = nn.Sequential(nn.Conv2d(in_channel * 2, 1, kernel_size=1, bias=False), nn.BatchNorm2d(1))
         self.momentum_mlp = nn.Sequential(nn.Conv1d(in_channel * 2, 2, kernel_size=1, bias=False), nn.BatchNorm1d(2))
+        self.fused = True
 
     def crossover_suppression(self, cur, neighbor, bn, n, k):
         """:55-72 — 1 + cos(angle between the last move and each candidate move), clamped to [0,1]; no gradient."""
@@ -55,7 +57,20 @@ class Walk(nn.Module):
 
     def forward(self, xyz, x, adj, cur):
         """x [B,C,N] features, adj [B,N,k] neighbour indices (self excluded), cur [B,curve_num,1] start nodes
-        -> curves [B,C,curve_num,curve_length]."""
+        -> curves [B,C,curve_num,curve_length]. One HIP launch per direction (pc3d_curve_walk_*_f32) when the channel
+        count is one the kernel is built for; the step-by-step formulation below otherwise."""
+        B, C, N = x.size()
+        if self.fused and x.is_cuda and C in ops.CURVE_WALK_CHANNELS and adj.shape[2] <= 64:
+            from .curvenet_util import folded_pw
+            _, _, aw, ab = folded_pw(self.agent_mlp)
+            _, _, mw, mb = folded_pw(self.momentum_mlp)
+            curves = ops.curve_walk(x.transpose(1, 2).contiguous().float(), adj.to(torch.int32),
+                                    cur.reshape(B, self.curve_num).to(torch.int32), aw, ab, mw, mb, self.curve_length)
+            return curves.permute(0, 3, 1, 2)                  # [B,cn,L,C] -> [B,C,cn,L]
+        return self.forward_steps(xyz, x, adj, cur)
+
+    def forward_steps(self, xyz, x, adj, cur):
+        """The same walk as ~30 torch launches per step (model/walk.py:74-153 restated with batched gathers)."""
         B, C, N = x.size()
         cn, k = self.curve_num, self.k
         feats = x.transpose(1, 2).contiguous()                 # [B,N,C]

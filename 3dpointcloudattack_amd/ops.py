@@ -722,6 +722,64 @@ def edge_max(PQ, idx, slope=0.2):
 
 
 # ------------------------------------------------------------------------------------------------------
+# K16: CurveNet guided walk
+# ------------------------------------------------------------------------------------------------------
+CURVE_WALK_CHANNELS = (8, 16, 32, 64)
+
+
+class _CurveWalkFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats, adj, start, aw, ab, mw, mb, L):
+        B, N, C = feats.shape
+        k, cn = adj.shape[2], start.shape[1]
+        dev = feats.device
+        curves = torch.empty((B, cn, L, C), dtype=torch.float32, device=dev)
+        pre = torch.empty((B, cn, L, C), dtype=torch.float32, device=dev)
+        mom = torch.empty((B, cn, L, 2), dtype=torch.float32, device=dev)
+        nodes = torch.empty((B, cn, L), dtype=torch.int32, device=dev)
+        pick = torch.empty((B, cn, L), dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call("pc3d_curve_walk_fwd_f32", feats.data_ptr(), adj.data_ptr(), start.data_ptr(), aw.data_ptr(),
+                      ab.data_ptr(), mw.data_ptr(), mb.data_ptr(), B, N, C, k, cn, L, curves.data_ptr(),
+                      nodes.data_ptr(), pick.data_ptr(), pre.data_ptr(), mom.data_ptr(), _stream())
+        ctx.save_for_backward(feats, adj, aw, ab, mw, mb, curves, nodes, pick, pre, mom)
+        ctx.L = L
+        return curves
+
+    @staticmethod
+    def backward(ctx, g):
+        feats, adj, aw, ab, mw, mb, curves, nodes, pick, pre, mom = ctx.saved_tensors
+        B, N, C = feats.shape
+        k, cn = adj.shape[2], nodes.shape[1]
+        g = g.contiguous()
+        gF = torch.zeros((B, N, C), dtype=torch.float32, device=g.device)
+        coef = torch.zeros((B, N), dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            _lib.call("pc3d_curve_walk_bwd_f32", g.data_ptr(), feats.data_ptr(), adj.data_ptr(), aw.data_ptr(),
+                      ab.data_ptr(), mw.data_ptr(), mb.data_ptr(), B, N, C, k, cn, ctx.L, curves.data_ptr(),
+                      nodes.data_ptr(), pick.data_ptr(), pre.data_ptr(), mom.data_ptr(), gF.data_ptr(),
+                      coef.data_ptr(), _stream())
+        gF.addcmul_(coef.unsqueeze(-1), aw[:C])      # the rank-1 score term: every candidate row gets coef * w_nbr
+        return gF, None, None, None, None, None, None, None
+
+
+def curve_walk(feats, adj, start, agent_w, agent_b, mom_w, mom_b, length):
+    """Guided walk of CurveNet (model/walk.py:74-153) in one launch per direction: feats [B,N,C] (C in
+    CURVE_WALK_CHANNELS), adj [B,N,k] int32 (k <= 64), start [B,cn] int32, folded agent / momentum weights
+    ([2C], [1], [2,2C], [2]) -> curves [B,cn,length,C]; differentiable in feats (weights are frozen)."""
+    _check(feats, "feats")
+    B, N, C = feats.shape
+    if C not in CURVE_WALK_CHANNELS or adj.shape[2] > 64:
+        raise ValueError(f"curve_walk: C={C}, k={adj.shape[2]} (supported: C in {CURVE_WALK_CHANNELS}, k <= 64)")
+    if adj.dtype != torch.int32 or start.dtype != torch.int32:
+        raise TypeError("curve_walk: adj / start must be int32")
+    if agent_w.numel() != 2 * C or agent_b.numel() != 1 or tuple(mom_w.shape) != (2, 2 * C) or mom_b.numel() != 2:
+        raise ValueError("curve_walk: weight shapes must be [2C], [1], [2,2C], [2]")
+    ws = [w.detach().contiguous().float() for w in (agent_w.reshape(-1), agent_b.reshape(-1), mom_w, mom_b.reshape(-1))]
+    return _CurveWalkFn.apply(feats.contiguous(), adj.contiguous(), start.contiguous(), *ws, int(length))
+
+
+# ------------------------------------------------------------------------------------------------------
 # K12: AOF spectral front-end
 # ------------------------------------------------------------------------------------------------------
 def graph_laplacian(xyz, k=30, cf=True):

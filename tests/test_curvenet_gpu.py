@@ -35,3 +35,55 @@ def test_curvenet_logits_and_input_grad_vs_reference(dev):
         got, gref = x.grad.cpu().numpy(), fx[f"{nm}_gx"]
         assert np.isfinite(got).all()
         assert np.linalg.norm(got - gref) / np.linalg.norm(gref) < 5e-3, nm     # measured 5e-4 / 4e-5
+
+
+def _walk_case(dev, C, k, cn, L, N, B=3, seed=0):
+    wk = importlib.import_module("3dpointcloudattack_amd.model.walk")
+    ops = importlib.import_module("3dpointcloudattack_amd.ops")
+    g = torch.Generator().manual_seed(seed)
+    w = wk.Walk(C, k, cn, L)
+    with torch.no_grad():
+        for bn in (w.agent_mlp[1], w.momentum_mlp[1]):        # non-trivial eval-mode BatchNorm statistics
+            bn.weight.copy_(torch.rand(bn.weight.shape, generator=g) + 0.5)
+            bn.bias.copy_(torch.randn(bn.bias.shape, generator=g) * 0.1)
+            bn.running_mean.copy_(torch.randn(bn.bias.shape, generator=g) * 0.1)
+            bn.running_var.copy_(torch.rand(bn.bias.shape, generator=g) + 0.5)
+        w.agent_mlp[0].weight.copy_(torch.randn(w.agent_mlp[0].weight.shape, generator=g) * 0.5)
+        w.momentum_mlp[0].weight.copy_(torch.randn(w.momentum_mlp[0].weight.shape, generator=g) * 0.5)
+    w = w.eval().to(dev)
+    xyz = torch.rand(B, N, 3, generator=g).to(dev)
+    x = torch.randn(B, C, N, generator=g).to(dev)
+    adj = ops.knn_raw(xyz, xyz, k + 1)[1][:, :, 1:].long()                     # self excluded, like CIC.forward
+    start = torch.stack([torch.randperm(N, generator=g)[:cn] for _ in range(B)]).to(dev).unsqueeze(2)
+    return w, xyz.transpose(1, 2).contiguous(), x, adj, start
+
+
+@pytest.mark.parametrize("C,k,cn,L,N", [(16, 20, 100, 5, 1024), (32, 20, 100, 5, 512), (8, 7, 10, 30, 200),
+                                        (64, 63, 5, 3, 128), (16, 1, 3, 4, 64), (32, 20, 17, 6, 300)])
+def test_fused_walk_matches_step_by_step(dev, C, k, cn, L, N):
+    """pc3d_curve_walk_fwd/bwd_f32 (one launch each) vs the step-by-step torch formulation of model/walk.py:74-153,
+    which the golden CurveNet fixtures pin against the reference: same curves (the walk takes hard arg-max decisions, so
+    a different pick would change a whole curve) and the same gradient with respect to the features."""
+    w, xyz, x, adj, start = _walk_case(dev, C, k, cn, L, N)
+    xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+    w.fused = True
+    got = w(xyz, xa, adj, start)
+    w.fused = False
+    ref = w(xyz, xb, adj, start)
+    assert got.shape == ref.shape == (x.shape[0], C, cn, L)
+    same = ((got - ref).abs().amax(dim=(1, 3)) <= 1e-5 * (1 + ref.abs().amax(dim=(1, 3))))   # per (cloud, curve)
+    assert same.float().mean() >= 0.99, same.float().mean()
+    gout = torch.randn(ref.shape, generator=torch.Generator().manual_seed(1)).to(dev) * same[:, None, :, None]
+    (got * gout).sum().backward()
+    (ref * gout).sum().backward()
+    err = (xa.grad - xb.grad).norm() / xb.grad.norm()
+    assert torch.isfinite(xa.grad).all() and err < 2e-4, err
+
+
+def test_fused_walk_rejects_unsupported_shapes(dev):
+    ops = importlib.import_module("3dpointcloudattack_amd.ops")
+    f = torch.zeros(1, 8, 12, device=dev)
+    with pytest.raises(ValueError):
+        ops.curve_walk(f, torch.zeros(1, 8, 3, dtype=torch.int32, device=dev), torch.zeros(1, 2, dtype=torch.int32, device=dev),
+                       torch.zeros(24, device=dev), torch.zeros(1, device=dev), torch.zeros(2, 24, device=dev),
+                       torch.zeros(2, device=dev), 3)
