@@ -49,6 +49,10 @@ SIGNATURES = {
     "pc3d_act_pool_bwd_f32": [_P, _P, _P, _I, _I, _I, _F, _P, _P],
     "pc3d_curve_walk_fwd_f32": [_P] * 7 + [_I] * 6 + [_P] * 5 + [_P],
     "pc3d_curve_walk_bwd_f32": [_P] * 7 + [_I] * 6 + [_P] * 7 + [_P],
+    "pc3d_edge_act_f32": [_P, _P, _P, _I, _I, _I, _I, _F, _P, _P],
+    "pc3d_edge_act_bwd_f32": [_P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P],
+    "pc3d_act_mean_f32": [_P, _I, _I, _I, _I, _F, _P, _P],
+    "pc3d_act_mean_bwd_f32": [_P, _P, _I, _I, _I, _I, _F, _P, _P],
     "pc3d_edge_max_f32": [_P, _P, _I, _I, _I, _I, _F, _P, _P, _P],
     "pc3d_edge_max_bwd_f32": [_P, _P, _P, _I, _I, _I, _F, _P, _P],
     "pc3d_group_max_linear_bwd_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],

@@ -166,10 +166,50 @@ class LPFA(nn.Module):
         self.mlp = nn.Sequential(*layers)
 
     def forward(self, x, xyz, idx=None):
+        if self.initial and len(self.mlp) == 1:
+            return self._initial_edge_max(xyz, idx)
+        if not self.initial and x.shape[1] % 4 == 0 and all(l[0].out_channels % 4 == 0 for l in self.mlp):
+            return self._edge_act_mean(x, xyz, idx)
         x = self.group_feature(x, xyz, idx)
         for layer in self.mlp:
             x = pw(layer, x)
         return x.max(dim=-1, keepdim=False)[0] if self.initial else x.mean(dim=-1, keepdim=False)
+
+    def _initial_edge_max(self, xyz, idx):
+        """The first LPFA (:199-203, :226-236 with initial=True and one MLP layer) without the [B,32,N,k] edge tensor
+        (335 MB at B=32, N=4096): W [p_i ; p_j ; p_j - p_i] = (Wb + Wc) p_j + (Wa - Wc) p_i, and LeakyReLU is monotone,
+        so max_j leaky(bn(W e_ij)) = leaky(max_j P_j + Q_i): one [N,3] x [3,2C] GEMM + pc3d_edge_max_f32."""
+        _, _, w, b = folded_pw(self.mlp[0])
+        wa, wb, wc = w[:, 0:3], w[:, 3:6], w[:, 6:9]
+        pts = _cl(xyz)
+        if idx is None:
+            idx32 = ops.knn_raw(pts.detach(), pts.detach(), self.k)[1]          # the k nearest, self first
+        else:
+            idx32 = idx[:, :, :self.k].to(torch.int32).contiguous()
+        PQ = F.linear(pts, torch.cat((wb + wc, wa - wc), 0), torch.cat((torch.zeros_like(b), b)))
+        return ops.edge_max(PQ, idx32, self.mlp[0][2].negative_slope).transpose(1, 2)
+
+    def _edge_act_mean(self, x, xyz, idx):
+        """:204-236 with initial=False, channels-last and without the geometry tensor: xyz2feature is linear in
+        [p_i ; p_j ; p_j - p_i], so  (x_j - x_i) + G geo_ij + t = A_j + B_i  with A = x + (Gb + Gc) p and
+        B = (Ga - Gc) p + t - x.  One launch builds leaky(A_j + B_i) [B,N,k,C] (pc3d_edge_act_f32), the MLP is a
+        channels-last GEMM per layer and the last LeakyReLU is fused with the neighbour mean (pc3d_act_mean_f32)."""
+        _, _, g, t = folded_pw(self.xyz2feature)
+        ga, gb, gc = g[:, 0:3], g[:, 3:6], g[:, 6:9]
+        pts, feats = _cl(xyz), _cl(x)
+        if idx is None:
+            idx32 = ops.knn_raw(pts.detach(), pts.detach(), self.k)[1]
+        else:
+            idx32 = idx[:, :, :self.k].to(torch.int32).contiguous()
+        A = feats + F.linear(pts, gb + gc)
+        Bc = F.linear(pts, ga - gc, t) - feats
+        E = ops.edge_act(A, Bc, idx32, 0.2)                                    # [B,N,k,C]
+        for li, layer in enumerate(self.mlp):
+            _, act, w, b = folded_pw(layer)
+            E = F.linear(E, w, b)
+            if li + 1 < len(self.mlp):
+                E = F.leaky_relu(E, act.negative_slope)
+        return ops.act_mean(E, self.mlp[-1][2].negative_slope).transpose(1, 2)   # [B,C',N]
 
     def group_feature(self, x, xyz, idx):
         """[B,9,N,k] = [p_i, p_j, p_j - p_i] (initial) or leaky((x_j - x_i) + xyz2feature(that)) [B,C,N,k]."""
@@ -258,7 +298,15 @@ class CIC(nn.Module):
             xyz = xyz.transpose(1, 2)
         shortcut = x
         x = pw(self.conv1, x)
-        idx = knn(xyz, self.k)                                     # [B,N,k+1], self first
+        # [B,N,k+1], self first. Consecutive blocks at the same resolution receive the SAME xyz tensor object (it is
+        # returned unchanged below), so the graph is computed once per resolution instead of once per block.
+        # (The version counter guards against a caller updating its input tensor in place between forwards.)
+        cached = getattr(xyz, "_pc3d_knn", None)
+        if cached is not None and cached[:2] == (self.k, xyz._version):
+            idx = cached[2]
+        else:
+            idx = knn(xyz, self.k)
+            xyz._pc3d_knn = (self.k, xyz._version, idx)
         if self.use_curve:
             curves = self.curvegrouping(x, xyz, idx[:, :, 1:])     # avoid self-loops
             x = self.curveaggregation(x, curves)

@@ -722,6 +722,74 @@ def edge_max(PQ, idx, slope=0.2):
 
 
 # ------------------------------------------------------------------------------------------------------
+# K17: CurveNet local point-feature aggregation (edge activation, activation + neighbour mean)
+# ------------------------------------------------------------------------------------------------------
+class _EdgeActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, A, Bc, idx, slope):
+        B, N, C = A.shape
+        K = idx.shape[2]
+        E = torch.empty((B, N, K, C), dtype=torch.float32, device=A.device)
+        with torch.cuda.device(A.device):
+            _lib.call("pc3d_edge_act_f32", A.data_ptr(), Bc.data_ptr(), idx.data_ptr(), B, N, K, C, float(slope),
+                      E.data_ptr(), _stream())
+        ctx.save_for_backward(E, idx)
+        ctx.slope = float(slope)
+        return E
+
+    @staticmethod
+    def backward(ctx, gE):
+        E, idx = ctx.saved_tensors
+        B, N, K, C = E.shape
+        gE = gE.contiguous()
+        gA = torch.zeros((B, N, C), dtype=torch.float32, device=E.device)
+        gBc = torch.empty((B, N, C), dtype=torch.float32, device=E.device)
+        with torch.cuda.device(E.device):
+            _lib.call("pc3d_edge_act_bwd_f32", gE.data_ptr(), E.data_ptr(), idx.data_ptr(), B, N, K, C, ctx.slope,
+                      gA.data_ptr(), gBc.data_ptr(), _stream())
+        return gA, gBc, None, None
+
+
+def edge_act(A, Bc, idx, slope=0.2):
+    """E[b,i,j,:] = leaky(A[b,idx[b,i,j],:] + Bc[b,i,:]): A, Bc [B,N,C] (C % 4 == 0), idx [B,N,K] int32 -> [B,N,K,C];
+    differentiable in A and Bc."""
+    _check(A, "A"), _check(Bc, "Bc")
+    if A.shape != Bc.shape or A.shape[2] % 4 or idx.dtype != torch.int32 or idx.shape[:2] != A.shape[:2]:
+        raise ValueError("edge_act: A, Bc [B,N,C] with C % 4 == 0 and idx [B,N,K] int32 expected")
+    return _EdgeActFn.apply(A.contiguous(), Bc.contiguous(), idx.contiguous(), slope)
+
+
+class _ActMeanFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, Z, slope):
+        B, N, K, C = Z.shape
+        out = torch.empty((B, N, C), dtype=torch.float32, device=Z.device)
+        with torch.cuda.device(Z.device):
+            _lib.call("pc3d_act_mean_f32", Z.data_ptr(), B, N, K, C, float(slope), out.data_ptr(), _stream())
+        ctx.save_for_backward(Z)
+        ctx.slope = float(slope)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (Z,) = ctx.saved_tensors
+        B, N, K, C = Z.shape
+        g = g.contiguous()
+        gZ = torch.empty_like(Z)
+        with torch.cuda.device(Z.device):
+            _lib.call("pc3d_act_mean_bwd_f32", Z.data_ptr(), g.data_ptr(), B, N, K, C, ctx.slope, gZ.data_ptr(), _stream())
+        return gZ, None
+
+
+def act_mean(Z, slope=0.2):
+    """out[b,i,:] = mean_j leaky(Z[b,i,j,:]) for Z [B,N,K,C] (C % 4 == 0) in one pass; differentiable."""
+    _check(Z, "Z")
+    if Z.dim() != 4 or Z.shape[3] % 4:
+        raise ValueError("act_mean: Z must be [B,N,K,C] with C % 4 == 0")
+    return _ActMeanFn.apply(Z.contiguous(), slope)
+
+
+# ------------------------------------------------------------------------------------------------------
 # K16: CurveNet guided walk
 # ------------------------------------------------------------------------------------------------------
 CURVE_WALK_CHANNELS = (8, 16, 32, 64)

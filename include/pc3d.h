@@ -314,6 +314,20 @@ int pc3d_curve_walk_bwd_f32(const float* gcurves, const float* feats, const int3
                             int cn, int L, const float* curves, const int32_t* nodes, const int32_t* pick,
                             const float* pre, const float* mom, float* gfeats, float* coef, void* stream);
 
+/* K17  the two bandwidth-bound halves of CurveNet's local point-feature aggregation (model/curvenet_util.py:199-236,
+ * `LPFA.group_feature` / `LPFA.forward`) around its 1x1-conv GEMM; channels-last, C % 4 == 0:
+ *   edge_act: E[b,i,j,:] = leaky_slope(A[b,idx[b,i,j],:] + Bc[b,i,:])   A, Bc [B,N,C], idx [B,N,K] -> E [B,N,K,C]
+ *             backward: gBc [B,N,C] overwritten, gA [B,N,C] ACCUMULATED (zero it first; float atomics)
+ *   act_mean: out[b,i,:] = mean_j leaky_slope(Z[b,i,j,:])                Z [B,N,K,C] -> out [B,N,C]
+ *             backward: gZ overwritten (deterministic). */
+int pc3d_edge_act_f32(const float* A, const float* Bc, const int32_t* idx, int B, int N, int K, int C, float slope,
+                      float* E, void* stream);
+int pc3d_edge_act_bwd_f32(const float* gE, const float* E, const int32_t* idx, int B, int N, int K, int C, float slope,
+                          float* gA, float* gBc, void* stream);
+int pc3d_act_mean_f32(const float* Z, int B, int N, int K, int C, float slope, float* out, void* stream);
+int pc3d_act_mean_bwd_f32(const float* Z, const float* gout, int B, int N, int K, int C, float slope, float* gZ,
+                          void* stream);
+
 /* K12  dense graph Laplacian L = D - A of the symmetrised kNN graph with Gaussian weights A_ij = exp(-|pi-pj|^2)
  * (attack/AOF/TAOF_attack.py:31-52, attack/AOF/Eval_AOF.py:72-93). idx [B,N,K] from pc3d_knn_f32 (self included, as
  * in the reference's topk); L [B,N,N] f32 is overwritten. Only the N*K graph edges are evaluated. */
