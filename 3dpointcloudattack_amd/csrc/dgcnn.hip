@@ -409,9 +409,9 @@ extern "C" int pc3d_gather_max_bwd_f32(const float* g, const int32_t* arg, int B
   if (B == 0) return PC3D_OK;
   PC3D_REQUIRE(g && arg && gP, "pc3d_gather_max_bwd_f32: null pointer");
   hipStream_t st = as_stream(stream);
-  hipError_t e = hipMemsetAsync(gP, 0, (size_t)B * N * C * sizeof(float), st);
+  hipError_t e = zero_async(gP, (size_t)B * N * C, st);
   if (e != hipSuccess) {
-    set_error("pc3d_gather_max_bwd_f32: memset failed: %s", hipGetErrorString(e));
+    set_error("pc3d_gather_max_bwd_f32: zero fill failed: %s", hipGetErrorString(e));
     return (int)e;
   }
   hipLaunchKernelGGL(gather_max_bwd_kernel, dim3((unsigned)(((int64_t)N * C + 255) / 256), B), dim3(256), 0, st, g, arg,
@@ -440,9 +440,9 @@ extern "C" int pc3d_edge_max_bwd_f32(const float* g, const float* out, const int
   if (B == 0) return PC3D_OK;
   PC3D_REQUIRE(g && out && arg && gPQ, "pc3d_edge_max_bwd_f32: null pointer");
   hipStream_t st = as_stream(stream);
-  hipError_t e = hipMemsetAsync(gPQ, 0, (size_t)B * N * 2 * C * sizeof(float), st);
+  hipError_t e = zero_async(gPQ, (size_t)B * N * 2 * C, st);
   if (e != hipSuccess) {
-    set_error("pc3d_edge_max_bwd_f32: memset failed: %s", hipGetErrorString(e));
+    set_error("pc3d_edge_max_bwd_f32: zero fill failed: %s", hipGetErrorString(e));
     return (int)e;
   }
   hipLaunchKernelGGL(edge_max_bwd_kernel, dim3((unsigned)(((int64_t)N * C + 255) / 256), B), dim3(256), 0, st, g, out,

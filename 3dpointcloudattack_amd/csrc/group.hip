@@ -484,10 +484,10 @@ extern "C" int pc3d_group_gather_bwd_f32(const float* g_out, const int32_t* idx,
   PC3D_REQUIRE(g_out && idx, "pc3d_group_gather_bwd_f32: null pointer");
   hipStream_t st = as_stream(stream);
   hipError_t e = hipSuccess;
-  if (grad_xyz) e = hipMemsetAsync(grad_xyz, 0, (size_t)B * N * 3 * sizeof(float), st);
-  if (e == hipSuccess && grad_feat) e = hipMemsetAsync(grad_feat, 0, (size_t)B * N * D * sizeof(float), st);
+  if (grad_xyz) e = zero_async(grad_xyz, (size_t)B * N * 3, st);
+  if (e == hipSuccess && grad_feat) e = zero_async(grad_feat, (size_t)B * N * D, st);
   if (e != hipSuccess) {
-    set_error("pc3d_group_gather_bwd_f32: memset failed: %s", hipGetErrorString(e));
+    set_error("pc3d_group_gather_bwd_f32: zero fill failed: %s", hipGetErrorString(e));
     return (int)e;
   }
   GatherBwdArgs a{g_out, idx, center_idx, N, S, ns, D, (has_xyz ? 3 : 0) + D, has_xyz, grad_xyz, grad_feat};

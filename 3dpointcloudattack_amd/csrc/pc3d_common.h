@@ -42,6 +42,33 @@ static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// Zero-fill as a KERNEL. hipMemsetAsync must not be used by this library: captured into a hipGraph (the attack loops
+// replay graphs) its memset node wrote garbage from the second replay on (ROCm 7.0, tools/exp_graph_memset.py).
+__global__ __launch_bounds__(256) static void zero_fill_kernel(float4* __restrict__ p4, size_t n4, float* __restrict__ tail,
+                                                               int ntail) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n4) p4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < (size_t)ntail) tail[i] = 0.f;
+}
+__global__ __launch_bounds__(256) static void zero_fill_scalar_kernel(float* __restrict__ p, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = 0.f;
+}
+// n floats at p (float4 stores when p is 16-byte aligned, as any torch allocation is).
+static inline hipError_t zero_async(float* p, size_t n, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  if (reinterpret_cast<uintptr_t>(p) & 15) {
+    hipLaunchKernelGGL(zero_fill_scalar_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, n);
+    return hipGetLastError();
+  }
+  const size_t n4 = n / 4;
+  const int ntail = (int)(n % 4);
+  const size_t blocks = (n4 + 255) / 256 + (n4 == 0 ? 1 : 0);
+  hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<float4*>(p), n4,
+                     p + n4 * 4, ntail);
+  return hipGetLastError();
+}
+
 // Wave-level reductions through DPP/ds_swizzle-backed shuffles (64 lanes).
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll

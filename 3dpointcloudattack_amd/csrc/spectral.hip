@@ -55,9 +55,9 @@ extern "C" int pc3d_graph_laplacian_f32(const float* xyz, int64_t x_bs, int64_t 
   if (B == 0) return PC3D_OK;
   PC3D_REQUIRE(xyz && idx && L, "pc3d_graph_laplacian_f32: null pointer");
   hipStream_t st = as_stream(stream);
-  hipError_t e = hipMemsetAsync(L, 0, (size_t)B * N * N * sizeof(float), st);
+  hipError_t e = zero_async(L, (size_t)B * N * N, st);
   if (e != hipSuccess) {
-    set_error("pc3d_graph_laplacian_f32: memset failed: %s", hipGetErrorString(e));
+    set_error("pc3d_graph_laplacian_f32: zero fill failed: %s", hipGetErrorString(e));
     return (int)e;
   }
   LapArgs a{{xyz, x_bs, x_ps, x_cs}, idx, N, K, L};

@@ -1,0 +1,163 @@
+"""hipGraph replay of a frozen victim's forward and backward.
+
+The victims with many small layers (CurveNet: ~900 launches per forward+backward at B=32, N=4096) are bound by the
+host's launch rate, not by the GPU, once their hot ops are single kernels. ``GraphedVictim`` captures one hipGraph for
+the forward and one for the backward of ``model(x)`` per input shape (``torch.cuda.make_graphed_callables``) and
+replays them from inside ordinary autograd code, so the attack loops (attack/{CW,GeoA3,KNN}) stay as they are.
+
+What makes a replay safe here, and what is checked:
+  * only victims that declare ``deterministic_forward`` (a pure function of the input: no RNG, no data-dependent
+    shapes) are wrapped — ``wrap()`` returns any other model unchanged;
+  * a graph holds its intermediates in its own memory, so a second forward would overwrite what the first one's
+    backward needs. Calls with gradients enabled and calls under ``no_grad`` replay separate captures, outputs are
+    returned as copies, and a gradient-enabled call that arrives while the previous one is still waiting for its
+    backward (its output is still referenced) runs eagerly instead;
+  * the capture is keyed on the version counters of the victim's parameters and buffers: loading other weights or
+    moving the model re-captures.
+"""
+import weakref
+
+import torch
+import torch.nn as nn
+
+MAX_CAPTURES = 4     # per wrapper; oldest capture is dropped beyond this
+
+
+class _Guard(torch.autograd.Function):
+    """Copies the graph's static outputs and ties the backward to the capture slot that produced them."""
+
+    @staticmethod
+    def forward(ctx, slot, ticket, *outs):
+        ctx.slot, ctx.ticket = slot, ticket
+        return tuple(o.clone() for o in outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        slot = ctx.slot
+        if slot.ticket != ctx.ticket:
+            raise RuntimeError("GraphedVictim: backward of a forward whose graph memory has since been reused")
+        slot.pending = False
+        return (None, None) + grads
+
+
+class _Slot:
+    def __init__(self, fn):
+        self.fn = fn
+        self.ticket = 0
+        self.pending = False
+        self.out_ref = None
+
+
+class GraphedVictim(nn.Module):
+    """``model`` with its forward/backward replayed from hipGraphs. Attribute access falls through to the model
+    (``fused_attack_grad``, ``deterministic_forward``, ...)."""
+
+    def __init__(self, model, warmup=3):
+        super().__init__()
+        self.model = model
+        self._warmup = warmup
+        self._slots = {}
+        self.stats = {"replayed": 0, "eager": 0, "captures": 0}
+
+    def __getattr__(self, name):
+        try:
+            return super().__getattr__(name)
+        except AttributeError:
+            return getattr(super().__getattr__("model"), name)
+
+    def state_dict(self, *a, **k):
+        return self.model.state_dict(*a, **k)
+
+    def load_state_dict(self, *a, **k):
+        return self.model.load_state_dict(*a, **k)
+
+    def _weights_key(self):
+        return tuple((t.data_ptr(), t._version) for t in list(self.model.parameters()) + list(self.model.buffers()))
+
+    def _capture(self, x, with_grad):
+        model = self.model
+        probe = x.detach().clone().requires_grad_(with_grad)
+        with torch.set_grad_enabled(with_grad):
+            out = model(probe)
+        outs = out if isinstance(out, (tuple, list)) else (out,)
+        uniq, where = [], []                 # where[i]: index into the graphed outputs, or ("const", value)
+        for o in outs:                       # victims return the same tensor several times (x, x, x)
+            if not torch.is_tensor(o):
+                where.append(("const", o))
+                continue
+            for i, u in enumerate(uniq):
+                if u is o:
+                    where.append(i)
+                    break
+            else:
+                where.append(len(uniq))
+                uniq.append(o)
+        picks = [next(i for i, o in enumerate(outs) if o is u) for u in uniq]
+        is_seq = isinstance(out, (tuple, list))
+
+        def fn(inp):
+            o = model(inp)
+            o = o if isinstance(o, (tuple, list)) else (o,)
+            return tuple(o[i] for i in picks)
+
+        if with_grad:
+            g = torch.cuda.make_graphed_callables(fn, (x.detach().clone().requires_grad_(True),),
+                                                  num_warmup_iters=self._warmup)
+        else:
+            static_in = x.detach().clone()
+            side = torch.cuda.Stream(device=x.device)
+            side.wait_stream(torch.cuda.current_stream(x.device))
+            with torch.cuda.stream(side), torch.no_grad():
+                for _ in range(self._warmup):
+                    fn(static_in)
+            torch.cuda.current_stream(x.device).wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.no_grad(), torch.cuda.graph(graph):
+                static_out = fn(static_in)
+
+            def g(inp):
+                static_in.copy_(inp)
+                graph.replay()
+                return static_out
+        slot = _Slot(g)
+        slot.where, slot.is_seq = where, is_seq
+        self.stats["captures"] += 1
+        return slot
+
+    def forward(self, x):
+        model = self.model
+        if (not torch.is_tensor(x) or not x.is_cuda or model.training or not getattr(model, "deterministic_forward", False)
+                or torch.cuda.is_current_stream_capturing()):
+            return model(x)
+        with_grad = torch.is_grad_enabled() and x.requires_grad
+        key = (tuple(x.shape), x.dtype, x.device, with_grad, self._weights_key())
+        slot = self._slots.get(key)
+        if slot is None:
+            while len(self._slots) >= MAX_CAPTURES:
+                self._slots.pop(next(iter(self._slots)))
+            slot = self._slots[key] = self._capture(x, with_grad)
+        if with_grad and slot.pending and slot.out_ref is not None and slot.out_ref() is not None:
+            self.stats["eager"] += 1         # the previous forward still waits for its backward: do not touch its memory
+            return model(x)
+        self.stats["replayed"] += 1
+        outs = slot.fn(x)
+        if with_grad:
+            slot.ticket += 1
+            outs = _Guard.apply(slot, slot.ticket, *outs)
+            slot.pending = True
+            slot.out_ref = weakref.ref(outs[0])
+        else:
+            outs = tuple(o.clone() for o in outs)
+        res = tuple(w[1] if isinstance(w, tuple) else outs[w] for w in slot.where)
+        return res if slot.is_seq else res[0]
+
+
+def wrap(model, enable=True):
+    """``GraphedVictim(model)`` for victims that declare a deterministic forward, the model itself otherwise."""
+    if not enable or isinstance(model, GraphedVictim) or not getattr(model, "deterministic_forward", False):
+        return model
+    g = model.__dict__.get("_pc3d_graphed")
+    if g is None:                            # kept on the model (not as a sub-module) so that repeated attack calls
+        g = GraphedVictim(model)             # on the same victim reuse the captures
+        object.__setattr__(model, "_pc3d_graphed", g)
+    return g

@@ -43,8 +43,16 @@ class CurveNet(_FrozenFusedMixin, nn.Module):
         xyz = xyz.float()
         feats = self.lpfa(xyz, xyz)
         pos = xyz
-        for blk in (self.cic11, self.cic12, self.cic21, self.cic22, self.cic31, self.cic32, self.cic41, self.cic42):
-            pos, feats = blk(pos, feats)
+        blocks = (self.cic11, self.cic12, self.cic21, self.cic22, self.cic31, self.cic32, self.cic41, self.cic42)
+        graphs = {}                                  # kNN graphs of THIS forward, shared by blocks at one resolution
+        for blk in blocks:
+            object.__setattr__(blk, "_graph_cache", graphs)
+        try:
+            for blk in blocks:
+                pos, feats = blk(pos, feats)
+        finally:
+            for blk in blocks:
+                object.__setattr__(blk, "_graph_cache", None)
         x = pw(self.conv0, feats)
         x = torch.cat((F.adaptive_max_pool1d(x, 1), F.adaptive_avg_pool1d(x, 1)), dim=1).squeeze(-1)
         x = F.relu(pw(self.conv1, x, bn=self.bn1))

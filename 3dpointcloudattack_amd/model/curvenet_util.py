@@ -299,14 +299,16 @@ class CIC(nn.Module):
         shortcut = x
         x = pw(self.conv1, x)
         # [B,N,k+1], self first. Consecutive blocks at the same resolution receive the SAME xyz tensor object (it is
-        # returned unchanged below), so the graph is computed once per resolution instead of once per block.
-        # (The version counter guards against a caller updating its input tensor in place between forwards.)
-        cached = getattr(xyz, "_pc3d_knn", None)
-        if cached is not None and cached[:2] == (self.k, xyz._version):
-            idx = cached[2]
+        # returned unchanged below), so within one CurveNet.forward (which hands every block a fresh dict) the graph
+        # is computed once per resolution instead of once per block.
+        cache = self.__dict__.get("_graph_cache")
+        hit = cache.get((id(xyz), self.k)) if cache is not None else None
+        if hit is not None and hit[0] is xyz:
+            idx = hit[1]
         else:
             idx = knn(xyz, self.k)
-            xyz._pc3d_knn = (self.k, xyz._version, idx)
+            if cache is not None:
+                cache[(id(xyz), self.k)] = (xyz, idx)
         if self.use_curve:
             curves = self.curvegrouping(x, xyz, idx[:, :, 1:])     # avoid self-loops
             x = self.curveaggregation(x, curves)
