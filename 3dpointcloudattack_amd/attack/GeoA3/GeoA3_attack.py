@@ -15,6 +15,8 @@ import torch
 import torch.nn as nn
 import torch.optim as optim
 
+from ... import graphed as _graphed
+
 from .knn_utils import knn_gather, knn_points
 from .loss_utils import (_get_kappa_adv, _get_kappa_ori, chamfer_loss, curvature_loss, hausdorff_loss, norm_l2_loss,
                          pseudo_chamfer_loss, uniform_loss)
@@ -129,6 +131,9 @@ def geoA3_attack(net, pt_model, ptm_model, pts_model, dgcnn_model, cur_model, pc
             m.eval()
         transfer.append(m)
     targeted = cfg.attack_method != 'untarget'
+    # a victim with a deterministic forward replays its forward/backward from hipGraphs (graphed.py; the wrapper is
+    # kept on the model, so every batch of a run reuses the captures). cfg.graph_victim = False launches eagerly.
+    net = _graphed.wrap(net, enable=getattr(cfg, "graph_victim", True))
 
     pc = pc.transpose(2, 1).float().to(dev)
     normal = estimate_normal(pc, k=3)

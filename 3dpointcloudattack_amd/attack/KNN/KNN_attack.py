@@ -11,6 +11,7 @@ import numpy as np
 import torch
 import torch.optim as optim
 
+from ... import graphed as _graphed
 from ... import ops
 from ..CW.CW_utils import clip_utils as _clip_utils
 from ..CW.CW_utils import dist_utils as _dist_utils
@@ -32,7 +33,8 @@ class CWKNN:
     """Class for CW attack."""
 
     def __init__(self, model, pt_model, ptm_model, pts_model, dgcnn_model, cur_model, adv_func, dist_func, clip_func,
-                 attack_lr=1e-3, num_iter=2500, attack_method='untarget', device=None, verbose=False, fused=True):
+                 attack_lr=1e-3, num_iter=2500, attack_method='untarget', device=None, verbose=False, fused=True,
+                 graph=True):
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
 
         def prep(m):
@@ -42,7 +44,8 @@ class CWKNN:
             m.eval()
             return m
 
-        self.model = prep(model)
+        # a victim with a deterministic forward replays its forward/backward from hipGraphs (graphed.py)
+        self.model = _graphed.wrap(prep(model), enable=graph)
         self.pt_model = prep(pt_model)
         self.ptm_model = prep(ptm_model)
         self.pts_model = prep(pts_model)

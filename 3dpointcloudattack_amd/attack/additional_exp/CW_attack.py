@@ -24,6 +24,8 @@ import numpy as np
 import torch
 import torch.optim as optim
 
+from ... import graphed as _graphed
+
 
 class AdvLossAdapter:
     """Gives a CW_utils.adv_utils-style functor pair the ``whether_target`` keyword this attack calls with (:245-259)."""
@@ -67,10 +69,11 @@ class CW:
     def __init__(self, model, adv_func, dist_func, attack_lr=1e-2,
                  init_weight=10., max_weight=80., binary_step=10, num_iter=500, whether_target=True, whether_1d=True,
                  whether_renormalization=False,
-                 whether_3Dtransform=False, whether_resample=False, device=None, verbose=False):
+                 whether_3Dtransform=False, whether_resample=False, device=None, verbose=False, graph=True):
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.model = model.to(self.device)
         self.model.eval()
+        self.model = _graphed.wrap(self.model, enable=graph)   # hipGraph replay for deterministic victims
         self.adv_func = adv_func
         self.dist_func = dist_func
         self.attack_lr = attack_lr

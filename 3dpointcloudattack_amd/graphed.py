@@ -10,8 +10,8 @@ What makes a replay safe here, and what is checked:
     shapes) are wrapped — ``wrap()`` returns any other model unchanged;
   * a graph holds its intermediates in its own memory, so a second forward would overwrite what the first one's
     backward needs. Calls with gradients enabled and calls under ``no_grad`` replay separate captures, outputs are
-    returned as copies, and a gradient-enabled call that arrives while the previous one is still waiting for its
-    backward (its output is still referenced) runs eagerly instead;
+    returned as copies, and a gradient-enabled call that arrives while an earlier one still waits for its backward
+    (its autograd node is alive) replays another replica of the capture (up to MAX_REPLICAS), then runs eagerly;
   * the capture is keyed on the version counters of the victim's parameters and buffers: loading other weights or
     moving the model re-captures.
 """
@@ -20,7 +20,14 @@ import weakref
 import torch
 import torch.nn as nn
 
-MAX_CAPTURES = 4     # per wrapper; oldest capture is dropped beyond this
+MAX_CAPTURES = 4     # distinct (shape, mode, weights) keys per wrapper; the oldest is dropped beyond this
+MAX_REPLICAS = 4     # captures of ONE key that may wait for their backward at the same time (EOT-style loops that
+                     # run several forwards before one backward); further forwards run eagerly
+
+
+class _Token:
+    """Lives exactly as long as the autograd node of one replayed forward (it hangs off that node's ctx)."""
+    __slots__ = ("__weakref__",)
 
 
 class _Guard(torch.autograd.Function):
@@ -29,6 +36,8 @@ class _Guard(torch.autograd.Function):
     @staticmethod
     def forward(ctx, slot, ticket, *outs):
         ctx.slot, ctx.ticket = slot, ticket
+        ctx.token = _Token()
+        slot.token_ref = weakref.ref(ctx.token)
         return tuple(o.clone() for o in outs)
 
     @staticmethod
@@ -45,7 +54,35 @@ class _Slot:
         self.fn = fn
         self.ticket = 0
         self.pending = False
-        self.out_ref = None
+        self.token_ref = None
+
+    def busy(self):
+        """A gradient-enabled forward was replayed here and its autograd node is still alive without having run its
+        backward: the graph's memory holds what that backward will read."""
+        return self.pending and self.token_ref is not None and self.token_ref() is not None
+
+
+def _cached_tensors(model):
+    """Every tensor reachable from plain attributes of the model's modules (weight caches; not parameters/buffers)."""
+    found, seen = [], set()
+
+    def walk(v, depth=0):
+        if torch.is_tensor(v):
+            if id(v) not in seen:
+                seen.add(id(v))
+                found.append(v)
+        elif isinstance(v, (tuple, list)) and depth < 6:
+            for e in v:
+                walk(e, depth + 1)
+        elif isinstance(v, dict) and depth < 6:
+            for e in v.values():
+                walk(e, depth + 1)
+
+    for mod in model.modules():
+        for name, val in vars(mod).items():
+            if name not in ("_parameters", "_buffers", "_modules") and not isinstance(val, nn.Module):
+                walk(val)
+    return found
 
 
 class GraphedVictim(nn.Module):
@@ -121,6 +158,9 @@ class GraphedVictim(nn.Module):
                 return static_out
         slot = _Slot(g)
         slot.where, slot.is_seq = where, is_seq
+        # The graphs hold raw pointers to every tensor the forward read, including the victims' folded-weight caches
+        # (created lazily, dropped by .eval()/.to() even when nothing changed): keep those alive with the capture.
+        slot.keepalive = _cached_tensors(model)
         self.stats["captures"] += 1
         return slot
 
@@ -131,21 +171,24 @@ class GraphedVictim(nn.Module):
             return model(x)
         with_grad = torch.is_grad_enabled() and x.requires_grad
         key = (tuple(x.shape), x.dtype, x.device, with_grad, self._weights_key())
-        slot = self._slots.get(key)
-        if slot is None:
+        slots = self._slots.get(key)
+        if slots is None:
             while len(self._slots) >= MAX_CAPTURES:
                 self._slots.pop(next(iter(self._slots)))
-            slot = self._slots[key] = self._capture(x, with_grad)
-        if with_grad and slot.pending and slot.out_ref is not None and slot.out_ref() is not None:
-            self.stats["eager"] += 1         # the previous forward still waits for its backward: do not touch its memory
+            slots = self._slots[key] = [self._capture(x, with_grad)]
+        slot = next((s for s in slots if not s.busy()), None) if with_grad else slots[0]
+        if slot is None and len(slots) < MAX_REPLICAS:
+            slot = self._capture(x, with_grad)
+            slots.append(slot)
+        if slot is None:
+            self.stats["eager"] += 1         # every replica still waits for its backward: do not touch their memory
             return model(x)
         self.stats["replayed"] += 1
         outs = slot.fn(x)
         if with_grad:
             slot.ticket += 1
-            outs = _Guard.apply(slot, slot.ticket, *outs)
             slot.pending = True
-            slot.out_ref = weakref.ref(outs[0])
+            outs = _Guard.apply(slot, slot.ticket, *outs)
         else:
             outs = tuple(o.clone() for o in outs)
         res = tuple(w[1] if isinstance(w, tuple) else outs[w] for w in slot.where)

@@ -35,7 +35,8 @@ class _FrozenFusedMixin:
         object.__setattr__(self, "_fused_cache", None)
 
     def train(self, mode=True):
-        self._invalidate()
+        if mode != self.training:
+            self._invalidate()
         return super().train(mode)
 
     def _apply(self, fn, *a, **k):

@@ -48,28 +48,31 @@ def test_replay_matches_eager(dev, name):
         assert (gg - ge).norm() <= 2e-3 * ge.norm() + 1e-12, (trial, g.stats)
         with torch.no_grad():
             torch.testing.assert_close(g(x)[0], m(x)[0], rtol=1e-4, atol=1e-5)
-    assert g.stats["replayed"] >= 6 and g.stats["eager"] == 0 and g.stats["captures"] == 2
+    assert g.stats["replayed"] >= 6 and g.stats["eager"] == 0 and g.stats["captures"] == 2, g.stats
 
 
-def test_second_forward_before_backward_runs_eagerly(dev):
+def test_forwards_waiting_for_backward_keep_their_memory(dev):
+    """Several forwards before one backward (expectation-over-transformation loops): each replays its own replica of
+    the capture, beyond MAX_REPLICAS the call runs eagerly; the gradients are those of the eager victim. The first
+    forward's OUTPUT tensor is dropped on purpose: what keeps a replica busy is its autograd node."""
     m = _victim(dev, "dgcnn")
     g = graphed.wrap(m)
     gen = torch.Generator().manual_seed(1)
-    x1 = (torch.rand(2, 3, 256, generator=gen) - 0.5).to(dev).requires_grad_()
-    x2 = (torch.rand(2, 3, 256, generator=gen) - 0.5).to(dev).requires_grad_()
+    n = graphed.MAX_REPLICAS + 1
+    xs = [(torch.rand(2, 3, 256, generator=gen) - 0.5).to(dev).requires_grad_() for _ in range(n)]
     w = torch.randn(2, 40, generator=gen).to(dev)
-    g(x1.detach().clone().requires_grad_())[0].sum().backward()          # capture
-    a = g(x1)[0]
-    b = g(x2)[0]                                                         # a still waits for its backward
-    assert g.stats["eager"] == 1
-    ((a + b) * w).sum().backward()
-    r1, r2 = x1.detach().clone().requires_grad_(), x2.detach().clone().requires_grad_()
-    ((m(r1)[0] + m(r2)[0]) * w).sum().backward()
-    for got, ref in ((x1.grad, r1.grad), (x2.grad, r2.grad)):
-        assert (got - ref).norm() <= 2e-3 * ref.norm() + 1e-12
-    del a, b
-    g(x1)[0].sum().backward()                                            # free again: replayed
-    assert g.stats["eager"] == 1
+    loss = 0.
+    for x in xs:
+        loss = loss + (g(x)[0] * w).sum()
+    assert g.stats["captures"] == graphed.MAX_REPLICAS and g.stats["eager"] == 1
+    loss.backward()
+    rs = [x.detach().clone().requires_grad_() for x in xs]
+    sum((m(r)[0] * w).sum() for r in rs).backward()
+    for x, r in zip(xs, rs):
+        assert (x.grad - r.grad).norm() <= 2e-3 * r.grad.norm() + 1e-12
+    before = dict(g.stats)
+    g(xs[0].detach().clone().requires_grad_())[0].sum().backward()      # all replicas are free again: a replay
+    assert g.stats["eager"] == before["eager"] and g.stats["captures"] == before["captures"]
 
 
 def test_recaptures_when_weights_change(dev):
@@ -87,3 +90,23 @@ def test_recaptures_when_weights_change(dev):
 def test_non_deterministic_victims_are_left_alone(dev):
     ssg = importlib.import_module("3dpointcloudattack_amd.model.pointnet2_SSG").PointNet_Ssg(num_classes=40)
     assert graphed.wrap(ssg) is ssg
+
+
+def test_capture_survives_cache_invalidation(dev):
+    """.eval() / .to(device) drop the victims' folded-weight caches even when nothing changed; a capture made before
+    must keep replaying correctly (it keeps the tensors it was captured with alive)."""
+    m = _victim(dev, "pointnet")
+    g = graphed.wrap(m)
+    gen = torch.Generator().manual_seed(5)
+    x = (torch.rand(3, 3, 200, generator=gen) - 0.5).to(dev)
+    w = torch.randn(3, 40, generator=gen).to(dev)
+    _grad(g, x, w)
+    ref_l, ref_g, _ = _grad(m, x, w)
+    for _ in range(3):
+        m.train(True), m.eval(), m.to(dev), m._invalidate()
+        junk = [torch.full((1 << 16,), float("nan"), device=dev) for _ in range(64)]    # reuse whatever was freed
+        l, gr, _ = _grad(g, x, w)
+        del junk
+        torch.testing.assert_close(l, ref_l, rtol=1e-4, atol=1e-5)
+        assert (gr - ref_g).norm() <= 2e-3 * ref_g.norm() + 1e-12
+    assert g.stats["captures"] == 1

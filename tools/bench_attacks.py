@@ -1,5 +1,6 @@
-"""Whole-attack wall time per iteration for BASELINE.json configs[2] (GeoA3 on DGCNN, B=32 N=1024) and configs[3]
-(KNN attack on PointNet++ SSG, B=64 N=2048), short runs; prints JSON."""
+"""Whole-attack wall time per iteration for BASELINE.json configs[2] (GeoA3 on DGCNN, B=32 N=1024), configs[3]
+(KNN attack on PointNet++ SSG, B=64 N=2048) and one GPU's share of configs[4] (CW and GeoA3 on CurveNet, B=32
+N=4096), short runs; prints JSON. PC3D_GRAPH_VICTIM=0 launches the victims eagerly."""
 import importlib, sys, os, json, time, types
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -14,7 +15,44 @@ def mk(modname, cls, seed=0, **kw):
     m.load_state_dict(seeded_state_dict(m, seed)); return m.to(dev).eval()
 rng = np.random.default_rng(0)
 which = sys.argv[1:] or ["geoa3", "knn", "aof"]
+GRAPH = os.environ.get("PC3D_GRAPH_VICTIM", "1") != "0"
 res = {}
+if "cw_curvenet" in which:
+    B, N, IT = 32, 4096, 30
+    net = mk("curvenet", "CurveNet", 0, num_classes=40)
+    pcs = torch.from_numpy(np.stack([unit_cloud(rng, N) for _ in range(B)]))
+    with torch.no_grad():
+        lab = net(pcs.transpose(1, 2).contiguous().to(dev))[0].argmax(1).cpu()
+    cw = M("3dpointcloudattack_amd.attack.CW.CW_attack")
+    adv = M("3dpointcloudattack_amd.attack.CW.CW_utils.adv_utils"); du = M("3dpointcloudattack_amd.attack.CW.CW_utils.dist_utils")
+    cu = M("3dpointcloudattack_amd.attack.CW.CW_utils.clip_utils")
+    ts = []
+    for it in (6, 6, 6 + IT):
+        atk = cw.CW(net, net, adv.UntargetedLogitsAdvLoss(kappa=0.), cu.ClipPointsLinf(budget=0.18), du.ChamferDist(method='adv2ori'),
+                    attack_lr=1e-2, binary_step=1, num_iter=it, graph=GRAPH)
+        torch.manual_seed(0); np.random.seed(0)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        atk.attack(pcs, lab)
+        torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+    res["cw_curvenet_B32_N4096_ms_per_iter"] = (ts[2] - ts[1]) / IT * 1e3
+    print(res, flush=True)
+if "geoa3_curvenet" in which:
+    B, N, IT = 32, 4096, 30
+    net = mk("curvenet", "CurveNet", 0, num_classes=40)
+    pcs = torch.from_numpy(np.stack([unit_cloud(rng, N) for _ in range(B)]))
+    with torch.no_grad():
+        lab = net(pcs.transpose(1, 2).contiguous().to(dev))[0].argmax(1).cpu()
+    ga = M("3dpointcloudattack_amd.attack.GeoA3.GeoA3_attack")
+    ts = []
+    for it in (6, 6, 6 + IT):
+        cfg = _geo_cfg(iter_max_steps=it, binary_max_steps=1, npoint=N, cls_loss_type='CE', hd_loss_weight=0.1, curv_loss_weight=1.0)
+        cfg.graph_victim = GRAPH
+        torch.manual_seed(0); np.random.seed(0)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        ga.geoA3_attack(net, None, None, None, None, None, pcs, lab, cfg, 0, 1)
+        torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+    res["geoa3_curvenet_B32_N4096_ms_per_iter"] = (ts[2] - ts[1]) / IT * 1e3
+    print(res, flush=True)
 if "geoa3" in which:
     B, N, IT = 32, 1024, 60
     net = mk("dgcnn", "DGCNN", 0, args=types.SimpleNamespace(k=20, emb_dims=1024, dropout=0.5), output_channels=40)
@@ -24,6 +62,7 @@ if "geoa3" in which:
     ga = M("3dpointcloudattack_amd.attack.GeoA3.GeoA3_attack")
     for it in (10, 10, 10 + IT):
         cfg = _geo_cfg(iter_max_steps=it, binary_max_steps=1, npoint=N, cls_loss_type='CE', hd_loss_weight=0.1, curv_loss_weight=1.0)
+        cfg.graph_victim = GRAPH
         torch.manual_seed(0); np.random.seed(0)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         ga.geoA3_attack(net, None, None, None, None, None, pcs, lab, cfg, 0, 1)

@@ -40,6 +40,18 @@ for nm in sys.argv[1:] or ["curvenet", "dgcnn"]:
         g_g = step(fg, x).clone()
         res[nm] = {"eager_ms": round(eager, 3), "graphed_ms": round(graphed, 3), "grad_maxabs_diff": float((g_e - g_g).abs().max()),
                    "grad_maxabs": float(g_e.abs().max())}
+        # forward + loss + backward in ONE graph (what a whole-iteration capture does)
+        sx = x.clone().requires_grad_()
+        side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                torch.autograd.grad(f(sx).logsumexp(1).sum(), sx)
+        torch.cuda.current_stream().wait_stream(side)
+        one = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(one):
+            (sg,) = torch.autograd.grad(f(sx).logsumexp(1).sum(), sx)
+        res[nm]["one_graph_ms"] = round(timeit(lambda: one.replay()), 3)
+        res[nm]["one_graph_grad_diff"] = float((sg - g_e).abs().max())
     except Exception as e:
         res[nm] = {"eager_ms": round(eager, 3), "error": repr(e)[:400]}
     print(nm, res[nm], flush=True)
