@@ -34,23 +34,39 @@ __global__ __launch_bounds__(256) void edge_act_fwd_kernel(const float4* __restr
   E[t] = leaky4(make_float4(a.x + c.x, a.y + c.y, a.z + c.z, a.w + c.w), slope);
 }
 
-// one thread per (point, float4 channel group): gBc = sum_j g_pre, gA[idx] += g_pre (float atomics)
-__global__ __launch_bounds__(256) void edge_act_bwd_kernel(const float4* __restrict__ gE, const float4* __restrict__ E,
-                                                           const int* __restrict__ idx, int N, int K, int C4,
+// one thread per (point, channel): gBc = sum_j g_pre, gA[idx] += g_pre. Consecutive lanes own consecutive channels, so
+// every atomic instruction of a wave lands on whole contiguous rows (64 / C of them) instead of strided quarters.
+__global__ __launch_bounds__(256) void edge_act_bwd_kernel(const float* __restrict__ gE, const float* __restrict__ E,
+                                                           const int* __restrict__ idx, int N, int K, int C,
                                                            float slope, float* __restrict__ gA,
-                                                           float4* __restrict__ gBc, int64_t total) {
+                                                           float* __restrict__ gBc, int64_t total) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= total) return;
-  const int c4 = (int)(t % C4);
-  const int64_t bi = t / C4, b = bi / N;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int j = 0; j < K; ++j) {
-    const int64_t e = bi * K + j;
-    const float4 g = leaky_grad4(gE[e * C4 + c4], E[e * C4 + c4], slope);
-    acc.x += g.x, acc.y += g.y, acc.z += g.z, acc.w += g.w;
-    const int r = min(max(idx[e], 0), N - 1);
-    float* dst = gA + ((b * N + r) * C4 + c4) * 4;
-    atomicAdd(dst, g.x), atomicAdd(dst + 1, g.y), atomicAdd(dst + 2, g.z), atomicAdd(dst + 3, g.w);
+  const int c = (int)(t % C);
+  const int64_t bi = t / C, b = bi / N;
+  const float* ge = gE + bi * K * C + c;
+  const float* ev = E + bi * K * C + c;
+  const int* id = idx + bi * K;
+  float* ga = gA + b * N * C + c;
+  float acc = 0.f;
+  int j = 0;
+  for (; j + 4 <= K; j += 4) {   // four edges in flight
+    float g[4], o[4];
+    int r[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) g[u] = ge[(int64_t)(j + u) * C], o[u] = ev[(int64_t)(j + u) * C], r[u] = id[j + u];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float v = o[u] > 0.f ? g[u] : g[u] * slope;
+      acc += v;
+      atomicAdd(ga + (int64_t)min(max(r[u], 0), N - 1) * C, v);
+    }
+  }
+  for (; j < K; ++j) {
+    const float g = ge[(int64_t)j * C];
+    const float v = ev[(int64_t)j * C] > 0.f ? g : g * slope;
+    acc += v;
+    atomicAdd(ga + (int64_t)min(max(id[j], 0), N - 1) * C, v);
   }
   gBc[t] = acc;
 }
@@ -118,11 +134,11 @@ extern "C" int pc3d_edge_act_bwd_f32(const float* gE, const float* E, const int3
                                      float slope, float* gA, float* gBc, void* stream) {
   LPFA_SIZES("pc3d_edge_act_bwd_f32");
   PC3D_REQUIRE(gE && E && idx && gA && gBc, "pc3d_edge_act_bwd_f32: null pointer");
-  const int64_t total = (int64_t)B * N * (C / 4);
+  const int64_t total = (int64_t)B * N * C;
   unsigned blocks;
   if (int rc = lpfa_grid(total, &blocks, "pc3d_edge_act_bwd_f32")) return rc;
-  hipLaunchKernelGGL(edge_act_bwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), (const float4*)gE,
-                     (const float4*)E, idx, N, K, C / 4, slope, gA, (float4*)gBc, total);
+  hipLaunchKernelGGL(edge_act_bwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), gE, E, idx, N, K, C, slope,
+                     gA, gBc, total);
   PC3D_LAUNCH_CHECK("pc3d_edge_act_bwd_f32");
   return PC3D_OK;
 }
