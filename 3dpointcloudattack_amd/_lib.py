@@ -49,6 +49,8 @@ SIGNATURES = {
     "pc3d_act_pool_bwd_f32": [_P, _P, _P, _I, _I, _I, _F, _P, _P],
     "pc3d_curve_walk_fwd_f32": [_P] * 7 + [_I] * 6 + [_P] * 5 + [_P],
     "pc3d_curve_walk_bwd_f32": [_P] * 7 + [_I] * 6 + [_P] * 7 + [_P],
+    "pc3d_curve_agg_kv_f32": [_P] * 9 + [_I] * 5 + [_P, _P, _P],
+    "pc3d_curve_agg_kv_bwd_f32": [_P] * 11 + [_I] * 5 + [_P, _P],
     "pc3d_edge_act_f32": [_P, _P, _P, _I, _I, _I, _I, _F, _P, _P],
     "pc3d_edge_act_bwd_f32": [_P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P],
     "pc3d_act_mean_f32": [_P, _I, _I, _I, _I, _F, _P, _P],

@@ -332,8 +332,31 @@ class CurveAggregation(nn.Module):
         self.convl = nn.Conv1d(mid_feature, mid_feature, kernel_size=1, bias=False)
         self.convd = nn.Sequential(nn.Conv1d(mid_feature * 2, in_channel, kernel_size=1, bias=False), nn.BatchNorm1d(in_channel))
         self.line_conv_att = nn.Conv2d(in_channel, 1, kernel_size=1, bias=False)
+        self.fused = True
 
     def forward(self, x, curves):
+        B, C, cn, cl = curves.shape
+        mid = C // 2
+        if self.fused and x.is_cuda and ops.curve_agg_lds_bytes(cn, cl, C, mid) <= 64 * 1024:
+            return self._forward_kv(x, curves)
+        return self.forward_steps(x, curves)
+
+    def _forward_kv(self, x, curves):
+        """One launch turns the curves into attention keys / values with convc and convd already applied
+        (pc3d_curve_agg_kv_f32); per point that leaves  leaky(x + softmax(x^T K_inter) V_inter + softmax(x^T K_intra)
+        V_intra): two batched GEMMs and two softmaxes."""
+        cn = curves.shape[2]
+        fold = lambda m: folded_pw(m)[2:]                                            # noqa: E731
+        (w_att, _), (wa, _), (wb, _), (wc, _) = fold(self.line_conv_att), fold(self.conva), fold(self.convb), fold(self.convc)
+        (wn, _), (wl, _), (wd, bd) = fold(self.convn), fold(self.convl), fold(self.convd)
+        Kp, Vp = ops.curve_agg_kv(curves.permute(0, 2, 3, 1), w_att, wa, wb, wn, wl, wc, wd, bd)
+        xT = x.transpose(1, 2)                                                        # [B,N,C]
+        s = torch.bmm(xT, Kp)                                                         # [B,N,cn+cl]
+        w = torch.cat((F.softmax(s[:, :, :cn], dim=-1), F.softmax(s[:, :, cn:], dim=-1)), dim=-1)
+        return F.leaky_relu(torch.baddbmm(xT, w, Vp), negative_slope=0.2).transpose(1, 2)
+
+    def forward_steps(self, x, curves):
+        """The same block as the reference's sequence of 1x1 convs, softmaxes and products (:393-437)."""
         att = pw(self.line_conv_att, curves)                                          # [B,1,cn,cl]
         inter = pw(self.conva, torch.sum(curves * F.softmax(att, dim=-1), dim=-1))    # [B,mid,cn]
         intra = pw(self.convb, torch.sum(curves * F.softmax(att, dim=-2), dim=-2))    # [B,mid,cl]

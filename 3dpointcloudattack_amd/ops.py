@@ -790,6 +790,56 @@ def act_mean(Z, slope=0.2):
 
 
 # ------------------------------------------------------------------------------------------------------
+# K18: CurveNet curve aggregation, per-cloud half (attention keys / values from the curves)
+# ------------------------------------------------------------------------------------------------------
+def curve_agg_lds_bytes(cn, cl, C, mid, backward=True):
+    R = cn + cl
+    return 4 * ((6 if backward else 3) * cn * cl + R * C + 2 * R * mid + (R if backward else 0))
+
+
+class _CurveAggKVFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, curves, *ws):
+        B, cn, cl, C = curves.shape
+        mid = ws[1].shape[0]
+        R = cn + cl
+        Kp = torch.empty((B, C, R), dtype=torch.float32, device=curves.device)
+        Vp = torch.empty((B, R, C), dtype=torch.float32, device=curves.device)
+        with torch.cuda.device(curves.device):
+            _lib.call("pc3d_curve_agg_kv_f32", curves.data_ptr(), *[w.data_ptr() for w in ws], B, cn, cl, C, mid,
+                      Kp.data_ptr(), Vp.data_ptr(), _stream())
+        ctx.save_for_backward(curves, *ws)
+        return Kp, Vp
+
+    @staticmethod
+    def backward(ctx, gKp, gVp):
+        curves, *ws = ctx.saved_tensors
+        B, cn, cl, C = curves.shape
+        mid = ws[1].shape[0]
+        gKp, gVp = gKp.contiguous(), gVp.contiguous()
+        gc = torch.empty_like(curves)
+        with torch.cuda.device(curves.device):
+            _lib.call("pc3d_curve_agg_kv_bwd_f32", gKp.data_ptr(), gVp.data_ptr(), curves.data_ptr(),
+                      *[w.data_ptr() for w in ws], B, cn, cl, C, mid, gc.data_ptr(), _stream())
+        return (gc,) + (None,) * len(ws)
+
+
+def curve_agg_kv(curves, w_att, Wa, Wb, Wn, Wl, Wc, Wd, bd):
+    """Attention keys Kp [B,C,cn+cl] and values Vp [B,cn+cl,C] of CurveNet's curve aggregation from channels-last
+    curves [B,cn,cl,C] and the block's (frozen, folded) weights — see include/pc3d.h K18; differentiable in curves."""
+    _check(curves, "curves")
+    B, cn, cl, C = curves.shape
+    mid = Wa.shape[0]
+    shapes = ((C,), (mid, C), (mid, C), (mid, mid), (mid, mid), (mid, C), (C, 2 * mid), (C,))
+    ws = [w.detach().contiguous().float() for w in (w_att.reshape(-1), Wa, Wb, Wn, Wl, Wc, Wd, bd)]
+    if any(tuple(w.shape) != sh for w, sh in zip(ws, shapes)):
+        raise ValueError(f"curve_agg_kv: weight shapes must be {shapes}")
+    if curve_agg_lds_bytes(cn, cl, C, mid) > 64 * 1024:
+        raise ValueError(f"curve_agg_kv: cn={cn} cl={cl} C={C} mid={mid} does not fit the 64 KB LDS window")
+    return _CurveAggKVFn.apply(curves.contiguous(), *ws)
+
+
+# ------------------------------------------------------------------------------------------------------
 # K16: CurveNet guided walk
 # ------------------------------------------------------------------------------------------------------
 CURVE_WALK_CHANNELS = (8, 16, 32, 64)

@@ -328,6 +328,21 @@ int pc3d_act_mean_f32(const float* Z, int B, int N, int K, int C, float slope, f
 int pc3d_act_mean_bwd_f32(const float* Z, const float* gout, int B, int N, int K, int C, float slope, float* gZ,
                           void* stream);
 
+/* K18  per-cloud half of CurveNet's curve aggregation (model/curvenet_util.py:379-437 `CurveAggregation.forward`):
+ * curves [B,cn,cl,C] (channels-last) -> attention keys Kp [B,C,R] and values Vp [B,R,C], R = cn + cl, such that the
+ * block's output is leaky(x + softmax_rows(x^T Kp[:, :cn]) Vp[:cn] + softmax_rows(x^T Kp[:, cn:]) Vp[cn:]).
+ * w_att [C] (line_conv_att), Wa / Wb / Wc [mid,C] (conva / convb / convc), Wn / Wl [mid,mid] (convn / convl),
+ * Wd [C,2 mid] + bd [C] (convd with its eval BatchNorm folded; bd is added to the first cn value rows).
+ * LDS-resident: 4 (3 cn cl + R C + 2 R mid) bytes forward, 4 (6 cn cl + R C + 2 R mid + R) backward, <= 64 KB.
+ * Backward: gcurves [B,cn,cl,C] overwritten from gKp / gVp; deterministic. */
+int pc3d_curve_agg_kv_f32(const float* curves, const float* w_att, const float* Wa, const float* Wb, const float* Wn,
+                          const float* Wl, const float* Wc, const float* Wd, const float* bd, int B, int cn, int cl,
+                          int C, int mid, float* Kp, float* Vp, void* stream);
+int pc3d_curve_agg_kv_bwd_f32(const float* gKp, const float* gVp, const float* curves, const float* w_att,
+                              const float* Wa, const float* Wb, const float* Wn, const float* Wl, const float* Wc,
+                              const float* Wd, const float* bd, int B, int cn, int cl, int C, int mid, float* gcurves,
+                              void* stream);
+
 /* K12  dense graph Laplacian L = D - A of the symmetrised kNN graph with Gaussian weights A_ij = exp(-|pi-pj|^2)
  * (attack/AOF/TAOF_attack.py:31-52, attack/AOF/Eval_AOF.py:72-93). idx [B,N,K] from pc3d_knn_f32 (self included, as
  * in the reference's topk); L [B,N,N] f32 is overwritten. Only the N*K graph edges are evaluated. */
