@@ -291,6 +291,51 @@ __global__ __launch_bounds__(256) void edge_max_bwd_kernel(const float* g, const
   atomicAdd(base + (int64_t)arg[o] * 2 * C + c, gp);
 }
 
+// The same backward without global atomics: a workgroup owns CH channels of one cloud and accumulates the scattered
+// dP rows in LDS ([N][CH+1] floats, the +1 spreads the rows over the banks), then writes its column block of dP once.
+// Each lane's global atomic above lands in a different row (the arg-max neighbour differs per channel), i.e. 64
+// separate L2 transactions per wave instruction: 130 us per call on average in DGCNN's four layers at B=32, N=1024.
+template <int CH>
+__global__ __launch_bounds__(256) void edge_max_bwd_lds_kernel(const float* __restrict__ g, const float* __restrict__ out,
+                                                               const int32_t* __restrict__ arg, int N, int C, float slope,
+                                                               float* __restrict__ gPQ) {
+  extern __shared__ float emb_acc[];   // [N][CH+1]
+  constexpr int ST = CH + 1;
+  const int b = blockIdx.y, c0 = blockIdx.x * CH;
+  for (int e = threadIdx.x; e < N * ST; e += 256) emb_acc[e] = 0.f;
+  __syncthreads();
+  float* base = gPQ + (int64_t)b * N * 2 * C;
+  for (int i = threadIdx.x; i < N; i += 256) {
+    const int64_t o = ((int64_t)b * N + i) * C + c0;
+    float gv[CH], ov[CH];
+    int av[CH];
+#pragma unroll
+    for (int q = 0; q < CH; q += 4) {
+      const float4 a = *reinterpret_cast<const float4*>(g + o + q), w = *reinterpret_cast<const float4*>(out + o + q);
+      const int4 r = *reinterpret_cast<const int4*>(arg + o + q);
+      gv[q] = a.x, gv[q + 1] = a.y, gv[q + 2] = a.z, gv[q + 3] = a.w;
+      ov[q] = w.x, ov[q + 1] = w.y, ov[q + 2] = w.z, ov[q + 3] = w.w;
+      av[q] = r.x, av[q + 1] = r.y, av[q + 2] = r.z, av[q + 3] = r.w;
+    }
+#pragma unroll
+    for (int q = 0; q < CH; ++q) {
+      gv[q] *= ov[q] > 0.f ? 1.f : slope;
+      atomicAdd(&emb_acc[min(max(av[q], 0), N - 1) * ST + q], gv[q]);
+    }
+    float* qrow = base + (int64_t)i * 2 * C + C + c0;
+#pragma unroll
+    for (int q = 0; q < CH; q += 4) *reinterpret_cast<float4*>(qrow + q) = make_float4(gv[q], gv[q + 1], gv[q + 2], gv[q + 3]);
+  }
+  __syncthreads();
+  for (int r = threadIdx.x; r < N; r += 256) {
+    float* prow = base + (int64_t)r * 2 * C + c0;
+#pragma unroll
+    for (int q = 0; q < CH; q += 4)
+      *reinterpret_cast<float4*>(prow + q) =
+          make_float4(emb_acc[r * ST + q], emb_acc[r * ST + q + 1], emb_acc[r * ST + q + 2], emb_acc[r * ST + q + 3]);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Global pooling head of DGCNN / CurveNet (model/dgcnn.py:317-320, model/curvenet.py:64-67):
 //   z = leaky_slope(Y) (slope 0 = ReLU); out[b, c] = max_i z[b,i,c]; out[b, C + c] = mean_i z[b,i,c]
@@ -440,6 +485,20 @@ extern "C" int pc3d_edge_max_bwd_f32(const float* g, const float* out, const int
   if (B == 0) return PC3D_OK;
   PC3D_REQUIRE(g && out && arg && gPQ, "pc3d_edge_max_bwd_f32: null pointer");
   hipStream_t st = as_stream(stream);
+  const bool al = ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(arg) |
+                    reinterpret_cast<uintptr_t>(gPQ)) & 15) == 0;
+  if (al && C % 8 == 0 && (size_t)N * 9 * sizeof(float) <= 64 * 1024) {
+    hipLaunchKernelGGL(edge_max_bwd_lds_kernel<8>, dim3(C / 8, B), dim3(256), (size_t)N * 9 * sizeof(float), st, g, out,
+                       arg, N, C, slope, gPQ);
+    PC3D_LAUNCH_CHECK("pc3d_edge_max_bwd_f32");
+    return PC3D_OK;
+  }
+  if (al && C % 4 == 0 && (size_t)N * 5 * sizeof(float) <= 64 * 1024) {
+    hipLaunchKernelGGL(edge_max_bwd_lds_kernel<4>, dim3(C / 4, B), dim3(256), (size_t)N * 5 * sizeof(float), st, g, out,
+                       arg, N, C, slope, gPQ);
+    PC3D_LAUNCH_CHECK("pc3d_edge_max_bwd_f32");
+    return PC3D_OK;
+  }
   hipError_t e = zero_async(gPQ, (size_t)B * N * 2 * C, st);
   if (e != hipSuccess) {
     set_error("pc3d_edge_max_bwd_f32: zero fill failed: %s", hipGetErrorString(e));

@@ -112,11 +112,12 @@ def test_dgcnn_logits_and_input_grad_vs_reference(dev, fx):
     assert _knn_sets_ok(fx["x"], idx, fx["xyz_knn"], 20) <= 0.01 * idx.shape[0] * idx.shape[1]
 
 
-@pytest.mark.parametrize("C", [64, 256, 12])
-def test_edge_max_fwd_bwd_vs_torch(ops, dev, C):
-    """ops.edge_max = leaky(max_j P_j + Q_i) on [P | Q] rows, forward and backward, vs torch gather/max/leaky."""
-    torch.manual_seed(C)
-    B, N, K = 2, 90, 7
+@pytest.mark.parametrize("C,N", [(64, 90), (256, 90), (12, 90), (64, 1024), (32, 2500), (8, 5000), (4, 33)])
+def test_edge_max_fwd_bwd_vs_torch(ops, dev, C, N):
+    """ops.edge_max = leaky(max_j P_j + Q_i) on [P | Q] rows, forward and backward, vs torch gather/max/leaky. The sizes
+    walk the three backward kernels: 8 / 4 channels per workgroup accumulated in LDS, global atomics beyond 64 KB."""
+    torch.manual_seed(C + N)
+    B, K = 2, 7
     PQ = torch.randn(B, N, 2 * C, device=dev, requires_grad=True)
     idx = torch.randint(0, N, (B, N, K), device=dev, dtype=torch.int32)
     out = ops.edge_max(PQ, idx, 0.2)
