@@ -532,6 +532,76 @@ def gen_curvenet():
     print("curvenet.npz:", len(fx), "arrays")
 
 
+def gen_curvenet_blocks():
+    """The reference's Walk (model/walk.py), CurveAggregation and LPFA (model/curvenet_util.py) run as stand-alone
+    modules on NON-trivial weights and BatchNorm statistics (the whole-network fixture above uses a near-identity
+    initialisation under which the walk's momentum path barely matters): inputs, state_dicts, outputs and input
+    gradients. Pins the K16 / K17 / K18 kernels directly against the reference."""
+    install_cpu_shim()
+    from model.walk import Walk
+    from model import curvenet_util as cu
+    g = torch.Generator().manual_seed(97531)
+    rng = np.random.default_rng(97531)
+
+    def randomise(mod):
+        with torch.no_grad():
+            for name, p in mod.named_parameters():
+                if p.dim() > 1:
+                    p.copy_(torch.randn(p.shape, generator=g) / float(p[0].numel()) ** 0.5)
+                else:
+                    p.copy_(torch.randn(p.shape, generator=g) * 0.2 + (1.0 if name.endswith("weight") else 0.0))
+            for name, b in mod.named_buffers():
+                if name.endswith("running_mean"):
+                    b.copy_(torch.randn(b.shape, generator=g) * 0.1)
+                elif name.endswith("running_var"):
+                    b.copy_(torch.rand(b.shape, generator=g) + 0.5)
+        return mod.eval()
+
+    def save_sd(fx, prefix, mod):
+        for k, v in mod.state_dict().items():
+            fx[f"{prefix}.sd.{k}"] = v.numpy()
+
+    fx = {}
+    B, N, C, k, cn, cl = 2, 256, 16, 20, 100, 5
+    xyz = torch.from_numpy(np.stack([unit_cloud(rng, N) for _ in range(B)]).transpose(0, 2, 1).copy())     # [B,3,N]
+    idx = cu.knn(xyz, k)                                                                                  # [B,N,k+1]
+    fx["xyz"], fx["idx"] = xyz.numpy(), idx.numpy()
+    # --- Walk
+    walk = randomise(Walk(C, k, cn, cl))
+    x = torch.randn(B, C, N, generator=g).requires_grad_()
+    start = torch.stack([torch.randperm(N, generator=g)[:cn] for _ in range(B)]).unsqueeze(2)              # [B,cn,1]
+    curves = walk(xyz, x, idx[:, :, 1:], start)
+    w = torch.randn(curves.shape, generator=g)
+    (curves * w).sum().backward()
+    fx["walk.x"], fx["walk.start"], fx["walk.curves"], fx["walk.w"], fx["walk.gx"] = (
+        x.detach().numpy(), start.numpy(), curves.detach().numpy(), w.numpy(), x.grad.numpy())
+    save_sd(fx, "walk", walk)
+    # --- CurveAggregation
+    agg = randomise(cu.CurveAggregation(C))
+    x = torch.randn(B, C, N, generator=g).requires_grad_()
+    cv = torch.randn(B, C, cn, cl, generator=g).requires_grad_()
+    y = agg(x, cv)
+    w = torch.randn(y.shape, generator=g)
+    (y * w).sum().backward()
+    fx["agg.x"], fx["agg.curves"], fx["agg.y"], fx["agg.w"], fx["agg.gx"], fx["agg.gcurves"] = (
+        x.detach().numpy(), cv.detach().numpy(), y.detach().numpy(), w.numpy(), x.grad.numpy(), cv.grad.numpy())
+    save_sd(fx, "agg", agg)
+    # --- LPFA: first layer (initial=True, features = the points) and an inner layer
+    for tag, mod, feat in (("lpfa0", randomise(cu.LPFA(9, 32, k, mlp_num=1, initial=True)), None),
+                           ("lpfa1", randomise(cu.LPFA(C, C, k, mlp_num=1, initial=False)), torch.randn(B, C, N, generator=g))):
+        pts = xyz.clone().requires_grad_()
+        f = pts if feat is None else feat.clone().requires_grad_()
+        y = mod(f, pts, idx=idx[:, :, :k])
+        w = torch.randn(y.shape, generator=g)
+        (y * w).sum().backward()
+        fx[f"{tag}.y"], fx[f"{tag}.w"], fx[f"{tag}.gxyz"] = y.detach().numpy(), w.numpy(), pts.grad.numpy()
+        if feat is not None:
+            fx[f"{tag}.x"], fx[f"{tag}.gx"] = feat.numpy(), f.grad.numpy()
+        save_sd(fx, tag, mod)
+    np.savez_compressed(os.path.join(OUT, "curvenet_blocks.npz"), **fx)
+    print("curvenet_blocks.npz:", len(fx), "arrays")
+
+
 def gen_cw_additional():
     """Short runs of the REAL attack/additional_exp/CW_attack.py (B=1) on seeded PointNet weights. No functor of the
     reference accepts the `whether_target` keyword this attack passes (:245-259), so the adversarial functors are
@@ -623,7 +693,7 @@ def gen_formats():
     print("formats.npz:", len(fx), "arrays")
 
 
-SECTIONS = {"formats": gen_formats, "cw_additional": gen_cw_additional, "curvenet": gen_curvenet, "aof": gen_aof, "geoa3": gen_geoa3, "dgcnn": gen_dgcnn, "metrics": gen_metrics, "pointnet": gen_pointnet, "cw": gen_cw, "pointnet2": gen_pointnet2, "knn": gen_knn}
+SECTIONS = {"curvenet_blocks": gen_curvenet_blocks, "formats": gen_formats, "cw_additional": gen_cw_additional, "curvenet": gen_curvenet, "aof": gen_aof, "geoa3": gen_geoa3, "dgcnn": gen_dgcnn, "metrics": gen_metrics, "pointnet": gen_pointnet, "cw": gen_cw, "pointnet2": gen_pointnet2, "knn": gen_knn}
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(SECTIONS)

@@ -166,3 +166,75 @@ def test_curve_aggregation_kv_matches_step_by_step(dev, C, cn, cl, N):
     (ref * gout).sum().backward()
     for a, b in ((xa.grad, xb.grad), (ca.grad, cb.grad)):
         assert (a - b).norm() <= 5e-4 * b.norm() + 1e-12, ((a - b).norm(), b.norm())
+
+
+def _load_block(mod, fx, prefix, dev):
+    sd = {k[len(prefix) + 4:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith(prefix + ".sd.")}
+    mod.load_state_dict(sd)
+    return mod.eval().to(dev)
+
+
+def _rel(a, b):
+    a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
+    return float((a - b).norm() / b.norm())
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_walk_vs_reference_fixture(dev, fused):
+    """K16 (and the step-by-step formulation it is tested against) vs the REAL reference Walk on non-trivial weights
+    and BatchNorm statistics (tests/golden/curvenet_blocks.npz, generated by make_golden.py from model/walk.py): this
+    is what pins the momentum path, including the reference's `.view(B,1,cn,2)` reinterpretation of the softmax."""
+    fx = np.load(os.path.join(GOLDEN, "curvenet_blocks.npz"))
+    wk = importlib.import_module("3dpointcloudattack_amd.model.walk")
+    B, C, N = fx["walk.x"].shape
+    k, (cn, cl) = fx["idx"].shape[2] - 1, fx["walk.curves"].shape[2:]
+    w = _load_block(wk.Walk(C, k, cn, cl), fx, "walk", dev)
+    w.fused = fused
+    x = torch.from_numpy(fx["walk.x"]).to(dev).requires_grad_()
+    xyz = torch.from_numpy(fx["xyz"]).to(dev)
+    adj = torch.from_numpy(fx["idx"]).to(dev)[:, :, 1:]
+    got = w(xyz, x, adj, torch.from_numpy(fx["walk.start"]).to(dev))
+    ref = torch.from_numpy(fx["walk.curves"]).to(dev)
+    same = (got - ref).abs().amax(dim=(1, 3)) <= 1e-5 * (1 + ref.abs().amax(dim=(1, 3)))        # per (cloud, curve)
+    assert same.float().mean() >= 0.99, same.float().mean()
+    (got * torch.from_numpy(fx["walk.w"]).to(dev)).sum().backward()
+    if bool(same.all()):
+        assert _rel(x.grad, fx["walk.gx"]) < 1e-4
+    else:                                   # a flipped near-tie pick changes that curve's contribution only
+        assert _rel(x.grad, fx["walk.gx"]) < 0.2
+
+
+def test_curve_aggregation_vs_reference_fixture(dev):
+    """K18 + the two batched GEMMs vs the real reference CurveAggregation (model/curvenet_util.py:379-437)."""
+    fx = np.load(os.path.join(GOLDEN, "curvenet_blocks.npz"))
+    cu = importlib.import_module("3dpointcloudattack_amd.model.curvenet_util")
+    C = fx["agg.x"].shape[1]
+    agg = _load_block(cu.CurveAggregation(C), fx, "agg", dev)
+    for fused in (True, False):
+        agg.fused = fused
+        x = torch.from_numpy(fx["agg.x"]).to(dev).requires_grad_()
+        cv = torch.from_numpy(fx["agg.curves"]).to(dev).requires_grad_()
+        y = agg(x, cv)
+        assert _rel(y, fx["agg.y"]) < 2e-5, fused
+        (y * torch.from_numpy(fx["agg.w"]).to(dev)).sum().backward()
+        assert _rel(x.grad, fx["agg.gx"]) < 1e-4 and _rel(cv.grad, fx["agg.gcurves"]) < 1e-4, fused
+
+
+def test_lpfa_vs_reference_fixture(dev):
+    """The first LPFA (EdgeConv identity -> pc3d_edge_max_f32) and an inner LPFA (K17: pc3d_edge_act_f32 + GEMM +
+    pc3d_act_mean_f32) vs the real reference LPFA (model/curvenet_util.py:175-236) on the reference's own kNN graph."""
+    fx = np.load(os.path.join(GOLDEN, "curvenet_blocks.npz"))
+    cu = importlib.import_module("3dpointcloudattack_amd.model.curvenet_util")
+    idx = torch.from_numpy(fx["idx"]).to(dev)
+    k = idx.shape[2] - 1
+    C = fx["lpfa1.x"].shape[1]
+    for tag, mod in (("lpfa0", cu.LPFA(9, 32, k, mlp_num=1, initial=True)), ("lpfa1", cu.LPFA(C, C, k, mlp_num=1, initial=False))):
+        mod = _load_block(mod, fx, tag, dev)
+        pts = torch.from_numpy(fx["xyz"]).to(dev).requires_grad_()
+        f = pts if tag == "lpfa0" else torch.from_numpy(fx["lpfa1.x"]).to(dev).requires_grad_()
+        y = mod(f, pts, idx=idx[:, :, :k])
+        assert _rel(y, fx[f"{tag}.y"]) < 2e-5, tag
+        (y * torch.from_numpy(fx[f"{tag}.w"]).to(dev)).sum().backward()
+        assert _rel(pts.grad, fx[f"{tag}.gxyz"]) < 2e-4, tag
+        if tag == "lpfa1":
+            assert _rel(f.grad, fx["lpfa1.gx"]) < 1e-4
