@@ -61,6 +61,34 @@ def ev_ms(fn, iters, stream):
     return e0.elapsed_time(e1) / iters
 
 
+def chamfer_cpu_baseline():
+    """SURVEY §8(d) "CPU baseline beside it", metric 2: the reference's two CPU Chamfer paths per cloud pair, via the
+    oracle's restatements — float64 direct-difference matrix + two min-reductions (utils/dis_utils_numpy.py:13-26) and
+    torch-CPU cdist + min (utils/dis_utils_torch.py:8-16) — median of 3 after two warm-ups, all host cores."""
+    from oracle import ref_numpy as orn
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(max(1, min(16, ncpu)))
+    res = {"numpy_f64_ms_per_pair": {}, "torch_cpu_ms_per_pair": {}, "cores": torch.get_num_threads(), "kind": "port"}
+    for n in (1024, 2048, 4096):
+        rs = np.random.default_rng(99 + n)
+        a = unit_cloud(rs, n)
+        b = (a + 0.01 * rs.standard_normal(a.shape)).astype(np.float32)
+        ta, tb = torch.from_numpy(a)[None], torch.from_numpy(b)[None]
+
+        def torch_path():
+            m = torch.cdist(ta, tb, p=2)
+            return float(m.min(dim=2)[0].mean() + m.min(dim=1)[0].mean())
+        for key, fn in (("numpy_f64_ms_per_pair", lambda: orn.chamfer(a, b)), ("torch_cpu_ms_per_pair", torch_path)):
+            fn(), fn()
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                fn()
+                ts.append(time.perf_counter() - t0)
+            res[key][f"N{n}"] = sorted(ts)[1] * 1e3
+    return res
+
+
 def cpu_baseline(pcs, labels, seconds_budget=20.0):
     """The oracle's CPU restatement of the same CW iteration (torch-CPU, all host cores), bounded sample."""
     from oracle import ref_torch as ort
@@ -269,6 +297,9 @@ def main():
             out["sweep"] = sweep
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(pcs, labels)
+            out["chamfer"]["cpu_baseline"] = chamfer_cpu_baseline()
+            out["chamfer"]["cpu_baseline"]["gpu_us_per_pair"] = {
+                "N4096": chamfer["launch_us"] / B, **{k: v["launch_us"] / B for k, v in chamfer["other_sizes"].items()}}
         elif world == 1:
             out["cpu_baseline"] = None
     if dist_on:
