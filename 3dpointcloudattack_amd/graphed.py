@@ -102,6 +102,18 @@ class GraphedVictim(nn.Module):
         except AttributeError:
             return getattr(super().__getattr__("model"), name)
 
+    # captures are tied to this process's device memory: copies and pickles of the wrapper (a deepcopy of the victim
+    # takes its cached wrapper along) start without them
+    def __deepcopy__(self, memo):
+        import copy
+        return GraphedVictim(copy.deepcopy(self.model, memo), warmup=self._warmup)
+
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st["_slots"] = {}
+        st["stats"] = {"replayed": 0, "eager": 0, "captures": 0}
+        return st
+
     def state_dict(self, *a, **k):
         return self.model.state_dict(*a, **k)
 
