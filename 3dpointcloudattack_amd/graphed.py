@@ -187,16 +187,19 @@ class GraphedVictim(nn.Module):
         if slots is None:
             while len(self._slots) >= MAX_CAPTURES:
                 self._slots.pop(next(iter(self._slots)))
-            slots = self._slots[key] = [self._capture(x, with_grad)]
+            with torch.cuda.device(x.device):            # capture on the input's device, whatever the current one is
+                slots = self._slots[key] = [self._capture(x, with_grad)]
         slot = next((s for s in slots if not s.busy()), None) if with_grad else slots[0]
         if slot is None and len(slots) < MAX_REPLICAS:
-            slot = self._capture(x, with_grad)
+            with torch.cuda.device(x.device):
+                slot = self._capture(x, with_grad)
             slots.append(slot)
         if slot is None:
             self.stats["eager"] += 1         # every replica still waits for its backward: do not touch their memory
             return model(x)
         self.stats["replayed"] += 1
-        outs = slot.fn(x)
+        with torch.cuda.device(x.device):
+            outs = slot.fn(x)
         if with_grad:
             slot.ticket += 1
             slot.pending = True
