@@ -161,6 +161,9 @@ def geoA3_attack(net, pt_model, ptm_model, pts_model, dgcnn_model, cur_model, pc
         constrain_loss = torch.full((b,), 1e10, device=dev)
         input_all = None
         loss_curves = []
+        # the constants of this search step go to the device ONCE: a host->device copy inside every _forward_step
+        # (reference :174) stalls the launch queue each iteration
+        scale_dev = scale_const.float().to(dev)
 
         for step in range(cfg.iter_max_steps):
             if cfg.is_partial_var:
@@ -245,7 +248,7 @@ def geoA3_attack(net, pt_model, ptm_model, pts_model, dgcnn_model, cur_model, pc
 
             prev_constrain = constrain_loss
             logits_curr, normal_curr_iter, loss, loss_n, cls_loss, dis_loss, hd_loss, nor_loss, constrain_loss, info = \
-                _forward_step(net, pc_ori, input_curr_iter, normal_ori, kappa_ori, target, scale_const, cfg, targeted)
+                _forward_step(net, pc_ori, input_curr_iter, normal_ori, kappa_ori, target, scale_dev, cfg, targeted)
             if share_forward:
                 with torch.no_grad():   # input_all still holds this iteration's iterate: the optimiser steps below
                     output_label = torch.argmax(logits_curr.detach(), dim=1)
