@@ -127,7 +127,7 @@ def uniform_loss(adv_pc, percentages=[0.004, 0.006, 0.008, 0.010, 0.012], radius
         nsample = int(n * p)
         r = math.sqrt(p * radius)
         disk_area = math.pi * (radius ** 2) * p / nsample
-        expect_len = torch.sqrt(torch.tensor([disk_area], device=adv_pc.device))
+        expect_len = math.sqrt(disk_area)     # a host scalar: no per-call host->device copy
         fps_idx = ops.fps(adv_pc, npoint, None)
         new_xyz = pointnet2_utils.index_points(adv_pc, fps_idx)
         idx = ops.ball_query(r, nsample, adv_pc, new_xyz.detach())

@@ -18,7 +18,7 @@ def jitter_input(data, sigma=0.01, clip=0.05):
     assert data.size(1) == 3
     assert (clip > 0)
     B, _, N = data.size()
-    return torch.clamp(sigma * torch.randn(B, 3, N), -1 * clip, clip).to(data.device)
+    return ops.h2d(torch.clamp(sigma * torch.randn(B, 3, N), -1 * clip, clip), data.device)
 
 
 def _nbr_cov(pc, k):
@@ -61,8 +61,8 @@ def estimate_normal_via_ori_normal(pc_adv, pc_ori, normal_ori, k):
 def get_perpendicular_jitter(vector, sigma=0.01, clip=0.05):
     """utility.py:113-117."""
     b, _, n = vector.size()
-    aux_vector1 = sigma * torch.randn(b, 3, n).to(vector.device)
-    aux_vector2 = sigma * torch.randn(b, 3, n).to(vector.device)
+    aux_vector1 = ops.h2d(sigma * torch.randn(b, 3, n), vector.device)
+    aux_vector2 = ops.h2d(sigma * torch.randn(b, 3, n), vector.device)
     return torch.clamp(torch.cross(vector, aux_vector1, dim=1), -1 * clip, clip) + \
         torch.clamp(torch.cross(vector, aux_vector2, dim=1), -1 * clip, clip)
 
@@ -76,8 +76,8 @@ def estimate_perpendicular(pc, k, sigma=0.01, clip=0.05):
         larger = torch.topk(eigenvalue, 2, dim=2, largest=True, sorted=False)[1]     # [b,n,2]
         v1 = torch.gather(eigenvector, 3, larger[:, :, 0][:, :, None, None].expand(b, n, 3, 1)).squeeze(3).permute(0, 2, 1)
         v2 = torch.gather(eigenvector, 3, larger[:, :, 1][:, :, None, None].expand(b, n, 3, 1)).squeeze(3).permute(0, 2, 1)
-        aux1 = sigma * torch.randn(b, n).unsqueeze(1).to(pc.device)
-        aux2 = sigma * torch.randn(b, n).unsqueeze(1).to(pc.device)
+        aux1 = ops.h2d(sigma * torch.randn(b, n).unsqueeze(1), pc.device)
+        aux2 = ops.h2d(sigma * torch.randn(b, n).unsqueeze(1), pc.device)
     return torch.clamp(v1 * aux1, -1 * clip, clip) + torch.clamp(v2 * aux2, -1 * clip, clip)
 
 
@@ -93,7 +93,7 @@ def farthest_points_sample(obj_points, num_points):
     reference compares Euclidean norms; FPS on squared distances selects the same points (sqrt is monotone)."""
     assert obj_points.size(1) == 3
     b, _, n = obj_points.size()
-    start = torch.randint(n, [b, 1]).view(-1).to(device=obj_points.device, dtype=torch.int32)
+    start = ops.h2d(torch.randint(n, [b, 1]).view(-1), obj_points.device, torch.int32)
     sel = ops.fps(obj_points.float(), num_points, start, cf=True).long()
     return torch.gather(obj_points, 2, sel.unsqueeze(1).expand(b, 3, num_points))
 

@@ -25,6 +25,7 @@ import torch
 import torch.optim as optim
 
 from ... import graphed as _graphed
+from ... import ops
 
 
 class AdvLossAdapter:
@@ -60,7 +61,7 @@ def _small_rotation(dev):
         m = [[c, 0, s], [0, 1, 0], [-s, 0, c]]
     else:
         m = [[1, 0, 0], [0, 1, 0], [0, 0, 1]]
-    return torch.tensor(m, dtype=torch.float32, device=dev).unsqueeze(0)
+    return ops.h2d(torch.tensor(m, dtype=torch.float32), dev).unsqueeze(0)
 
 
 class CW:
@@ -165,7 +166,7 @@ class CW:
                         if self.whether_resample:
                             # the cloud twice, K of its 2K columns drawn without replacement (:236-239: index 0 excluded)
                             indices = random.sample(range(1, K * 2), K)
-                            x = torch.index_select(torch.cat((x, x), 2), 2, torch.tensor(indices, dtype=torch.long, device=dev))
+                            x = torch.index_select(torch.cat((x, x), 2), 2, ops.h2d(torch.tensor(indices, dtype=torch.long), dev))
                         losses.append(self.adv_func(self._forward(x), goal, whether_target=wt).mean())
                     adv_loss = torch.mean(torch.stack(losses))
                 else:

@@ -80,7 +80,7 @@ def index_points(points, idx):
 def _fps_start(B, N, device):
     # the reference draws the first index from the GLOBAL CPU generator every forward (:72, SURVEY A-4); same call,
     # same stream position -> same start indices under the same seed
-    return torch.randint(0, N, (B,), dtype=torch.long).to(device=device, dtype=torch.int32)
+    return ops.h2d(torch.randint(0, N, (B,), dtype=torch.long), device, torch.int32)     # no queue stall (ops.h2d)
 
 
 def farthest_point_sample(xyz, npoint, start=None):

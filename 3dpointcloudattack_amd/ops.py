@@ -789,6 +789,19 @@ def act_mean(Z, slope=0.2):
     return _ActMeanFn.apply(Z.contiguous(), slope)
 
 
+def h2d(t, device, dtype=None):
+    """Host tensor -> device WITHOUT stalling the launch queue. A plain `.to(device)` of a pageable host tensor is a
+    synchronous copy that first waits for everything already queued on the stream, so one such call per iteration
+    (an FPS start index, a jitter draw, a search-step constant) removes the host's run-ahead: measured 0.6 ms per
+    iteration in GeoA3 on DGCNN. Staged through pinned memory the copy is just another stream operation."""
+    device = torch.device(device)
+    if dtype is not None:
+        t = t.to(dtype)
+    if t.device.type != "cpu" or device.type != "cuda":
+        return t.to(device)
+    return t.pin_memory().to(device, non_blocking=True)
+
+
 # ------------------------------------------------------------------------------------------------------
 # K18: CurveNet curve aggregation, per-cloud half (attention keys / values from the curves)
 # ------------------------------------------------------------------------------------------------------
