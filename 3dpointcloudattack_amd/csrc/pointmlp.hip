@@ -280,7 +280,6 @@ struct PMBwdArgs {
   PtsViewMut gx;          // T == null: gradient wrt the tower input; T given: gradient wrt the RAW points x
   float* part_gT;         // [B, ntiles, 16] per-tile partial of d/dT (9 used) or null
   int accumulate;         // gx += instead of gx =
-  int stop;               // profiling aid (PC3D_BWD_STOP=3|5): return after phase A / C; 0 = run everything
 };
 
 // Workgroup = (batch b, 32 points), 4 waves; <= 36 KiB LDS so four workgroups share a CU (the kernel is a chain of
@@ -432,7 +431,6 @@ __global__ __launch_bounds__(256) void pointmlp3_max_bwd_kernel(PMBwdArgs a) {
     }
   }
   __syncthreads();
-  if (a.stop == 3) return;
 
   // ---- C. g1[pt][j] = sum_k2 g2[pt][k2] W2[k2][j] on MFMA: wave = (j block wave&1, K half wave>>1)
   {
@@ -468,7 +466,6 @@ __global__ __launch_bounds__(256) void pointmlp3_max_bwd_kernel(PMBwdArgs a) {
     }
   }
   __syncthreads();
-  if (a.stop == 5) return;
 
   // ---- D. g'[p][c] = sum_j W1[j][c] g1[p][j]  (gradient wrt the tower input x' = x @ T)
   float* gp = xs;  // [3][32] scratch
@@ -577,7 +574,7 @@ extern "C" int pc3d_pointmlp3_max_bwd_f32(const float* x, int64_t x_bs, int64_t 
   PC3D_REQUIRE(x && W1 && b1 && W2 && b2 && W3 && W2T && argidx && mask1 && mask2 && g_pooled && grad_x,
                "pc3d_pointmlp3_max_bwd_f32: null pointer");
   PMBwdArgs a{{x, x_bs, x_ps, x_cs}, N, C3, T, W1, b1, W2, b2, W3, W2T, argidx, mask1, mask2, g_pooled, {grad_x, gx_bs, gx_ps, gx_cs},
-              part_gT, accumulate, getenv("PC3D_BWD_STOP") ? atoi(getenv("PC3D_BWD_STOP")) : 0};
+              part_gT, accumulate};
   hipLaunchKernelGGL(pointmlp3_max_bwd_kernel, dim3(cdiv(N, PM_BTP), B), dim3(256), 0, as_stream(stream), a);
   PC3D_LAUNCH_CHECK("pc3d_pointmlp3_max_bwd_f32");
   return PC3D_OK;
