@@ -14,6 +14,7 @@ import numpy as np
 import torch
 import torch.optim as optim
 
+from ... import graphed as _graphed
 from ... import ops
 from ..CW.CW_utils import adv_utils as _adv_utils
 
@@ -210,6 +211,7 @@ class CWTAOF:
                 with torch.cuda.graph(g):
                     iterate()
                 run = g.replay
+                st["graph_keep"] = (g, _graphed._cached_tensors(self.model))   # the graph points into the weight caches
                 st["o_bestdist"].fill_(1e10), st["o_bestscore"].fill_(-1), st["o_bestattack"].zero_()
                 begin_step(adv0, reuse_basis=True)
             for _ in range(self.num_iter):

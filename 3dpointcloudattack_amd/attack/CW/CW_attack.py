@@ -38,10 +38,12 @@ def _logits_of(out):
 
 class _GraphRunner:
     """Replays captured iterations; batches calls into the unrolled graph. The captured launches hold raw pointers
-    into the state dict's tensors, so the runner keeps that dict alive for as long as it lives."""
+    into the state dict's tensors AND into the victim's folded / transposed weight caches, so the runner keeps both
+    alive for as long as it lives (a later re-fold of the victim — other weights loaded, a device move — then leaves
+    this runner replaying the weights it was captured with instead of reading freed memory)."""
 
-    def __init__(self, st, g1, gu, unroll):
-        self._keep, self.g1, self.gu, self.unroll, self.pending = st, g1, gu, unroll, 0
+    def __init__(self, st, g1, gu, unroll, weights=()):
+        self._keep, self.g1, self.gu, self.unroll, self.pending = (st, weights), g1, gu, unroll, 0
 
     def __call__(self, i=None):
         self.pending += 1
@@ -311,7 +313,8 @@ class CW:
                 for _ in range(unroll):
                     self._iterate(st)
         st["graph"] = g1
-        st["graph_run"] = _GraphRunner(st, g1, gu, unroll)
+        victim = self.model.model if isinstance(self.model, _graphed.GraphedVictim) else self.model
+        st["graph_run"] = _GraphRunner(st, g1, gu, unroll, weights=_graphed._cached_tensors(victim))
         return st["graph_run"]
 
     def _end_binary_step(self, st):

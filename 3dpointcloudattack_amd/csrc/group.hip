@@ -49,6 +49,7 @@ __global__ __launch_bounds__(FPS_T) void fps_kernel(FpsArgs a) {
     dist[e] = (i < a.N) ? 1e10f : -1.f;  // padding can never win the arg-max
   }
   int far = a.start ? a.start[b] : 0;
+  far = far < 0 ? 0 : (far >= a.N ? a.N - 1 : far);  // a start index outside the cloud cannot fault the launch
   __syncthreads();
   for (int s = 0; s < a.S; ++s) {
     if (tid == 0) a.out[(int64_t)b * a.S + s] = far;
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(FPS_T) void fps_kernel(FpsArgs a) {
       const int oi = red_i[buf][w];
       if (ov > fv || (ov == fv && oi < fi)) fv = ov, fi = oi;
     }
-    far = fi;
+    if (fi != 0x7fffffff) far = fi;  // no finite candidate (NaN cloud): stay put instead of indexing LDS at 2^31
   }
 }
 
@@ -151,19 +152,22 @@ __global__ __launch_bounds__(256) void group_gather_kernel(GatherArgs a) {
   if (row >= (int64_t)a.S * a.ns) return;
   const int s = (int)(row / a.ns);
   const int i = a.idx[((int64_t)b * a.S) * a.ns + row];
+  // an index outside [0,N) (ball query's "no point in the ball" marker N, garbage from a NaN cloud) reads as a zero
+  // row instead of faulting the GPU; the reference fails with a device assert there
+  const bool ok = (unsigned)i < (unsigned)a.N;
   float* o = a.out + (((int64_t)b * a.S) * a.ns + row) * a.C;
   int c0 = 0;
   if (a.x.p) {
     if (lane < 3) {
-      float v = a.x.p[(int64_t)b * a.x.bs + (int64_t)i * a.x.ps + lane * a.x.cs];
-      if (a.center.p) v -= a.center.p[(int64_t)b * a.center.bs + (int64_t)s * a.center.ps + lane * a.center.cs];
+      float v = ok ? a.x.p[(int64_t)b * a.x.bs + (int64_t)i * a.x.ps + lane * a.x.cs] : 0.f;
+      if (ok && a.center.p) v -= a.center.p[(int64_t)b * a.center.bs + (int64_t)s * a.center.ps + lane * a.center.cs];
       o[lane] = v;
     }
     c0 = 3;
   }
   if (a.feat) {
-    const float* f = a.feat + ((int64_t)b * a.N + i) * a.D;
-    for (int d = lane; d < a.D; d += 64) o[c0 + d] = f[d];
+    const float* f = a.feat + ((int64_t)b * a.N + (ok ? i : 0)) * a.D;
+    for (int d = lane; d < a.D; d += 64) o[c0 + d] = ok ? f[d] : 0.f;
   }
 }
 
@@ -198,8 +202,10 @@ __global__ __launch_bounds__(256) void group_gather_bwd_kernel(GatherBwdArgs a) 
 #pragma unroll
   for (int q = 0; q < GGB_MAXC / 64; ++q) tail[q] = 0.f;
   float csum = 0.f;                                       // lane < 3: sum of g[..., lane] over this wave's rows
+  const bool i0_ok = (unsigned)i0 < (unsigned)a.N;
   for (int j = wave; j < a.ns; j += 4) {
     const int i = idx[j];
+    if ((unsigned)i >= (unsigned)a.N) continue;           // zero row in the forward: nothing flows back
     const float* g = gbase + (int64_t)j * a.C;
     if (a.has_x && a.gx && lane < 3) csum += g[lane];
     if (merge && j > 0 && i == i0) {                      // a repeat of the first index: accumulate, no atomics
@@ -221,7 +227,7 @@ __global__ __launch_bounds__(256) void group_gather_bwd_kernel(GatherBwdArgs a) 
   }
   if (lane < 3) s_ctr[wave][lane] = csum;
   __syncthreads();
-  if (merge) {
+  if (merge && i0_ok) {
     for (int c = threadIdx.x; c < a.C; c += 256) {
       const float v = (s_tail[0][c] + s_tail[1][c]) + (s_tail[2][c] + s_tail[3][c]);
       if (v == 0.f) continue;
@@ -232,7 +238,8 @@ __global__ __launch_bounds__(256) void group_gather_bwd_kernel(GatherBwdArgs a) 
       }
     }
   }
-  if (a.has_x && a.gx && a.cidx && threadIdx.x < 3) {
+  if (a.has_x && a.gx && a.cidx && threadIdx.x < 3 &&
+      (unsigned)a.cidx[(int64_t)b * a.S + s] < (unsigned)a.N) {
     const float v = (s_ctr[0][threadIdx.x] + s_ctr[1][threadIdx.x]) + (s_ctr[2][threadIdx.x] + s_ctr[3][threadIdx.x]);
     atomicAdd(a.gx + ((int64_t)b * a.N + a.cidx[(int64_t)b * a.S + s]) * 3 + threadIdx.x, -v);
   }

@@ -49,6 +49,20 @@ class _Guard(torch.autograd.Function):
         return (None, None) + grads
 
 
+class _OwnGrad(torch.autograd.Function):
+    """Identity whose backward clones: ``make_graphed_callables`` hands the graph's STATIC grad-input buffer to
+    autograd, and AccumulateGrad may adopt it as ``x.grad`` of a leaf input — a caller that accumulates over two
+    backward passes without clearing ``.grad`` would then read the second replay's values twice. One [B,3,N] copy."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.clone()
+
+
 class _Slot:
     def __init__(self, fn):
         self.fn = fn
@@ -171,7 +185,7 @@ class GraphedVictim(nn.Module):
         slot = _Slot(g)
         slot.where, slot.is_seq = where, is_seq
         # The graphs hold raw pointers to every tensor the forward read, including the victims' folded-weight caches
-        # (created lazily, dropped by .eval()/.to() even when nothing changed): keep those alive with the capture.
+        # (created lazily, re-folded when weights change): keep those alive with the capture.
         slot.keepalive = _cached_tensors(model)
         self.stats["captures"] += 1
         return slot
@@ -199,7 +213,7 @@ class GraphedVictim(nn.Module):
             return model(x)
         self.stats["replayed"] += 1
         with torch.cuda.device(x.device):
-            outs = slot.fn(x)
+            outs = slot.fn(_OwnGrad.apply(x) if with_grad else x)
         if with_grad:
             slot.ticket += 1
             slot.pending = True

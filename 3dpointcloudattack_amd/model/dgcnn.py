@@ -78,15 +78,13 @@ class DGCNN(_FrozenFusedMixin, nn.Module):
         self.linear3 = nn.Linear(256, output_channels)
         self._folded_cache = None
 
-    def folded(self):
-        if self._folded_cache is None:
-            edges = [_fold_edge(self.conv1[0], self.bn1), _fold_edge(self.conv2[0], self.bn2),
-                     _fold_edge(self.conv3[0], self.bn3), _fold_edge(self.conv4[0], self.bn4)]
-            c5 = _fold_bn(self.conv5[0].weight, None, self.bn5)
-            head = (_fold_bn(self.linear1.weight, None, self.bn6), _fold_bn(self.linear2.weight, self.linear2.bias, self.bn7),
-                    _plain(self.linear3.weight, self.linear3.bias))
-            object.__setattr__(self, "_folded_cache", (edges, c5, head))
-        return self._folded_cache
+    def _fold(self):
+        edges = [_fold_edge(self.conv1[0], self.bn1), _fold_edge(self.conv2[0], self.bn2),
+                 _fold_edge(self.conv3[0], self.bn3), _fold_edge(self.conv4[0], self.bn4)]
+        c5 = _fold_bn(self.conv5[0].weight, None, self.bn5)
+        head = (_fold_bn(self.linear1.weight, None, self.bn6), _fold_bn(self.linear2.weight, self.linear2.bias, self.bn7),
+                _plain(self.linear3.weight, self.linear3.bias))
+        return edges, c5, head
 
     def forward(self, x):
         self._require_fused(x)

@@ -24,28 +24,45 @@ def _fold_bn(weight, bias, bn):
 
 
 def _plain(weight, bias):
-    return weight.detach().reshape(weight.shape[0], -1).float().contiguous(), bias.detach().float().contiguous()
+    """Snapshot (never a view of the parameter: a captured graph keeps replaying the weights it was captured with)."""
+    return weight.detach().reshape(weight.shape[0], -1).float().clone(), bias.detach().float().clone()
 
 
 class _FrozenFusedMixin:
-    """Shared machinery: folded-weight cache, invalidated whenever parameters may have changed."""
+    """Shared machinery: the folded-weight cache of a frozen module. The cache is keyed on (data_ptr, version) of every
+    parameter / buffer it was folded from (the module's own and those of plain sub-modules; sub-modules that carry this
+    mixin key their own caches), so ``load_state_dict`` on ANY ancestor, in-place weight updates and real device moves
+    re-fold, while a no-op ``.to()`` / ``.eval()`` keeps the tensors a captured hipGraph may point at."""
+
+    def _own_tensors(self):
+        stack = [self]
+        while stack:
+            m = stack.pop()
+            for t in m._parameters.values():
+                if t is not None:
+                    yield t
+            for t in m._buffers.values():
+                if t is not None:
+                    yield t
+            for c in m._modules.values():
+                if c is not None and not isinstance(c, _FrozenFusedMixin):
+                    stack.append(c)
+
+    def _source_key(self):
+        return tuple((t.data_ptr(), t._version) for t in self._own_tensors())
+
+    def folded(self):
+        """The module's folded weights (built by ``_fold``), re-folded when a source tensor changed."""
+        key = self._source_key()
+        d = self.__dict__
+        if d.get("_folded_cache") is None or d.get("_folded_key") != key:
+            object.__setattr__(self, "_folded_cache", self._fold())
+            object.__setattr__(self, "_folded_key", key)
+        return d["_folded_cache"]
 
     def _invalidate(self):
         object.__setattr__(self, "_folded_cache", None)
         object.__setattr__(self, "_fused_cache", None)
-
-    def train(self, mode=True):
-        if mode != self.training:
-            self._invalidate()
-        return super().train(mode)
-
-    def _apply(self, fn, *a, **k):
-        self._invalidate()
-        return super()._apply(fn, *a, **k)
-
-    def load_state_dict(self, *a, **k):
-        self._invalidate()
-        return super().load_state_dict(*a, **k)
 
     def _require_fused(self, x):
         if self.training:
@@ -76,18 +93,16 @@ class STN3d(_FrozenFusedMixin, nn.Module):
         self.bn5 = nn.BatchNorm1d(256)
         self._folded_cache = None
 
-    def folded(self):
-        if self._folded_cache is None:
-            tower = _fold_bn(self.conv1.weight, self.conv1.bias, self.bn1) + \
-                _fold_bn(self.conv2.weight, self.conv2.bias, self.bn2) + \
-                _fold_bn(self.conv3.weight, self.conv3.bias, self.bn3)
-            tower = tower + (tower[2].t().contiguous(),)      # W2^T for the backward kernel
-            head = (_fold_bn(self.fc1.weight, self.fc1.bias, self.bn4),
-                    _fold_bn(self.fc2.weight, self.fc2.bias, self.bn5),
-                    _plain(self.fc3.weight, self.fc3.bias))
-            iden = torch.eye(3, dtype=torch.float32, device=self.fc3.weight.device).reshape(1, 9)
-            object.__setattr__(self, "_folded_cache", (tower, head, iden))
-        return self._folded_cache
+    def _fold(self):
+        tower = _fold_bn(self.conv1.weight, self.conv1.bias, self.bn1) + \
+            _fold_bn(self.conv2.weight, self.conv2.bias, self.bn2) + \
+            _fold_bn(self.conv3.weight, self.conv3.bias, self.bn3)
+        tower = tower + (tower[2].t().contiguous(),)      # W2^T for the backward kernel
+        head = (_fold_bn(self.fc1.weight, self.fc1.bias, self.bn4),
+                _fold_bn(self.fc2.weight, self.fc2.bias, self.bn5),
+                _plain(self.fc3.weight, self.fc3.bias))
+        iden = torch.eye(3, dtype=torch.float32, device=self.fc3.weight.device).reshape(1, 9)
+        return tower, head, iden
 
     def forward(self, x):
         self._require_fused(x)
@@ -119,14 +134,11 @@ class PointNetfeat(_FrozenFusedMixin, nn.Module):
                 "(every attack driver builds PointNetCls(k, feature_transform=False): attack/CW/Eval_CW.py:97)")
         self._folded_cache = None
 
-    def folded(self):
-        if self._folded_cache is None:
-            tower = _fold_bn(self.conv1.weight, self.conv1.bias, self.bn1) + \
-                _fold_bn(self.conv2.weight, self.conv2.bias, self.bn2) + \
-                _fold_bn(self.conv3.weight, self.conv3.bias, self.bn3)
-            tower = tower + (tower[2].t().contiguous(),)      # W2^T for the backward kernel
-            object.__setattr__(self, "_folded_cache", tower)
-        return self._folded_cache
+    def _fold(self):
+        tower = _fold_bn(self.conv1.weight, self.conv1.bias, self.bn1) + \
+            _fold_bn(self.conv2.weight, self.conv2.bias, self.bn2) + \
+            _fold_bn(self.conv3.weight, self.conv3.bias, self.bn3)
+        return tower + (tower[2].t().contiguous(),)       # W2^T for the backward kernel
 
     def forward(self, x):
         self._require_fused(x)
@@ -153,13 +165,10 @@ class PointNetCls(_FrozenFusedMixin, nn.Module):
         self.relu = nn.ReLU()
         self._folded_cache = None
 
-    def folded(self):
-        if self._folded_cache is None:
-            head = (_fold_bn(self.fc1.weight, self.fc1.bias, self.bn1),
-                    _fold_bn(self.fc2.weight, self.fc2.bias, self.bn2),   # dropout is identity in eval
-                    _plain(self.fc3.weight, self.fc3.bias))
-            object.__setattr__(self, "_folded_cache", head)
-        return self._folded_cache
+    def _fold(self):
+        return (_fold_bn(self.fc1.weight, self.fc1.bias, self.bn1),
+                _fold_bn(self.fc2.weight, self.fc2.bias, self.bn2),   # dropout is identity in eval
+                _plain(self.fc3.weight, self.fc3.bias))
 
     def fused_loss_and_grad(self, x, target, kind, kappa=0.0):
         """Attack fast path (no autograd): (logp [B,k], pred [B], per-sample adv loss [B], d mean(loss)/dx).
@@ -191,18 +200,30 @@ def _t(w):
     return w.t().contiguous()
 
 
+def _fused_sources(model):
+    return model.feat.stn.folded(), model.feat.folded(), model.folded()
+
+
+def fused_pack(model):
+    """The launch-minimal path's weight pack, rebuilt when any of the folded caches it was built from was re-folded.
+    Callers that bake its pointers into a hipGraph keep the returned dict alive next to the graph."""
+    pk = model.__dict__.get("_fused_cache")
+    if pk is None or any(a is not b for a, b in zip(pk["src"], _fused_sources(model))):
+        pk = _fused_pack(model)
+        object.__setattr__(model, "_fused_cache", pk)
+    return pk
+
+
 def _fused_pack(model):
     """Everything the launch-minimal path needs, built once from the folded weights: heads as (W, b) plus the
     transposed copies the backward launches read (weights are frozen, so W^T is a constant)."""
-    stn = model.feat.stn
-    tower_s, head_s, iden = stn.folded()
-    tower_c = model.feat.folded()
-    head_c = model.folded()
+    src = _fused_sources(model)
+    (tower_s, head_s, iden), tower_c, head_c = src
     (w1s, b1s), (w2s, b2s), (w3s, b3s) = head_s
     (w1c, b1c), (w2c, b2c), (w3c, b3c) = head_c
     w3s_t = torch.zeros((w3s.shape[1], 16), dtype=torch.float32, device=w3s.device)   # [256,16], 9 used
     w3s_t[:, :9] = w3s.t()
-    return dict(tower_s=tower_s, tower_c=tower_c,
+    return dict(src=src, tower_s=tower_s, tower_c=tower_c,
                 s=(w1s, b1s, w2s, b2s, w3s, (b3s + iden.view(-1)).contiguous()),
                 c=(w1c, b1c, w2c, b2c, w3c, b3c),
                 s_t=(_t(w1s), _t(w2s), w3s_t.contiguous()), c_t=(_t(w1c), _t(w2c), _t(w3c)))
@@ -212,10 +233,7 @@ def fused_forward(model, x, tail=True):
     """Launch-minimal forward of PointNetCls: 2 tower launches (+2 folds) + 6 head launches, no autograd graph.
     Returns (logits [B,k] PRE-softmax, ctx) — ctx feeds fused_input_grad."""
     model._require_fused(x)
-    pk = getattr(model, "_fused_cache", None)
-    if pk is None or model._folded_cache is None:
-        pk = _fused_pack(model)
-        object.__setattr__(model, "_fused_cache", pk)
+    pk = fused_pack(model)
     w1s, b1s, w2s, b2s, w3s, b3s = pk["s"]
     w1c, b1c, w2c, b2c, w3c, b3c = pk["c"]
     pooled_s, idx_s, masks_s = ops.pointmlp3_max_fwd_raw(x, pk["tower_s"], True, want_masks=True)

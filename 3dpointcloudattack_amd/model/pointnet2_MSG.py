@@ -24,12 +24,9 @@ class PointNet_Msg(_FrozenFusedMixin, nn.Module):
         self.fc3 = nn.Linear(256, num_class)
         self._folded_cache = None
 
-    def folded(self):
-        if self._folded_cache is None:
-            object.__setattr__(self, "_folded_cache", (_fold_bn(self.fc1.weight, self.fc1.bias, self.bn1),
-                                                        _fold_bn(self.fc2.weight, self.fc2.bias, self.bn2),
-                                                        _plain(self.fc3.weight, self.fc3.bias)))
-        return self._folded_cache
+    def _fold(self):
+        return (_fold_bn(self.fc1.weight, self.fc1.bias, self.bn1), _fold_bn(self.fc2.weight, self.fc2.bias, self.bn2),
+                _plain(self.fc3.weight, self.fc3.bias))
 
     def forward(self, xyz):
         self._require_fused(xyz)

@@ -161,11 +161,8 @@ class PointNetSetAbstraction(_FrozenFusedMixin, nn.Module):
         self.group_all = group_all
         self._folded_cache = None
 
-    def folded(self):
-        if self._folded_cache is None:
-            object.__setattr__(self, "_folded_cache",
-                               [_fold_bn2d(c, b) for c, b in zip(self.mlp_convs, self.mlp_bns)])
-        return self._folded_cache
+    def _fold(self):
+        return [_fold_bn2d(c, b) for c, b in zip(self.mlp_convs, self.mlp_bns)]
 
     def forward(self, xyz, points):
         """xyz [B,3,N], points [B,D,N] or None -> new_xyz [B,3,S], new_points [B,D',S]."""
@@ -203,19 +200,17 @@ class PointNetSetAbstractionMsg(_FrozenFusedMixin, nn.Module):
             self.bn_blocks.append(bns)
         self._folded_cache = None
 
-    def folded(self):
-        if self._folded_cache is None:
-            D = self.in_channel
-            # kernel layout is [xyz(3), feat(D)]; the reference's first conv expects [feat(D), xyz(3)]
-            perm = torch.cat([torch.arange(D, D + 3), torch.arange(0, D)]) if D > 0 else None
-            out = []
-            for convs, bns in zip(self.conv_blocks, self.bn_blocks):
-                layers = []
-                for j, (c, b) in enumerate(zip(convs, bns)):
-                    layers.append(_fold_bn2d(c, b, perm.to(c.weight.device) if (j == 0 and perm is not None) else None))
-                out.append(layers)
-            object.__setattr__(self, "_folded_cache", out)
-        return self._folded_cache
+    def _fold(self):
+        D = self.in_channel
+        # kernel layout is [xyz(3), feat(D)]; the reference's first conv expects [feat(D), xyz(3)]
+        perm = torch.cat([torch.arange(D, D + 3), torch.arange(0, D)]) if D > 0 else None
+        out = []
+        for convs, bns in zip(self.conv_blocks, self.bn_blocks):
+            layers = []
+            for j, (c, b) in enumerate(zip(convs, bns)):
+                layers.append(_fold_bn2d(c, b, perm.to(c.weight.device) if (j == 0 and perm is not None) else None))
+            out.append(layers)
+        return out
 
     def forward(self, xyz, points):
         self._require_fused(xyz)
@@ -247,11 +242,8 @@ class PointNetFeaturePropagation(_FrozenFusedMixin, nn.Module):
             last_channel = out_channel
         self._folded_cache = None
 
-    def folded(self):
-        if self._folded_cache is None:
-            object.__setattr__(self, "_folded_cache",
-                               [_fold_bn2d(c, b) for c, b in zip(self.mlp_convs, self.mlp_bns)])
-        return self._folded_cache
+    def _fold(self):
+        return [_fold_bn2d(c, b) for c, b in zip(self.mlp_convs, self.mlp_bns)]
 
     def forward(self, xyz1, xyz2, points1, points2):
         self._require_fused(xyz1)

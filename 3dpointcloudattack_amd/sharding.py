@@ -53,13 +53,26 @@ def broadcast_frozen_weights(models, src=0, group=None):
 
 
 def gather_results(local_tensors, group=None):
-    """all_gather a list of per-rank result tensors (equal shapes across ranks) and concatenate along dim 0.
+    """all_gather a list of per-rank result tensors and concatenate along dim 0. Shards may differ in their first
+    dimension (``shard_range`` hands out sizes that differ by one when total % world != 0): the per-rank lengths are
+    exchanged first (one tiny all_gather), every rank pads to the longest shard for the equal-shape collective RCCL
+    needs, and the padding is trimmed after it. Trailing dimensions and dtypes must agree across ranks.
     Returns the list of global tensors on every rank."""
     world = dist.get_world_size(group)
+    if not local_tensors:
+        return []
+    dev = local_tensors[0].device
+    mine = torch.tensor([t.shape[0] for t in local_tensors], dtype=torch.int64, device=dev)
+    lens = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(lens, mine, group=group)
+    lens = torch.stack(lens).cpu()                       # [world, n_tensors]
     out = []
-    for t in local_tensors:
+    for j, t in enumerate(local_tensors):
         t = t.contiguous()
+        longest = int(lens[:, j].max())
+        if t.shape[0] < longest:
+            t = torch.cat([t, t.new_zeros((longest - t.shape[0],) + tuple(t.shape[1:]))])
         parts = [torch.empty_like(t) for _ in range(world)]
         dist.all_gather(parts, t, group=group)
-        out.append(torch.cat(parts, dim=0))
+        out.append(torch.cat([p[:int(lens[r, j])] for r, p in enumerate(parts)], dim=0))
     return out

@@ -110,3 +110,19 @@ def test_capture_survives_cache_invalidation(dev):
         torch.testing.assert_close(l, ref_l, rtol=1e-4, atol=1e-5)
         assert (gr - ref_g).norm() <= 2e-3 * ref_g.norm() + 1e-12
     assert g.stats["captures"] == 1
+
+
+def test_leaf_grad_accumulates_across_replays(dev):
+    """the replayed backward must not hand its static grad buffer to AccumulateGrad — two backward passes
+    into the same leaf without clearing .grad give g1 + g2, as eager does."""
+    m = _victim(dev, "pointnet")
+    g = graphed.wrap(m)
+    gen = torch.Generator().manual_seed(8)
+    x = (torch.rand(2, 3, 160, generator=gen) - 0.5).to(dev)
+    w1, w2 = torch.randn(2, 40, generator=gen).to(dev), torch.randn(2, 40, generator=gen).to(dev)
+    xe, xg = x.clone().requires_grad_(), x.clone().requires_grad_()
+    for model, leaf in ((m, xe), (g, xg)):
+        (model(leaf)[0] * w1).sum().backward()
+        (model(leaf)[0] * w2).sum().backward()
+    assert g.stats["replayed"] >= 2
+    assert (xg.grad - xe.grad).norm() <= 2e-3 * xe.grad.norm()

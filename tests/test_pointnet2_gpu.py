@@ -237,3 +237,31 @@ def test_mlp_relu_max_fwd_bwd_vs_autograd(dev, G, ns, dims):
     torch.testing.assert_close(out.double(), ref.detach(), rtol=2e-5, atol=2e-5)
     (ref * up.double()).sum().backward()
     torch.testing.assert_close(g1.double(), x.grad.double(), rtol=2e-3, atol=2e-4)
+
+
+def test_empty_ball_and_nan_cloud_do_not_fault(dev):
+    ops = importlib.import_module("3dpointcloudattack_amd.ops")
+    """ADVICE r1: ball query marks "no point inside the radius" with N (what the reference's sort leaves there,
+    model/pointnet2_utils.py:97-103) and a NaN cloud gives FPS no arg-max winner. The reference then dies in a device
+    assert; here the indices stay in range / the gather reads such rows as zeros and sends no gradient through them."""
+    g = torch.Generator().manual_seed(0)
+    B, N, S, ns = 2, 200, 8, 16
+    xyz = (torch.rand(B, N, 3, generator=g) - 0.5).to(dev)
+    far = torch.full((B, S, 3), 50.0, device=dev)
+    far[:, 0] = xyz[:, 7]                                    # one centroid does have neighbours
+    idx = ops.ball_query(0.2, ns, xyz, far)
+    assert (idx[:, 1:] == N).all() and (idx[:, 0] < N).all()
+    feat = torch.randn(B, N, 5, generator=g).to(dev).requires_grad_()
+    x = xyz.clone().requires_grad_()
+    out = ops.group_gather(x, feat, idx, centers=far)
+    assert out.shape == (B, S, ns, 8) and (out[:, 1:] == 0).all() and torch.isfinite(out).all()
+    out.sum().backward()
+    torch.cuda.synchronize()
+    assert torch.isfinite(x.grad).all() and torch.isfinite(feat.grad).all()
+    nan_cloud = torch.full((B, N, 3), float("nan"), device=dev)
+    fi = ops.fps(nan_cloud, 16, torch.tensor([3, 10_000], dtype=torch.int32, device=dev))   # 2nd start is out of range
+    torch.cuda.synchronize()
+    assert ((fi >= 0) & (fi < N)).all()
+    nb = ops.group_gather(nan_cloud, None, ops.ball_query(0.2, ns, nan_cloud, nan_cloud[:, :S]))
+    torch.cuda.synchronize()
+    assert nb.shape == (B, S, ns, 3) and (nb == 0).all()     # NaN distances are never inside a ball

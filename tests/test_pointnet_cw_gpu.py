@@ -182,6 +182,54 @@ def test_graph_replay_equals_eager(dev):
     assert outs[0][2:] == outs[1][2:]
 
 
+def test_captured_runner_survives_second_attack_on_same_victim(dev):
+    """a captured iteration graph bakes in pointers to the victim's folded / transposed weight
+    caches. Constructing another CW on the same victim (``model.to()``), an explicit cache invalidation and loading
+    OTHER weights must not make a later replay of the first runner read freed memory: it replays the weights it was
+    captured with, bit for bit equal to an eager run started from the same state."""
+    cwm, adv, dist, clip = _mods()
+    model, _ = hip_pointnet(0, dev)
+    trans_model, _ = hip_pointnet(1, dev)
+    rng = np.random.default_rng(41)
+    pcs = torch.from_numpy(np.stack([unit_cloud(rng, 256) for _ in range(4)]))
+    with torch.no_grad():
+        labels = model(pcs.transpose(1, 2).contiguous().to(dev))[0].argmax(1).cpu()
+
+    def make(graph):
+        atk = cwm.CW(model, trans_model, adv_func=adv.UntargetedLogitsAdvLoss(5.), clip_func=clip.ClipPointsLinf(0.18),
+                     dist_func=dist.ChamferDist(), binary_step=1, num_iter=8, graph=graph)
+        torch.manual_seed(5)
+        st = atk._begin(pcs, labels)
+        atk._begin_binary_step(st)
+        return atk, st
+
+    atk_e, st_e = make(False)
+    for _ in range(3 + 6):                       # the runner's 3 warm-up passes are real iterations
+        atk_e._iterate(st_e)
+    atk_a, st_a = make(True)
+    run_a = atk_a._make_runner(st_a, warmup=3, unroll=2)
+    run_a(), run_a(), run_a()
+    run_a.flush()
+    # what used to free the tensors graph A points at:
+    atk_b, st_b = make(True)                     # CW.__init__ -> model.to(device)
+    run_b = atk_b._make_runner(st_b)
+    run_b(), run_b.flush()
+    model._invalidate(), model.feat._invalidate(), model.feat.stn._invalidate()
+    keep_sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model.load_state_dict(ort.seeded_state_dict(model, 9))      # re-folds: new tensors, old ones only A keeps alive
+    with torch.no_grad():
+        model(pcs[:1].transpose(1, 2).contiguous().to(dev))
+    junk = [torch.full((1 << 18,), float("nan"), device=dev) for _ in range(64)]   # reuse whatever was freed
+    run_a(), run_a(), run_a()
+    run_a.flush()
+    torch.cuda.synchronize()
+    del junk
+    model.load_state_dict(keep_sd)
+    for k in ("adv", "exp_avg", "exp_avg_sq", "bestdist", "o_bestdist", "o_bestattack", "pred"):
+        assert torch.equal(st_a[k], st_e[k]), k
+    assert int(st_a["step"]) == int(st_e["step"]) == 9
+
+
 @pytest.mark.parametrize("kind,kappa", [("untargeted_logits", 5.0), ("logits", 0.0), ("cross_entropy", 0.0)])
 def test_fused_loss_and_grad_equals_autograd_path(dev, kind, kappa):
     """The launch-minimal path (own head kernels, T chained inside the tower kernels) vs forward()+autograd."""

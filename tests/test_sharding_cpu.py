@@ -31,9 +31,9 @@ def _worker(rank, world, port, ret):
     sha = ort.state_sha256(model.state_dict())
     lo, hi = sharding.shard_range(7, rank, world)
     local = torch.arange(lo, hi, dtype=torch.float32).view(-1, 1).repeat(1, 3)
-    pad = torch.full((4 - local.shape[0], 3), -1.0)     # equal shapes across ranks for all_gather
-    (glob,) = sharding.gather_results([torch.cat([local, pad])])
-    ret[rank] = (sha, nbytes, (lo, hi), glob.numpy().copy())
+    # 7 samples over 2 ranks: shards of 4 and 3 — no manual padding, gather_results handles unequal shards
+    glob, ids = sharding.gather_results([local, torch.arange(lo, hi)])
+    ret[rank] = (sha, nbytes, (lo, hi), glob.numpy().copy(), ids.numpy().copy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -51,7 +51,8 @@ def test_broadcast_and_gather_world2():
     assert ret[0][2] == (0, 4) and ret[1][2] == (4, 7)
     g = ret[0][3]
     assert np.array_equal(g, ret[1][3])
-    assert g[:4, 0].tolist() == [0, 1, 2, 3] and g[4:7, 0].tolist() == [4, 5, 6] and g[7, 0] == -1
+    assert g.shape == (7, 3) and g[:, 0].tolist() == [0, 1, 2, 3, 4, 5, 6]
+    assert ret[0][4].tolist() == ret[1][4].tolist() == list(range(7))
 
 
 def test_shard_range_covers_everything():
