@@ -64,10 +64,14 @@ class CW:
 
     def __init__(self, model, trans_model, adv_func, clip_func, dist_func, attack_lr=1e-2,
                  init_weight=10., max_weight=80., binary_step=10, num_iter=500, attack_method="untarget",
-                 device=None, verbose=False, fused=True, graph=True):
+                 device=None, verbose=False, fused=True, graph=True, sample_seeds=None, global_batch=None):
         """Arguments as attack/CW/CW_attack.py:26-38. Extra keyword-only style options (defaults keep the
         reference behaviour): device (default: current CUDA device), verbose (reference prints), fused (use the
-        fused Adam+clip launch when clip_func is recognised)."""
+        fused Adam+clip launch when clip_func is recognised). For sharded runs: `sample_seeds` (one int
+        per sample of the batch handed to attack()) draws each sample's 1e-7 start noise (:94) from its own CPU
+        generator instead of the shared global stream, and `global_batch` is the size of the unsharded batch whose
+        `.mean()` (:160-165) this shard's losses belong to — with both, a sample's trajectory does not depend on the
+        rank / batch it is attacked in."""
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.model = model.to(self.device)
         self.model.eval()
@@ -91,6 +95,8 @@ class CW:
         self.verbose = verbose
         self.fused = fused
         self.graph = graph
+        self.sample_seeds = sample_seeds
+        self.global_batch = global_batch
 
     # -- helpers ---------------------------------------------------------------------------------------
     def _success(self, pred, label):
@@ -159,8 +165,14 @@ class CW:
         if self.attack_method == 'top1_error':
             # reference (:86-89, B=1): target := runner-up class of the clean prediction
             target = label = logits.topk(2, dim=1, largest=True, sorted=True)[1][:, 1].detach()
+        gens = None
+        if self.sample_seeds is not None:
+            assert len(self.sample_seeds) == B, "sample_seeds needs one seed per sample"
+            gens = [torch.Generator().manual_seed(int(sd)) for sd in self.sample_seeds]
         return dict(
-            B=B, K=K, ori=ori_data, target=target, label=label, budget=self._fused_clip_budget(),
+            B=B, K=K, ori=ori_data, target=target, label=label, budget=self._fused_clip_budget(), gens=gens,
+            # losses are batch means (:160-165): a shard of a larger batch scales its terms by B/global_batch
+            ratio=(float(B) / float(self.global_batch)) if self.global_batch else 1.0,
             # weight factor for budget regularization (host, consulted once per binary step)
             lower_bound=np.zeros((B,)), upper_bound=np.ones((B,)) * self.max_weight,
             current_weight=np.ones((B,)) * self.init_weight,
@@ -176,7 +188,11 @@ class CW:
         """Fresh start point, Adam state and per-step bests (reference :94-100)."""
         dev, B, K = self.device, st["B"], st["K"]
         # same RNG stream as the reference: CPU generator, then upload (:94)
-        adv_data = st["ori"].clone().detach() + torch.randn((B, 3, K)).to(dev) * 1e-7
+        if st["gens"] is None:
+            noise = torch.randn((B, 3, K))
+        else:
+            noise = torch.stack([torch.randn((3, K), generator=g) for g in st["gens"]])
+        adv_data = st["ori"].clone().detach() + noise.to(dev) * 1e-7
         adv_data.requires_grad_()
         if "adv" not in st:
             # first binary step: allocate the per-step state once; later steps refill it IN PLACE so a captured
@@ -184,7 +200,7 @@ class CW:
             st["adv"] = adv_data
             st["bestdist"] = torch.full((B,), 1e10, dtype=torch.float32, device=dev)
             st["bestscore"] = torch.full((B,), -1, dtype=torch.long, device=dev)
-            st["weights"] = torch.from_numpy(st["current_weight"]).float().to(dev)
+            st["weights"] = torch.from_numpy(st["current_weight"] * st["ratio"]).float().to(dev)
             if st["budget"] is not None:
                 st["exp_avg"] = torch.zeros_like(adv_data)
                 st["exp_avg_sq"] = torch.zeros_like(adv_data)
@@ -193,7 +209,7 @@ class CW:
                 st["adv"].copy_(adv_data)
                 st["bestdist"].fill_(1e10)
                 st["bestscore"].fill_(-1)
-                st["weights"].copy_(torch.from_numpy(st["current_weight"]).float())
+                st["weights"].copy_(torch.from_numpy(st["current_weight"] * st["ratio"]).float())
                 if st["budget"] is not None:
                     st["exp_avg"].zero_()
                     st["exp_avg_sq"].zero_()
@@ -215,7 +231,7 @@ class CW:
                 if hasattr(self.model, "fused_attack_grad") and st["K"] <= ops.CW_UPDATE_MAX_POINTS:
                     # 17 launches: the classifier tail writes pred + advances the step word, one update launch
                     _, _, gx_model = self.model.fused_attack_grad(cur, st["target"], *fml, pred_out=st["pred"],
-                                                                  step=st["step"])
+                                                                  step=st["step"], scale=st["ratio"] / st["B"])
                     nn_idx = None
                     if dk == 2:
                         _, nn_idx = ops.nn_raw(cur, ori_data, True, True)
@@ -225,7 +241,8 @@ class CW:
                                   input_val=st["input_val"], dist_val=st["dist_val"], dist_kind=dk, w=st["weights"],
                                   nn_idx=nn_idx)
                     return
-                _, pred, _, gx_model = self.model.fused_loss_and_grad(cur, st["target"], *fml)
+                _, pred, _, gx_model = self.model.fused_loss_and_grad(cur, st["target"], *fml,
+                                                                      scale=st["ratio"] / st["B"])
                 ops.cw_bookkeep(cur, ori_data, pred, label, self.attack_method == 'untarget', st["bestdist"],
                                 st["bestscore"], st["o_bestdist"], st["o_bestscore"], st["o_bestattack"],
                                 input_val=st["input_val"], dist_val=st["dist_val"], step=st["step"])
@@ -238,7 +255,8 @@ class CW:
             return
         if fml is not None:
             with torch.no_grad():  # victim forward + adversarial loss + backward-to-input without autograd
-                logits, pred, _, gx_model = self.model.fused_loss_and_grad(adv_data.detach(), st["target"], *fml)
+                logits, pred, _, gx_model = self.model.fused_loss_and_grad(adv_data.detach(), st["target"], *fml,
+                                                                           scale=st["ratio"] / st["B"])
         else:
             logits = _logits_of(self.model(adv_data))
             pred = torch.argmax(logits, dim=1)  # [B]
@@ -267,6 +285,8 @@ class CW:
                                self.attack_lr, ori=ori_data, budget=st["budget"])
             return
         adv_loss = self.adv_func(logits, st["target"]).mean()
+        if st["ratio"] != 1.0:
+            adv_loss = adv_loss * st["ratio"]
         loss = adv_loss + dist_loss
         if st["budget"] is None:
             opt = st["opt"]

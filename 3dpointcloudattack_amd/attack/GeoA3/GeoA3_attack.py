@@ -51,6 +51,22 @@ def lp_clip(offset, cc_linf):
     return torch.where(lengths < cc_linf, offset, offset_scaled)
 
 
+def _draw_offset(b, c, n, dev, cfg, gens):
+    """The N(0, 1e-3) start offsets (:278-279, :293-294). Default: drawn on the device like the reference on a GPU.
+    ``cfg.host_rng = True`` draws them from torch's global CPU generator (what the reference does on a CPU-only box —
+    the golden fixtures); ``cfg.sample_seeds`` (one int per sample) draws sample i's offsets from its own CPU
+    generator, so a sample's trajectory does not depend on which batch / rank it runs in."""
+    if gens is not None:
+        return torch.stack([torch.zeros(c, n).normal_(0., 1e-3, generator=g) for g in gens]).to(dev)
+    if getattr(cfg, "host_rng", False):
+        o = torch.zeros(b, c, n)
+        nn.init.normal_(o, mean=0, std=1e-3)
+        return o.to(dev)
+    o = torch.zeros(b, c, n, device=dev)
+    nn.init.normal_(o, mean=0, std=1e-3)
+    return o
+
+
 def _forward_step(net, pc_ori, input_curr_iter, normal_ori, ori_kappa, target, scale_const, cfg, targeted):
     """:103-183 — one forward of the victim and all loss terms; returns the reference's 10-tuple."""
     b, _, n = input_curr_iter.size()
@@ -114,7 +130,10 @@ def _forward_step(net, pc_ori, input_curr_iter, normal_ori, ori_kappa, target, s
 
     scale_const = scale_const.float().to(dev)
     loss_n = cls_loss + scale_const * constrain_loss
-    loss = loss_n.mean()
+    # cfg.global_batch: this batch is a shard of a larger one — divide by the GLOBAL size so every sample's gradient
+    # (and with it Adam's eps-sensitive step) is what the unsharded run computes
+    gb = getattr(cfg, "global_batch", None)
+    loss = loss_n.sum() / float(gb) if gb else loss_n.mean()
     info = ''
     return output_curr_iter, normal_curr_iter, loss, loss_n, cls_loss, dis_loss, hd_loss, curv_loss, constrain_loss, info
 
@@ -145,6 +164,10 @@ def geoA3_attack(net, pt_model, ptm_model, pts_model, dgcnn_model, cur_model, pc
 
     kappa_ori = _get_kappa_ori(pc_ori, normal_ori, cfg.curv_loss_knn) if cfg.curv_loss_weight != 0 else None
 
+    seeds = getattr(cfg, "sample_seeds", None)
+    gens = [torch.Generator().manual_seed(int(sd)) for sd in seeds] if seeds is not None else None
+    assert gens is None or len(gens) == b, "cfg.sample_seeds needs one seed per sample"
+
     lower_bound = torch.zeros(b)
     scale_const = torch.ones(b) * cfg.initial_const
     upper_bound = torch.ones(b) * 1e10
@@ -172,8 +195,7 @@ def geoA3_attack(net, pt_model, ptm_model, pts_model, dgcnn_model, cur_model, pc
                         init_point_idx = np.random.randint(n)
                         intra_KNN = knn_points(pc_ori[:, :, init_point_idx].unsqueeze(2).permute(0, 2, 1),
                                                pc_ori.permute(0, 2, 1), K=cfg.knn_range + 1)
-                    part_offset = torch.zeros(b, 3, cfg.knn_range, device=dev)
-                    nn.init.normal_(part_offset, mean=0, std=1e-3)
+                    part_offset = _draw_offset(b, 3, cfg.knn_range, dev, cfg, gens)
                     part_offset.requires_grad_()
                     if cfg.optim == 'adam':
                         optimizer = torch.optim.Adam([part_offset], lr=cfg.lr)
@@ -185,8 +207,7 @@ def geoA3_attack(net, pt_model, ptm_model, pts_model, dgcnn_model, cur_model, pc
                     periodical_pc = input_all.detach().clone() if input_all is not None else pc_ori.clone()
             else:
                 if step == 0:
-                    offset = torch.zeros(b, 3, n, device=dev)
-                    nn.init.normal_(offset, mean=0, std=1e-3)
+                    offset = _draw_offset(b, 3, n, dev, cfg, gens)
                     offset.requires_grad_()
                     if cfg.optim == 'adam':
                         optimizer = optim.Adam([offset], lr=cfg.lr)

@@ -138,6 +138,15 @@ class GraphedVictim(nn.Module):
         return tuple((t.data_ptr(), t._version) for t in list(self.model.parameters()) + list(self.model.buffers()))
 
     def _capture(self, x, with_grad):
+        """Capture under a saved host RNG state: the probe / warm-up / capture passes run the Python forward several
+        times, the call they serve counts as ONE forward (its draws are re-issued by consume_forward_rng)."""
+        rng = torch.get_rng_state()
+        try:
+            return self._capture_impl(x, with_grad)
+        finally:
+            torch.set_rng_state(rng)
+
+    def _capture_impl(self, x, with_grad):
         model = self.model
         probe = x.detach().clone().requires_grad_(with_grad)
         with torch.set_grad_enabled(with_grad):
@@ -212,6 +221,9 @@ class GraphedVictim(nn.Module):
             self.stats["eager"] += 1         # every replica still waits for its backward: do not touch their memory
             return model(x)
         self.stats["replayed"] += 1
+        hook = getattr(model, "consume_forward_rng", None)
+        if hook is not None:
+            hook(x)                          # host-side RNG draws of the forward the replay stands in for
         with torch.cuda.device(x.device):
             outs = slot.fn(_OwnGrad.apply(x) if with_grad else x)
         if with_grad:

@@ -4,7 +4,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .curvenet_util import CIC, LPFA, pw
+from .curvenet_util import CIC, LPFA, hold_rng_position, pw
 from .pointnet import _FrozenFusedMixin
 
 curve_config = {
@@ -14,7 +14,21 @@ curve_config = {
 
 
 class CurveNet(_FrozenFusedMixin, nn.Module):
-    deterministic_forward = True   # forward is a pure function of its input (no RNG): attack loops may share it
+    # forward is a pure function of its input: attack loops may share / replay it. Its only RNG use is the discarded
+    # FPS start draw (curvenet_util.hold_rng_position), which a hipGraph replay re-issues through consume_forward_rng.
+    deterministic_forward = True
+
+    def _blocks(self):
+        return (self.cic11, self.cic12, self.cic21, self.cic22, self.cic31, self.cic32, self.cic41, self.cic42)
+
+    def consume_forward_rng(self, x):
+        """Advance torch's CPU generator exactly as one forward on x [B,3,N] does (one discarded draw per down-sampling
+        block) — called by GraphedVictim instead of the Python forward it replays."""
+        B, n = x.shape[0], x.shape[-1]
+        for blk in self._blocks():
+            if n != blk.npoint:
+                hold_rng_position(B, n)
+                n = blk.npoint
 
     def __init__(self, num_classes=40, k=20, setting='default'):
         super(CurveNet, self).__init__()
@@ -43,7 +57,7 @@ class CurveNet(_FrozenFusedMixin, nn.Module):
         xyz = xyz.float()
         feats = self.lpfa(xyz, xyz)
         pos = xyz
-        blocks = (self.cic11, self.cic12, self.cic21, self.cic22, self.cic31, self.cic32, self.cic41, self.cic42)
+        blocks = self._blocks()
         graphs = {}                                  # kNN graphs of THIS forward, shared by blocks at one resolution
         for blk in blocks:
             object.__setattr__(blk, "_graph_cache", graphs)

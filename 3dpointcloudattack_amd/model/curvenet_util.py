@@ -111,8 +111,16 @@ def index_points(points, idx):
     return ops.group_gather(None, points.float(), idx32.contiguous())
 
 
+def hold_rng_position(B, N):
+    """The reference's CurveNet FPS starts at ``torch.randint(0, N, (B,)) * 0`` (:81): index 0, but torch's global CPU
+    generator still advances on every call. The same draw is made (and discarded) here so that seeded runs consume
+    the identical stream — it feeds CW's start noise and PointNet++'s FPS starts later on. CPU-only, no device work."""
+    torch.randint(0, N, (B,), dtype=torch.long)
+
+
 def farthest_point_sample(xyz, npoint):
     """:69-90 — deterministic: starts at index 0 (:81)."""
+    hold_rng_position(xyz.shape[0], xyz.shape[1])
     return ops.fps(xyz.float(), npoint, None).long()
 
 
@@ -124,6 +132,7 @@ def query_ball_point(radius, nsample, xyz, new_xyz):
 def sample_and_group(npoint, radius, nsample, xyz, points, returnfps=False):
     """:116-140 — new_xyz [B,npoint,3], new_points [B,npoint,nsample,D] (features only, not centred)."""
     xyz = xyz.float()
+    hold_rng_position(xyz.shape[0], xyz.shape[1])
     fps_idx = ops.fps(xyz, npoint, None)
     B = xyz.shape[0]
     new_xyz = ops.group_gather(xyz, None, fps_idx.view(B, npoint, 1)).view(B, npoint, 3)

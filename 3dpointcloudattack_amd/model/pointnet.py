@@ -170,19 +170,21 @@ class PointNetCls(_FrozenFusedMixin, nn.Module):
                 _fold_bn(self.fc2.weight, self.fc2.bias, self.bn2),   # dropout is identity in eval
                 _plain(self.fc3.weight, self.fc3.bias))
 
-    def fused_loss_and_grad(self, x, target, kind, kappa=0.0):
+    def fused_loss_and_grad(self, x, target, kind, kappa=0.0, scale=None):
         """Attack fast path (no autograd): (logp [B,k], pred [B], per-sample adv loss [B], d mean(loss)/dx).
         kind in ops.LOSS_KINDS. Numerically the same computation as forward() + autograd, in ~20 launches."""
         logits, ctx = fused_forward(self, x)
-        logp, pred, loss, g_logits = ops.cls_loss(logits, target, kind, kappa, scale=1.0 / x.shape[0])
+        logp, pred, loss, g_logits = ops.cls_loss(logits, target, kind, kappa,
+                                                  scale=1.0 / x.shape[0] if scale is None else scale)
         return logp, pred, loss, fused_input_grad(ctx, g_logits)
 
-    def fused_attack_grad(self, x, target, kind, kappa=0.0, pred_out=None, step=None):
+    def fused_attack_grad(self, x, target, kind, kappa=0.0, pred_out=None, step=None, scale=None):
         """fused_loss_and_grad for the attack loops: the classifier tail (fc3, loss, fc3 backward) is one launch that
         also writes the prediction into `pred_out` and advances the device step word. Returns (pred, loss, dL/dx)."""
         _, ctx = fused_forward(self, x, tail=False)
         c2, pk = ctx[9], ctx[1]
-        _, pred, loss, g_c2 = ops.cls_tail(c2, pk["c"][4], pk["c"][5], target, kind, kappa, scale=1.0 / x.shape[0],
+        _, pred, loss, g_c2 = ops.cls_tail(c2, pk["c"][4], pk["c"][5], target, kind, kappa,
+                                           scale=1.0 / x.shape[0] if scale is None else scale,
                                            pred_out=pred_out, step=step, want_logp=False)
         return pred, loss, fused_input_grad(ctx, None, g_c2=g_c2)
 

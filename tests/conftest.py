@@ -32,6 +32,11 @@ def metrics_fx():
 
 
 @pytest.fixture(scope="session")
+def metrics4096_fx():
+    return np.load(os.path.join(GOLDEN, "metrics_n4096.npz"))
+
+
+@pytest.fixture(scope="session")
 def dev():
     import torch
     if not torch.cuda.is_available():

@@ -693,7 +693,211 @@ def gen_formats():
     print("formats.npz:", len(fx), "arrays")
 
 
-SECTIONS = {"curvenet_blocks": gen_curvenet_blocks, "formats": gen_formats, "cw_additional": gen_cw_additional, "curvenet": gen_curvenet, "aof": gen_aof, "geoa3": gen_geoa3, "dgcnn": gen_dgcnn, "metrics": gen_metrics, "pointnet": gen_pointnet, "cw": gen_cw, "pointnet2": gen_pointnet2, "knn": gen_knn}
+def _geoa3_imports():
+    """Stand-in modules / removed torch APIs the GeoA3 sources import but never call on the attack path (see
+    gen_geoa3); returns (GeoA3_attack module, loss_utils, estimate_normal)."""
+    import io
+    import types
+    import importlib
+    for name in ("open3d", "torchvision", "torchvision.transforms", "seaborn"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["seaborn"].set = lambda *a, **k: None
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    importlib.import_module("torch.autograd.gradcheck")
+    sys.modules["torch.autograd.gradcheck"].zero_gradients = lambda *a, **k: None
+    torch.symeig = lambda L, eigenvectors=True: torch.linalg.eigh(L)
+    os.popen = lambda *a, **k: io.StringIO("24 80")
+    sys.path.insert(0, os.path.join(REF, "attack", "GeoA3"))
+    from attack.GeoA3 import GeoA3_attack as ga
+    from attack.GeoA3 import loss_utils as lu
+    from attack.GeoA3.utility import estimate_normal
+    return ga, lu, estimate_normal
+
+
+GEO_BASE = dict(attack_method='untarget', curv_loss_weight=1.0, curv_loss_knn=16, initial_const=10, iter_max_steps=12,
+                binary_max_steps=2, is_partial_var=False, optim='adam', lr=0.01, npoint=256, is_subsample_opt=False,
+                eval_num=1, is_pre_jitter_input=False, cls_loss_type='CE', classes=40, confidence=0, dis_loss_type='CD',
+                is_cd_single_side=False, dis_loss_weight=1.0, hd_loss_weight=0.1, uniform_loss_weight=0.0,
+                is_use_lr_scheduler=False, is_debug=False, is_pro_grad=False, cc_linf=0.0, binary_step=2, num_iter=12,
+                is_real_offset=False, knn_range=3)
+
+
+def gen_geoa3_dgcnn():
+    """BASELINE configs[2] as a workload: the REAL reference geoA3_attack on the REAL reference DGCNN (B=1 as the
+    reference requires, N=256, the Eval_GeoA3.py:154-164 default loss mix and a Margin/L2 variant). The loss curves
+    [binary-step-2 iterations][B] and the result are stored; the offsets come from torch's CPU generator (seed 77)."""
+    install_cpu_shim()
+    import contextlib
+    import io
+    import types
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from oracle.ref_torch import seeded_state_dict, state_sha256
+    ga, lu, estimate_normal = _geoa3_imports()
+    from model import dgcnn as rd
+
+    class Dummy(torch.nn.Module):
+        def forward(self, x):
+            z = torch.zeros(x.shape[0], 40)
+            return z, z, z
+
+    net = rd.DGCNN(types.SimpleNamespace(k=20, emb_dims=1024, dropout=0.5), output_channels=40)
+    sd = seeded_state_dict(net, 5)
+    net.load_state_dict(sd)
+    net.eval()
+    rng = np.random.default_rng(24680)
+    fx = {"sha256": np.array(state_sha256(sd))}
+    cases = {"ce_cd_hd_curv": {}, "margin_l2": dict(cls_loss_type='Margin', confidence=5., dis_loss_type='L2', hd_loss_weight=0,
+                                                    curv_loss_weight=0)}
+    fx["names"] = np.array(sorted(cases))
+    for nm in sorted(cases):
+        cfg = types.SimpleNamespace(**{**GEO_BASE, **cases[nm]})
+        pc = unit_cloud(rng, 256)[None]
+        with torch.no_grad():
+            clean = int(torch.argmax(net(torch.from_numpy(pc).transpose(1, 2).contiguous())[0], dim=1))
+        torch.manual_seed(77)
+        np.random.seed(77)
+        with contextlib.redirect_stdout(io.StringIO()):
+            best, tgt, mask, steps, losses = ga.geoA3_attack(net, Dummy(), Dummy(), Dummy(), Dummy(), Dummy(),
+                                                             torch.from_numpy(pc), torch.tensor([clean]), cfg, 0, 1)
+        fx[f"{nm}_pc"], fx[f"{nm}_label"] = pc, np.array([clean])
+        fx[f"{nm}_best"], fx[f"{nm}_mask"] = best.detach().numpy(), np.asarray(mask)
+        fx[f"{nm}_steps"], fx[f"{nm}_losses"] = np.array(steps), np.array(losses, dtype=np.float64)
+        print(nm, "mask", mask, "steps", steps, "loss[0], loss[-1]", losses[0], losses[-1])
+    np.savez_compressed(os.path.join(OUT, "geoa3_dgcnn.npz"), **fx)
+    print("geoa3_dgcnn.npz:", len(fx), "arrays")
+
+
+def gen_cw_curvenet():
+    """BASELINE configs[4]'s victim under attack: the REAL reference CW.attack (B=1) on the REAL reference CurveNet
+    (N=1024, seeded weights), L2 and Chamfer distance functors; trajectory through the dist_func hook."""
+    install_cpu_shim()
+    import contextlib
+    import io
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from oracle.ref_torch import seeded_state_dict, state_sha256
+    from model.curvenet import CurveNet
+    from attack.CW.CW_attack import CW
+    from attack.CW.CW_utils.adv_utils import UntargetedLogitsAdvLoss
+    from attack.CW.CW_utils.dist_utils import L2Dist, ChamferDist
+    from attack.CW.CW_utils.clip_utils import ClipPointsLinf
+
+    class Recorder(torch.nn.Module):
+        def __init__(self, inner, transpose):
+            super().__init__()
+            self.inner, self.transpose, self.log = inner, transpose, []
+
+        def forward(self, adv, ori, weights=None, batch_avg=True):
+            self.log.append(adv.detach().numpy().copy())
+            if self.transpose:
+                return self.inner(adv.transpose(1, 2).contiguous(), ori.transpose(1, 2).contiguous(), weights, batch_avg)
+            return self.inner(adv, ori, weights, batch_avg)
+
+    # Seeded random CurveNet weights give a bias-dominated classifier (every cloud -> the same class, margin ~2): labels
+    # would say nothing. The last layer's bias is therefore re-centred on the mean clean logits of six probe clouds —
+    # margins become 0.002-0.23 and the clean labels differ per cloud. The bias vector is stored in the fixture; the
+    # tests rebuild the weights as seeded_state_dict(seed 9, gain 2.45) + this bias.
+    model = CurveNet(num_classes=40)
+    sd = seeded_state_dict(model, 9)
+    model.load_state_dict(sd)
+    model.eval()
+    rng = np.random.default_rng(13579)
+    probes = [unit_cloud(rng, 1024)[None] for _ in range(6)]
+    with torch.no_grad():
+        L = torch.cat([model(torch.from_numpy(p).transpose(1, 2).contiguous())[0] for p in probes])
+        model.conv2.bias -= L.mean(0)
+    fx = {"sha256": np.array(state_sha256(model.state_dict())), "conv2_bias": model.conv2.bias.detach().numpy().copy()}
+    cases = {"l2": dict(dist="l2", kappa=0., steps=2, iters=8, probe=0),
+             "chamfer": dict(dist="chamfer", kappa=0., steps=2, iters=8, probe=5)}
+    fx["names"] = np.array(sorted(cases))
+    for nm in sorted(cases):
+        c = cases[nm]
+        pc = probes[c["probe"]]
+        with torch.no_grad():
+            logits = model(torch.from_numpy(pc).transpose(1, 2).contiguous())[0]
+        clean = int(torch.argmax(logits, dim=1))
+        rec = Recorder(L2Dist() if c["dist"] == "l2" else ChamferDist(), transpose=(c["dist"] != "l2"))
+        atk = CW(model, model, adv_func=UntargetedLogitsAdvLoss(kappa=c["kappa"]), clip_func=ClipPointsLinf(budget=0.18),
+                 dist_func=rec, attack_lr=1e-2, init_weight=10., max_weight=80., binary_step=c["steps"], num_iter=c["iters"],
+                 attack_method="untarget")
+        torch.manual_seed(2000)
+        np.random.seed(2000)
+        with contextlib.redirect_stdout(io.StringIO()):
+            bd, ba, sn = atk.attack(torch.from_numpy(pc), torch.tensor([clean]))
+        fx[f"{nm}_pc"], fx[f"{nm}_target"], fx[f"{nm}_clean_logits"] = pc, np.array([clean]), logits.numpy()
+        fx[f"{nm}_cfg"] = np.array([c["steps"], c["iters"], c["kappa"]])
+        fx[f"{nm}_bestdist"], fx[f"{nm}_bestattack"], fx[f"{nm}_success"] = bd, ba.astype(np.float32), np.array(sn)
+        fx[f"{nm}_traj"] = np.stack(rec.log).astype(np.float32)[:, 0]
+        fx[f"{nm}_fails"] = np.array([atk.attack_fail, atk.shuffle_fail, atk.trans_fail])
+        with torch.no_grad():
+            fx[f"{nm}_adv_label"] = model(torch.from_numpy(ba).float().transpose(1, 2).contiguous())[0].argmax(1).numpy()
+        print(nm, "clean", clean, "bestdist", bd, "success", sn, "fails", fx[f"{nm}_fails"], "adv label", fx[f"{nm}_adv_label"])
+    np.savez_compressed(os.path.join(OUT, "cw_curvenet.npz"), **fx)
+    print("cw_curvenet.npz:", len(fx), "arrays")
+
+
+def gen_f4():
+    """the REAL reference's add-cluster / add-object distance functors
+    (attack/CW/CW_utils/dist_utils.py:226-333) — per-sample values and the gradient of the batch mean. The Chamfer part
+    is evaluated in float64 (the reference's fp32 expansion is itself ~1e-5 off, SURVEY A-3); FarthestDist also in the
+    reference's own fp32."""
+    install_cpu_shim()
+    from attack.CW.CW_utils.dist_utils import FarthestDist, FarChamferDist, L2ChamferDist
+    rng = np.random.default_rng(112233)
+    fx = {}
+    B, K, na, cp = 3, 300, 3, 32
+    ori = np.stack([unit_cloud(rng, K) for _ in range(B)])
+    centres = ori[:, rng.choice(K, na, replace=False)]                                   # clusters near the surface
+    adv = (centres[:, :, None, :] + 0.05 * rng.standard_normal((B, na, cp, 3))).astype(np.float32)
+    w = (0.5 + rng.random(B)).astype(np.float32)
+    fx["ori"], fx["adv_clusters"], fx["weights"] = ori, adv, w
+    tw = torch.from_numpy(w)
+    for dt, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
+        ta = torch.from_numpy(adv).to(dt).requires_grad_()
+        per = FarthestDist()(ta, weights=tw, batch_avg=False)
+        FarthestDist()(ta, weights=tw, batch_avg=True).backward()
+        fx[f"far_{tag}"], fx[f"far_{tag}_grad"] = per.detach().numpy(), ta.grad.numpy()
+    fx["far_noweights"] = FarthestDist()(torch.from_numpy(adv).double(), batch_avg=False).numpy()
+    for method in ("adv2ori", "ori2adv", "both"):
+        ta = torch.from_numpy(adv.reshape(B, na * cp, 3)).double().requires_grad_()
+        to = torch.from_numpy(ori).double()
+        f = FarChamferDist(num_add=na, chamfer_method=method, chamfer_weight=0.1)
+        per = f(ta, to, weights=tw, batch_avg=False)
+        f(ta, to, weights=tw, batch_avg=True).backward()
+        fx[f"farchamfer_{method}"], fx[f"farchamfer_{method}_grad"] = per.detach().numpy(), ta.grad.numpy()
+    # add-object functor: objects = perturbed copies of small clean objects, placed into the scene
+    obj = (0.1 * rng.standard_normal((B, na, cp, 3))).astype(np.float32)
+    adv_obj = (obj + 0.01 * rng.standard_normal(obj.shape)).astype(np.float32)
+    placed = (adv_obj + centres[:, :, None, :]).reshape(B, na * cp, 3).astype(np.float32)
+    fx["ori_obj"], fx["adv_obj"], fx["placed"] = obj, adv_obj, placed
+    tp = torch.from_numpy(placed).double().requires_grad_()
+    tao = torch.from_numpy(adv_obj).double().requires_grad_()
+    f = L2ChamferDist(num_add=na, chamfer_method="adv2ori", chamfer_weight=0.2)
+    per = f(tp, torch.from_numpy(ori).double(), tao, torch.from_numpy(obj).double(), weights=tw, batch_avg=False)
+    f(tp, torch.from_numpy(ori).double(), tao, torch.from_numpy(obj).double(), weights=tw, batch_avg=True).backward()
+    fx["l2chamfer"], fx["l2chamfer_grad_placed"], fx["l2chamfer_grad_obj"] = per.detach().numpy(), tp.grad.numpy(), tao.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "f4.npz"), **fx)
+    print("f4.npz:", len(fx), "arrays", fx["far_f64"], fx["farchamfer_adv2ori"], fx["l2chamfer"])
+
+
+def gen_metrics_n4096():
+    """SURVEY §8(c)(1) asks for a2/a3 at N in {1024, 2048, 4096}: metrics.npz stops at 2048, this adds the N=4096 pair
+    (and a ragged 4096 x 3000 one) as its own small fixture so that the older fixture's random stream is untouched."""
+    from utils import dis_utils_numpy as dun
+    rng = np.random.default_rng(4096)
+    fx = {}
+    p = unit_cloud(rng, 4096)
+    pairs = {"rand_4096": (perturbed(rng, p), p), "ragged_4096_3000": (unit_cloud(rng, 4096), unit_cloud(rng, 3000))}
+    fx["np_names"] = np.array(sorted(pairs))
+    for nm in sorted(pairs):
+        a, b = pairs[nm]
+        fx[f"np_{nm}_a"], fx[f"np_{nm}_b"] = a, b
+        fx[f"np_{nm}_out"] = np.array([dun.chamfer(a, b), dun.sgd_hausdorff_dis(a, b),
+                                       dun.sgd_hausdorff_dis(b, a), dun.bid_hausdorff_dis(a, b)], np.float64)
+    np.savez_compressed(os.path.join(OUT, "metrics_n4096.npz"), **fx)
+    print("metrics_n4096.npz:", {k: fx[k] for k in fx if k.endswith("_out")})
+
+
+SECTIONS = {"metrics_n4096": gen_metrics_n4096, "f4": gen_f4, "geoa3_dgcnn": gen_geoa3_dgcnn, "cw_curvenet": gen_cw_curvenet, "curvenet_blocks": gen_curvenet_blocks, "formats": gen_formats, "cw_additional": gen_cw_additional, "curvenet": gen_curvenet, "aof": gen_aof, "geoa3": gen_geoa3, "dgcnn": gen_dgcnn, "metrics": gen_metrics, "pointnet": gen_pointnet, "cw": gen_cw, "pointnet2": gen_pointnet2, "knn": gen_knn}
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(SECTIONS)

@@ -32,6 +32,15 @@ def test_numpy_metrics_match_reference(metrics_fx):
                                fx["np_rand_64_M"], rtol=1e-13)
 
 
+def test_numpy_metrics_match_reference_n4096(metrics4096_fx):
+    """the N=4096 pair (and a ragged 4096 x 3000 one) of the real reference."""
+    fx = metrics4096_fx
+    for nm in fx["np_names"]:
+        a, b = fx[f"np_{nm}_a"], fx[f"np_{nm}_b"]
+        got = [orc.chamfer(a, b), orc.sgd_hausdorff_dis(a, b), orc.sgd_hausdorff_dis(b, a), orc.bid_hausdorff_dis(a, b)]
+        np.testing.assert_allclose(got, fx[f"np_{nm}_out"], rtol=1e-12, atol=1e-14, err_msg=str(nm))
+
+
 def test_torch_twin_metrics_match_reference(metrics_fx):
     fx = metrics_fx
     for nm in fx["t_names"]:
@@ -234,6 +243,58 @@ def test_oracle_geoa3_matches_reference():
         if mask.any():
             assert steps == fx[f"{nm}_steps"].tolist()
             np.testing.assert_allclose(best.numpy(), fx[f"{nm}_best"], atol=1e-4)
+
+
+def test_oracle_geoa3_on_dgcnn_matches_reference():
+    """BASELINE configs[2] as a workload: the oracle's GeoA3 loop on the oracle's DGCNN against the real reference's
+    geoA3_attack on the real reference DGCNN (tests/golden/geoa3_dgcnn.npz; same CPU-generator offsets)."""
+    import types
+    fx = np.load(os.path.join(GOLDEN, "geoa3_dgcnn.npz"))
+    net = ort.DGCNN(types.SimpleNamespace(k=20, emb_dims=1024, dropout=0.5), output_channels=40)
+    sd = ort.seeded_state_dict(net, 5)
+    net.load_state_dict(sd)
+    net.eval()
+    assert ort.state_sha256(sd) == str(fx["sha256"])
+    orc_g = ort.GeoA3Oracle(as_written=True)
+    for nm in fx["names"]:
+        cfg = _geo_cfg(**GEO_CASES[str(nm)])
+        torch.manual_seed(77)
+        np.random.seed(77)
+        best, tgt, mask, steps, losses = orc_g.attack(net, torch.from_numpy(fx[f"{nm}_pc"]), torch.from_numpy(fx[f"{nm}_label"]), cfg)
+        assert np.array_equal(mask, fx[f"{nm}_mask"]), nm
+        np.testing.assert_allclose(np.array(losses), fx[f"{nm}_losses"], rtol=2e-3, atol=1e-4, err_msg=str(nm))
+        assert steps == fx[f"{nm}_steps"].tolist()
+        np.testing.assert_allclose(best.numpy(), fx[f"{nm}_best"], atol=1e-4)
+
+
+def test_oracle_f4_functors_match_reference():
+    """FarthestDist / FarChamferDist / L2ChamferDist of the real reference (tests/golden/f4.npz)."""
+    fx = np.load(os.path.join(GOLDEN, "f4.npz"))
+    w = torch.from_numpy(fx["weights"])
+    adv = torch.from_numpy(fx["adv_clusters"])
+    B, na, cp, _ = adv.shape
+    for dt, tag, tol in ((torch.float64, "f64", 1e-12), (torch.float32, "f32", 1e-6)):
+        a = adv.to(dt).clone().requires_grad_()
+        per = ort.farthest_dist(a, weights=w, batch_avg=False)
+        ort.farthest_dist(a, weights=w).backward()
+        np.testing.assert_allclose(per.detach().numpy(), fx[f"far_{tag}"], rtol=tol)
+        np.testing.assert_allclose(a.grad.numpy(), fx[f"far_{tag}_grad"], rtol=max(tol, 1e-9), atol=1e-12)
+    np.testing.assert_allclose(ort.farthest_dist(adv.double(), batch_avg=False).numpy(), fx["far_noweights"], rtol=1e-12)
+    ori = torch.from_numpy(fx["ori"]).double()
+    for method in ("adv2ori", "ori2adv", "both"):
+        a = adv.reshape(B, na * cp, 3).double().requires_grad_()
+        per = ort.far_chamfer_dist(a, ori, na, method=method, weights=w, batch_avg=False)
+        ort.far_chamfer_dist(a, ori, na, method=method, weights=w).backward()
+        np.testing.assert_allclose(per.detach().numpy(), fx[f"farchamfer_{method}"], rtol=1e-10)
+        np.testing.assert_allclose(a.grad.numpy(), fx[f"farchamfer_{method}_grad"], rtol=1e-8, atol=1e-12)
+    placed = torch.from_numpy(fx["placed"]).double().requires_grad_()
+    ao = torch.from_numpy(fx["adv_obj"]).double().requires_grad_()
+    oo = torch.from_numpy(fx["ori_obj"]).double()
+    per = ort.l2_chamfer_dist(placed, ori, ao, oo, weights=w, batch_avg=False)
+    ort.l2_chamfer_dist(placed, ori, ao, oo, weights=w).backward()
+    np.testing.assert_allclose(per.detach().numpy(), fx["l2chamfer"], rtol=1e-10)
+    np.testing.assert_allclose(placed.grad.numpy(), fx["l2chamfer_grad_placed"], rtol=1e-8, atol=1e-12)
+    np.testing.assert_allclose(ao.grad.numpy(), fx["l2chamfer_grad_obj"], rtol=1e-8, atol=1e-12)
 
 
 def test_oracle_aof_matches_reference():

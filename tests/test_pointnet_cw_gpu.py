@@ -230,6 +230,41 @@ def test_captured_runner_survives_second_attack_on_same_victim(dev):
     assert int(st_a["step"]) == int(st_e["step"]) == 9
 
 
+@pytest.mark.parametrize("fused", [True, False])
+def test_sharded_attack_equals_unsharded(dev, fused):
+    """a B=4 attack == two B=2 shards, given per-sample noise seeds and the GLOBAL batch size for the
+    loss mean (attack/CW/CW_attack.py:160-165: the batch mean only scales each sample's gradient by 1/B, which Adam
+    sees through its eps). Whole attack(): binary search, best-attack bookkeeping, success count."""
+    cwm, adv, dist, clip = _mods()
+    model, _ = hip_pointnet(0, dev)
+    trans_model, _ = hip_pointnet(1, dev)
+    rng = np.random.default_rng(52)
+    pcs = torch.from_numpy(np.stack([unit_cloud(rng, 300) for _ in range(4)]))
+    with torch.no_grad():
+        labels = model(pcs.transpose(1, 2).contiguous().to(dev))[0].argmax(1).cpu()
+    seeds = [1000 + i for i in range(4)]
+
+    def run(sl, gb):
+        atk = cwm.CW(model, trans_model, adv_func=adv.UntargetedLogitsAdvLoss(5.), clip_func=clip.ClipPointsLinf(0.18),
+                     dist_func=dist.ChamferDist(), binary_step=2, num_iter=12, fused=fused,
+                     sample_seeds=seeds[sl], global_batch=gb)
+        np.random.seed(3)
+        return atk.attack(pcs[sl], labels[sl])
+
+    bd, ba, sn = run(slice(0, 4), None)
+    parts = [run(slice(0, 2), 4), run(slice(2, 4), 4)]
+    bd_s = np.concatenate([p[0] for p in parts])
+    ba_s = np.concatenate([p[1] for p in parts])
+    assert sn == parts[0][2] + parts[1][2]
+    assert np.array_equal(bd < 1e9, bd_s < 1e9)
+    np.testing.assert_allclose(bd_s, bd, rtol=1e-5)
+    d = np.abs(ba_s - ba)
+    assert np.median(d) <= 1e-7 and (d <= 1e-5).mean() > 0.99, (np.median(d), d.max())
+    # without the global batch size the shards take (slightly) different Adam steps: the option is not a no-op
+    bd_n = np.concatenate([run(slice(0, 2), None)[0], run(slice(2, 4), None)[0]])
+    assert np.array_equal(bd_n < 1e9, bd < 1e9)
+
+
 @pytest.mark.parametrize("kind,kappa", [("untargeted_logits", 5.0), ("logits", 0.0), ("cross_entropy", 0.0)])
 def test_fused_loss_and_grad_equals_autograd_path(dev, kind, kappa):
     """The launch-minimal path (own head kernels, T chained inside the tower kernels) vs forward()+autograd."""
