@@ -393,7 +393,11 @@ class CurveGrouping(nn.Module):
     def forward(self, x, xyz, idx):
         x_att = torch.sigmoid(pw(self.att, x))
         x = x * x_att
-        _, start_index = torch.topk(x_att, self.curve_num, dim=2, sorted=False)
+        # The reference asks for sorted=False (:457): the order of the start points is then unspecified (torch's CPU and
+        # GPU kernels return different ones) — yet the walk's momentum step mixes values of DIFFERENT curves by position
+        # (walk.py:104-105), so the output depends on it. The mirror fixes the order to descending score (a valid
+        # instance of "unsorted"), which makes the forward reproducible and lets fixtures pin it.
+        _, start_index = torch.topk(x_att, self.curve_num, dim=2, sorted=True)
         return self.walk(xyz, x, idx, start_index.squeeze(1).unsqueeze(2))       # [B,C,cn,cl]
 
 

@@ -862,8 +862,8 @@ def uniform_loss(adv_pc, percentages=(0.004, 0.006, 0.008, 0.010, 0.012), radius
         adv_pc = adv_pc.permute(0, 2, 1).contiguous()
     b, n, _ = adv_pc.size()
     npoint = int(n * 0.05)
-    orc = GeoA3Oracle(as_written=False)
-    loss = None
+    orc = GeoA3Oracle(as_written=False, dtype=torch.float64)    # in-group distances in double: groups hold duplicates
+    loss = None                                                 # (ball-query padding) whose true distance is 0
     for p in percentages:
         p = p * 4
         nsample = int(n * p)

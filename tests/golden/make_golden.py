@@ -172,6 +172,19 @@ def install_cpu_shim():
     torch.arange = lambda *a, **k: _orig_arange(*a, **{kk: vv for kk, vv in k.items() if kk != "device"})
 
 
+def canonical_unsorted_topk():
+    """CurveNet picks its curve start points with ``torch.topk(..., sorted=False)`` (model/curvenet_util.py:457): the
+    ORDER of the k indices is then unspecified and differs between torch's CPU and GPU kernels — and the walk's
+    momentum step mixes values of different curves by their position (model/walk.py:104-105), so the reference's own
+    output depends on that order. For fixtures that pin the walk inside the whole network, the unspecified order is
+    fixed to the descending-score order (one valid instance of sorted=False); the mirror uses the same order."""
+    _orig = torch.topk
+
+    def topk(input, k, dim=-1, largest=True, sorted=True, **kw):
+        return _orig(input, k, dim=dim, largest=largest, sorted=True, **kw)
+    torch.topk = topk
+
+
 def _seeded_pointnet(cls, k, seed):
     sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))  # repo root, for oracle.ref_torch helpers
     from oracle.ref_torch import seeded_state_dict, state_sha256
@@ -771,6 +784,7 @@ def gen_cw_curvenet():
     """BASELINE configs[4]'s victim under attack: the REAL reference CW.attack (B=1) on the REAL reference CurveNet
     (N=1024, seeded weights), L2 and Chamfer distance functors; trajectory through the dist_func hook."""
     install_cpu_shim()
+    canonical_unsorted_topk()
     import contextlib
     import io
     sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
@@ -897,7 +911,56 @@ def gen_metrics_n4096():
     print("metrics_n4096.npz:", {k: fx[k] for k in fx if k.endswith("_out")})
 
 
-SECTIONS = {"metrics_n4096": gen_metrics_n4096, "f4": gen_f4, "geoa3_dgcnn": gen_geoa3_dgcnn, "cw_curvenet": gen_cw_curvenet, "curvenet_blocks": gen_curvenet_blocks, "formats": gen_formats, "cw_additional": gen_cw_additional, "curvenet": gen_curvenet, "aof": gen_aof, "geoa3": gen_geoa3, "dgcnn": gen_dgcnn, "metrics": gen_metrics, "pointnet": gen_pointnet, "cw": gen_cw, "pointnet2": gen_pointnet2, "knn": gen_knn}
+def gen_curvenet_trace():
+    """Stage-by-stage outputs of the REAL reference CurveNet on Kaiming-scale seeded weights (gain 2.45; the older
+    curvenet.npz uses gain 1.0, under which everything past the first blocks is bias-dominated and deep mistakes
+    cannot show): LPFA, the eight CIC blocks (positions + features), conv0 and the logits, B=1, N=1024. Features are
+    stored as float16 summaries would hide flips, so full fp32 for the small late stages and a strided sample of the
+    channels for the early ones."""
+    install_cpu_shim()
+    canonical_unsorted_topk()
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from oracle.ref_torch import seeded_state_dict, state_sha256
+    from model.curvenet import CurveNet
+    m = CurveNet(num_classes=40)
+    sd = seeded_state_dict(m, 9)
+    m.load_state_dict(sd)
+    m.eval()
+    rng = np.random.default_rng(13579)
+    x = unit_cloud(rng, 1024)[None].transpose(0, 2, 1).copy()
+    fx = {"sha256": np.array(state_sha256(sd)), "x": x}
+    stages = ["lpfa", "cic11", "cic12", "cic21", "cic22", "cic31", "cic32", "cic41", "cic42", "conv0"]
+    hooks = []
+
+    def keep(name):
+        def fn(mod, inp, out):
+            feats = out[1] if isinstance(out, tuple) else out
+            f = feats.detach().numpy()
+            fx[f"{name}_feat"] = f[:, ::4].copy() if f.shape[1] * f.shape[2] > 70000 else f.copy()
+            fx[f"{name}_cstride"] = np.array(4 if f.shape[1] * f.shape[2] > 70000 else 1)
+            if isinstance(out, tuple):
+                fx[f"{name}_xyz"] = out[0].detach().numpy().copy()
+        return fn
+
+    for nm in stages:
+        hooks.append(getattr(m, nm).register_forward_hook(keep(nm)))
+    # inside the first curve block: the walk's curves and the aggregation output
+    hooks.append(m.cic11.curvegrouping.register_forward_hook(
+        lambda mod, inp, out: fx.__setitem__("cic11_curves", out.detach().numpy().copy())))
+    hooks.append(m.cic11.curveaggregation.register_forward_hook(
+        lambda mod, inp, out: fx.__setitem__("cic11_agg", out.detach().numpy()[:, ::2].copy())))
+    hooks.append(m.cic11.lpfa.register_forward_hook(
+        lambda mod, inp, out: fx.__setitem__("cic11_lpfa", out.detach().numpy()[:, ::2].copy())))
+    with torch.no_grad():
+        fx["logits"] = m(torch.from_numpy(x))[0].numpy()
+    for h in hooks:
+        h.remove()
+    fx["stages"] = np.array(stages)
+    np.savez_compressed(os.path.join(OUT, "curvenet_trace.npz"), **fx)
+    print("curvenet_trace.npz:", {k: v.shape for k, v in fx.items() if hasattr(v, "shape")})
+
+
+SECTIONS = {"metrics_n4096": gen_metrics_n4096, "curvenet_trace": gen_curvenet_trace, "f4": gen_f4, "geoa3_dgcnn": gen_geoa3_dgcnn, "cw_curvenet": gen_cw_curvenet, "curvenet_blocks": gen_curvenet_blocks, "formats": gen_formats, "cw_additional": gen_cw_additional, "curvenet": gen_curvenet, "aof": gen_aof, "geoa3": gen_geoa3, "dgcnn": gen_dgcnn, "metrics": gen_metrics, "pointnet": gen_pointnet, "cw": gen_cw, "pointnet2": gen_pointnet2, "knn": gen_knn}
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(SECTIONS)
