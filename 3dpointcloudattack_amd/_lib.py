@@ -27,6 +27,8 @@ _PTS = [_P, _L, _L, _L]  # pointer + (batch, point, channel) element strides
 SIGNATURES = {
     "pc3d_nn_f32": _PTS + _PTS + [_I, _I, _I, _P, _P, _P],
     "pc3d_nn_bidir_f32": _PTS + _PTS + [_I, _I, _I, _P, _P, _P, _P, _P],
+    "pc3d_nn_bidir_shared_ws_bytes": [_I, _I, _I],
+    "pc3d_nn_bidir_shared_f32": _PTS + _PTS + [_I, _I, _I, _P, _P, _P, _P, _P, _L, _P],
     "pc3d_rowreduce_f32": [_P, _I, _I, _I, _I, _P, _P],
     "pc3d_nn_bwd_f32": _PTS + _PTS + [_I, _I, _I]
     + [_P, _P, _L, _L, _F] + [_P, _P, _L, _L, _F]
@@ -72,6 +74,9 @@ SIGNATURES = {
     "pc3d_cls_loss_f32": [_P, _I, _I, _I, _P, _I, _F, _F, _P, _P, _P, _P, _P],
 }
 
+# entry points that do not return a status code
+RESTYPES = {"pc3d_nn_bidir_shared_ws_bytes": c_int64}
+
 _lib = None
 
 
@@ -96,7 +101,7 @@ def load():
     lib.pc3d_last_error.argtypes = []
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)
-        fn.restype = c_int
+        fn.restype = RESTYPES.get(name, c_int)
         fn.argtypes = argtypes
     _lib = lib
     return lib

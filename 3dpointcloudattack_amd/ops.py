@@ -59,8 +59,30 @@ def nn_raw(q, r, q_cf=False, r_cf=False, want_idx=True):
     return d, i
 
 
-def nn_bidir_raw(a, b, a_cf=False, b_cf=False):
-    """Both directions in one launch: (dA [B,N], iA [B,N], dB [B,M], iB [B,M])."""
+_NN_WS = {}     # (device index, stream) -> scratch tensor of the shared-evaluation search, grown on demand
+
+
+def _nn_workspace(dev, nbytes):
+    """Scratch for pc3d_nn_bidir_shared_f32: one cached buffer per (device, stream) — work on one stream is ordered, so
+    consecutive calls may reuse it; it only ever grows (a captured hipGraph keeps pointing at a buffer that stays
+    alive and that later, smaller calls on the same stream still fit into)."""
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), _stream())
+    ws = _NN_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        if ws is not None and torch.cuda.is_current_stream_capturing():
+            _NN_KEEP.append(ws)          # an earlier capture on this stream may still point at the old buffer
+        ws = torch.empty((max(nbytes, 1 << 20),), dtype=torch.uint8, device=dev)
+        _NN_WS[key] = ws
+    return ws
+
+
+_NN_KEEP = []
+
+
+def nn_bidir_raw(a, b, a_cf=False, b_cf=False, want_idx=True, two_scan=False):
+    """Both directions: (dA [B,N], iA [B,N], dB [B,M], iB [B,M]); iA/iB are None with want_idx=False. One evaluation
+    of every distance feeds both directions (pc3d_nn_bidir_shared_f32); two_scan=True runs the older kernel that
+    scans once per direction (pc3d_nn_bidir_f32) — same results, kept for comparison."""
     ap, abs_, aps, acs, B, N = _pts(a, a_cf, "a")
     bp, bbs, bps, bcs, B2, M = _pts(b, b_cf, "b")
     if B != B2:
@@ -69,12 +91,18 @@ def nn_bidir_raw(a, b, a_cf=False, b_cf=False):
         raise ValueError("empty point set")
     dev = a.device
     dA = torch.empty((B, N), dtype=torch.float32, device=dev)
-    iA = torch.empty((B, N), dtype=torch.int32, device=dev)
     dB = torch.empty((B, M), dtype=torch.float32, device=dev)
-    iB = torch.empty((B, M), dtype=torch.int32, device=dev)
+    iA = torch.empty((B, N), dtype=torch.int32, device=dev) if want_idx else None
+    iB = torch.empty((B, M), dtype=torch.int32, device=dev) if want_idx else None
     with torch.cuda.device(dev):
-        _lib.call("pc3d_nn_bidir_f32", ap, abs_, aps, acs, bp, bbs, bps, bcs, B, N, M,
-                  dA.data_ptr(), iA.data_ptr(), dB.data_ptr(), iB.data_ptr(), _stream())
+        if two_scan:
+            _lib.call("pc3d_nn_bidir_f32", ap, abs_, aps, acs, bp, bbs, bps, bcs, B, N, M,
+                      dA.data_ptr(), _ptr(iA), dB.data_ptr(), _ptr(iB), _stream())
+        else:
+            need = int(_lib.load().pc3d_nn_bidir_shared_ws_bytes(B, N, M))
+            ws = _nn_workspace(dev, need)
+            _lib.call("pc3d_nn_bidir_shared_f32", ap, abs_, aps, acs, bp, bbs, bps, bcs, B, N, M,
+                      dA.data_ptr(), _ptr(iA), dB.data_ptr(), _ptr(iB), ws.data_ptr(), ws.numel(), _stream())
     return dA, iA, dB, iB
 
 

@@ -54,6 +54,23 @@ int pc3d_nn_bidir_f32(const float* a, int64_t a_bs, int64_t a_ps, int64_t a_cs,
                       int B, int N, int M,
                       float* dA, int32_t* iA, float* dB, int32_t* iB, void* stream);
 
+/* Both directions from ONE evaluation of every distance (the two-scan form above computes each d(a_i,b_j) twice):
+ * a workgroup keeps 64*Q points of `a` in registers, scans a range of `b` from LDS, takes the row minima as before
+ * and reduces the column minima across the lanes with a halving butterfly (v_permlane32/16_swap + DPP); what one
+ * workgroup cannot finish (column minima per tile of `a`; row minima when `b` is split to fill the chip) goes through
+ * the caller's workspace and is folded by a second, small launch. Same results as pc3d_nn_bidir_f32, bit for bit
+ * (distances; indices = lowest index attaining the minimum). Replaces the same reference code as pc3d_nn_f32 for the
+ * callers that need both directions: distance.py:40-50,58-70 (ChamferDistance/HausdorffDistance return both),
+ * utils/dis_utils_numpy.py:23-38, utils/dis_utils_torch.py:14-28, attack/GeoA3/loss_utils.py:36-46.
+ * ws: device scratch of at least pc3d_nn_bidir_shared_ws_bytes(B,N,M) bytes, 16-byte aligned, owned by the caller,
+ * free to reuse once the stream has passed this call. dA/iA/dB/iB: any may be NULL. */
+int64_t pc3d_nn_bidir_shared_ws_bytes(int B, int N, int M);
+int pc3d_nn_bidir_shared_f32(const float* a, int64_t a_bs, int64_t a_ps, int64_t a_cs,
+                             const float* b, int64_t b_bs, int64_t b_ps, int64_t b_cs,
+                             int B, int N, int M,
+                             float* dA, int32_t* iA, float* dB, int32_t* iB,
+                             void* ws, int64_t ws_bytes, void* stream);
+
 /* Row reductions of a [B,N] f32 matrix into out[B].
  *   op:  0 = mean, 1 = max, 2 = sum        pre: 0 = identity, 1 = sqrt(max(x,0)) applied per element first
  * mean/max of squared distances = ChamferDistance/HausdorffDistance (distance.py:44-49,64-69);

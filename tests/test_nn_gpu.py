@@ -143,3 +143,38 @@ def test_full_size_properties(ops, dev):
             rows = rng.choice(N, 64, replace=False)
             d64, i64 = orc.nn_sq(a[k, rows].cpu().numpy(), b[k].cpu().numpy())
             np.testing.assert_allclose(dA[k, rows].cpu().numpy(), d64, rtol=1e-6)
+
+
+@pytest.mark.parametrize("B,N,M", [(1, 1, 1), (1, 1, 300), (2, 300, 1), (3, 63, 65), (2, 129, 4097), (2, 4100, 70),
+                                   (5, 256, 256), (32, 1024, 1024), (7, 2048, 1500), (32, 4096, 4096), (1, 9000, 8200)])
+def test_shared_evaluation_equals_two_scan_bitwise(ops, dev, B, N, M):
+    """pc3d_nn_bidir_shared_f32 (one distance evaluation feeds both directions, butterfly column reduction, partials
+    folded by a second launch) against pc3d_nn_bidir_f32 (one scan per direction): identical distances bit for bit,
+    identical indices (both resolve ties to the lowest index), for every work split the planner picks."""
+    g = torch.Generator().manual_seed(N * 31 + M)
+    b = torch.randn(B, M, 3, generator=g)
+    a = torch.randn(B, N, 3, generator=g)
+    if N == M:
+        a = b + 0.01 * torch.randn(B, N, 3, generator=g)
+    a, b = a.to(dev), b.to(dev)
+    ref = ops.nn_bidir_raw(a, b, two_scan=True)
+    got = ops.nn_bidir_raw(a, b)
+    for r, x, nm in zip(ref, got, ("dA", "iA", "dB", "iB")):
+        assert torch.equal(r, x), (nm, int((r != x).sum()))
+    dA, iA, dB, iB = ops.nn_bidir_raw(a, b, want_idx=False)            # values only
+    assert iA is None and iB is None and torch.equal(dA, ref[0]) and torch.equal(dB, ref[2])
+    acf = a.transpose(1, 2).contiguous()                                # [B,3,N] layout of the attack loops
+    got_cf = ops.nn_bidir_raw(acf, b, True, False)
+    assert all(torch.equal(r, x) for r, x in zip(ref, got_cf))
+
+
+def test_shared_evaluation_ties_and_duplicates(ops, dev):
+    """Exact ties (duplicated points on both sides) resolve to the LOWEST index in both directions."""
+    base = torch.tensor([[1., 0, 0], [0, 1, 0], [0, 0, 1], [1, 0, 0]], device=dev)
+    a = base.repeat(130, 1)[None]                                       # 520 points, every point 130 times
+    b = base[[1, 3, 2]].repeat(90, 1)[None]                             # 270 points: (0,1,0), (1,0,0), (0,0,1), ...
+    dA, iA, dB, iB = ops.nn_bidir_raw(a, b)
+    assert float(dA.abs().max()) == 0.0 and float(dB.abs().max()) == 0.0
+    assert iA[0, :4].tolist() == [1, 0, 2, 1] and iB[0, :3].tolist() == [1, 0, 2]
+    ref = ops.nn_bidir_raw(a, b, two_scan=True)
+    assert torch.equal(iA, ref[1]) and torch.equal(iB, ref[3])
