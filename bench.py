@@ -214,16 +214,74 @@ def main():
     if dist_on:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if dist_on:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+
+    def across_ranks(x):
+        """(max over ranks, [value of every rank]) of a host scalar; one all_reduce (works on RCCL and on gloo)."""
+        if not dist_on:
+            return x, [x]
+        t = torch.zeros(world, dtype=torch.float64, device=dev)
+        t[rank] = x
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        per = [float(v) for v in t.cpu()]
+        return max(per), per
+
+    elapsed, per_rank_elapsed = across_ranks(elapsed)
     ms_per_step = elapsed * 1e3 / args.steps
     iters_per_s = world * args.steps / elapsed     # whole job: every rank advances its own batch each step
 
+    # ---- the other shapes of the same path, on EVERY rank (the collectives inside line up): north_star's N = 2048 /
+    # 4096 clouds, the reference's default L2 regulariser, and one GPU's share of BASELINE configs[4] (CW on CurveNet,
+    # 32 of the 256 clouds, N=4096). Reported as whole-job rates over the slowest rank, with the per-rank times.
+    stream = torch.cuda.current_stream()
+    sweep = None
+    if not args.no_sweep:
+        sweep = {}
+
+        def time_cw(victim, trans, npts, dname, warm, iters, seed):
+            rs = np.random.default_rng(seed + 1000 * rank)
+            d2 = torch.from_numpy(np.stack([unit_cloud(rs, npts) for _ in range(B)]))
+            with torch.no_grad():
+                l2 = victim(d2.transpose(1, 2).contiguous().to(dev))[0].argmax(1).cpu()
+            atk = CW(victim, trans, adv_func=adv_utils.UntargetedLogitsAdvLoss(kappa=KAPPA),
+                     clip_func=clip_utils.ClipPointsLinf(budget=BUDGET),
+                     dist_func=dist_utils.L2Dist() if dname == "l2" else dist_utils.ChamferDist(),
+                     attack_lr=LR, binary_step=10, num_iter=500, device=dev)
+            torch.manual_seed(7 + rank)
+            s2 = atk._begin(d2, l2)
+            atk._begin_binary_step(s2)
+            r2 = atk._make_runner(s2)
+            for i in range(warm):
+                r2(i)
+            ms, per = across_ranks(ev_ms(r2, iters, stream))
+            return {"iters_per_s": world * 1e3 / ms, "ms_per_step": ms, "per_rank_ms": per}
+
+        for npts, dname in ((NPTS, "l2"), (2048, "chamfer"), (4096, "chamfer")):
+            sweep[f"cw_pointnet_{dname}_B{B}_N{npts}"] = time_cw(model, trans_model, npts, dname, 10, 60, 4321 + npts)
+        CurveNet = M("3dpointcloudattack_amd.model.curvenet").CurveNet
+        cnet = CurveNet(num_classes=NCLS)
+        if rank == 0:
+            cnet.load_state_dict(seeded_state(cnet, 9))
+        cnet = cnet.to(dev).eval()
+        if dist_on:
+            sharding.broadcast_frozen_weights([cnet], src=0)
+        sweep[f"cfg5_share_cw_curvenet_chamfer_B{B}_N4096"] = time_cw(cnet, cnet, 4096, "chamfer", 4, 12, 555)
+
+    # ---- the one collective at the end of a job: gather every rank's results (unequal shards are padded inside)
+    gather = None
+    if dist_on:
+        res_local = [st["o_bestattack"].detach(), st["o_bestdist"].detach(), st["pred"].detach()]
+        if os.environ.get("PC3D_BENCH_REHEARSAL"):      # gloo has no GPU all_gather
+            res_local = [t.cpu() for t in res_local]
+        torch.cuda.synchronize()
+        tg = time.perf_counter()
+        res_all = sharding.gather_results(res_local)
+        torch.cuda.synchronize()
+        gms, _ = across_ranks((time.perf_counter() - tg) * 1e3)
+        gather = {"ms": gms, "tensors": [list(t.shape) for t in res_all],
+                  "bytes": int(sum(t.numel() * t.element_size() for t in res_all))}
+
     out = None
     if rank == 0:
-        stream = torch.cuda.current_stream()
         # ---- roofline of the dominant kernel: the fused per-point MLP + max forward (fp32 MFMA)
         x = st["adv"].detach()
         tower = model.feat.folded()
@@ -233,34 +291,72 @@ def main():
         k_ms = ev_ms(lambda: ops.pointmlp3_max_fwd_raw(x, tower, False, fold=False), 50, stream)
         ach = flops / (k_ms * 1e-3) / 1e12
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm_counters.json")
+        pmc = os.path.join(ROOT, "profiles", "r02_pmc_hbm_counters.json")
         if os.path.exists(pmc):
             # HBM bytes per launch from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE
-            # runs of this same command, KiB units). gfx950 correction (MI355X_MICROARCH.md §HBM): FETCH_SIZE counts
-            # 64 B per 128-B request for 16-B-per-lane reads -> doubled; WRITE_SIZE is exact.
-            c = json.load(open(pmc)).get("pc3d::pointmlp3_max_fwd_kernel|grid=131072")
+            # runs of this same command at this round's kernels, KiB units). gfx950 correction (MI355X_MICROARCH.md
+            # §HBM): FETCH_SIZE counts 64 B per 128-B request for 16-B-per-lane reads -> doubled; WRITE_SIZE is exact.
+            # (PMC collection needs the rocprofv3 wrapper, so it cannot run inside this process; the file is regenerated
+            # by tools/prof_pmc.sh whenever a kernel on this line changes.)
+            pj = json.load(open(pmc))
+            c = next((v for k, v in pj.items() if k.startswith("pc3d::pointmlp3_max_fwd_kernel|grid=131072")), None)
             if c and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
                 traffic = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
         roofline = {"kernel": "pointmlp3_max_fwd_kernel", "bound": "mfma", "achieved": ach,
                     "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS,
                     "traffic": traffic, "launch_us": k_ms * 1e3, "launches_per_step": 2}
-        # ---- the Chamfer kernel at N=4096 (north_star's second figure): VALU-bound, HBM share reported too
+        # ---- the Chamfer kernel at N=4096 (north_star's second figure): VALU-bound, HBM share reported too.
+        # Three timings per size: `values` = what Chamfer / Hausdorff VALUES need (utils/dis_utils_*.py, the metric's
+        # kernel: scan + fold launches, no arg-min), `with_idx` = values + both arg-min index arrays (what the
+        # backward of the distance functors needs), `two_scan` = the round-1 kernel (one scan per direction).
+        pmc_all = {}
+        pmc2 = os.path.join(ROOT, "profiles", "r02_pmc_hbm_counters.json")
+        if os.path.exists(pmc2):
+            pmc_all = json.load(open(pmc2))
+
+        def counter_bytes(keys):
+            """HBM bytes per call (sum over the launches of one call) from the committed PMC passes of THIS bench
+            command (tools/prof_pmc.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs, mean per dispatch; KiB units;
+            FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note for 16-B-per-lane reads), or None when a kernel of
+            the call is not covered. keys: "kernel name|grid=<work-items>|lds=<bytes>" as that script writes them."""
+            tot = 0.0
+            for k in keys:
+                c = pmc_all.get(k)
+                if not c or "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+                    return None
+                tot += (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+            return tot
+
         def chamfer_point(Nc):
             a = torch.randn(B, Nc, 3, device=dev)
             b = a + 0.01 * torch.randn_like(a)
-            for _ in range(3):
-                ops.nn_bidir_raw(a, b)
-            c_ms = ev_ms(lambda: ops.nn_bidir_raw(a, b), 20, stream)
+            res = {}
+            for tag, kw in (("values", {"want_idx": False, "two_scan": False}), ("with_idx", {"two_scan": False}),
+                            ("two_scan", {"two_scan": True})):
+                for _ in range(3):
+                    ops.nn_bidir_raw(a, b, **kw)
+                res[tag] = ev_ms(lambda: ops.nn_bidir_raw(a, b, **kw), 20, stream)
+            c_ms = res["values"]
             alg_bytes = B * (2 * Nc * 12 + 2 * Nc * 8)          # 40*N bytes per cloud pair (SURVEY §8(d))
             alg_ops = 10.0 * B * Nc * Nc                         # SURVEY §8(d): 8 (shared distance) + 2 (running mins) per pair
-            issued_ops = 2.0 * B * Nc * Nc * 6.875               # what the kernel issues: 6 + 0.5 + 3/8 per pair and direction
-            return {"kernel": "nn_kernel", "config": f"B={B} N=M={Nc} bidirectional", "launch_us": c_ms * 1e3,
+            issued_ops = 8.4 * B * Nc * Nc                       # DESIGN.md §3: instructions the shared-evaluation scan issues per pair
+            return {"kernel": "nn_shared_kernel + nn_shared_finalize_kernel", "config": f"B={B} N=M={Nc} bidirectional",
+                    "launch_us": c_ms * 1e3, "with_idx_us": res["with_idx"] * 1e3, "two_scan_us": res["two_scan"] * 1e3,
                     "hbm_alg_GBps": alg_bytes / (c_ms * 1e-3) / 1e9,
                     "hbm_frac": alg_bytes / (c_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "valu_frac": alg_ops / (c_ms * 1e-3) / VALU_LANE_OPS_PEAK,
+                    "valu_frac_with_idx": alg_ops / (res["with_idx"] * 1e-3) / VALU_LANE_OPS_PEAK,
+                    "valu_frac_two_scan": alg_ops / (res["two_scan"] * 1e-3) / VALU_LANE_OPS_PEAK,
                     "valu_issue_frac": issued_ops / (c_ms * 1e-3) / VALU_LANE_OPS_PEAK, "bound": "valu"}
         chamfer = chamfer_point(4096)
-        chamfer["other_sizes"] = {f"N{n}": {k: v for k, v in chamfer_point(n).items() if k in ("launch_us", "hbm_alg_GBps", "valu_frac", "valu_issue_frac")}
+        # B=32, N=M=4096: scan grid 16 tiles x 32 clouds x 4 splits of 256 threads, 12 KiB LDS; fold grid 16 x 32 x 2
+        cb = counter_bytes(("void pc3d::nn_shared_kernel<4, false>|grid=524288|lds=12288",
+                            "pc3d::nn_shared_finalize_kernel|grid=262144|lds=0"))
+        chamfer["hbm_counter_bytes"] = cb                      # FETCH+WRITE of the values path's launches, per call
+        chamfer["hbm_counter_GBps"] = (cb / (chamfer["launch_us"] * 1e-6) / 1e9) if cb else None
+        chamfer["other_sizes"] = {f"N{n}": {k: v for k, v in chamfer_point(n).items()
+                                            if k in ("launch_us", "with_idx_us", "two_scan_us", "hbm_alg_GBps", "valu_frac",
+                                                     "valu_frac_with_idx", "valu_frac_two_scan")}
                                   for n in (1024, 2048)}
         out = {
             "metric": "attack iters/s (B=32, N=1024, PointNet) + Chamfer HBM GB/s vs peak",
@@ -274,27 +370,9 @@ def main():
                        "cloud_iters_per_s": iters_per_s * B},
             "roofline": roofline, "chamfer": chamfer,
         }
-        if not args.no_sweep and world == 1:
-            # north_star's other sizes / the reference's default regulariser, short runs of the same loop (N=1 only)
-            sweep = {}
-            for npts, dname in ((NPTS, "l2"), (2048, "chamfer"), (4096, "chamfer")):
-                rs = np.random.default_rng(4321 + npts)
-                d2 = torch.from_numpy(np.stack([unit_cloud(rs, npts) for _ in range(B)]))
-                with torch.no_grad():
-                    l2 = model(d2.transpose(1, 2).contiguous().to(dev))[0].argmax(1).cpu()
-                atk = CW(model, trans_model, adv_func=adv_utils.UntargetedLogitsAdvLoss(kappa=KAPPA),
-                         clip_func=clip_utils.ClipPointsLinf(budget=BUDGET),
-                         dist_func=dist_utils.L2Dist() if dname == "l2" else dist_utils.ChamferDist(),
-                         attack_lr=LR, binary_step=10, num_iter=500, device=dev)
-                torch.manual_seed(7)
-                s2 = atk._begin(d2, l2)
-                atk._begin_binary_step(s2)
-                r2 = atk._make_runner(s2)
-                for i in range(10):
-                    r2(i)
-                ms = ev_ms(r2, 60, stream)
-                sweep[f"cw_pointnet_{dname}_B{B}_N{npts}"] = {"iters_per_s": 1e3 / ms, "ms_per_step": ms}
-            out["sweep"] = sweep
+        out["sweep"] = sweep
+        out["per_rank_ms_per_step"] = [e * 1e3 / args.steps for e in per_rank_elapsed]
+        out["gather_results"] = gather
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(pcs, labels)
             out["chamfer"]["cpu_baseline"] = chamfer_cpu_baseline()

@@ -35,7 +35,8 @@ def _check_idx(q, r, d_gpu, i_gpu):
 @pytest.mark.parametrize("B,N,M", [(1, 1, 1), (2, 64, 64), (3, 100, 257), (2, 1024, 1024), (1, 300, 5000),
                                    (2, 4100, 70), (1, 4096, 4096)])
 @pytest.mark.parametrize("cf", [False, True])
-def test_nn_bidir_matches_oracle(ops, dev, B, N, M, cf):
+@pytest.mark.parametrize("two_scan", [False, True])
+def test_nn_bidir_matches_oracle(ops, dev, B, N, M, cf, two_scan):
     rng = np.random.default_rng(N * 7 + M)
     a = np.stack([_cloud(rng, N) for _ in range(B)])
     b = np.stack([_cloud(rng, M) for _ in range(B)])
@@ -44,7 +45,7 @@ def test_nn_bidir_matches_oracle(ops, dev, B, N, M, cf):
     ta, tb = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
     if cf:  # channel-first views [B,3,N], the attack's native layout
         ta, tb = ta.transpose(1, 2).contiguous(), tb.transpose(1, 2).contiguous()
-    dA, iA, dB, iB = ops.nn_bidir_raw(ta, tb, cf, cf)
+    dA, iA, dB, iB = ops.nn_bidir_raw(ta, tb, cf, cf, two_scan=two_scan)
     dA, iA, dB, iB = dA.cpu().numpy(), iA.cpu().numpy(), dB.cpu().numpy(), iB.cpu().numpy()
     for k in range(B):
         _check_idx(a[k], b[k], dA[k], iA[k])
@@ -158,13 +159,13 @@ def test_shared_evaluation_equals_two_scan_bitwise(ops, dev, B, N, M):
         a = b + 0.01 * torch.randn(B, N, 3, generator=g)
     a, b = a.to(dev), b.to(dev)
     ref = ops.nn_bidir_raw(a, b, two_scan=True)
-    got = ops.nn_bidir_raw(a, b)
+    got = ops.nn_bidir_raw(a, b, two_scan=False)
     for r, x, nm in zip(ref, got, ("dA", "iA", "dB", "iB")):
         assert torch.equal(r, x), (nm, int((r != x).sum()))
-    dA, iA, dB, iB = ops.nn_bidir_raw(a, b, want_idx=False)            # values only
+    dA, iA, dB, iB = ops.nn_bidir_raw(a, b, want_idx=False, two_scan=False)   # values only
     assert iA is None and iB is None and torch.equal(dA, ref[0]) and torch.equal(dB, ref[2])
     acf = a.transpose(1, 2).contiguous()                                # [B,3,N] layout of the attack loops
-    got_cf = ops.nn_bidir_raw(acf, b, True, False)
+    got_cf = ops.nn_bidir_raw(acf, b, True, False, two_scan=False)
     assert all(torch.equal(r, x) for r, x in zip(ref, got_cf))
 
 
@@ -173,7 +174,7 @@ def test_shared_evaluation_ties_and_duplicates(ops, dev):
     base = torch.tensor([[1., 0, 0], [0, 1, 0], [0, 0, 1], [1, 0, 0]], device=dev)
     a = base.repeat(130, 1)[None]                                       # 520 points, every point 130 times
     b = base[[1, 3, 2]].repeat(90, 1)[None]                             # 270 points: (0,1,0), (1,0,0), (0,0,1), ...
-    dA, iA, dB, iB = ops.nn_bidir_raw(a, b)
+    dA, iA, dB, iB = ops.nn_bidir_raw(a, b, two_scan=False)
     assert float(dA.abs().max()) == 0.0 and float(dB.abs().max()) == 0.0
     assert iA[0, :4].tolist() == [1, 0, 2, 1] and iB[0, :3].tolist() == [1, 0, 2]
     ref = ops.nn_bidir_raw(a, b, two_scan=True)

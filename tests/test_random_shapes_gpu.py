@@ -23,7 +23,7 @@ def test_nn_bidir_random(ops, dev, seed):
     b = torch.from_numpy(r.standard_normal((B, M, 3)).astype(np.float32)).to(dev)
     if seed % 3 == 0:          # channel-first strided views
         a = a.transpose(1, 2).contiguous().transpose(1, 2)
-    dA, iA, dB, iB = ops.nn_bidir_raw(a, b)
+    dA, iA, dB, iB = ops.nn_bidir_raw(a, b, two_scan=bool(seed & 1))
     D = ((a.double()[:, :, None] - b.double()[:, None]) ** 2).sum(-1)
     rA, rB = D.min(dim=2), D.min(dim=1)
     torch.testing.assert_close(dA.double(), rA[0], rtol=2e-6, atol=1e-12)

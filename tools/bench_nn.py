@@ -10,7 +10,7 @@ PEAK = 256 * 4 * 32 * 2.4e9
 for B, N in ((32, 1024), (32, 2048), (32, 4096), (64, 2048), (256, 4096)):
     a = torch.randn(B, N, 3, device=dev); b = a + 0.01 * torch.randn_like(a)
     row = {"B": B, "N": N}
-    for tag, kw in (("shared", {}), ("shared_noidx", {"want_idx": False}), ("two_scan", {"two_scan": True})):
+    for tag, kw in (("shared", {"two_scan": False}), ("shared_noidx", {"want_idx": False, "two_scan": False}), ("two_scan", {"two_scan": True})):
         for _ in range(3): ops.nn_bidir_raw(a, b, **kw)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -21,7 +21,7 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         if r["Counter_Name"] != ctr:
             continue
         name = r["Kernel_Name"].split("(")[0]
-        acc[f"{name}|grid={r['Grid_Size']}"].append(float(r["Counter_Value"]))
+        acc[f"{name}|grid={r['Grid_Size']}|lds={r['LDS_Block_Size']}"].append(float(r["Counter_Value"]))
     for k, v in acc.items():
         res[k][ctr] = sum(v) / len(v)
         res[k]["dispatches"] = len(v)
