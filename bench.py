@@ -299,7 +299,7 @@ def main():
             # (PMC collection needs the rocprofv3 wrapper, so it cannot run inside this process; the file is regenerated
             # by tools/prof_pmc.sh whenever a kernel on this line changes.)
             pj = json.load(open(pmc))
-            c = next((v for k, v in pj.items() if k.startswith("pc3d::pointmlp3_max_fwd_kernel|grid=131072")), None)
+            c = pj.get("pc3d::pointmlp3_max_fwd_kernel|grid=131072|run=0")
             if c and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
                 traffic = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
         roofline = {"kernel": "pointmlp3_max_fwd_kernel", "bound": "mfma", "achieved": ach,
@@ -318,7 +318,8 @@ def main():
             """HBM bytes per call (sum over the launches of one call) from the committed PMC passes of THIS bench
             command (tools/prof_pmc.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs, mean per dispatch; KiB units;
             FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note for 16-B-per-lane reads), or None when a kernel of
-            the call is not covered. keys: "kernel name|grid=<work-items>|lds=<bytes>" as that script writes them."""
+            the call is not covered. keys: "kernel name|grid=<work-items>|run=<k>" as that script writes them (run k = the
+            k-th change of that kernel's grid in dispatch order: this function's call order below fixes it)."""
             tot = 0.0
             for k in keys:
                 c = pmc_all.get(k)
@@ -349,9 +350,10 @@ def main():
                     "valu_frac_two_scan": alg_ops / (res["two_scan"] * 1e-3) / VALU_LANE_OPS_PEAK,
                     "valu_issue_frac": issued_ops / (c_ms * 1e-3) / VALU_LANE_OPS_PEAK, "bound": "valu"}
         chamfer = chamfer_point(4096)
-        # B=32, N=M=4096: scan grid 16 tiles x 32 clouds x 4 splits of 256 threads, 12 KiB LDS; fold grid 16 x 32 x 2
-        cb = counter_bytes(("void pc3d::nn_shared_kernel<4, false>|grid=524288|lds=12288",
-                            "pc3d::nn_shared_finalize_kernel|grid=262144|lds=0"))
+        # B=32, N=M=4096 is the FIRST Chamfer point measured (run 0): scan grid 16 tiles x 32 clouds x 4 splits of 256
+        # threads, fold grid 16 x 32 x 2 of 256
+        cb = counter_bytes(("void pc3d::nn_shared_kernel<4, false>|grid=524288|run=0",
+                            "pc3d::nn_shared_finalize_kernel|grid=262144|run=0"))
         chamfer["hbm_counter_bytes"] = cb                      # FETCH+WRITE of the values path's launches, per call
         chamfer["hbm_counter_GBps"] = (cb / (chamfer["launch_us"] * 1e-6) / 1e9) if cb else None
         chamfer["other_sizes"] = {f"N{n}": {k: v for k, v in chamfer_point(n).items()

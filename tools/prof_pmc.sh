@@ -17,11 +17,18 @@ res = collections.defaultdict(dict)
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob(f"{root}/gpurun_out/pmc_{tag}_{ctr}/*/*counter_collection.csv")
     acc = collections.defaultdict(list)
+    # key = kernel name | total work-items | run: dispatches of one kernel name are split into runs wherever its grid
+    # changes, because two problem sizes can share a total grid (bench.py's N=4096 and N=2048 Chamfer points do) and
+    # dynamic LDS does not show in LDS_Block_Size
+    last_grid, run_of = {}, collections.defaultdict(int)
     for r in csv.DictReader(open(f[0])):
         if r["Counter_Name"] != ctr:
             continue
         name = r["Kernel_Name"].split("(")[0]
-        acc[f"{name}|grid={r['Grid_Size']}|lds={r['LDS_Block_Size']}"].append(float(r["Counter_Value"]))
+        if last_grid.get(name) not in (None, r["Grid_Size"]):
+            run_of[name] += 1
+        last_grid[name] = r["Grid_Size"]
+        acc[f"{name}|grid={r['Grid_Size']}|run={run_of[name]}"].append(float(r["Counter_Value"]))
     for k, v in acc.items():
         res[k][ctr] = sum(v) / len(v)
         res[k]["dispatches"] = len(v)
