@@ -1,0 +1,244 @@
+// Dense point-wise layers of the victims as ONE fp32-MFMA kernel:   Y[M,N] = act( gate(X)[M,K] . W[N,K]^T + bias[N] )
+//
+// Replaces the library GEMMs (hipBLASLt through F.linear / torch._addmm_activation) + separate activation passes of
+//   * the shared MLPs of PointNet++ set abstraction, layers 1-2 (model/pointnet2_utils.py:190-197,243-257: Conv2d 1x1 +
+//     BatchNorm2d + ReLU over [B,C,ns,S] — here channels-last rows [B*S*ns, C] with BN folded into W, bias),
+//   * DGCNN's EdgeConv point-wise products [P | Q] = x [U ; V]^T and conv5 (model/dgcnn.py:297-320),
+//   * CurveNet's 1x1 convolutions (model/curvenet_util.py:189-193,321-331),
+// and, with W^T in place of W and `gate` = the layer's own output, their backward to the input
+//   dX = (dY * act'(Y)) . W   (weights are frozen: no weight gradient exists on the attack path).
+//
+// Exact fp32: v_mfma_f32_32x32x2_f32 (products and accumulation in fp32, no tf32-style truncation), so logits keep
+// their label parity with the reference.
+//
+// Tiling (gfx950): workgroup = 128 rows x 128 columns, 4 waves in 2 x 2, each wave 64 x 64 = 2 x 2 MFMA tiles (64
+// accumulator VGPRs). K advances in steps of 32 through LDS: As[128][32+4], Bs[128][32+4] (the +4 floats per row keep
+// ds_read_b128 conflict-free); the next step's global loads (8 x float4 per thread) are issued before the current
+// step's MFMAs and parked in registers. Operand k-order inside a step: lane half h of MFMA e of group t holds
+// k = 8 t + 4 h + e for BOTH operands, so one ds_read_b128 per 32-row block feeds four MFMAs.
+// 64 MFMAs (4096 cycles on the matrix pipe) per 16 ds_read_b128 and 8 global float4 loads per wave and step.
+#include "pc3d_common.h"
+
+namespace pc3d {
+
+using gm_f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int GM_T = 256;
+constexpr int GM_BK = 32, GM_LD = GM_BK + 4;
+
+struct GemmArgs {
+  const float* X;      // [M, K], row stride ldx
+  const float* W;      // [N, K] row-major (row stride K)
+  const float* bias;   // [N] or null
+  const float* gate;   // [M, K] (row stride ldg) or null: X is read as  gate > 0 ? X : gslope * X
+  float* Y;            // [M, N], row stride ldy
+  int64_t ldx, ldg, ldy;
+  int M, N, K;
+  int act;             // 0 none, 1 ReLU, 2 LeakyReLU(slope)
+  float slope, gslope;
+};
+
+__device__ __forceinline__ float4 gm_load4(const float* p, int k, int K, bool row_ok) {
+  // 4 consecutive k of one row with zero fill past K / past the matrix edge; float4 when aligned and fully inside
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (!row_ok) return v;
+  if (k + 3 < K && ((reinterpret_cast<uintptr_t>(p + k) & 15) == 0)) return *reinterpret_cast<const float4*>(p + k);
+  if (k < K) v.x = p[k];
+  if (k + 1 < K) v.y = p[k + 1];
+  if (k + 2 < K) v.z = p[k + 2];
+  if (k + 3 < K) v.w = p[k + 3];
+  return v;
+}
+
+// WM x WN waves of 64 x 64 outputs each: <2,2> = 128 x 128 tile (wide layers), <4,1> = 256 x 64 (layers with <= 64
+// outputs: no half-empty MFMA tiles, and the kernel is then bound by reading / writing the [M, 64] activations).
+template <int WM, int WN, int TM, int TN, bool DB, int OCC>
+__global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_nt_kernel(GemmArgs a) {
+  constexpr int NT = WM * WN * 64;               // threads
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr int RPS = NT / 8;                    // tile rows covered by one pass of the staging threads
+  constexpr int QA = BM / RPS, QB = BN / RPS;    // float4 per thread and step of the X / W tile
+  static_assert(BM % RPS == 0 && BN % RPS == 0, "tile rows must be a multiple of the staging pass");
+  extern __shared__ __attribute__((aligned(16))) float gm_lds[];   // 2 x (As[BM][GM_LD] + Bs[BN][GM_LD])
+  // XCD-aware tile order: consecutive workgroup ids land on different XCDs (round-robin dispatch), so give each XCD a
+  // contiguous band of row tiles — its L2 then holds one band of X and all of W instead of a slice of everything.
+  const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
+  const int ntile = tiles_m * tiles_n;
+  int wg = blockIdx.x;
+  {
+    const int nx = 8, per = (ntile + nx - 1) / nx;
+    const int xcd = wg % nx, slot = wg / nx;
+    const int t = xcd * per + slot;
+    if (slot >= per || t >= ntile) return;   // (grid is rounded up to a multiple of 8 bands)
+    wg = t;
+  }
+  const int tm = wg / tiles_n, tn = wg - tm * tiles_n;   // column tiles of one row band are neighbours: X stays in L2
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave / WN) * (TM * 32), wn = (wave % WN) * (TN * 32);
+  const int r = lane & 31, h = lane >> 5;
+
+  gm_f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // global -> register staging: tile element (row = q*32 + tid/8, k = (tid%8)*4): 8 threads cover one row's 32 k
+  // => 128 B contiguous per row
+  const int lrow = tid >> 3, lk = (tid & 7) * 4;
+  float4 xa[QA], wb[QB];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int q = 0; q < QA; ++q) {
+      const int gm = m0 + q * RPS + lrow;
+      float4 v = gm_load4(a.X + (int64_t)gm * a.ldx, k0 + lk, a.K, gm < a.M);
+      if (a.gate) {
+        const float4 g = gm_load4(a.gate + (int64_t)gm * a.ldg, k0 + lk, a.K, gm < a.M);
+        v.x = g.x > 0.f ? v.x : a.gslope * v.x;
+        v.y = g.y > 0.f ? v.y : a.gslope * v.y;
+        v.z = g.z > 0.f ? v.z : a.gslope * v.z;
+        v.w = g.w > 0.f ? v.w : a.gslope * v.w;
+      }
+      xa[q] = v;
+    }
+#pragma unroll
+    for (int q = 0; q < QB; ++q) {
+      const int gn = n0 + q * RPS + lrow;
+      wb[q] = gm_load4(a.W + (int64_t)gn * a.K, k0 + lk, a.K, gn < a.N);
+    }
+  };
+  auto stash = [&](float* As, float* Bs) {
+#pragma unroll
+    for (int q = 0; q < QA; ++q) *reinterpret_cast<float4*>(As + (q * RPS + lrow) * GM_LD + lk) = xa[q];
+#pragma unroll
+    for (int q = 0; q < QB; ++q) *reinterpret_cast<float4*>(Bs + (q * RPS + lrow) * GM_LD + lk) = wb[q];
+  };
+
+  constexpr int BUF = (BM + BN) * GM_LD;
+  fetch(0);
+  stash(gm_lds, gm_lds + BM * GM_LD);
+  __syncthreads();
+  int cur = 0;
+  for (int k0 = 0; k0 < a.K; k0 += GM_BK) {
+    const bool more = k0 + GM_BK < a.K;
+    if (more) fetch(k0 + GM_BK);   // global loads in flight during this step's MFMAs
+    const float* As = gm_lds + cur * BUF;
+    const float* Bs = As + BM * GM_LD;
+    const int kleft = a.K - k0;
+    const int groups = kleft >= GM_BK ? GM_BK / 8 : (kleft + 7) / 8;   // narrow layers (K = 3) run one group, not four
+    for (int t = 0; t < groups; ++t) {
+      float4 av[TM], bv[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) av[i] = *reinterpret_cast<const float4*>(As + (wm + i * 32 + r) * GM_LD + 8 * t + 4 * h);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bv[j] = *reinterpret_cast<const float4*>(Bs + (wn + j * 32 + r) * GM_LD + 8 * t + 4 * h);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].x, bv[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].y, bv[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].z, bv[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].w, bv[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+    if (DB) {
+      if (more) {
+        float* An = gm_lds + (cur ^ 1) * BUF;    // the other buffer: nobody reads it during this step
+        stash(An, An + BM * GM_LD);
+      }
+      __syncthreads();                           // one barrier per step (double-buffered tiles)
+      cur ^= 1;
+    } else if (more) {
+      __syncthreads();                           // everyone is done reading the tile
+      stash(gm_lds, gm_lds + BM * GM_LD);
+      __syncthreads();
+    }
+  }
+
+  // epilogue: D[row = sample][col = output]: lane holds column r, rows (e & 3) + 8 (e >> 2) + 4 h of each 32 x 32 tile
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wn + j * 32 + r;
+    if (col >= a.N) continue;
+    const float bj = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (row < a.M) {
+          float v = acc[i][j][e] + bj;
+          if (a.act == 1) v = v > 0.f ? v : 0.f;
+          else if (a.act == 2) v = v > 0.f ? v : a.slope * v;
+          a.Y[(int64_t)row * a.ldy + col] = v;
+        }
+      }
+  }
+}
+
+}  // namespace pc3d
+
+using namespace pc3d;
+
+static int g_gemm_variant = -1;
+extern "C" int pc3d_gemm_nt_tune(int variant) {   // tuning hook (tools/bench_gemm.py), not part of the ABI
+  g_gemm_variant = variant;
+  return 0;
+}
+
+extern "C" int pc3d_gemm_nt_f32(const float* X, int64_t ldx, const float* W, const float* bias, const float* gate,
+                                int64_t ldg, float gate_slope, int M, int N, int K, int act, float slope, float* Y,
+                                int64_t ldy, void* stream) {
+  PC3D_REQUIRE(M >= 0 && N >= 1 && K >= 1, "pc3d_gemm_nt_f32: bad sizes M=%d N=%d K=%d", M, N, K);
+  PC3D_REQUIRE(act >= 0 && act <= 2, "pc3d_gemm_nt_f32: bad activation %d", act);
+  if (M == 0) return PC3D_OK;
+  PC3D_REQUIRE(X && W && Y, "pc3d_gemm_nt_f32: null pointer");
+  PC3D_REQUIRE(ldx >= K && ldy >= N && (!gate || ldg >= K), "pc3d_gemm_nt_f32: row stride smaller than the row");
+  GemmArgs a{};
+  a.X = X, a.W = W, a.bias = bias, a.gate = gate, a.Y = Y, a.ldx = ldx, a.ldg = ldg, a.ldy = ldy;
+  a.M = M, a.N = N, a.K = K, a.act = act, a.slope = slope, a.gslope = gate_slope;
+  // Tile shapes, measured on MI355X (tools/bench_gemm.py, us; hipBLASLt beside them):
+  //   layer [M,N,K]                 0: 128x128 DB   2: 128x64   4: 64x128   5: 128x128/8 waves   hipBLASLt
+  //   DGCNN conv5 [32768,1024,512]       387           361         350            320               275
+  //   SSG SA2 l2  [524288,128,128]       264           225         226            212               174
+  //   SSG SA1 l2  [1048576,64,64]        339           160         242            222               146
+  //   SSG SA1 l1  [1048576,64,3]         213            86         120            104                80
+  // Wave tiles of 32 x 64 (two accumulator tiles, ~100 VGPRs) beat 64 x 64 everywhere: these layers are short in K
+  // (2-16 steps), so what counts is how many workgroups a CU holds to cover the load -> MFMA -> store latency of each.
+  //   0 / 1: 128x128, 4 waves of 64x64, double / single buffered     2: 128x64, 4 waves of 32x64 (N <= 64)
+  //   3: 256x64, 4 waves of 64x64, double buffered                    4: 64x128, 4 waves of 32x64
+  //   5 / 6: 128x128, 8 waves of 32x64, single / double buffered
+  int v = g_gemm_variant;
+  if (v < 0) v = (N <= 64) ? 2 : 5;
+  int bm, bn, db;
+  switch (v) {
+    case 1: bm = 128, bn = 128, db = 0; break;
+    case 2: bm = 128, bn = 64, db = 0; break;
+    case 3: bm = 256, bn = 64, db = 1; break;
+    case 4: bm = 64, bn = 128, db = 0; break;
+    case 5: bm = 128, bn = 128, db = 0; break;
+    case 6: bm = 128, bn = 128, db = 1; break;
+    default: bm = 128, bn = 128, db = 1; break;
+  }
+  const long tiles = (long)cdiv(M, bm) * cdiv(N, bn);
+  PC3D_REQUIRE(tiles <= 0x7fffff00L, "pc3d_gemm_nt_f32: too many tiles (%ld)", tiles);
+  const int per = (int)((tiles + 7) / 8);
+  const size_t lds = (size_t)(db ? 2 : 1) * (bm + bn) * GM_LD * sizeof(float);
+  const dim3 grid(per * 8), block(v == 5 || v == 6 ? 512 : GM_T);
+  hipStream_t st = as_stream(stream);
+  switch (v) {
+    case 1: hipLaunchKernelGGL((gemm_nt_kernel<2, 2, 2, 2, false, 3>), grid, block, lds, st, a); break;
+    case 2: hipLaunchKernelGGL((gemm_nt_kernel<4, 1, 1, 2, false, 4>), grid, block, lds, st, a); break;
+    case 3: hipLaunchKernelGGL((gemm_nt_kernel<4, 1, 2, 2, true, 2>), grid, block, lds, st, a); break;
+    case 4: hipLaunchKernelGGL((gemm_nt_kernel<2, 2, 1, 2, false, 4>), grid, block, lds, st, a); break;
+    case 5: hipLaunchKernelGGL((gemm_nt_kernel<4, 2, 1, 2, false, 2>), grid, block, lds, st, a); break;
+    case 6: hipLaunchKernelGGL((gemm_nt_kernel<4, 2, 1, 2, true, 2>), grid, block, lds, st, a); break;
+    default: hipLaunchKernelGGL((gemm_nt_kernel<2, 2, 2, 2, true, 2>), grid, block, lds, st, a); break;
+  }
+  PC3D_LAUNCH_CHECK("pc3d_gemm_nt_f32");
+  return PC3D_OK;
+}

@@ -56,7 +56,7 @@ def pw(mod, x, bn=None):
     requires_grad on and pays for dL/dW in every attack step)."""
     _, act, w, b = folded_pw(mod, bn)
     if x.dim() == 2:
-        y = F.linear(x, w, b)
+        y = ops.linear_act(x, w, b)
     else:
         shp = x.shape
         y = torch.matmul(w, x.reshape(shp[0], shp[1], -1))
@@ -195,7 +195,7 @@ class LPFA(nn.Module):
             idx32 = ops.knn_raw(pts.detach(), pts.detach(), self.k)[1]          # the k nearest, self first
         else:
             idx32 = idx[:, :, :self.k].to(torch.int32).contiguous()
-        PQ = F.linear(pts, torch.cat((wb + wc, wa - wc), 0), torch.cat((torch.zeros_like(b), b)))
+        PQ = ops.linear_act(pts, torch.cat((wb + wc, wa - wc), 0), torch.cat((torch.zeros_like(b), b)))
         return ops.edge_max(PQ, idx32, self.mlp[0][2].negative_slope).transpose(1, 2)
 
     def _edge_act_mean(self, x, xyz, idx):
@@ -210,14 +210,13 @@ class LPFA(nn.Module):
             idx32 = ops.knn_raw(pts.detach(), pts.detach(), self.k)[1]
         else:
             idx32 = idx[:, :, :self.k].to(torch.int32).contiguous()
-        A = feats + F.linear(pts, gb + gc)
-        Bc = F.linear(pts, ga - gc, t) - feats
+        A = feats + ops.linear_act(pts, gb + gc)
+        Bc = ops.linear_act(pts, ga - gc, t) - feats
         E = ops.edge_act(A, Bc, idx32, 0.2)                                    # [B,N,k,C]
         for li, layer in enumerate(self.mlp):
             _, act, w, b = folded_pw(layer)
-            E = F.linear(E, w, b)
-            if li + 1 < len(self.mlp):
-                E = F.leaky_relu(E, act.negative_slope)
+            last = li + 1 == len(self.mlp)       # the last layer's LeakyReLU is fused with the neighbour mean below
+            E = ops.linear_act(E, w, b, None if last else "leaky", 0.0 if last else act.negative_slope)
         return ops.act_mean(E, self.mlp[-1][2].negative_slope).transpose(1, 2)   # [B,C',N]
 
     def group_feature(self, x, xyz, idx):

@@ -5,7 +5,8 @@ EdgeConv is evaluated without the [B,2C,N,k] edge tensor: with W = [Wa | Wb] (1x
     W [x_j - x_i ; x_i] = Wa x_j + (Wb - Wa) x_i = P_j + Q_i ,
 and because eval-BatchNorm (folded into Wa, Wb) and LeakyReLU are monotone per channel once the BN scale is folded,
     max_j leaky(bn(W e_ij)) = leaky(max_j P_j + Q_i + t).
-So an EdgeConv layer = ONE point-wise GEMM against [Wa ; Wb - Wa] (rows [P | Q]) + one launch that gathers, takes the
+So an EdgeConv layer = ONE point-wise product against [Wa ; Wb - Wa] (rows [P | Q]; pc3d_gemm_nt_f32, the hand-written
+fp32-MFMA kernel — as are conv5 and the head) + one launch that gathers, takes the
 neighbour max, adds Q and applies the LeakyReLU (pc3d_edge_max_f32); the dynamic graph comes from pc3d_knn_f32 (xyz) /
 pc3d_knn_feat_f32 (fp32 MFMA distance blocks in LDS, K-lists across the lanes). The reference builds
 335-671 MB edge tensors per layer at B=32.
@@ -96,13 +97,13 @@ class DGCNN(_FrozenFusedMixin, nn.Module):
             with torch.no_grad():                           # graph indices are constants for autograd (topk indices)
                 fd = f.detach()
                 idx = ops.knn_raw(fd, fd, self.k)[1] if li == 0 else ops.knn_feat(fd, self.k)
-            PQ = F.linear(f, UV, tb)                        # [U x | V x + t] in one GEMM
+            PQ = ops.linear_act(f, UV, tb)                  # [U x | V x + t] in one fp32-MFMA launch
             f = ops.edge_max(PQ, idx, 0.2)                  # leaky(max_j P_j + Q_i) == max_j leaky(bn(conv(e_ij)))
             feats.append(f)
         g = torch.cat(feats, dim=2)                         # [B,N,512]
-        g = ops.act_maxmean_pool(F.linear(g, *c5), 0.2)     # leaky + adaptive max / avg pool over N in one pass
-        g = F.leaky_relu(F.linear(g, *head[0]), negative_slope=0.2)
-        g = F.leaky_relu(F.linear(g, *head[1]), negative_slope=0.2)
-        g = F.linear(g, *head[2])
+        g = ops.act_maxmean_pool(ops.linear_act(g, *c5), 0.2)   # leaky + adaptive max / avg pool over N in one pass
+        g = ops.linear_act(g, *head[0], "leaky", 0.2)
+        g = ops.linear_act(g, *head[1], "leaky", 0.2)
+        g = ops.linear_act(g, *head[2])
         g = F.log_softmax(g, -1)
         return g, g, g

@@ -108,9 +108,9 @@ class STN3d(_FrozenFusedMixin, nn.Module):
         self._require_fused(x)
         tower, head, iden = self.folded()
         g = ops.pointmlp3_max(x, tower, True)                 # relu(bn3(conv3)) then max == max then relu
-        g = F.relu(F.linear(g, *head[0]))
-        g = F.relu(F.linear(g, *head[1]))
-        g = F.linear(g, *head[2]) + iden
+        g = ops.linear_act(g, *head[0], "relu")
+        g = ops.linear_act(g, *head[1], "relu")
+        g = ops.linear_act(g, *head[2]) + iden
         return g.view(-1, 3, 3)
 
 
@@ -192,9 +192,9 @@ class PointNetCls(_FrozenFusedMixin, nn.Module):
         self._require_fused(x)
         head = self.folded()
         g, trans, trans_feat = self.feat(x)
-        g = F.relu(F.linear(g, *head[0]))
-        g = F.relu(F.linear(g, *head[1]))
-        g = F.linear(g, *head[2])
+        g = ops.linear_act(g, *head[0], "relu")
+        g = ops.linear_act(g, *head[1], "relu")
+        g = ops.linear_act(g, *head[2])
         return F.log_softmax(g, dim=1), trans, trans_feat
 
 

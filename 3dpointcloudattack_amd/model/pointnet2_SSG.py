@@ -3,6 +3,8 @@ Same sub-module names / state_dict keys; sampling and grouping run on the HIP ke
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import ops
+
 from .pointnet import _FrozenFusedMixin, _fold_bn, _plain
 from .pointnet2_utils import PointNetSetAbstraction
 
@@ -34,8 +36,8 @@ class PointNet_Ssg(_FrozenFusedMixin, nn.Module):
         l2_xyz, l2_points = self.sa2(l1_xyz, l1_points)
         l3_xyz, l3_points = self.sa3(l2_xyz, l2_points)
         x = l3_points.reshape(B, 1024)
-        x = F.relu(F.linear(x, *head[0]))      # dropout is identity in eval
-        x = F.relu(F.linear(x, *head[1]))
-        x = F.linear(x, *head[2])
+        x = ops.linear_act(x, *head[0], "relu")      # dropout is identity in eval
+        x = ops.linear_act(x, *head[1], "relu")
+        x = ops.linear_act(x, *head[2])
         x = F.log_softmax(x, -1)
         return x, x, x

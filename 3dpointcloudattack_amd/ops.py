@@ -573,6 +573,94 @@ def cw_step(p, g, m, v, step, lr, ori, budget, dist_kind=0, w=None, l2norm=None,
 
 
 # ------------------------------------------------------------------------------------------------------
+# K8b: point-wise dense layers (frozen weights) on the fp32-MFMA GEMM
+# ------------------------------------------------------------------------------------------------------
+_ACTS = {None: 0, "none": 0, "relu": 1, "leaky": 2}
+GEMM_SMALL_M = 64
+
+
+def F_leaky(y, slope):
+    return torch.nn.functional.leaky_relu_(y, slope)
+
+
+_WT_CACHE = {}      # (data_ptr, version, shape) -> (weak owner check, W^T): the backward's operand; weights are frozen
+
+
+def _w_transposed(w):
+    key = (w.data_ptr(), w._version, tuple(w.shape))
+    hit = _WT_CACHE.get(key)
+    if hit is None or hit[0]() is None:
+        import weakref
+        if len(_WT_CACHE) > 512:
+            _WT_CACHE.clear()
+        hit = (weakref.ref(w), w.t().contiguous())
+        _WT_CACHE[key] = hit
+    return hit[1]
+
+
+def gemm_nt(x2d, w, bias=None, act=None, slope=0.0, gate=None, gate_slope=0.0, out=None):
+    """Y[M,N] = act(gate(x2d)[M,K] @ w[N,K]^T + bias) on pc3d_gemm_nt_f32 (exact fp32 MFMA). x2d / gate / out may be
+    row-strided views (last dimension contiguous)."""
+    _check(x2d, "x")
+    _check(w, "w")
+    M, K = x2d.shape
+    N = w.shape[0]
+    if w.shape[1] != K or not w.is_contiguous():
+        raise ValueError("gemm_nt: w must be a contiguous [N,K] matrix matching x's K")
+    if x2d.stride(1) != 1 or (gate is not None and (gate.stride(1) != 1 or gate.shape != x2d.shape)):
+        raise ValueError("gemm_nt: x / gate need a contiguous last dimension and equal shapes")
+    if M <= GEMM_SMALL_M and K % 8 == 0 and x2d.stride(0) % 4 == 0 and out is None:
+        # a handful of rows (the classifier heads: M = batch): the 128-row tile would leave all but N/128 CUs idle and
+        # walk K serially; the small-batch kernel (32 x 16 tiles, K split over the 8 waves of a workgroup) is 10-30x
+        # faster there. It has ReLU in its epilogue; the LeakyReLU / the input mask of the backward are elementwise
+        # passes over [M, N] / [M, K] with M <= 64 rows.
+        xs = x2d if gate is None else torch.where(gate > 0, x2d, gate_slope * x2d)
+        y = linear(xs, w, bias, relu=(act == "relu"))
+        return F_leaky(y, slope) if act == "leaky" else y
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=x2d.device)
+    with torch.cuda.device(x2d.device):
+        _lib.call("pc3d_gemm_nt_f32", x2d.data_ptr(), x2d.stride(0), w.data_ptr(), _ptr(bias), _ptr(gate),
+                  gate.stride(0) if gate is not None else 0, float(gate_slope), M, N, K, _ACTS[act], float(slope),
+                  out.data_ptr(), out.stride(0), _stream())
+    return out
+
+
+class _LinearActFn(torch.autograd.Function):
+    """act(x @ w.T + b) with the weights frozen: backward = ONE launch of the same kernel on W^T with the activation's
+    derivative applied to dY on load (gate = the saved output)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act, slope):
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        if x2.stride(1) != 1:
+            x2 = x2.contiguous()
+        y = gemm_nt(x2, w, b, act, slope)
+        ctx.act, ctx.slope, ctx.shp = act, slope, shp
+        ctx.save_for_backward(y if act in ("relu", "leaky") else None, w)
+        return y.view(*shp[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, gy):
+        y, w = ctx.saved_tensors
+        g2 = gy.reshape(-1, gy.shape[-1])
+        if g2.stride(1) != 1:
+            g2 = g2.contiguous()
+        gx = gemm_nt(g2, _w_transposed(w), None, None, 0.0, gate=y,
+                     gate_slope=ctx.slope if ctx.act == "leaky" else 0.0)
+        return gx.view(ctx.shp), None, None, None, None
+
+
+def linear_act(x, w, b=None, act=None, slope=0.0):
+    """[..., K] -> [..., N]: act(x @ w.T + b) for frozen (w, b); differentiable in x. act in {None, "relu", "leaky"}."""
+    w = w.detach()
+    if not w.is_contiguous():
+        w = w.contiguous()
+    return _LinearActFn.apply(x, w, b.detach() if b is not None else None, act, float(slope))
+
+
+# ------------------------------------------------------------------------------------------------------
 # K5/K6/K7: PointNet++ sampling & grouping
 # ------------------------------------------------------------------------------------------------------
 def fps(xyz, npoint, start=None, cf=False):
@@ -997,15 +1085,16 @@ def _group_linear_max_fwd(x, w, b):
             _lib.call("pc3d_group_linear_max_f32", x.data_ptr(), w.data_ptr(), b.data_ptr(), G, ns, C2, C3,
                       out.data_ptr(), arg.data_ptr(), _stream())
         return out, arg
-    y = torch._addmm_activation(b, x.reshape(G * ns, C2), w.t(), use_gelu=False).view(G, ns, -1)
+    y = gemm_nt(x.reshape(G * ns, C2), w, b, "relu").view(G, ns, -1)
     return y.max(dim=1)
 
 
 class _MLPReLUMaxFn(torch.autograd.Function):
     """The whole shared MLP of a set-abstraction layer + the max over the group, x [G,ns,C0] -> [G,C_last], with a
-    hand-written backward: hidden layers are GEMMs with a bias+ReLU epilogue; the last layer + max is the fused MFMA
-    launch; backward = sparse row accumulation through the max (which also applies the last hidden ReLU's mask), then
-    per hidden layer one GEMM and — except for the first — one mask pass. Frozen weights: only dL/dx."""
+    hand-written backward: hidden layers run on pc3d_gemm_nt_f32 (fp32 MFMA, bias + ReLU in the epilogue); the last
+    layer + max is the fused MFMA launch; backward = sparse row accumulation through the max (which also applies the
+    last hidden ReLU's mask), then per hidden layer ONE launch of the same kernel on W^T that applies the previous
+    ReLU's mask while loading dY — no separate mask pass over the [G*ns, C] tensors. Frozen weights: only dL/dx."""
 
     @staticmethod
     def forward(ctx, x, *wb):
@@ -1013,7 +1102,7 @@ class _MLPReLUMaxFn(torch.autograd.Function):
         ws, bs = wb[0::2], wb[1::2]
         acts = [x.reshape(G * ns, C0)]
         for w, b in zip(ws[:-1], bs[:-1]):
-            acts.append(torch._addmm_activation(b, acts[-1], w.t(), use_gelu=False))
+            acts.append(gemm_nt(acts[-1], w, b, "relu"))
         out, arg = _group_linear_max_fwd(acts[-1].view(G, ns, -1), ws[-1], bs[-1])
         ctx.save_for_backward(out, arg, *acts[1:], *ws)
         ctx.meta = (G, ns, C0, len(ws))
@@ -1033,9 +1122,9 @@ class _MLPReLUMaxFn(torch.autograd.Function):
             _lib.call("pc3d_group_max_linear_bwd_f32", g.data_ptr(), out.data_ptr(), arg.data_ptr(), ws[-1].data_ptr(),
                       G, ns, C2, ws[-1].shape[0], _ptr(last_hidden), gx.data_ptr(), _stream())
         for li in range(nl - 2, -1, -1):                                # hidden layers, last to first
-            gx = gx.mm(ws[li])                                          # gradient wrt that layer's input
-            if li > 0:
-                gx = torch.ops.aten.threshold_backward(gx, acts[li - 1], 0)
+            # gradient wrt that layer's input; the incoming gradient is masked by the layer's own ReLU on load (the
+            # last hidden layer's mask was applied by the max-backward kernel above)
+            gx = gemm_nt(gx, _w_transposed(ws[li]), gate=(acts[li] if li < nl - 2 else None), gate_slope=0.0)
         return (gx.view(G, ns, C0),) + (None,) * (2 * nl)
 
 

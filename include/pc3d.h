@@ -71,6 +71,20 @@ int pc3d_nn_bidir_shared_f32(const float* a, int64_t a_bs, int64_t a_ps, int64_t
                              float* dA, int32_t* iA, float* dB, int32_t* iB,
                              void* ws, int64_t ws_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * K8b  point-wise dense layer on fp32 MFMA:  Y[M,N] = act( gate(X)[M,K] . W[N,K]^T + bias[N] ).
+ * Replaces the library GEMM + activation passes of the shared MLPs of PointNet++ set abstraction
+ * (model/pointnet2_utils.py:190-197,243-257), DGCNN's EdgeConv products and conv5 (model/dgcnn.py:297-320) and
+ * CurveNet's 1x1 convolutions (model/curvenet_util.py:189-193,321-331), with eval BatchNorm folded into W / bias.
+ * Backward to the input (frozen weights, no weight gradient): the same entry point on W^T with X = dY and
+ * gate = the layer's output Y:  dX = (dY * act'(Y)) . W   (gate_slope = 0 for ReLU, = slope for LeakyReLU).
+ * X: [M,K] row stride ldx; W: [N,K] row-major; bias [N] or NULL; gate [M,K] row stride ldg or NULL (X is then read
+ * as gate > 0 ? X : gate_slope * X); act: 0 none, 1 ReLU, 2 LeakyReLU(slope); Y: [M,N] row stride ldy. Exact fp32
+ * (v_mfma_f32_32x32x2_f32). Any M, N, K >= 1.
+ * ------------------------------------------------------------------------------------------------------- */
+int pc3d_gemm_nt_f32(const float* X, int64_t ldx, const float* W, const float* bias, const float* gate, int64_t ldg,
+                     float gate_slope, int M, int N, int K, int act, float slope, float* Y, int64_t ldy, void* stream);
+
 /* Row reductions of a [B,N] f32 matrix into out[B].
  *   op:  0 = mean, 1 = max, 2 = sum        pre: 0 = identity, 1 = sqrt(max(x,0)) applied per element first
  * mean/max of squared distances = ChamferDistance/HausdorffDistance (distance.py:44-49,64-69);
