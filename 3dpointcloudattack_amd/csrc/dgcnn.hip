@@ -30,6 +30,10 @@ struct KnnFeatArgs {
   int32_t* idx;    // [B,N,K]
 };
 
+// (Round 2, measured: a barrier-free variant — every wave owning 16 queries on v_mfma_f32_16x16x4_f32, distances
+// transposed through a wave-private LDS strip — took 228 us against this kernel's 162 at B=32, N=1024, C=64, K=20,
+// and 136 against 97 at K=1: the cost that does not scale with C or K (scan, seed sort, LDS round trips) dominates
+// both forms, not the barriers. Cheaper list insertions (7 VALU, knn_list.h) moved this kernel from 171 to 162 us.)
 // Register diet on purpose (~80 VGPRs -> 4+ waves per SIMD): the insertions are chains of dependent VALU/SALU
 // hops, and only other resident waves hide them. So the A operand (the 32 query rows) sits in LDS, the B operand is
 // streamed from global memory a few float4 ahead, and nothing but the accumulator tile and the lists stays live.

@@ -43,15 +43,26 @@ __device__ __forceinline__ float wave_min_dpp(float v) {
   return readlane_f(v, 63);
 }
 
+// v_writelane_b32 (hipcc 7.2 has no builtin; the LLVM intrinsic is reachable by name, and unlike inline asm it is seen
+// by the hazard recogniser)
+extern "C" __device__ int knn_writelane(int value, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
+
 // insert (dc, ic) — wave-uniform — AFTER every entry <= dc (candidates arrive in ascending index order, so equal
-// distances keep the lower index first); the entry in lane 63 falls off
+// distances keep the lower index first); the entry in lane 63 falls off. The list is sorted, so the lanes with
+// ld <= dc are exactly the lanes below the insertion point: the compare's 64-bit mask IS the "keep" predicate of the
+// shift (one v_cmp, two DPP moves, two v_cndmask on that mask, two v_writelane for the new entry — 7 VALU).
 __device__ __forceinline__ void knn_list_insert(float& ld, int& li, float dc, int ic, int lane) {
-  const int pos = __builtin_popcountll(__builtin_amdgcn_ballot_w64(ld <= dc));
-  // lane l <- lane l-1 (v_mov_b32_dpp wave_shr:1); lane 0 is never read when pos > 0, and is `pos` otherwise
+  const bool k = ld <= dc;
+  const int pos = __builtin_popcountll(__builtin_amdgcn_ballot_w64(k));
+  // lane l <- lane l-1 (v_mov_b32_dpp wave_shr:1)
   const float sd = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ld), 0x138, 0xf, 0xf, false));
   const int si = __builtin_amdgcn_update_dpp(0, li, 0x138, 0xf, 0xf, false);
-  ld = lane < pos ? ld : (lane == pos ? dc : sd);
-  li = lane < pos ? li : (lane == pos ? ic : si);
+  ld = k ? ld : sd;
+  li = k ? li : si;
+  if (pos < 64) {   // uniform (always true when dc beats the list's last entry, which callers check)
+    ld = __builtin_bit_cast(float, knn_writelane(__builtin_bit_cast(int, dc), pos, __builtin_bit_cast(int, ld)));
+    li = knn_writelane(ic, pos, li);
+  }
 }
 
 }  // namespace pc3d
