@@ -1,0 +1,97 @@
+// Point normals from the k-NN covariance (attack/GeoA3/utility.py:43-92 estimate_normal): per point, the k neighbours
+// (self excluded) are centred, their 3 x 3 covariance is formed and the eigenvector of its smallest eigenvalue is
+// the normal; its sign is fixed against the summed neighbour directions (:73-75).
+//
+// The reference (and round 1 of this library) ran a batched 3 x 3 `symeig` / `torch.linalg.eigh`: on ROCm that is
+// rocsolver's general tridiagonalisation path, 5.0 ms per call at B=32, N=1024 (larf_left_kernel_small ...). A
+// symmetric 3 x 3 problem has a closed form: eigenvalues from the trigonometric solution of the characteristic cubic,
+// the eigenvector as the largest cross product of two rows of (A - lambda I). One thread per point, arithmetic in
+// double (the covariance of 3 neighbours has rank 2: lambda_min / lambda_max ~ 1e-7 in fp32), microseconds per call.
+#include "pc3d_common.h"
+
+namespace pc3d {
+
+struct NormalArgs {
+  PtsView x;            // [B,N] points
+  const int32_t* idx;   // [B,N,K1] neighbour lists, self first (K1 = k + 1)
+  int N, K1;
+  PtsViewMut out;       // [B,N] normals
+};
+
+__global__ __launch_bounds__(256) void estimate_normal_kernel(NormalArgs a) {
+  const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.N) return;
+  const float* xb = a.x.p + (int64_t)b * a.x.bs;
+  const int32_t* nb = a.idx + ((int64_t)b * a.N + i) * a.K1 + 1;   // skip self
+  const int k = a.K1 - 1;
+  // fp32 centring exactly as the reference does it (mean, subtract, sum): the sign test below is taken against the
+  // SUM of the centred neighbours, which is rounding noise of this arithmetic (utility.py:73-75)
+  float mx = 0.f, my = 0.f, mz = 0.f;
+  for (int j = 0; j < k; ++j) {
+    const float* p = xb + (int64_t)nb[j] * a.x.ps;
+    mx += p[0], my += p[a.x.cs], mz += p[2 * a.x.cs];
+  }
+  mx /= (float)k, my /= (float)k, mz /= (float)k;
+  double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
+  float sx = 0.f, sy = 0.f, sz = 0.f;
+  for (int j = 0; j < k; ++j) {
+    const float* p = xb + (int64_t)nb[j] * a.x.ps;
+    const float dx = p[0] - mx, dy = p[a.x.cs] - my, dz = p[2 * a.x.cs] - mz;
+    sx += dx, sy += dy, sz += dz;
+    c00 += (double)dx * dx, c01 += (double)dx * dy, c02 += (double)dx * dz;
+    c11 += (double)dy * dy, c12 += (double)dy * dz, c22 += (double)dz * dz;
+  }
+  const double f = 1.0 / (double)(k > 1 ? k - 1 : 1);
+  c00 *= f, c01 *= f, c02 *= f, c11 *= f, c12 *= f, c22 *= f;
+  // smallest eigenvalue (Smith 1961)
+  const double q = (c00 + c11 + c22) / 3.0;
+  const double p1 = c01 * c01 + c02 * c02 + c12 * c12;
+  const double d0 = c00 - q, d1 = c11 - q, d2 = c22 - q;
+  const double p2 = d0 * d0 + d1 * d1 + d2 * d2 + 2.0 * p1;
+  double nx = 0.0, ny = 0.0, nz = 1.0;
+  if (p2 > 0.0) {
+    const double p = sqrt(p2 / 6.0), ip = 1.0 / p;
+    const double b00 = d0 * ip, b11 = d1 * ip, b22 = d2 * ip, b01 = c01 * ip, b02 = c02 * ip, b12 = c12 * ip;
+    double r = 0.5 * (b00 * (b11 * b22 - b12 * b12) - b01 * (b01 * b22 - b12 * b02) + b02 * (b01 * b12 - b11 * b02));
+    r = r < -1.0 ? -1.0 : (r > 1.0 ? 1.0 : r);
+    const double phi = acos(r) / 3.0;
+    const double lmin = q + 2.0 * p * cos(phi + 2.0943951023931953);   // + 2 pi / 3
+    // eigenvector: the largest cross product of two rows of A - lmin I
+    const double r0x = c00 - lmin, r0y = c01, r0z = c02;
+    const double r1x = c01, r1y = c11 - lmin, r1z = c12;
+    const double r2x = c02, r2y = c12, r2z = c22 - lmin;
+    const double ax = r0y * r1z - r0z * r1y, ay = r0z * r1x - r0x * r1z, az = r0x * r1y - r0y * r1x;
+    const double bx = r0y * r2z - r0z * r2y, by = r0z * r2x - r0x * r2z, bz = r0x * r2y - r0y * r2x;
+    const double cx = r1y * r2z - r1z * r2y, cy = r1z * r2x - r1x * r2z, cz = r1x * r2y - r1y * r2x;
+    const double na = ax * ax + ay * ay + az * az, nbn = bx * bx + by * by + bz * bz, nc = cx * cx + cy * cy + cz * cz;
+    double vx = ax, vy = ay, vz = az, nn = na;
+    if (nbn > nn) vx = bx, vy = by, vz = bz, nn = nbn;
+    if (nc > nn) vx = cx, vy = cy, vz = cz, nn = nc;
+    if (nn > 0.0) {
+      const double inv = 1.0 / sqrt(nn);
+      nx = vx * inv, ny = vy * inv, nz = vz * inv;
+    }
+  }
+  // sign = -sign(<n, sum of the centred neighbours>) (sign(0) = 0, as torch.sign)
+  const double dotp = nx * (double)sx + ny * (double)sy + nz * (double)sz;
+  const double sg = dotp > 0.0 ? -1.0 : (dotp < 0.0 ? 1.0 : 0.0);
+  float* o = a.out.p + (int64_t)b * a.out.bs + (int64_t)i * a.out.ps;
+  o[0] = (float)(sg * nx), o[a.out.cs] = (float)(sg * ny), o[2 * a.out.cs] = (float)(sg * nz);
+}
+
+}  // namespace pc3d
+
+using namespace pc3d;
+
+extern "C" int pc3d_estimate_normal_f32(const float* x, int64_t x_bs, int64_t x_ps, int64_t x_cs, const int32_t* idx,
+                                        int B, int N, int K1, float* out, int64_t o_bs, int64_t o_ps, int64_t o_cs,
+                                        void* stream) {
+  PC3D_REQUIRE(B >= 0 && N >= 1 && K1 >= 2, "pc3d_estimate_normal_f32: bad sizes B=%d N=%d K1=%d (self + >= 1 neighbour)", B, N, K1);
+  PC3D_REQUIRE(B <= 65535, "pc3d_estimate_normal_f32: B=%d exceeds grid.y limit", B);
+  if (B == 0) return PC3D_OK;
+  PC3D_REQUIRE(x && idx && out, "pc3d_estimate_normal_f32: null pointer");
+  NormalArgs a{{x, x_bs, x_ps, x_cs}, idx, N, K1, {out, o_bs, o_ps, o_cs}};
+  hipLaunchKernelGGL(estimate_normal_kernel, dim3(cdiv(N, 256), B), dim3(256), 0, as_stream(stream), a);
+  PC3D_LAUNCH_CHECK("pc3d_estimate_normal_f32");
+  return PC3D_OK;
+}

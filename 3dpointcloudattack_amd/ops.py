@@ -572,6 +572,18 @@ def cw_step(p, g, m, v, step, lr, ori, budget, dist_kind=0, w=None, l2norm=None,
     return p
 
 
+def estimate_normal(pts, idx, cf=False):
+    """Normals [B,N,3] of pts [B,N,3] (or [B,3,N] with cf) from neighbour lists idx [B,N,k+1] int32 (self first)."""
+    p, bs, ps, cs, B, N = _pts(pts, cf, "pts")
+    if idx.dtype != torch.int32 or not idx.is_contiguous() or idx.shape[:2] != (B, N):
+        raise ValueError("estimate_normal: idx must be a contiguous int32 [B,N,k+1] tensor")
+    out = torch.empty((B, N, 3), dtype=torch.float32, device=pts.device)
+    with torch.cuda.device(pts.device):
+        _lib.call("pc3d_estimate_normal_f32", p, bs, ps, cs, idx.data_ptr(), B, N, idx.shape[2], out.data_ptr(),
+                  3 * N, 3, 1, _stream())
+    return out
+
+
 # ------------------------------------------------------------------------------------------------------
 # K8b: point-wise dense layers (frozen weights) on the fp32-MFMA GEMM
 # ------------------------------------------------------------------------------------------------------

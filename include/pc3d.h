@@ -85,6 +85,14 @@ int pc3d_nn_bidir_shared_f32(const float* a, int64_t a_bs, int64_t a_ps, int64_t
 int pc3d_gemm_nt_f32(const float* X, int64_t ldx, const float* W, const float* bias, const float* gate, int64_t ldg,
                      float gate_slope, int M, int N, int K, int act, float slope, float* Y, int64_t ldy, void* stream);
 
+/* Point normals from the k-NN covariance (attack/GeoA3/utility.py:43-92 estimate_normal): eigenvector of the smallest
+ * eigenvalue of the 3 x 3 covariance of the k neighbours (closed form, double arithmetic), sign fixed against the
+ * summed centred neighbours (:73-75). Replaces a batched 3 x 3 symeig (rocsolver: 5 ms per call at B=32, N=1024).
+ * x: [B,N] points (element strides); idx: [B,N,K1] int32 neighbour lists with the point itself first (K1 = k + 1,
+ * as pc3d_knn_f32 returns them for a self-query); out: [B,N] normals (element strides). */
+int pc3d_estimate_normal_f32(const float* x, int64_t x_bs, int64_t x_ps, int64_t x_cs, const int32_t* idx,
+                             int B, int N, int K1, float* out, int64_t o_bs, int64_t o_ps, int64_t o_cs, void* stream);
+
 /* Row reductions of a [B,N] f32 matrix into out[B].
  *   op:  0 = mean, 1 = max, 2 = sum        pre: 0 = identity, 1 = sqrt(max(x,0)) applied per element first
  * mean/max of squared distances = ChamferDistance/HausdorffDistance (distance.py:44-49,64-69);

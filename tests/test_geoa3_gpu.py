@@ -110,3 +110,29 @@ def test_geoa3_batched_and_optional_modes_run(dev):
         assert best.shape == (3, 3, 200) and mask.shape == (3,) and len(steps) == 3
         assert torch.isfinite(best).all() and np.isfinite(np.array(losses)).all()
         assert ga.geoA3_attack.last_transfer_fails["pt"] is not None
+
+
+@pytest.mark.parametrize("k", [3, 8, 16])
+def test_estimate_normal_closed_form_vs_eigh(dev, k):
+    """pc3d_estimate_normal_f32 (closed-form 3 x 3 eigen-solve) against the reference's formulation evaluated with
+    torch.linalg.eigh in float64 (utility.py:43-75): same axis for every point whose two smallest eigenvalues are
+    separated; unit length; deterministic."""
+    ut = _m("utility")
+    rng = np.random.default_rng(k)
+    pcs = np.stack([unit_cloud(rng, 700) for _ in range(3)])
+    pc = torch.from_numpy(pcs).transpose(1, 2).contiguous().to(dev)                 # [B,3,N]
+    n1 = ut.estimate_normal(pc, k)
+    assert n1.shape == pc.shape and torch.equal(n1, ut.estimate_normal(pc, k))
+    centred, cov = ut._nbr_cov(pc, k)
+    ev, evec = torch.linalg.eigh(cov.double().cpu())
+    ref = evec[..., 0]                                                               # [B,N,3] smallest eigenvalue
+    got = n1.permute(0, 2, 1).double().cpu()
+    norm = got.norm(dim=2)
+    # unit length — or exactly zero where the centred neighbours sum to exactly 0 in fp32: the reference multiplies by
+    # -sign(<n, sum>) and torch.sign(0) = 0 (utility.py:73-75)
+    zero = norm == 0
+    assert float((norm[~zero] - 1).abs().max()) < 1e-5 and float(zero.float().mean()) < 0.1
+    separated = ((ev[..., 1] - ev[..., 0]) > 1e-3 * ev[..., 2]) & ~zero
+    cosang = (got * ref).sum(2).abs()
+    assert float(separated.float().mean()) > (0.5 if k == 3 else 0.9)
+    assert float(cosang[separated].min()) > 1 - 1e-4, float(cosang[separated].min())
