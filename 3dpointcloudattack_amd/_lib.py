@@ -31,6 +31,8 @@ SIGNATURES = {
     "pc3d_nn_bidir_shared_f32": _PTS + _PTS + [_I, _I, _I, _P, _P, _P, _P, _P, _L, _P],
     "pc3d_gemm_nt_f32": [_P, _L, _P, _P, _P, _L, _F, _I, _I, _I, _I, _F, _P, _L, _P],
     "pc3d_estimate_normal_f32": _PTS + [_P, _I, _I, _I] + _PTS + [_P],
+    "pc3d_group_act_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P],
+    "pc3d_group_act_bwd_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P],
     "pc3d_rowreduce_f32": [_P, _I, _I, _I, _I, _P, _P],
     "pc3d_nn_bwd_f32": _PTS + _PTS + [_I, _I, _I]
     + [_P, _P, _L, _L, _F] + [_P, _P, _L, _L, _F]

@@ -246,6 +246,85 @@ __global__ __launch_bounds__(256) void group_gather_bwd_kernel(GatherBwdArgs a) 
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// First layer of a set-abstraction MLP WITHOUT the grouped input tensor. The layer is linear in [x_j - c_s ; f_j], so
+//   W1 [x_j - c_s ; f_j] + b1 = (Wx x_j + Wf f_j) - Wx c_s + b1 = P[idx[s,j]] + Bc[s]
+// with ONE product per POINT (P = [x | f] W1^T: B*N rows) instead of one per grouped row (B*S*ns rows: 16x more at
+// SSG's second layer, and K = 131 / 259 there is not even a multiple of 4), and
+//   group_act : H[b,s,j,:] = act(P[b,idx[b,s,j],:] + Bc[b,s,:])
+// is the gather the layer needed anyway, now emitting the layer-1 OUTPUT (model/pointnet2_utils.py:118-135,190-197).
+// Backward: dP[idx] += g', dBc[s] = sum_j g' with g' = act'(H) g; like group_gather_bwd, the rows that repeat the
+// group's first index (ball query's padding, 56-65 % of all entries) are summed on chip and sent as one atomic per
+// channel. An index outside [0, NA) reads as a zero row of P and receives no gradient.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void group_act_fwd_kernel(const float4* __restrict__ P, const float4* __restrict__ Bc,
+                                                            const int* __restrict__ idx, int NA, int S, int K, int C4,
+                                                            float slope, float4* __restrict__ H, int64_t total) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int c4 = (int)(t % C4);
+  const int64_t e = t / C4;            // (b, s, j)
+  const int64_t bs = e / K;            // (b, s)
+  const int64_t b = bs / S;
+  const int i = idx[e];
+  const float4 c = Bc[bs * C4 + c4];
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if ((unsigned)i < (unsigned)NA) a = P[(b * NA + i) * C4 + c4];
+  float4 v = make_float4(a.x + c.x, a.y + c.y, a.z + c.z, a.w + c.w);
+  v.x = v.x > 0.f ? v.x : v.x * slope, v.y = v.y > 0.f ? v.y : v.y * slope;
+  v.z = v.z > 0.f ? v.z : v.z * slope, v.w = v.w > 0.f ? v.w : v.w * slope;
+  H[t] = v;
+}
+
+constexpr int GAB_MAXC = 512;   // channels (<= 8 per lane)
+
+__global__ __launch_bounds__(256) void group_act_bwd_kernel(const float* __restrict__ gH, const float* __restrict__ H,
+                                                            const int* __restrict__ idx, int NA, int S, int K, int C,
+                                                            float slope, float* __restrict__ gP,
+                                                            float* __restrict__ gBc) {
+  extern __shared__ float gab_lds[];            // [2][4][C]: per-wave group sums and padded-tail sums
+  const int s = blockIdx.x, b = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t g0 = ((int64_t)b * S + s) * K;
+  const int* id = idx + g0;
+  const int i0 = id[0];
+  float tot[GAB_MAXC / 64], tail[GAB_MAXC / 64];
+#pragma unroll
+  for (int q = 0; q < GAB_MAXC / 64; ++q) tot[q] = 0.f, tail[q] = 0.f;
+  for (int j = wave; j < K; j += 4) {
+    const int i = id[j];
+    const float* g = gH + (g0 + j) * C;
+    const float* h = H + (g0 + j) * C;
+    const bool ok = (unsigned)i < (unsigned)NA;
+    const bool rep = j > 0 && i == i0;          // wave-uniform
+    float* dst = gP + ((int64_t)b * NA + (ok ? i : 0)) * C;
+#pragma unroll
+    for (int q = 0; q < GAB_MAXC / 64; ++q) {
+      const int c = 64 * q + lane;
+      if (c < C) {
+        const float v = h[c] > 0.f ? g[c] : g[c] * slope;
+        tot[q] += v;
+        if (rep) tail[q] += v;
+        else if (ok) atomicAdd(dst + c, v);
+      }
+    }
+  }
+  float* s_tot = gab_lds;
+  float* s_tail = gab_lds + 4 * C;
+#pragma unroll
+  for (int q = 0; q < GAB_MAXC / 64; ++q) {
+    const int c = 64 * q + lane;
+    if (c < C) s_tot[wave * C + c] = tot[q], s_tail[wave * C + c] = tail[q];
+  }
+  __syncthreads();
+  const bool i0_ok = (unsigned)i0 < (unsigned)NA;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    gBc[((int64_t)b * S + s) * C + c] = (s_tot[c] + s_tot[C + c]) + (s_tot[2 * C + c] + s_tot[3 * C + c]);
+    const float v = (s_tail[c] + s_tail[C + c]) + (s_tail[2 * C + c] + s_tail[3 * C + c]);
+    if (v != 0.f && i0_ok) atomicAdd(gP + ((int64_t)b * NA + i0) * C + c, v);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Backward of  out[g,c] = max_r relu(x[g,r,:] . W[c,:] + b[c])  (the last 1x1 conv + ReLU + max over the group of a
 // PointNet++ set-abstraction layer, model/pointnet2_utils.py:190-197) to x. `max` hands each channel's gradient to ONE
 // row of its group, so dL/dx[g,r,:] = sum_{c: arg[g,c]==r, out[g,c]>0} gout[g,c] W[c,:] is a sparse row accumulation
@@ -518,6 +597,37 @@ extern "C" int pc3d_group_max_linear_bwd_f32(const float* gout, const float* out
   else if (ns <= 64) hipLaunchKernelGGL(group_max_linear_bwd_kernel<64>, grid, block, lds, st, a);
   else hipLaunchKernelGGL(group_max_linear_bwd_kernel<128>, grid, block, lds, st, a);
   PC3D_LAUNCH_CHECK("pc3d_group_max_linear_bwd_f32");
+  return PC3D_OK;
+}
+
+extern "C" int pc3d_group_act_f32(const float* P, const float* Bc, const int32_t* idx, int B, int NA, int S, int K, int C,
+                                  float slope, float* H, void* stream) {
+  PC3D_REQUIRE(B >= 0 && NA >= 1 && S >= 1 && K >= 1 && C >= 4 && C % 4 == 0, "pc3d_group_act_f32: bad sizes B=%d NA=%d S=%d K=%d C=%d (C %% 4 == 0)", B, NA, S, K, C);
+  if (B == 0) return PC3D_OK;
+  PC3D_REQUIRE(P && Bc && idx && H, "pc3d_group_act_f32: null pointer");
+  const int64_t total = (int64_t)B * S * K * (C / 4);
+  const int64_t nb = (total + 255) / 256;
+  PC3D_REQUIRE(nb <= 0x7fffffffLL, "pc3d_group_act_f32: problem too large for one launch");
+  hipLaunchKernelGGL(group_act_fwd_kernel, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), (const float4*)P,
+                     (const float4*)Bc, idx, NA, S, K, C / 4, slope, (float4*)H, total);
+  PC3D_LAUNCH_CHECK("pc3d_group_act_f32");
+  return PC3D_OK;
+}
+
+extern "C" int pc3d_group_act_bwd_f32(const float* gH, const float* H, const int32_t* idx, int B, int NA, int S, int K,
+                                      int C, float slope, float* gP, float* gBc, void* stream) {
+  PC3D_REQUIRE(B >= 0 && NA >= 1 && S >= 1 && K >= 1 && C >= 1 && C <= GAB_MAXC, "pc3d_group_act_bwd_f32: bad sizes B=%d NA=%d S=%d K=%d C=%d (C <= %d)", B, NA, S, K, C, GAB_MAXC);
+  PC3D_REQUIRE(B <= 65535, "pc3d_group_act_bwd_f32: B=%d exceeds grid.y limit", B);
+  if (B == 0) return PC3D_OK;
+  PC3D_REQUIRE(gH && H && idx && gP && gBc, "pc3d_group_act_bwd_f32: null pointer");
+  hipStream_t st = as_stream(stream);
+  if (hipError_t e = zero_async(gP, (size_t)B * NA * C, st); e != hipSuccess) {
+    set_error("pc3d_group_act_bwd_f32: zero fill failed: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  hipLaunchKernelGGL(group_act_bwd_kernel, dim3(S, B), dim3(256), (size_t)8 * C * sizeof(float), st, gH, H, idx, NA, S,
+                     K, C, slope, gP, gBc);
+  PC3D_LAUNCH_CHECK("pc3d_group_act_bwd_f32");
   return PC3D_OK;
 }
 

@@ -29,6 +29,31 @@ def _mlp_max(x, layers):
     return torch.max(x, 2)[0]
 
 
+def _split_first(layers):
+    """(Wx [C1,3], Wf [C1,D] or None, b1) of a folded first layer in the kernels' [xyz(3), feat(D)] input order."""
+    w1, b1 = layers[0]
+    return w1[:, :3].contiguous(), (w1[:, 3:].contiguous() if w1.shape[1] > 3 else None), b1
+
+
+def _grouped_mlp_max(xyz_t, pts, idx, fps_idx, layers, first):
+    """The shared MLP + group max of one grouping scale, first layer WITHOUT the grouped input tensor:
+    W1 [x_j - c_s ; f_j] + b1 = P[idx[s,j]] + Bc[s], P = Wx x + Wf f per POINT (B*N rows instead of B*S*ns: 16x fewer
+    at SSG's second layer), Bc = b1 - (Wx x)[centroid]; pc3d_group_act_f32 gathers P and applies the ReLU, i.e. it
+    emits the layer-1 OUTPUT where the reference (and round 1) gathered the layer-1 INPUT and ran a [B*S*ns, 3+D]
+    GEMM on it (model/pointnet2_utils.py:118-135,190-197)."""
+    wx, wf, b1 = first
+    C1 = wx.shape[0]
+    if C1 % 4 or C1 > ops.GROUP_ACT_MAX_C or len(layers) < 2 or idx.shape[2] > ops.GROUP_MAX_NS:
+        raise ValueError("set abstraction: unsupported MLP shape for the fused first layer")
+    B, N, _ = xyz_t.shape
+    S = fps_idx.shape[1]
+    px = ops.linear_act(xyz_t.contiguous(), wx)                       # [B,N,C1] = Wx x
+    P = px if pts is None else px + ops.linear_act(pts, wf)
+    Bc = b1 - ops.group_gather(None, px, fps_idx.view(B, S, 1)).view(B, S, C1)
+    h1 = ops.group_act(P, Bc, idx, 0.0)                               # [B,S,ns,C1] = relu(layer 1)
+    return ops.mlp_relu_max(h1, layers[1:])
+
+
 def _linear_relu(x, w, b):
     """relu(x @ w.T + b) over the last dimension on the fp32-MFMA point-wise kernel (pc3d_gemm_nt_f32: bias + ReLU in
     the epilogue; its backward applies the ReLU mask while loading dY, so neither direction makes a separate
@@ -147,18 +172,24 @@ class PointNetSetAbstraction(_FrozenFusedMixin, nn.Module):
         self._folded_cache = None
 
     def _fold(self):
-        return [_fold_bn2d(c, b) for c, b in zip(self.mlp_convs, self.mlp_bns)]
+        layers = [_fold_bn2d(c, b) for c, b in zip(self.mlp_convs, self.mlp_bns)]
+        return layers, _split_first(layers)
 
     def forward(self, xyz, points):
         """xyz [B,3,N], points [B,D,N] or None -> new_xyz [B,3,S], new_points [B,D',S]."""
         self._require_fused(xyz)
         xyz_t = xyz.permute(0, 2, 1).float()      # strided view; the kernels take strides
         pts = _cl(points)
+        layers, first = self.folded()
         if self.group_all:
             new_xyz, new_points = sample_and_group_all(xyz_t, pts)
+            new_points = _mlp_max(new_points, layers)   # [B,1,D'] channels-last 1x1 convs, no permutes
         else:
-            new_xyz, new_points, _, _ = _sample_and_group_i32(self.npoint, self.radius, self.nsample, xyz_t, pts)
-        new_points = _mlp_max(new_points, self.folded())   # [B,S,D'] channels-last 1x1 convs: one GEMM each, no permutes
+            B, N, _ = xyz_t.shape
+            fps_idx = ops.fps(xyz_t, self.npoint, _fps_start(B, N, xyz_t.device))                       # [B,S] i32
+            new_xyz = ops.group_gather(xyz_t, None, fps_idx.view(B, self.npoint, 1)).view(B, self.npoint, 3)
+            idx = ops.ball_query(self.radius, self.nsample, xyz_t, new_xyz)                              # [B,S,ns] i32
+            new_points = _grouped_mlp_max(xyz_t, pts, idx, fps_idx, layers, first)
         return new_xyz.permute(0, 2, 1), new_points.permute(0, 2, 1)
 
 
@@ -194,7 +225,7 @@ class PointNetSetAbstractionMsg(_FrozenFusedMixin, nn.Module):
             layers = []
             for j, (c, b) in enumerate(zip(convs, bns)):
                 layers.append(_fold_bn2d(c, b, perm.to(c.weight.device) if (j == 0 and perm is not None) else None))
-            out.append(layers)
+            out.append((layers, _split_first(layers)))
         return out
 
     def forward(self, xyz, points):
@@ -208,8 +239,8 @@ class PointNetSetAbstractionMsg(_FrozenFusedMixin, nn.Module):
         outs = []
         for i, radius in enumerate(self.radius_list):
             idx = ops.ball_query(radius, self.nsample_list[i], xyz_t, new_xyz)
-            g = ops.group_gather(xyz_t, pts, idx, centers=new_xyz.detach(), center_idx=fps_idx)
-            outs.append(_mlp_max(g, self.folded()[i]))
+            layers, first = self.folded()[i]
+            outs.append(_grouped_mlp_max(xyz_t, pts, idx, fps_idx, layers, first))
         return new_xyz.permute(0, 2, 1), torch.cat(outs, dim=-1).permute(0, 2, 1)
 
 

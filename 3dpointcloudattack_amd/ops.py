@@ -747,6 +747,46 @@ def group_gather(xyz, feat, idx, centers=None, center_idx=None):
 # ------------------------------------------------------------------------------------------------------
 # K3: DGCNN dynamic graph
 # ------------------------------------------------------------------------------------------------------
+class _GroupActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, P, Bc, idx, slope):
+        B, NA, C = P.shape
+        S, K = idx.shape[1], idx.shape[2]
+        H = torch.empty((B, S, K, C), dtype=torch.float32, device=P.device)
+        with torch.cuda.device(P.device):
+            _lib.call("pc3d_group_act_f32", P.data_ptr(), Bc.data_ptr(), idx.data_ptr(), B, NA, S, K, C, float(slope),
+                      H.data_ptr(), _stream())
+        ctx.save_for_backward(H, idx)
+        ctx.meta = (NA, float(slope))
+        return H
+
+    @staticmethod
+    def backward(ctx, gH):
+        H, idx = ctx.saved_tensors
+        NA, slope = ctx.meta
+        B, S, K, C = H.shape
+        gH = gH.contiguous()
+        gP = torch.empty((B, NA, C), dtype=torch.float32, device=H.device)
+        gBc = torch.empty((B, S, C), dtype=torch.float32, device=H.device)
+        with torch.cuda.device(H.device):
+            _lib.call("pc3d_group_act_bwd_f32", gH.data_ptr(), H.data_ptr(), idx.data_ptr(), B, NA, S, K, C, slope,
+                      gP.data_ptr(), gBc.data_ptr(), _stream())
+        return gP, gBc, None, None
+
+
+GROUP_ACT_MAX_C = 512
+
+
+def group_act(P, Bc, idx, slope=0.0):
+    """H[b,s,j,:] = act(P[b,idx[b,s,j],:] + Bc[b,s,:]) — P [B,NA,C] per point, Bc [B,S,C] per group, idx [B,S,K] int32
+    -> [B,S,K,C]; act = LeakyReLU(slope) (0 = ReLU). Differentiable in P and Bc. C % 4 == 0, C <= 512."""
+    _check(P, "P"), _check(Bc, "Bc")
+    if (P.dim() != 3 or Bc.dim() != 3 or idx.dim() != 3 or P.shape[2] % 4 or P.shape[2] > GROUP_ACT_MAX_C
+            or Bc.shape != (P.shape[0], idx.shape[1], P.shape[2]) or idx.dtype != torch.int32):
+        raise ValueError("group_act: P [B,NA,C], Bc [B,S,C] (C % 4 == 0, C <= 512), idx [B,S,K] int32 expected")
+    return _GroupActFn.apply(P.contiguous(), Bc.contiguous(), idx.contiguous(), slope)
+
+
 def knn_feat(x, K):
     """x [B,N,C] channels-last features -> int32 [B,N,K] nearest (self first) in feature space."""
     _check(x, "x")

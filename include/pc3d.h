@@ -93,6 +93,19 @@ int pc3d_gemm_nt_f32(const float* X, int64_t ldx, const float* W, const float* b
 int pc3d_estimate_normal_f32(const float* x, int64_t x_bs, int64_t x_ps, int64_t x_cs, const int32_t* idx,
                              int B, int N, int K1, float* out, int64_t o_bs, int64_t o_ps, int64_t o_cs, void* stream);
 
+/* First layer of a set-abstraction MLP without the grouped input tensor (model/pointnet2_utils.py:118-135,190-197): the
+ * layer is linear in [x_j - c_s ; f_j], so  W1 [x_j - c_s ; f_j] + b1 = P[idx[s,j]] + Bc[s]  with P = [x | f] W1^T per
+ * POINT (B*NA rows, pc3d_gemm_nt_f32) and Bc[s] = b1 - (Wx x)[centroid s].
+ *   pc3d_group_act_f32     : H[b,s,j,:] = act(P[b,idx[b,s,j],:] + Bc[b,s,:])   act = LeakyReLU(slope), slope 0 = ReLU
+ *   pc3d_group_act_bwd_f32 : gP[b,idx] += g', gBc[b,s] = sum_j g'  with g' = act'(H) gH (gP is zero-filled here; float
+ *                            atomics, ball-query padding merged on chip).
+ * P [B,NA,C], Bc [B,S,C], idx [B,S,K] int32 (outside [0,NA): zero row / no gradient), H, gH [B,S,K,C]; C % 4 == 0,
+ * C <= 512 for the backward. */
+int pc3d_group_act_f32(const float* P, const float* Bc, const int32_t* idx, int B, int NA, int S, int K, int C,
+                       float slope, float* H, void* stream);
+int pc3d_group_act_bwd_f32(const float* gH, const float* H, const int32_t* idx, int B, int NA, int S, int K, int C,
+                           float slope, float* gP, float* gBc, void* stream);
+
 /* Row reductions of a [B,N] f32 matrix into out[B].
  *   op:  0 = mean, 1 = max, 2 = sum        pre: 0 = identity, 1 = sqrt(max(x,0)) applied per element first
  * mean/max of squared distances = ChamferDistance/HausdorffDistance (distance.py:44-49,64-69);

@@ -55,4 +55,4 @@ def test_pointnet2_set_abstraction_refolds():
     assert net.sa1.folded() is old
     net.load_state_dict(_randomise(net, 4))
     new = net.sa1.folded()
-    assert new is not old and not torch.equal(new[0][0], old[0][0])
+    assert new is not old and not torch.equal(new[0][0][0], old[0][0][0])      # (layers, first-layer split)
