@@ -207,9 +207,10 @@ class CWTAOF:
                     for _ in range(2):
                         iterate()
                 torch.cuda.current_stream(dev).wait_stream(side)
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    iterate()
+                with _graphed.capture_guard():
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        iterate()
                 run = g.replay
                 st["graph_keep"] = (g, _graphed._cached_tensors(self.model))   # the graph points into the weight caches
                 st["o_bestdist"].fill_(1e10), st["o_bestscore"].fill_(-1), st["o_bestattack"].zero_()

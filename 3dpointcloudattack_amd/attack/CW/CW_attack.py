@@ -323,18 +323,22 @@ class CW:
         # warm-up passes are real iterations; account for them by NOT rolling anything back: callers start counting
         # after _make_runner (bench) or use _begin_binary_step to reset the state (attack()).
         st["adv"].grad = None
-        g1 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g1):
-            self._iterate(st)
-        gu = None
-        if unroll > 1:
-            gu = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gu):
-                for _ in range(unroll):
-                    self._iterate(st)
+        with _graphed.capture_guard():           # no cyclic-GC destruction of older graphs while a stream captures
+            g1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1):
+                self._iterate(st)
+            gu = None
+            if unroll > 1:
+                gu = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gu):
+                    for _ in range(unroll):
+                        self._iterate(st)
         st["graph"] = g1
         victim = self.model.model if isinstance(self.model, _graphed.GraphedVictim) else self.model
-        st["graph_run"] = _GraphRunner(st, g1, gu, unroll, weights=_graphed._cached_tensors(victim))
+        # the runner keeps the state's tensors alive, not the dict itself (st -> runner -> st would be a cycle that only
+        # the cycle collector frees, at an arbitrary later time)
+        keep = [v for v in st.values() if torch.is_tensor(v)]
+        st["graph_run"] = _GraphRunner(keep, g1, gu, unroll, weights=_graphed._cached_tensors(victim))
         return st["graph_run"]
 
     def _end_binary_step(self, st):

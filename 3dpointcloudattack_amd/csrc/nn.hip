@@ -45,8 +45,9 @@ __device__ __forceinline__ float nn_dist(float rx, float ry, float rz, float qx,
   return __builtin_fmaf(dz, dz, d);
 }
 
-template <int Q>
-__global__ __launch_bounds__(kNNThreads) void nn_kernel(NNArgs args, int mt_cap) {
+template <int Q, int WAVES>   // WAVES waves share the queries and split the staged reference tile (8 for small, launch-bound problems)
+__global__ __launch_bounds__(WAVES * 64) void nn_kernel(NNArgs args, int mt_cap) {
+  constexpr int kNNWaves = WAVES, kNNThreads = WAVES * 64;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const NNDir& D = args.dir[blockIdx.z];
   const int N = D.N, M = D.M;
@@ -528,12 +529,12 @@ __global__ __launch_bounds__(256) void nn_shared_finalize_kernel(NNFinalArgs F) 
   F.iB[(int64_t)b * F.M + t] = arg;
 }
 
-static size_t nn_lds_bytes(int M, int Q, int* mt_cap_out) {
+static size_t nn_lds_bytes(int M, int Q, int waves, int* mt_cap_out) {
   const int cap = kNNMaxTile;   // 1024 / 2048 / 4096 measured equal at B=32, N=4096
   const int mt = M < cap ? M : cap;
-  const int slice = ((mt + kNNWaves * kNNChunk - 1) / (kNNWaves * kNNChunk)) * kNNChunk;
-  const size_t tile = (size_t)3 * slice * kNNWaves * sizeof(float);
-  const size_t merge = (size_t)kNNWaves * kWave * Q * 8;
+  const int slice = ((mt + waves * kNNChunk - 1) / (waves * kNNChunk)) * kNNChunk;
+  const size_t tile = (size_t)3 * slice * waves * sizeof(float);
+  const size_t merge = (size_t)waves * kWave * Q * 8;
   *mt_cap_out = cap;
   return tile > merge ? tile : merge;
 }
@@ -545,18 +546,22 @@ static int nn_launch(const NNArgs& a, int ndir, int B, hipStream_t st) {
     if (a.dir[1].M > maxM) maxM = a.dir[1].M;
   }
   // Queries per lane: enough ILP to cover the LDS broadcast reads, but keep >= ~4 waves per SIMD's worth of
-  // workgroups on 256 CUs (grid = tiles x B x ndir, 4 waves each).
+  // workgroups on 256 CUs (grid = tiles x B x ndir).
   const long q_total = (long)maxN * B * ndir;
   int Q = 4;
   if (q_total / (kWave * 4) < 1024) Q = 2;
   if (q_total / (kWave * 2) < 1024) Q = 1;
+  // Small problems are bound by each workgroup's latency chain (stage the tile, scan it, merge), not by issue rate:
+  // eight waves split the staged tile instead of four, halving the scan each wave walks.
+  const int waves = (Q == 1 && maxM >= 512) ? 8 : 4;
   int mt_cap;
-  const size_t lds = nn_lds_bytes(maxM, Q, &mt_cap);
-  dim3 grid(cdiv(maxN, kWave * Q), B, ndir), block(kNNThreads);
-  switch (Q) {
-    case 1: hipLaunchKernelGGL(nn_kernel<1>, grid, block, lds, st, a, mt_cap); break;
-    case 2: hipLaunchKernelGGL(nn_kernel<2>, grid, block, lds, st, a, mt_cap); break;
-    default: hipLaunchKernelGGL(nn_kernel<4>, grid, block, lds, st, a, mt_cap); break;
+  const size_t lds = nn_lds_bytes(maxM, Q, waves, &mt_cap);
+  dim3 grid(cdiv(maxN, kWave * Q), B, ndir), block(waves * 64);
+  if (waves == 8) hipLaunchKernelGGL((nn_kernel<1, 8>), grid, block, lds, st, a, mt_cap);
+  else switch (Q) {
+    case 1: hipLaunchKernelGGL((nn_kernel<1, 4>), grid, block, lds, st, a, mt_cap); break;
+    case 2: hipLaunchKernelGGL((nn_kernel<2, 4>), grid, block, lds, st, a, mt_cap); break;
+    default: hipLaunchKernelGGL((nn_kernel<4, 4>), grid, block, lds, st, a, mt_cap); break;
   }
   PC3D_LAUNCH_CHECK("pc3d_nn");
   return PC3D_OK;

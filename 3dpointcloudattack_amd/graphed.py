@@ -15,10 +15,29 @@ What makes a replay safe here, and what is checked:
   * the capture is keyed on the version counters of the victim's parameters and buffers: loading other weights or
     moving the model re-captures.
 """
+import contextlib
+import gc
 import weakref
 
 import torch
 import torch.nn as nn
+
+
+@contextlib.contextmanager
+def capture_guard():
+    """Run a hipGraph capture with Python's cyclic garbage collector off (after one explicit collection).
+    A victim and its wrapper reference each other, as do an attack's state and its graph runner, so captured graphs
+    die in the CYCLE collector, at whatever allocation happens to trigger it — if that is inside another capture, the
+    graph's destructor runs HIP calls that are illegal while a stream is capturing and the process aborts (seen once
+    in a long test session: "Fatal Python error: Aborted ... Garbage-collecting" under torch.cuda.current_stream)."""
+    was = gc.isenabled()
+    gc.collect()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
 
 MAX_CAPTURES = 4     # distinct (shape, mode, weights) keys per wrapper; the oldest is dropped beyond this
 MAX_REPLICAS = 4     # captures of ONE key that may wait for their backward at the same time (EOT-style loops that
@@ -142,7 +161,8 @@ class GraphedVictim(nn.Module):
         times, the call they serve counts as ONE forward (its draws are re-issued by consume_forward_rng)."""
         rng = torch.get_rng_state()
         try:
-            return self._capture_impl(x, with_grad)
+            with capture_guard():
+                return self._capture_impl(x, with_grad)
         finally:
             torch.set_rng_state(rng)
 
