@@ -43,10 +43,13 @@ def _grouped_mlp_max(xyz_t, pts, idx, fps_idx, layers, first):
     GEMM on it (model/pointnet2_utils.py:118-135,190-197)."""
     wx, wf, b1 = first
     C1 = wx.shape[0]
-    if C1 % 4 or C1 > ops.GROUP_ACT_MAX_C or len(layers) < 2 or idx.shape[2] > ops.GROUP_MAX_NS:
-        raise ValueError("set abstraction: unsupported MLP shape for the fused first layer")
     B, N, _ = xyz_t.shape
     S = fps_idx.shape[1]
+    if C1 % 4 or C1 > ops.GROUP_ACT_MAX_C or len(layers) < 2 or idx.shape[2] > ops.GROUP_MAX_NS:
+        # widths the gather-with-activation kernel does not take: the plain form (gather the grouped input, then the MLP)
+        new_xyz = ops.group_gather(xyz_t, None, fps_idx.view(B, S, 1)).view(B, S, 3)
+        g = ops.group_gather(xyz_t, pts, idx, centers=new_xyz.detach(), center_idx=fps_idx)
+        return _mlp_max(g, layers)
     px = ops.linear_act(xyz_t.contiguous(), wx)                       # [B,N,C1] = Wx x
     P = px if pts is None else px + ops.linear_act(pts, wf)
     Bc = b1 - ops.group_gather(None, px, fps_idx.view(B, S, 1)).view(B, S, C1)

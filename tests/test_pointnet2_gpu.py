@@ -265,3 +265,66 @@ def test_empty_ball_and_nan_cloud_do_not_fault(dev):
     nb = ops.group_gather(nan_cloud, None, ops.ball_query(0.2, ns, nan_cloud, nan_cloud[:, :S]))
     torch.cuda.synchronize()
     assert nb.shape == (B, S, ns, 3) and (nb == 0).all()     # NaN distances are never inside a ball
+
+
+@pytest.mark.parametrize("B,NA,S,K,C", [(2, 50, 7, 5, 8), (3, 300, 40, 32, 64), (2, 512, 128, 64, 128), (1, 33, 33, 1, 4)])
+@pytest.mark.parametrize("slope", [0.0, 0.2])
+def test_group_act_fwd_bwd_vs_torch(dev, B, NA, S, K, C, slope):
+    """pc3d_group_act_f32 / _bwd_f32: H = act(P[idx] + Bc), gradients to P (scatter-add, ball-query style padding with
+    the group's first index merged on chip) and Bc (group sums) against plain torch indexing + autograd."""
+    ops = importlib.import_module("3dpointcloudattack_amd.ops")
+    g = torch.Generator().manual_seed(NA + K)
+    P = torch.randn(B, NA, C, generator=g).to(dev)
+    Bc = torch.randn(B, S, C, generator=g).to(dev)
+    idx = torch.randint(0, NA, (B, S, K), generator=g)
+    idx[:, :, K // 2:] = idx[:, :, :1]                       # padded tail: repeats of the first index, as ball query pads
+    if K > 2:
+        idx[0, 0, 1] = NA                                    # "no point" marker: zero row, no gradient
+    idx = idx.int().to(dev)
+    up = torch.randn(B, S, K, C, generator=g).to(dev)
+    Pa, Ba = P.clone().requires_grad_(), Bc.clone().requires_grad_()
+    H = ops.group_act(Pa, Ba, idx, slope)
+    (H * up).sum().backward()
+    Pr, Br = P.double().clone().requires_grad_(), Bc.double().clone().requires_grad_()
+    ok = (idx < NA)
+    gathered = torch.gather(Pr[:, None].expand(-1, S, -1, -1), 2, idx.clamp(max=NA - 1).long()[..., None].expand(-1, -1, -1, C))
+    pre = gathered * ok[..., None] + Br[:, :, None, :]
+    Hr = torch.where(pre > 0, pre, slope * pre)
+    (Hr * up.double()).sum().backward()
+    torch.testing.assert_close(H.double(), Hr, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(Ba.grad.double(), Br.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(Pa.grad.double(), Pr.grad, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("mlp,in_feat", [([64, 64, 128], 0), ([32, 48, 64], 13), ([30, 40], 5), ([16], 0)])
+def test_set_abstraction_vs_oracle_module(dev, mlp, in_feat):
+    """PointNetSetAbstraction end to end (FPS + ball query + the grouped first layer as P[idx] + Bc + the rest of the MLP
+    + max) against the oracle's restatement of model/pointnet2_utils.py:158-199 with the same weights and FPS start:
+    values and the gradient to the input points / features. Widths the gather-with-activation kernel does not take
+    (C1 % 4 != 0, one-layer MLPs) go through the plain gather + MLP form and must agree as well."""
+    pu = importlib.import_module("3dpointcloudattack_amd.model.pointnet2_utils")
+    B, N, S, ns = 2, 200, 24, 16
+    hip = pu.PointNetSetAbstraction(S, 0.4, ns, in_feat + 3, mlp, False)
+    ora = ort.PointNetSetAbstraction(S, 0.4, ns, in_feat + 3, mlp, False, exact=True)
+    sd = ort.seeded_state_dict(hip, 11)
+    hip.load_state_dict(sd), ora.load_state_dict(sd)
+    hip, ora = hip.eval().to(dev), ora.eval()
+    g = torch.Generator().manual_seed(3)
+    xyz = (torch.rand(B, 3, N, generator=g) - 0.5)
+    feat = torch.randn(B, in_feat, N, generator=g) if in_feat else None
+    xa = xyz.clone().to(dev).requires_grad_()
+    fa = feat.clone().to(dev).requires_grad_() if in_feat else None
+    xo = xyz.clone().requires_grad_()
+    fo = feat.clone().requires_grad_() if in_feat else None
+    torch.manual_seed(5)
+    nx, nf = hip(xa, fa)
+    torch.manual_seed(5)
+    ox, of = ora(xo, fo)
+    torch.testing.assert_close(nx.cpu(), ox, rtol=0, atol=0)
+    torch.testing.assert_close(nf.cpu(), of, rtol=1e-4, atol=1e-5)
+    up = torch.randn(of.shape, generator=g)
+    (nf * up.to(dev)).sum().backward()
+    (of * up).sum().backward()
+    assert (xa.grad.cpu() - xo.grad).norm() <= 2e-3 * xo.grad.norm() + 1e-8
+    if in_feat:
+        assert (fa.grad.cpu() - fo.grad).norm() <= 2e-3 * fo.grad.norm() + 1e-8
