@@ -30,6 +30,18 @@ SIGNATURES = {
     "pc3d_nn_bidir_shared_ws_bytes": [_I, _I, _I],
     "pc3d_nn_bidir_shared_f32": _PTS + _PTS + [_I, _I, _I, _P, _P, _P, _P, _P, _L, _P],
     "pc3d_gemm_nt_f32": [_P, _L, _P, _P, _P, _L, _F, _I, _I, _I, _I, _F, _P, _L, _P],
+    "pc3d_gemm_nt_res_f32": [_P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _F, _P, _L, _P],
+    "pc3d_gate_f32": [_P, _P, _L, _F, _P, _P],
+    "pc3d_gather_max_rows_f32": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
+    "pc3d_gather_max_rows_bwd_f32": [_P, _P, _I, _I, _I, _I, _P, _P],
+    "pc3d_att_scale_f32": [_P, _P, _L, _I, _P, _P, _P],
+    "pc3d_att_scale_bwd_f32": [_P, _P, _P, _P, _L, _I, _P, _P],
+    "pc3d_topk_desc_f32": [_P, _I, _I, _I, _P, _P],
+    "pc3d_curve_attn_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P],
+    "pc3d_curve_attn_bwd_ws_floats": [_I, _I, _I, _I, _I],
+    "pc3d_curve_attn_bwd_f32": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P],
+    "pc3d_lpfa_prep_f32": [_P, _P, _P, _P, _P, _L, _I, _P, _P, _P],
+    "pc3d_lpfa_prep_bwd_f32": [_P, _P, _P, _P, _L, _I, _P, _P, _P],
     "pc3d_estimate_normal_f32": _PTS + [_P, _I, _I, _I] + _PTS + [_P],
     "pc3d_group_act_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P],
     "pc3d_group_act_bwd_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P],
@@ -79,7 +91,7 @@ SIGNATURES = {
 }
 
 # entry points that do not return a status code
-RESTYPES = {"pc3d_nn_bidir_shared_ws_bytes": c_int64}
+RESTYPES = {"pc3d_nn_bidir_shared_ws_bytes": c_int64, "pc3d_curve_attn_bwd_ws_floats": c_int64}
 
 _lib = None
 

@@ -1,0 +1,539 @@
+// K19 — the channels-last glue of a CurveNet CIC block (model/curvenet_util.py:302-376, :379-466), gfx950.
+//
+// The reference keeps every tensor channels-first and strings each block together from 1x1 convolutions, BatchNorms,
+// element-wise adds / multiplies, softmaxes, two batched GEMMs and a top-k. With the walk (K16), the aggregation's
+// per-cloud half (K18), the edge kernels (K17) and the dense layers (gemm_nt) already channels-last kernels of this
+// library, what was left between them ran as a few hundred ATen / rocBLAS launches per forward+backward. This file
+// holds those pieces, so that a block is a chain of this library's launches on [B,N,C] rows:
+//   gate            G = y > 0 ? g : slope g                    (backward of "activation after a residual sum")
+//   att_scale       att = sigmoid(x . w), xs = x att            (CurveGrouping's self-attention score, :452-455)
+//   topk_desc       the curve_num best-scored start points      (:457, order fixed to descending — DESIGN.md A-15)
+//   curve_attn      leaky(x + softmax(x K_inter) V_inter + softmax(x K_intra) V_intra)   (CurveAggregation, :425-437,
+//                   per-point half; keys / values come from pc3d_curve_agg_kv_f32)
+//   lpfa_prep       A = x + G1 p, Bc = G2 p + t - x             (LPFA's geometry term in "A_j + B_i" form, :204-236)
+// All tensors fp32, channels-last, C % 4 == 0.
+#include "pc3d_common.h"
+
+namespace pc3d {
+
+// ---------------------------------------------------------------------------------------------------------
+// gate
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gate_kernel(const float* __restrict__ g, const float* __restrict__ y, float slope,
+                                                   float* __restrict__ out, int64_t n) {
+  const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 + 3 < n) {
+    const float4 gv = *reinterpret_cast<const float4*>(g + i4), yv = *reinterpret_cast<const float4*>(y + i4);
+    *reinterpret_cast<float4*>(out + i4) = make_float4(yv.x > 0.f ? gv.x : slope * gv.x, yv.y > 0.f ? gv.y : slope * gv.y,
+                                                       yv.z > 0.f ? gv.z : slope * gv.z, yv.w > 0.f ? gv.w : slope * gv.w);
+  } else {
+    for (int64_t i = i4; i < n; ++i) out[i] = y[i] > 0.f ? g[i] : slope * g[i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// att_scale: one thread per point (rows are 64-256 bytes; neighbouring threads own neighbouring rows)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void att_scale_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            int64_t M, int C, float* __restrict__ xs,
+                                                            float* __restrict__ att) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= M) return;
+  const float4* xr = reinterpret_cast<const float4*>(x + p * C);
+  const float4* wr = reinterpret_cast<const float4*>(w);
+  float s = 0.f;
+  for (int c = 0; c < C / 4; ++c) {
+    const float4 v = xr[c], u = wr[c];
+    s += v.x * u.x;
+    s += v.y * u.y;
+    s += v.z * u.z;
+    s += v.w * u.w;
+  }
+  const float a = 1.f / (1.f + expf(-s));
+  att[p] = a;
+  float4* o = reinterpret_cast<float4*>(xs + p * C);
+  for (int c = 0; c < C / 4; ++c) {
+    const float4 v = xr[c];
+    o[c] = make_float4(v.x * a, v.y * a, v.z * a, v.w * a);
+  }
+}
+
+// gx = g att + (g . x) att (1 - att) w
+__global__ __launch_bounds__(256) void att_scale_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                            const float* __restrict__ att, const float* __restrict__ w,
+                                                            int64_t M, int C, float* __restrict__ gx) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= M) return;
+  const float4* gr = reinterpret_cast<const float4*>(g + p * C);
+  const float4* xr = reinterpret_cast<const float4*>(x + p * C);
+  const float4* wr = reinterpret_cast<const float4*>(w);
+  float d = 0.f;
+  for (int c = 0; c < C / 4; ++c) {
+    const float4 v = xr[c], u = gr[c];
+    d += v.x * u.x + v.y * u.y + v.z * u.z + v.w * u.w;
+  }
+  const float a = att[p];
+  const float k = d * a * (1.f - a);
+  float4* o = reinterpret_cast<float4*>(gx + p * C);
+  for (int c = 0; c < C / 4; ++c) {
+    const float4 u = gr[c], ww = wr[c];
+    o[c] = make_float4(u.x * a + k * ww.x, u.y * a + k * ww.y, u.z * a + k * ww.z, u.w * a + k * ww.w);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// topk_desc: one workgroup per cloud sorts (score descending, index ascending) keys in LDS (bitonic network)
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned ordered_bits(float f) {   // monotone float -> unsigned (NaN above +inf, as torch ranks it)
+  const unsigned b = __builtin_bit_cast(unsigned, f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+__global__ __launch_bounds__(1024) void topk_desc_kernel(const float* __restrict__ score, int N, int K, int npow2,
+                                                         int32_t* __restrict__ idx) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long tk_keys[];
+  const int b = blockIdx.x;
+  for (int i = threadIdx.x; i < npow2; i += 1024)
+    tk_keys[i] = i < N ? (((unsigned long long)(~ordered_bits(score[(int64_t)b * N + i])) << 32) | (unsigned)i) : ~0ull;
+  __syncthreads();
+  for (int k = 2; k <= npow2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < npow2 / 2; i += 1024) {
+        const int lo = ((i / j) * 2 * j) + (i % j), hi = lo + j;
+        const bool asc = (lo & k) == 0;
+        const unsigned long long a = tk_keys[lo], c = tk_keys[hi];
+        if ((a > c) == asc) tk_keys[lo] = c, tk_keys[hi] = a;
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = threadIdx.x; i < K; i += 1024) idx[(int64_t)b * K + i] = (int32_t)(tk_keys[i] & 0xffffffffu);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// lpfa_prep
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lpfa_prep_fwd_kernel(const float* __restrict__ x, const float* __restrict__ pts,
+                                                            const float* __restrict__ G1, const float* __restrict__ G2,
+                                                            const float* __restrict__ t, int64_t M, int C,
+                                                            float* __restrict__ A, float* __restrict__ Bc) {
+  const int C4 = C / 4;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= M * C4) return;
+  const int c4 = (int)(i % C4);
+  const int64_t p = i / C4;
+  const float px = pts[p * 3], py = pts[p * 3 + 1], pz = pts[p * 3 + 2];
+  const float4 xv = *reinterpret_cast<const float4*>(x + p * C + 4 * c4);
+  const float xe[4] = {xv.x, xv.y, xv.z, xv.w};
+  float a[4], bb[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int c = 4 * c4 + e;
+    a[e] = xe[e] + (G1[c * 3] * px + G1[c * 3 + 1] * py + G1[c * 3 + 2] * pz);
+    bb[e] = (G2[c * 3] * px + G2[c * 3 + 1] * py + G2[c * 3 + 2] * pz + t[c]) - xe[e];
+  }
+  *reinterpret_cast<float4*>(A + p * C + 4 * c4) = make_float4(a[0], a[1], a[2], a[3]);
+  *reinterpret_cast<float4*>(Bc + p * C + 4 * c4) = make_float4(bb[0], bb[1], bb[2], bb[3]);
+}
+
+// gx = gA - gBc;  gpts = G1^T gA + G2^T gBc   (one thread per point)
+__global__ __launch_bounds__(256) void lpfa_prep_bwd_kernel(const float* __restrict__ gA, const float* __restrict__ gBc,
+                                                            const float* __restrict__ G1, const float* __restrict__ G2,
+                                                            int64_t M, int C, float* __restrict__ gx,
+                                                            float* __restrict__ gpts) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= M) return;
+  float s[3] = {0.f, 0.f, 0.f};
+  for (int c4 = 0; c4 < C / 4; ++c4) {
+    const float4 a = *reinterpret_cast<const float4*>(gA + p * C + 4 * c4);
+    const float4 b = *reinterpret_cast<const float4*>(gBc + p * C + 4 * c4);
+    *reinterpret_cast<float4*>(gx + p * C + 4 * c4) = make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
+    const float ae[4] = {a.x, a.y, a.z, a.w}, be[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = 4 * c4 + e;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) s[d] += G1[c * 3 + d] * ae[e] + G2[c * 3 + d] * be[e];
+    }
+  }
+  gpts[p * 3] = s[0], gpts[p * 3 + 1] = s[1], gpts[p * 3 + 2] = s[2];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// curve_attn: one thread per point; the cloud's keys (transposed to [R][C]) and values [R][C] sit in LDS and are read
+// as wave-uniform float4 (broadcast, one ds_read_b128 per four FMAs). Scores are recomputed per pass instead of being
+// stored (R = cn + cl ~ 105 of them per point): 3 C R FMAs per point forward.
+// ---------------------------------------------------------------------------------------------------------
+struct CurveAttnArgs {
+  const float* x;    // [B,N,C]
+  const float* Kp;   // [B,C,R]
+  const float* Vp;   // [B,R,C]
+  int N, cn, R;
+  float slope;
+  float* out;        // [B,N,C]
+  // backward
+  const float* gout; // [B,N,C]
+  float* gx;         // [B,N,C]
+  float* dS;         // [B,N,R]  d(loss)/d(score)
+  float* Wt;         // [B,N,R]  softmax weights
+  float* G;          // [B,N,C]  gated upstream gradient
+};
+
+template <int C>
+__device__ __forceinline__ float ca_dot(const float (&v)[C], const float* __restrict__ row) {
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < C; c += 4) {
+    const float4 k = *reinterpret_cast<const float4*>(row + c);
+    s += v[c] * k.x;
+    s += v[c + 1] * k.y;
+    s += v[c + 2] * k.z;
+    s += v[c + 3] * k.w;
+  }
+  return s;
+}
+
+template <int C>
+__device__ __forceinline__ void ca_stage(const CurveAttnArgs& a, int b, float* KT, float* V) {
+  const int R = a.R;
+  for (int e = threadIdx.x; e < R * C; e += 256) {
+    const int j = e / C, c = e - j * C;
+    KT[e] = a.Kp[((int64_t)b * C + c) * R + j];
+    V[e] = a.Vp[(int64_t)b * R * C + e];
+  }
+  __syncthreads();
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void curve_attn_fwd_kernel(CurveAttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float ca_lds[];
+  float* KT = ca_lds;
+  float* V = ca_lds + a.R * C;
+  const int b = blockIdx.y;
+  ca_stage<C>(a, b, KT, V);
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  const bool valid = p < a.N;
+  const float* xr = a.x + ((int64_t)b * a.N + (valid ? p : a.N - 1)) * C;
+  float x[C];
+#pragma unroll
+  for (int c = 0; c < C; c += 4) {
+    const float4 v = *reinterpret_cast<const float4*>(xr + c);
+    x[c] = v.x, x[c + 1] = v.y, x[c + 2] = v.z, x[c + 3] = v.w;
+  }
+  float m[2] = {-INFINITY, -INFINITY};
+  for (int j = 0; j < a.R; ++j) {
+    const float s = ca_dot<C>(x, KT + j * C);
+    if (j < a.cn) m[0] = fmaxf(m[0], s);
+    else m[1] = fmaxf(m[1], s);
+  }
+  float o[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) o[c] = x[c];
+#pragma unroll
+  for (int seg = 0; seg < 2; ++seg) {
+    const int j0 = seg ? a.cn : 0, j1 = seg ? a.R : a.cn;
+    if (j1 <= j0) continue;
+    float den = 0.f;
+    float acc[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[c] = 0.f;
+    for (int j = j0; j < j1; ++j) {
+      const float e = expf(ca_dot<C>(x, KT + j * C) - m[seg]);
+      den += e;
+#pragma unroll
+      for (int c = 0; c < C; c += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(V + j * C + c);
+        acc[c] += e * v.x, acc[c + 1] += e * v.y, acc[c + 2] += e * v.z, acc[c + 3] += e * v.w;
+      }
+    }
+    const float inv = 1.f / den;
+#pragma unroll
+    for (int c = 0; c < C; ++c) o[c] += acc[c] * inv;
+  }
+  if (!valid) return;
+  float* orow = a.out + ((int64_t)b * a.N + p) * C;
+#pragma unroll
+  for (int c = 0; c < C; c += 4)
+    *reinterpret_cast<float4*>(orow + c) =
+        make_float4(o[c] > 0.f ? o[c] : a.slope * o[c], o[c + 1] > 0.f ? o[c + 1] : a.slope * o[c + 1],
+                    o[c + 2] > 0.f ? o[c + 2] : a.slope * o[c + 2], o[c + 3] > 0.f ? o[c + 3] : a.slope * o[c + 3]);
+}
+
+// backward, per-point half: gx and, for the per-cloud reductions of the second kernel, dS / softmax weights / the gated
+// gradient.  With G = leaky'(out) gout, w = softmax per segment, dw_j = G . V_j, t = sum_seg w dw:
+//   dS_j = w_j (dw_j - t_seg),   gx = G + sum_j dS_j K[:, j]
+template <int C>
+__global__ __launch_bounds__(256) void curve_attn_bwd_point_kernel(CurveAttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float ca_lds[];
+  float* KT = ca_lds;
+  float* V = ca_lds + a.R * C;
+  const int b = blockIdx.y;
+  ca_stage<C>(a, b, KT, V);
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  const bool valid = p < a.N;
+  const int64_t row = (int64_t)b * a.N + (valid ? p : a.N - 1);
+  float x[C], G[C];
+#pragma unroll
+  for (int c = 0; c < C; c += 4) {
+    const float4 v = *reinterpret_cast<const float4*>(a.x + row * C + c);
+    const float4 g = *reinterpret_cast<const float4*>(a.gout + row * C + c);
+    const float4 o = *reinterpret_cast<const float4*>(a.out + row * C + c);
+    x[c] = v.x, x[c + 1] = v.y, x[c + 2] = v.z, x[c + 3] = v.w;
+    G[c] = o.x > 0.f ? g.x : a.slope * g.x, G[c + 1] = o.y > 0.f ? g.y : a.slope * g.y;
+    G[c + 2] = o.z > 0.f ? g.z : a.slope * g.z, G[c + 3] = o.w > 0.f ? g.w : a.slope * g.w;
+  }
+  float m[2] = {-INFINITY, -INFINITY};
+  for (int j = 0; j < a.R; ++j) {
+    const float s = ca_dot<C>(x, KT + j * C);
+    if (j < a.cn) m[0] = fmaxf(m[0], s);
+    else m[1] = fmaxf(m[1], s);
+  }
+  float den[2] = {0.f, 0.f}, u[2] = {0.f, 0.f};
+  for (int j = 0; j < a.R; ++j) {
+    const int seg = j < a.cn ? 0 : 1;
+    const float e = expf(ca_dot<C>(x, KT + j * C) - m[seg]);
+    den[seg] += e;
+    u[seg] += e * ca_dot<C>(G, V + j * C);
+  }
+  const float inv[2] = {den[0] > 0.f ? 1.f / den[0] : 0.f, den[1] > 0.f ? 1.f / den[1] : 0.f};
+  const float t[2] = {u[0] * inv[0], u[1] * inv[1]};
+  float dx[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) dx[c] = G[c];
+  float* dsr = a.dS + row * a.R;
+  float* wr = a.Wt + row * a.R;
+  for (int j = 0; j < a.R; ++j) {
+    const int seg = j < a.cn ? 0 : 1;
+    const float w = expf(ca_dot<C>(x, KT + j * C) - m[seg]) * inv[seg];
+    const float ds = w * (ca_dot<C>(G, V + j * C) - t[seg]);
+#pragma unroll
+    for (int c = 0; c < C; c += 4) {
+      const float4 k = *reinterpret_cast<const float4*>(KT + j * C + c);
+      dx[c] += ds * k.x, dx[c + 1] += ds * k.y, dx[c + 2] += ds * k.z, dx[c + 3] += ds * k.w;
+    }
+    if (valid) dsr[j] = ds, wr[j] = w;
+  }
+  if (!valid) return;
+#pragma unroll
+  for (int c = 0; c < C; c += 4) {
+    *reinterpret_cast<float4*>(a.gx + row * C + c) = make_float4(dx[c], dx[c + 1], dx[c + 2], dx[c + 3]);
+    *reinterpret_cast<float4*>(a.G + row * C + c) = make_float4(G[c], G[c + 1], G[c + 2], G[c + 3]);
+  }
+}
+
+// backward, per-cloud half: gKp[c][j] = sum_p x[p][c] dS[p][j],  gVp[j][c] = sum_p w[p][j] G[p][c]  over the points of
+// one slice of a cloud; tiles of 32 points through LDS, each thread accumulates 4 x 4 blocks of both products, partial
+// sums leave through (row-contiguous) float atomics into the zero-filled outputs.
+constexpr int CA_PT = 32;   // points per LDS tile
+
+template <int C>
+__global__ __launch_bounds__(256) void curve_attn_bwd_cloud_kernel(CurveAttnArgs a, float* __restrict__ gKp,
+                                                                   float* __restrict__ gVp, int per_split) {
+  extern __shared__ __attribute__((aligned(16))) float ca_lds[];
+  const int R = a.R, R4 = (R + 3) / 4, Rp = 4 * R4;
+  float* Xt = ca_lds;               // [CA_PT][C]
+  float* Gt = Xt + CA_PT * C;       // [CA_PT][C]
+  float* St = Gt + CA_PT * C;       // [CA_PT][Rp]
+  float* Wt = St + CA_PT * Rp;      // [CA_PT][Rp]
+  const int b = blockIdx.y;
+  const int p0 = blockIdx.x * per_split, p1 = min(p0 + per_split, a.N);
+  constexpr int CG = C / 4;
+  const int items = CG * R4;        // 4 x 4 blocks (channel group, score group)
+  float accK[2][16], accV[2][16];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) accK[u][e] = 0.f, accV[u][e] = 0.f;
+  for (int q0 = p0; q0 < p1; q0 += CA_PT) {
+    const int np = min(CA_PT, p1 - q0);
+    __syncthreads();
+    for (int e = threadIdx.x; e < CA_PT * C; e += 256) {
+      const int q = e / C;
+      const int64_t src = ((int64_t)b * a.N + q0 + q) * C + (e - q * C);
+      Xt[e] = q < np ? a.x[src] : 0.f;
+      Gt[e] = q < np ? a.G[src] : 0.f;
+    }
+    for (int e = threadIdx.x; e < CA_PT * Rp; e += 256) {
+      const int q = e / Rp, j = e - q * Rp;
+      const bool ok = q < np && j < R;
+      const int64_t src = ((int64_t)b * a.N + q0 + q) * R + j;
+      St[e] = ok ? a.dS[src] : 0.f;
+      Wt[e] = ok ? a.Wt[src] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int it = threadIdx.x + 256 * u;
+      if (it >= items) continue;
+      const int cg = it % CG, jg = it / CG;
+      for (int q = 0; q < CA_PT; ++q) {
+        const float4 xv = *reinterpret_cast<const float4*>(Xt + q * C + 4 * cg);
+        const float4 gv = *reinterpret_cast<const float4*>(Gt + q * C + 4 * cg);
+        const float4 sv = *reinterpret_cast<const float4*>(St + q * Rp + 4 * jg);
+        const float4 wv = *reinterpret_cast<const float4*>(Wt + q * Rp + 4 * jg);
+        const float xe[4] = {xv.x, xv.y, xv.z, xv.w}, ge[4] = {gv.x, gv.y, gv.z, gv.w};
+        const float se[4] = {sv.x, sv.y, sv.z, sv.w}, we[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+          for (int ji = 0; ji < 4; ++ji) {
+            accK[u][ci * 4 + ji] += xe[ci] * se[ji];
+            accV[u][ji * 4 + ci] += we[ji] * ge[ci];
+          }
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int it = threadIdx.x + 256 * u;
+    if (it >= items) continue;
+    const int cg = it % CG, jg = it / CG;
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+      for (int ji = 0; ji < 4; ++ji) {
+        const int c = 4 * cg + ci, j = 4 * jg + ji;
+        if (j < R) {
+          atomicAdd(gKp + ((int64_t)b * C + c) * R + j, accK[u][ci * 4 + ji]);
+          atomicAdd(gVp + ((int64_t)b * R + j) * C + c, accV[u][ji * 4 + ci]);
+        }
+      }
+  }
+}
+
+}  // namespace pc3d
+
+using namespace pc3d;
+
+extern "C" int pc3d_gate_f32(const float* g, const float* y, int64_t n, float slope, float* out, void* stream) {
+  PC3D_REQUIRE(n >= 0, "pc3d_gate_f32: bad size");
+  if (n == 0) return PC3D_OK;
+  PC3D_REQUIRE(g && y && out, "pc3d_gate_f32: null pointer");
+  PC3D_REQUIRE(((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(out)) & 15) == 0,
+               "pc3d_gate_f32: buffers must be 16-byte aligned");
+  const int64_t blocks = (n + 1023) / 1024;
+  PC3D_REQUIRE(blocks <= 0x7fffffffLL, "pc3d_gate_f32: too many elements");
+  hipLaunchKernelGGL(gate_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), g, y, slope, out, n);
+  PC3D_LAUNCH_CHECK("pc3d_gate_f32");
+  return PC3D_OK;
+}
+
+extern "C" int pc3d_att_scale_f32(const float* x, const float* w, int64_t M, int C, float* xs, float* att, void* stream) {
+  PC3D_REQUIRE(M >= 0 && C >= 4 && C % 4 == 0, "pc3d_att_scale_f32: bad sizes (C %% 4 == 0)");
+  if (M == 0) return PC3D_OK;
+  PC3D_REQUIRE(x && w && xs && att, "pc3d_att_scale_f32: null pointer");
+  hipLaunchKernelGGL(att_scale_fwd_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, as_stream(stream), x, w, M, C,
+                     xs, att);
+  PC3D_LAUNCH_CHECK("pc3d_att_scale_f32");
+  return PC3D_OK;
+}
+
+extern "C" int pc3d_att_scale_bwd_f32(const float* g, const float* x, const float* att, const float* w, int64_t M, int C,
+                                      float* gx, void* stream) {
+  PC3D_REQUIRE(M >= 0 && C >= 4 && C % 4 == 0, "pc3d_att_scale_bwd_f32: bad sizes (C %% 4 == 0)");
+  if (M == 0) return PC3D_OK;
+  PC3D_REQUIRE(g && x && att && w && gx, "pc3d_att_scale_bwd_f32: null pointer");
+  hipLaunchKernelGGL(att_scale_bwd_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, as_stream(stream), g, x, att,
+                     w, M, C, gx);
+  PC3D_LAUNCH_CHECK("pc3d_att_scale_bwd_f32");
+  return PC3D_OK;
+}
+
+extern "C" int pc3d_topk_desc_f32(const float* score, int B, int N, int K, int32_t* idx, void* stream) {
+  PC3D_REQUIRE(B >= 0 && N >= 1 && K >= 1 && K <= N && N <= 8192, "pc3d_topk_desc_f32: bad sizes B=%d N=%d K=%d (N <= 8192)",
+               B, N, K);
+  if (B == 0) return PC3D_OK;
+  PC3D_REQUIRE(score && idx, "pc3d_topk_desc_f32: null pointer");
+  int npow2 = 2;
+  while (npow2 < N) npow2 <<= 1;
+  hipLaunchKernelGGL(topk_desc_kernel, dim3(B), dim3(1024), (size_t)npow2 * 8, as_stream(stream), score, N, K, npow2, idx);
+  PC3D_LAUNCH_CHECK("pc3d_topk_desc_f32");
+  return PC3D_OK;
+}
+
+extern "C" int pc3d_lpfa_prep_f32(const float* x, const float* pts, const float* G1, const float* G2, const float* t,
+                                  int64_t M, int C, float* A, float* Bc, void* stream) {
+  PC3D_REQUIRE(M >= 0 && C >= 4 && C % 4 == 0, "pc3d_lpfa_prep_f32: bad sizes (C %% 4 == 0)");
+  if (M == 0) return PC3D_OK;
+  PC3D_REQUIRE(x && pts && G1 && G2 && t && A && Bc, "pc3d_lpfa_prep_f32: null pointer");
+  const int64_t blocks = (M * (C / 4) + 255) / 256;
+  PC3D_REQUIRE(blocks <= 0x7fffffffLL, "pc3d_lpfa_prep_f32: too many elements");
+  hipLaunchKernelGGL(lpfa_prep_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), x, pts, G1, G2, t, M,
+                     C, A, Bc);
+  PC3D_LAUNCH_CHECK("pc3d_lpfa_prep_f32");
+  return PC3D_OK;
+}
+
+extern "C" int pc3d_lpfa_prep_bwd_f32(const float* gA, const float* gBc, const float* G1, const float* G2, int64_t M,
+                                      int C, float* gx, float* gpts, void* stream) {
+  PC3D_REQUIRE(M >= 0 && C >= 4 && C % 4 == 0, "pc3d_lpfa_prep_bwd_f32: bad sizes (C %% 4 == 0)");
+  if (M == 0) return PC3D_OK;
+  PC3D_REQUIRE(gA && gBc && G1 && G2 && gx && gpts, "pc3d_lpfa_prep_bwd_f32: null pointer");
+  hipLaunchKernelGGL(lpfa_prep_bwd_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, as_stream(stream), gA, gBc, G1,
+                     G2, M, C, gx, gpts);
+  PC3D_LAUNCH_CHECK("pc3d_lpfa_prep_bwd_f32");
+  return PC3D_OK;
+}
+
+static bool curve_attn_ok(int B, int N, int C, int cn, int cl) {
+  return B >= 0 && B <= 65535 && N >= 1 && cn >= 0 && cl >= 0 && cn + cl >= 1 && cn + cl <= 128 &&
+         (C == 8 || C == 16 || C == 32 || C == 64);
+}
+
+#define PC3D_CA_DISPATCH(C_, KERNEL, ...)                                   \
+  switch (C_) {                                                             \
+    case 8: hipLaunchKernelGGL((KERNEL<8>), __VA_ARGS__); break;            \
+    case 16: hipLaunchKernelGGL((KERNEL<16>), __VA_ARGS__); break;          \
+    case 32: hipLaunchKernelGGL((KERNEL<32>), __VA_ARGS__); break;          \
+    default: hipLaunchKernelGGL((KERNEL<64>), __VA_ARGS__); break;          \
+  }
+
+extern "C" int pc3d_curve_attn_f32(const float* x, const float* Kp, const float* Vp, int B, int N, int C, int cn, int cl,
+                                   float slope, float* out, void* stream) {
+  PC3D_REQUIRE(curve_attn_ok(B, N, C, cn, cl),
+               "pc3d_curve_attn_f32: bad sizes B=%d N=%d C=%d cn=%d cl=%d (C in {8,16,32,64}, cn + cl <= 128)", B, N, C, cn, cl);
+  if (B == 0) return PC3D_OK;
+  PC3D_REQUIRE(x && Kp && Vp && out, "pc3d_curve_attn_f32: null pointer");
+  CurveAttnArgs a{};
+  a.x = x, a.Kp = Kp, a.Vp = Vp, a.N = N, a.cn = cn, a.R = cn + cl, a.slope = slope, a.out = out;
+  const size_t lds = (size_t)2 * a.R * C * sizeof(float);
+  PC3D_CA_DISPATCH(C, curve_attn_fwd_kernel, dim3(cdiv(N, 256), B), dim3(256), lds, as_stream(stream), a);
+  PC3D_LAUNCH_CHECK("pc3d_curve_attn_f32");
+  return PC3D_OK;
+}
+
+extern "C" int64_t pc3d_curve_attn_bwd_ws_floats(int B, int N, int C, int cn, int cl) {
+  return (int64_t)B * N * (2 * (int64_t)(cn + cl) + C);
+}
+
+extern "C" int pc3d_curve_attn_bwd_f32(const float* gout, const float* out, const float* x, const float* Kp,
+                                       const float* Vp, int B, int N, int C, int cn, int cl, float slope, float* gx,
+                                       float* gKp, float* gVp, float* ws, void* stream) {
+  PC3D_REQUIRE(curve_attn_ok(B, N, C, cn, cl),
+               "pc3d_curve_attn_bwd_f32: bad sizes B=%d N=%d C=%d cn=%d cl=%d (C in {8,16,32,64}, cn + cl <= 128)", B, N, C, cn, cl);
+  if (B == 0) return PC3D_OK;
+  PC3D_REQUIRE(gout && out && x && Kp && Vp && gx && gKp && gVp && ws, "pc3d_curve_attn_bwd_f32: null pointer");
+  const int R = cn + cl;
+  CurveAttnArgs a{};
+  a.x = x, a.Kp = Kp, a.Vp = Vp, a.N = N, a.cn = cn, a.R = R, a.slope = slope, a.out = const_cast<float*>(out);
+  a.gout = gout, a.gx = gx;
+  a.dS = ws, a.Wt = ws + (int64_t)B * N * R, a.G = ws + 2 * (int64_t)B * N * R;
+  hipStream_t st = as_stream(stream);
+  hipError_t e = zero_async(gKp, (size_t)B * C * R, st);
+  if (e == hipSuccess) e = zero_async(gVp, (size_t)B * C * R, st);
+  if (e != hipSuccess) {
+    set_error("pc3d_curve_attn_bwd_f32: zero fill failed: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  const size_t lds = (size_t)2 * R * C * sizeof(float);
+  PC3D_CA_DISPATCH(C, curve_attn_bwd_point_kernel, dim3(cdiv(N, 256), B), dim3(256), lds, st, a);
+  PC3D_LAUNCH_CHECK("pc3d_curve_attn_bwd_f32/point");
+  // slices of ~128 points per workgroup (at least one LDS tile), so that B * nsplit covers the chip
+  int per_split = 128;
+  while (per_split > CA_PT && (int64_t)B * cdiv(N, per_split) < 512) per_split /= 2;
+  const int Rp = 4 * ((R + 3) / 4);
+  const size_t lds2 = (size_t)(2 * CA_PT * C + 2 * CA_PT * Rp) * sizeof(float);
+  PC3D_CA_DISPATCH(C, curve_attn_bwd_cloud_kernel, dim3(cdiv(N, per_split), B), dim3(256), lds2, st, a, gKp, gVp, per_split);
+  PC3D_LAUNCH_CHECK("pc3d_curve_attn_bwd_f32/cloud");
+  return PC3D_OK;
+}

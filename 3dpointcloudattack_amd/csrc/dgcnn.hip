@@ -165,31 +165,32 @@ __global__ __launch_bounds__(KF_T) void knn_feat_kernel(KnnFeatArgs a) {
 // ---------------------------------------------------------------------------------------------------------
 struct GMaxArgs {
   const float* P;       // [B,N,C]
-  const int32_t* idx;   // [B,N,K]
+  const int32_t* idx;   // [B,S,K] (entries clamped to [0,N-1])
   const float* sign;    // [C] or null (all max)
   int N, C, K;
-  float* out;           // [B,N,C]
-  int32_t* arg;         // [B,N,C] winning neighbour (absolute point index) or null
+  float* out;           // [B,S,C]
+  int32_t* arg;         // [B,S,C] winning neighbour (absolute point index) or null
+  int S;                // output rows per cloud (S == N for a neighbour graph on the points themselves)
 };
 
 __global__ __launch_bounds__(256) void gather_max_kernel(GMaxArgs a) {
   const int b = blockIdx.y;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  if (i >= a.N) return;
-  const int32_t* nb = a.idx + ((int64_t)b * a.N + i) * a.K;
+  if (i >= a.S) return;
+  const int32_t* nb = a.idx + ((int64_t)b * a.S + i) * a.K;
   const float* Pb = a.P + (int64_t)b * a.N * a.C;
   for (int c = lane; c < a.C; c += 64) {
     const bool mx = (a.sign == nullptr) || (a.sign[c] >= 0.f);
     float best = mx ? -__builtin_inff() : __builtin_inff();
-    int bj = nb[0];
+    int bj = min(max(nb[0], 0), a.N - 1);
     for (int k = 0; k < a.K; ++k) {
-      const int j = nb[k];
+      const int j = min(max(nb[k], 0), a.N - 1);
       const float v = Pb[(int64_t)j * a.C + c];
       if (mx ? (v > best) : (v < best)) best = v, bj = j;
     }
-    a.out[((int64_t)b * a.N + i) * a.C + c] = best;
-    if (a.arg) a.arg[((int64_t)b * a.N + i) * a.C + c] = bj;
+    a.out[((int64_t)b * a.S + i) * a.C + c] = best;
+    if (a.arg) a.arg[((int64_t)b * a.S + i) * a.C + c] = bj;
   }
 }
 
@@ -200,38 +201,39 @@ __global__ __launch_bounds__(256) void gather_max4_kernel(GMaxArgs a, int lpp) {
   const int ppw = 256 / lpp;                       // points per workgroup
   const int i = blockIdx.x * ppw + threadIdx.x / lpp;
   const int l = threadIdx.x % lpp;
-  if (threadIdx.x >= ppw * lpp || i >= a.N) return;
-  const int32_t* nb = a.idx + ((int64_t)b * a.N + i) * a.K;
+  if (threadIdx.x >= ppw * lpp || i >= a.S) return;
+  const int32_t* nb = a.idx + ((int64_t)b * a.S + i) * a.K;
   const float* Pb = a.P + (int64_t)b * a.N * a.C + 4 * l;
   bool mx[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) mx[e] = (a.sign == nullptr) || (a.sign[4 * l + e] >= 0.f);
   float best[4];
   int bj[4];
-  const int j0 = nb[0];
+  const int j0 = min(max(nb[0], 0), a.N - 1);
 #pragma unroll
   for (int e = 0; e < 4; ++e) best[e] = mx[e] ? -__builtin_inff() : __builtin_inff(), bj[e] = j0;
   for (int k = 0; k < a.K; ++k) {
-    const int j = nb[k];
+    const int j = min(max(nb[k], 0), a.N - 1);
     const float4 v4 = *reinterpret_cast<const float4*>(Pb + (int64_t)j * a.C);
     const float v[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
     for (int e = 0; e < 4; ++e)
       if (mx[e] ? (v[e] > best[e]) : (v[e] < best[e])) best[e] = v[e], bj[e] = j;
   }
-  const int64_t o = ((int64_t)b * a.N + i) * a.C + 4 * l;
+  const int64_t o = ((int64_t)b * a.S + i) * a.C + 4 * l;
   *reinterpret_cast<float4*>(a.out + o) = make_float4(best[0], best[1], best[2], best[3]);
   if (a.arg) *reinterpret_cast<int4*>(a.arg + o) = make_int4(bj[0], bj[1], bj[2], bj[3]);
 }
 
-// backward: gP[b, arg[b,i,c], c] += g[b,i,c]   (gP zero-filled first)
-__global__ __launch_bounds__(256) void gather_max_bwd_kernel(const float* g, const int32_t* arg, int N, int C, float* gP) {
+// backward: gP[b, arg[b,i,c], c] += g[b,i,c]   (g, arg [B,S,C]; gP [B,N,C] zero-filled first)
+__global__ __launch_bounds__(256) void gather_max_bwd_kernel(const float* g, const int32_t* arg, int N, int S, int C,
+                                                             float* gP) {
   const int b = blockIdx.y;
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= (int64_t)N * C) return;
+  if (e >= (int64_t)S * C) return;
   const int c = (int)(e % C);
-  const int j = arg[(int64_t)b * N * C + e];
-  atomicAdd(gP + ((int64_t)b * N + j) * C + c, g[(int64_t)b * N * C + e]);
+  const int j = arg[(int64_t)b * S * C + e];
+  atomicAdd(gP + ((int64_t)b * N + j) * C + c, g[(int64_t)b * S * C + e]);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -434,39 +436,59 @@ extern "C" int pc3d_knn_feat_f32(const float* x, int B, int N, int C, int K, int
   return PC3D_OK;
 }
 
-extern "C" int pc3d_gather_max_f32(const float* P, const int32_t* idx, const float* sign, int B, int N, int C, int K,
-                                   float* out, int32_t* arg, void* stream) {
-  PC3D_REQUIRE(B >= 0 && N >= 1 && C >= 1 && K >= 1, "pc3d_gather_max_f32: bad sizes");
-  PC3D_REQUIRE(B <= 65535, "pc3d_gather_max_f32: B=%d exceeds grid.y limit", B);
+static int gather_max_launch(const char* name, const float* P, const int32_t* idx, const float* sign, int B, int N, int S,
+                             int C, int K, float* out, int32_t* arg, void* stream) {
+  PC3D_REQUIRE(B >= 0 && N >= 1 && S >= 1 && C >= 1 && K >= 1, "%s: bad sizes", name);
+  PC3D_REQUIRE(B <= 65535, "%s: B=%d exceeds grid.y limit", name, B);
   if (B == 0) return PC3D_OK;
-  PC3D_REQUIRE(P && idx && out, "pc3d_gather_max_f32: null pointer");
-  GMaxArgs a{P, idx, sign, N, C, K, out, arg};
+  PC3D_REQUIRE(P && idx && out, "%s: null pointer", name);
+  GMaxArgs a{P, idx, sign, N, C, K, out, arg, S};
   if (C % 4 == 0 && C <= 1024) {
     const int lpp = C / 4, ppw = 256 / lpp;
-    hipLaunchKernelGGL(gather_max4_kernel, dim3(cdiv(N, ppw), B), dim3(256), 0, as_stream(stream), a, lpp);
+    hipLaunchKernelGGL(gather_max4_kernel, dim3(cdiv(S, ppw), B), dim3(256), 0, as_stream(stream), a, lpp);
   } else {
-    hipLaunchKernelGGL(gather_max_kernel, dim3(cdiv(N, 4), B), dim3(256), 0, as_stream(stream), a);
+    hipLaunchKernelGGL(gather_max_kernel, dim3(cdiv(S, 4), B), dim3(256), 0, as_stream(stream), a);
   }
-  PC3D_LAUNCH_CHECK("pc3d_gather_max_f32");
+  PC3D_LAUNCH_CHECK(name);
   return PC3D_OK;
+}
+
+static int gather_max_bwd_launch(const char* name, const float* g, const int32_t* arg, int B, int N, int S, int C,
+                                 float* gP, void* stream) {
+  PC3D_REQUIRE(B >= 0 && N >= 1 && S >= 1 && C >= 1, "%s: bad sizes", name);
+  PC3D_REQUIRE(B <= 65535, "%s: B=%d exceeds grid.y limit", name, B);
+  if (B == 0) return PC3D_OK;
+  PC3D_REQUIRE(g && arg && gP, "%s: null pointer", name);
+  hipStream_t st = as_stream(stream);
+  hipError_t e = zero_async(gP, (size_t)B * N * C, st);
+  if (e != hipSuccess) {
+    set_error("%s: zero fill failed: %s", name, hipGetErrorString(e));
+    return (int)e;
+  }
+  hipLaunchKernelGGL(gather_max_bwd_kernel, dim3((unsigned)(((int64_t)S * C + 255) / 256), B), dim3(256), 0, st, g, arg,
+                     N, S, C, gP);
+  PC3D_LAUNCH_CHECK(name);
+  return PC3D_OK;
+}
+
+extern "C" int pc3d_gather_max_f32(const float* P, const int32_t* idx, const float* sign, int B, int N, int C, int K,
+                                   float* out, int32_t* arg, void* stream) {
+  return gather_max_launch("pc3d_gather_max_f32", P, idx, sign, B, N, N, C, K, out, arg, stream);
 }
 
 extern "C" int pc3d_gather_max_bwd_f32(const float* g, const int32_t* arg, int B, int N, int C, float* gP,
                                        void* stream) {
-  PC3D_REQUIRE(B >= 0 && N >= 1 && C >= 1, "pc3d_gather_max_bwd_f32: bad sizes");
-  PC3D_REQUIRE(B <= 65535, "pc3d_gather_max_bwd_f32: B=%d exceeds grid.y limit", B);
-  if (B == 0) return PC3D_OK;
-  PC3D_REQUIRE(g && arg && gP, "pc3d_gather_max_bwd_f32: null pointer");
-  hipStream_t st = as_stream(stream);
-  hipError_t e = zero_async(gP, (size_t)B * N * C, st);
-  if (e != hipSuccess) {
-    set_error("pc3d_gather_max_bwd_f32: zero fill failed: %s", hipGetErrorString(e));
-    return (int)e;
-  }
-  hipLaunchKernelGGL(gather_max_bwd_kernel, dim3((unsigned)(((int64_t)N * C + 255) / 256), B), dim3(256), 0, st, g, arg,
-                     N, C, gP);
-  PC3D_LAUNCH_CHECK("pc3d_gather_max_bwd_f32");
-  return PC3D_OK;
+  return gather_max_bwd_launch("pc3d_gather_max_bwd_f32", g, arg, B, N, N, C, gP, stream);
+}
+
+extern "C" int pc3d_gather_max_rows_f32(const float* P, const int32_t* idx, int B, int N, int S, int C, int K, float* out,
+                                        int32_t* arg, void* stream) {
+  return gather_max_launch("pc3d_gather_max_rows_f32", P, idx, nullptr, B, N, S, C, K, out, arg, stream);
+}
+
+extern "C" int pc3d_gather_max_rows_bwd_f32(const float* g, const int32_t* arg, int B, int N, int S, int C, float* gP,
+                                            void* stream) {
+  return gather_max_bwd_launch("pc3d_gather_max_rows_bwd_f32", g, arg, B, N, S, C, gP, stream);
 }
 
 extern "C" int pc3d_edge_max_f32(const float* PQ, const int32_t* idx, int B, int N, int C, int K, float slope,

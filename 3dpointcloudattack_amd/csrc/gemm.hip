@@ -1,4 +1,4 @@
-// Dense point-wise layers of the victims as ONE fp32-MFMA kernel:   Y[M,N] = act( gate(X)[M,K] . W[N,K]^T + bias[N] )
+// Dense point-wise layers of the victims as ONE fp32-MFMA kernel:   Y[M,N] = act( gate(X)[M,K] . W[N,K]^T + bias[N] + R[M,N] )
 //
 // Replaces the library GEMMs (hipBLASLt through F.linear / torch._addmm_activation) + separate activation passes of
 //   * the shared MLPs of PointNet++ set abstraction, layers 1-2 (model/pointnet2_utils.py:190-197,243-257: Conv2d 1x1 +
@@ -31,8 +31,9 @@ struct GemmArgs {
   const float* W;      // [N, K] row-major (row stride K)
   const float* bias;   // [N] or null
   const float* gate;   // [M, K] (row stride ldg) or null: X is read as  gate > 0 ? X : gslope * X
+  const float* res;    // [M, N] (row stride ldr) or null: added before the activation (residual / shortcut branch)
   float* Y;            // [M, N], row stride ldy
-  int64_t ldx, ldg, ldy;
+  int64_t ldx, ldg, ldy, ldr;
   int M, N, K;
   int act;             // 0 none, 1 ReLU, 2 LeakyReLU(slope)
   float slope, gslope;
@@ -172,6 +173,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_nt_kernel(GemmArgs a) 
         const int row = m0 + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
         if (row < a.M) {
           float v = acc[i][j][e] + bj;
+          if (a.res) v += a.res[(int64_t)row * a.ldr + col];
           if (a.act == 1) v = v > 0.f ? v : 0.f;
           else if (a.act == 2) v = v > 0.f ? v : a.slope * v;
           a.Y[(int64_t)row * a.ldy + col] = v;
@@ -190,16 +192,17 @@ extern "C" int pc3d_gemm_nt_tune(int variant) {   // tuning hook (tools/bench_ge
   return 0;
 }
 
-extern "C" int pc3d_gemm_nt_f32(const float* X, int64_t ldx, const float* W, const float* bias, const float* gate,
-                                int64_t ldg, float gate_slope, int M, int N, int K, int act, float slope, float* Y,
-                                int64_t ldy, void* stream) {
+static int gemm_nt_launch(const float* X, int64_t ldx, const float* W, const float* bias, const float* gate, int64_t ldg,
+                          float gate_slope, const float* R, int64_t ldr, int M, int N, int K, int act, float slope,
+                          float* Y, int64_t ldy, void* stream) {
   PC3D_REQUIRE(M >= 0 && N >= 1 && K >= 1, "pc3d_gemm_nt_f32: bad sizes M=%d N=%d K=%d", M, N, K);
   PC3D_REQUIRE(act >= 0 && act <= 2, "pc3d_gemm_nt_f32: bad activation %d", act);
   if (M == 0) return PC3D_OK;
   PC3D_REQUIRE(X && W && Y, "pc3d_gemm_nt_f32: null pointer");
-  PC3D_REQUIRE(ldx >= K && ldy >= N && (!gate || ldg >= K), "pc3d_gemm_nt_f32: row stride smaller than the row");
+  PC3D_REQUIRE(ldx >= K && ldy >= N && (!gate || ldg >= K) && (!R || ldr >= N),
+               "pc3d_gemm_nt_f32: row stride smaller than the row");
   GemmArgs a{};
-  a.X = X, a.W = W, a.bias = bias, a.gate = gate, a.Y = Y, a.ldx = ldx, a.ldg = ldg, a.ldy = ldy;
+  a.X = X, a.W = W, a.bias = bias, a.gate = gate, a.res = R, a.Y = Y, a.ldx = ldx, a.ldg = ldg, a.ldy = ldy, a.ldr = ldr;
   a.M = M, a.N = N, a.K = K, a.act = act, a.slope = slope, a.gslope = gate_slope;
   // Tile shapes, measured on MI355X (tools/bench_gemm.py, us; hipBLASLt beside them):
   //   layer [M,N,K]                 0: 128x128 DB   2: 128x64   4: 64x128   5: 128x128/8 waves   hipBLASLt
@@ -241,4 +244,17 @@ extern "C" int pc3d_gemm_nt_f32(const float* X, int64_t ldx, const float* W, con
   }
   PC3D_LAUNCH_CHECK("pc3d_gemm_nt_f32");
   return PC3D_OK;
+}
+
+extern "C" int pc3d_gemm_nt_f32(const float* X, int64_t ldx, const float* W, const float* bias, const float* gate,
+                                int64_t ldg, float gate_slope, int M, int N, int K, int act, float slope, float* Y,
+                                int64_t ldy, void* stream) {
+  return gemm_nt_launch(X, ldx, W, bias, gate, ldg, gate_slope, nullptr, 0, M, N, K, act, slope, Y, ldy, stream);
+}
+
+extern "C" int pc3d_gemm_nt_res_f32(const float* X, int64_t ldx, const float* W, const float* bias, const float* R,
+                                    int64_t ldr, int M, int N, int K, int act, float slope, float* Y, int64_t ldy,
+                                    void* stream) {
+  PC3D_REQUIRE(R != nullptr, "pc3d_gemm_nt_res_f32: null residual");
+  return gemm_nt_launch(X, ldx, W, bias, nullptr, 0, 0.f, R, ldr, M, N, K, act, slope, Y, ldy, stream);
 }

@@ -1,10 +1,9 @@
 """CurveNet classifier — MI355X mirror of model/curvenet.py:11-73 (same module tree / state_dict keys; returns RAW
 logits three times like the reference)."""
-import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
-from .curvenet_util import CIC, LPFA, hold_rng_position, pw
+from .. import ops
+from .curvenet_util import CIC, LPFA, hold_rng_position, pw_cl
 from .pointnet import _FrozenFusedMixin
 
 curve_config = {
@@ -54,21 +53,21 @@ class CurveNet(_FrozenFusedMixin, nn.Module):
 
     def forward(self, xyz):
         self._require_fused(xyz)
-        xyz = xyz.float()
-        feats = self.lpfa(xyz, xyz)
-        pos = xyz
+        # channels-last from here on: every block is a chain of this library's launches on [B,N,C] rows
+        pos = xyz.float().transpose(1, 2).contiguous()
+        feats = self.lpfa(None, pos, None, cl=True)
         blocks = self._blocks()
         graphs = {}                                  # kNN graphs of THIS forward, shared by blocks at one resolution
         for blk in blocks:
             object.__setattr__(blk, "_graph_cache", graphs)
         try:
             for blk in blocks:
-                pos, feats = blk(pos, feats)
+                pos, feats = blk(pos, feats, cl=True)
         finally:
             for blk in blocks:
                 object.__setattr__(blk, "_graph_cache", None)
-        x = pw(self.conv0, feats)
-        x = torch.cat((F.adaptive_max_pool1d(x, 1), F.adaptive_avg_pool1d(x, 1)), dim=1).squeeze(-1)
-        x = F.relu(pw(self.conv1, x, bn=self.bn1))
-        x = pw(self.conv2, self.dp1(x))
+        # conv0's ReLU is applied inside the pooling launch: [max_i relu(y) | mean_i relu(y)] (:66-68)
+        x = ops.act_maxmean_pool(pw_cl(self.conv0, feats, act=(None, 0.0)), 0.0)
+        x = pw_cl(self.conv1, x, bn=self.bn1, act=("relu", 0.0))
+        x = pw_cl(self.conv2, self.dp1(x))
         return x, x, x

@@ -74,6 +74,33 @@ def pw(mod, x, bn=None):
     raise NotImplementedError(f"pw: unsupported activation {type(act).__name__}")
 
 
+def _act_of(act):
+    """(name, slope) of a folded layer's activation module for ops.linear_act."""
+    if act is None:
+        return None, 0.0
+    if isinstance(act, nn.LeakyReLU):
+        return "leaky", act.negative_slope
+    if isinstance(act, nn.ReLU):
+        return "relu", 0.0
+    raise NotImplementedError(f"pw_cl: unsupported activation {type(act).__name__}")
+
+
+def pw_cl(mod, x, bn=None, res=None, act=None):
+    """Frozen pointwise layer on channels-last rows x [..., C] -> [..., O] (one fp32-MFMA launch; `mod` as in
+    folded_pw). res [..., O]: a residual branch summed in before the activation; act = (name, slope) overrides the
+    activation found in `mod` (the block's trailing LeakyReLU after a residual sum)."""
+    _, a, w, b = folded_pw(mod, bn)
+    name, slope = act if act is not None else _act_of(a)
+    if res is not None:
+        return ops.linear_res_act(x, w, b, res, name, slope)
+    return ops.linear_act(x, w, b, name, slope)
+
+
+def _cf(x):
+    """[B,N,C] -> contiguous [B,C,N]."""
+    return x.transpose(2, 1).contiguous()
+
+
 def _cl(x):
     """[B,C,N] -> contiguous [B,N,C]."""
     return x.transpose(2, 1).contiguous().float()
@@ -174,57 +201,72 @@ class LPFA(nn.Module):
             in_channel = out_channel
         self.mlp = nn.Sequential(*layers)
 
-    def forward(self, x, xyz, idx=None):
-        if self.initial and len(self.mlp) == 1:
-            return self._initial_edge_max(xyz, idx)
-        if not self.initial and x.shape[1] % 4 == 0 and all(l[0].out_channels % 4 == 0 for l in self.mlp):
-            return self._edge_act_mean(x, xyz, idx)
+    def _kernel_form(self, C):
+        if self.initial:
+            return len(self.mlp) == 1 and self.mlp[0][0].out_channels % 4 == 0
+        return C % 4 == 0 and all(l[0].out_channels % 4 == 0 for l in self.mlp)
+
+    def forward(self, x, xyz, idx=None, cl=False):
+        """Reference layout (default): x [B,C,N], xyz [B,3,N], idx [B,N,>=k] or None -> [B,C',N]. cl=True: channels-last
+        x [B,N,C] (ignored by the initial block), xyz [B,N,3], idx int32 [B,N,k] -> [B,N,C'] (what CurveNet.forward uses:
+        no layout changes between the kernels)."""
+        if cl:
+            return self._forward_cl(x, xyz, idx)
+        if xyz.is_cuda and self._kernel_form(0 if x is None else x.shape[1]):
+            idx32 = None if idx is None else idx[:, :, :self.k].to(torch.int32).contiguous()
+            return _cf(self._forward_cl(None if self.initial else _cl(x), _cl(xyz), idx32))
         x = self.group_feature(x, xyz, idx)
         for layer in self.mlp:
             x = pw(layer, x)
         return x.max(dim=-1, keepdim=False)[0] if self.initial else x.mean(dim=-1, keepdim=False)
 
-    def _initial_edge_max(self, xyz, idx):
+    def _forward_cl(self, x, pts, idx32):
+        if idx32 is None:
+            idx32 = ops.knn_raw(pts.detach(), pts.detach(), self.k)[1]          # the k nearest, self first
+        if not self._kernel_form(0 if x is None else x.shape[2]):
+            return _cl(self.forward(None if x is None else _cf(x), _cf(pts), idx32.long()))
+        return self._initial_edge_max(pts, idx32) if self.initial else self._edge_act_mean(x, pts, idx32)
+
+    def _derived(self, name, src, build):
+        """Tensors derived from folded weights, rebuilt when the folded tensor object changes."""
+        hit = self.__dict__.get(name)
+        if hit is None or hit[0] is not src:
+            hit = (src,) + tuple(build())
+            object.__setattr__(self, name, hit)
+        return hit[1:]
+
+    def _initial_edge_max(self, pts, idx32):
         """The first LPFA (:199-203, :226-236 with initial=True and one MLP layer) without the [B,32,N,k] edge tensor
         (335 MB at B=32, N=4096): W [p_i ; p_j ; p_j - p_i] = (Wb + Wc) p_j + (Wa - Wc) p_i, and LeakyReLU is monotone,
         so max_j leaky(bn(W e_ij)) = leaky(max_j P_j + Q_i): one [N,3] x [3,2C] GEMM + pc3d_edge_max_f32."""
         _, _, w, b = folded_pw(self.mlp[0])
-        wa, wb, wc = w[:, 0:3], w[:, 3:6], w[:, 6:9]
-        pts = _cl(xyz)
-        if idx is None:
-            idx32 = ops.knn_raw(pts.detach(), pts.detach(), self.k)[1]          # the k nearest, self first
-        else:
-            idx32 = idx[:, :, :self.k].to(torch.int32).contiguous()
-        PQ = ops.linear_act(pts, torch.cat((wb + wc, wa - wc), 0), torch.cat((torch.zeros_like(b), b)))
-        return ops.edge_max(PQ, idx32, self.mlp[0][2].negative_slope).transpose(1, 2)
+        wpq, bpq = self._derived("_pq_w", w, lambda: (torch.cat((w[:, 3:6] + w[:, 6:9], w[:, 0:3] - w[:, 6:9]), 0).contiguous(),
+                                                       torch.cat((torch.zeros_like(b), b))))
+        PQ = ops.linear_act(pts, wpq, bpq)
+        return ops.edge_max(PQ, idx32, self.mlp[0][2].negative_slope)           # [B,N,C]
 
-    def _edge_act_mean(self, x, xyz, idx):
+    def _edge_act_mean(self, x, pts, idx32):
         """:204-236 with initial=False, channels-last and without the geometry tensor: xyz2feature is linear in
         [p_i ; p_j ; p_j - p_i], so  (x_j - x_i) + G geo_ij + t = A_j + B_i  with A = x + (Gb + Gc) p and
-        B = (Ga - Gc) p + t - x.  One launch builds leaky(A_j + B_i) [B,N,k,C] (pc3d_edge_act_f32), the MLP is a
-        channels-last GEMM per layer and the last LeakyReLU is fused with the neighbour mean (pc3d_act_mean_f32)."""
+        B = (Ga - Gc) p + t - x (pc3d_lpfa_prep_f32).  One launch builds leaky(A_j + B_i) [B,N,k,C] (pc3d_edge_act_f32),
+        the MLP is a channels-last GEMM per layer and the last LeakyReLU is fused with the neighbour mean
+        (pc3d_act_mean_f32)."""
         _, _, g, t = folded_pw(self.xyz2feature)
-        ga, gb, gc = g[:, 0:3], g[:, 3:6], g[:, 6:9]
-        pts, feats = _cl(xyz), _cl(x)
-        if idx is None:
-            idx32 = ops.knn_raw(pts.detach(), pts.detach(), self.k)[1]
-        else:
-            idx32 = idx[:, :, :self.k].to(torch.int32).contiguous()
-        A = feats + ops.linear_act(pts, gb + gc)
-        Bc = ops.linear_act(pts, ga - gc, t) - feats
+        g1, g2 = self._derived("_geo_w", g, lambda: ((g[:, 3:6] + g[:, 6:9]).contiguous(), (g[:, 0:3] - g[:, 6:9]).contiguous()))
+        A, Bc = ops.lpfa_prep(x, pts, g1, g2, t)
         E = ops.edge_act(A, Bc, idx32, 0.2)                                    # [B,N,k,C]
         for li, layer in enumerate(self.mlp):
             _, act, w, b = folded_pw(layer)
             last = li + 1 == len(self.mlp)       # the last layer's LeakyReLU is fused with the neighbour mean below
             E = ops.linear_act(E, w, b, None if last else "leaky", 0.0 if last else act.negative_slope)
-        return ops.act_mean(E, self.mlp[-1][2].negative_slope).transpose(1, 2)   # [B,C',N]
+        return ops.act_mean(E, self.mlp[-1][2].negative_slope)                  # [B,N,C']
 
     def group_feature(self, x, xyz, idx):
         """[B,9,N,k] = [p_i, p_j, p_j - p_i] (initial) or leaky((x_j - x_i) + xyz2feature(that)) [B,C,N,k]."""
-        B, C, N = x.size()
+        B, C, N = (xyz if x is None else x).size()
         if idx is None:
             idx = knn(xyz, k=self.k)[:, :, :self.k]
-        idx32 = idx.to(torch.int32).contiguous()
+        idx32 = idx[:, :, :self.k].to(torch.int32).contiguous()
         pts = _cl(xyz)                                             # [B,N,3]
         nbr = ops.group_gather(pts, None, idx32)                   # [B,N,k,3] (differentiable in the points)
         ctr = pts.view(B, N, 1, 3).expand(-1, -1, self.k, -1)
@@ -300,30 +342,43 @@ class CIC(nn.Module):
         self.maxpool = MaskedMaxPool(npoint, radius, k)
         self.lpfa = LPFA(planes, planes, k, mlp_num=mlp_num, initial=False)
 
-    def forward(self, xyz, x):
-        if xyz.size(-1) != self.npoint:                            # FPS + ball-query max-pool down-sampling
-            xyz, x = self.maxpool(xyz.transpose(1, 2).contiguous(), x)
-            xyz = xyz.transpose(1, 2)
-        shortcut = x
-        x = pw(self.conv1, x)
-        # [B,N,k+1], self first. Consecutive blocks at the same resolution receive the SAME xyz tensor object (it is
-        # returned unchanged below), so within one CurveNet.forward (which hands every block a fresh dict) the graph
-        # is computed once per resolution instead of once per block.
+    def forward(self, xyz, x, cl=False):
+        """Reference layout (default): xyz [B,3,N], x [B,C,N] -> (xyz' [B,3,N'], [B,C',N']). cl=True: channels-last
+        xyz [B,N,3], x [B,N,C] -> ([B,N',3], [B,N',C']); the block itself always runs channels-last."""
+        if cl:
+            return self._forward_cl(xyz, x)
+        pts, y = self._forward_cl(_cl(xyz), _cl(x))
+        return (xyz if pts.shape[1] == xyz.shape[2] else _cf(pts)), _cf(y)
+
+    def _graph(self, pts):
+        """(idx [B,N,k+1] self first, the same without the self column, its first k columns), int32. Consecutive
+        blocks at one resolution receive the SAME point tensor object (it is returned unchanged below), so within one
+        CurveNet.forward (which hands every block a fresh dict) the graph is computed once per resolution."""
         cache = self.__dict__.get("_graph_cache")
-        hit = cache.get((id(xyz), self.k)) if cache is not None else None
-        if hit is not None and hit[0] is xyz:
-            idx = hit[1]
-        else:
-            idx = knn(xyz, self.k)
-            if cache is not None:
-                cache[(id(xyz), self.k)] = (xyz, idx)
+        hit = cache.get((id(pts), self.k)) if cache is not None else None
+        if hit is not None and hit[0] is pts:
+            return hit[1]
+        pd = pts.detach()
+        idx = ops.knn_raw(pd, pd, self.k + 1)[1]
+        g = (idx, idx[:, :, 1:].contiguous(), idx[:, :, :self.k].contiguous())
+        if cache is not None:
+            cache[(id(pts), self.k)] = (pts, g)
+        return g
+
+    def _forward_cl(self, pts, x):
+        if pts.shape[1] != self.npoint:                            # FPS + ball-query max-pool down-sampling
+            pts, x = self.maxpool(pts, x, cl=True)
+        shortcut = x
+        x = pw_cl(self.conv1, x)
+        _, adj, nbr = self._graph(pts)
         if self.use_curve:
-            curves = self.curvegrouping(x, xyz, idx[:, :, 1:])     # avoid self-loops
-            x = self.curveaggregation(x, curves)
-        x = pw(self.conv2, self.lpfa(x, xyz, idx=idx[:, :, :self.k]))
+            curves = self.curvegrouping(x, pts, adj, cl=True)      # adj: no self-loops
+            x = self.curveaggregation(x, curves, cl=True)
+        x = self.lpfa(x, pts, nbr, cl=True)
         if self.in_channels != self.output_channels:
-            shortcut = pw(self.shortcut, shortcut)
-        return xyz, self.relu(x + shortcut)
+            shortcut = pw_cl(self.shortcut, shortcut)
+        # relu(conv2(x) + shortcut) in conv2's epilogue
+        return pts, pw_cl(self.conv2, x, res=shortcut, act=("leaky", self.relu.negative_slope))
 
 
 class CurveAggregation(nn.Module):
@@ -342,26 +397,33 @@ class CurveAggregation(nn.Module):
         self.line_conv_att = nn.Conv2d(in_channel, 1, kernel_size=1, bias=False)
         self.fused = True
 
-    def forward(self, x, curves):
-        B, C, cn, cl = curves.shape
-        mid = C // 2
-        if self.fused and x.is_cuda and ops.curve_agg_lds_bytes(cn, cl, C, mid) <= 64 * 1024:
-            return self._forward_kv(x, curves)
+    def _kernel_form(self, x, cn, cl, C):
+        return (self.fused and x.is_cuda and C in ops.CURVE_ATTN_CHANNELS and cn + cl <= ops.CURVE_ATTN_MAX_R
+                and ops.curve_agg_lds_bytes(cn, cl, C, C // 2) <= 64 * 1024)
+
+    def forward(self, x, curves, cl=False):
+        """Reference layout (default): x [B,C,N], curves [B,C,cn,cl] -> [B,C,N]; cl=True: x [B,N,C], curves
+        [B,cn,cl,C] -> [B,N,C]."""
+        if cl:
+            B, cn, clen, C = curves.shape
+            if self._kernel_form(x, cn, clen, C):
+                return self._forward_kv(x, curves)
+            return _cl(self.forward_steps(_cf(x), curves.permute(0, 3, 1, 2)))
+        B, C, cn, clen = curves.shape
+        if self._kernel_form(x, cn, clen, C):
+            return _cf(self._forward_kv(_cl(x), curves.permute(0, 2, 3, 1)))
         return self.forward_steps(x, curves)
 
     def _forward_kv(self, x, curves):
-        """One launch turns the curves into attention keys / values with convc and convd already applied
+        """Two launches: the curves become attention keys / values with convc and convd already applied
         (pc3d_curve_agg_kv_f32); per point that leaves  leaky(x + softmax(x^T K_inter) V_inter + softmax(x^T K_intra)
-        V_intra): two batched GEMMs and two softmaxes."""
-        cn = curves.shape[2]
+        V_intra) (pc3d_curve_attn_f32). x [B,N,C], curves [B,cn,cl,C]."""
+        cn = curves.shape[1]
         fold = lambda m: folded_pw(m)[2:]                                            # noqa: E731
         (w_att, _), (wa, _), (wb, _), (wc, _) = fold(self.line_conv_att), fold(self.conva), fold(self.convb), fold(self.convc)
         (wn, _), (wl, _), (wd, bd) = fold(self.convn), fold(self.convl), fold(self.convd)
-        Kp, Vp = ops.curve_agg_kv(curves.permute(0, 2, 3, 1), w_att, wa, wb, wn, wl, wc, wd, bd)
-        xT = x.transpose(1, 2)                                                        # [B,N,C]
-        s = torch.bmm(xT, Kp)                                                         # [B,N,cn+cl]
-        w = torch.cat((F.softmax(s[:, :, :cn], dim=-1), F.softmax(s[:, :, cn:], dim=-1)), dim=-1)
-        return F.leaky_relu(torch.baddbmm(xT, w, Vp), negative_slope=0.2).transpose(1, 2)
+        Kp, Vp = ops.curve_agg_kv(curves, w_att, wa, wb, wn, wl, wc, wd, bd)
+        return ops.curve_attn(x, Kp, Vp, cn, 0.2)
 
     def forward_steps(self, x, curves):
         """The same block as the reference's sequence of 1x1 convs, softmaxes and products (:393-437)."""
@@ -389,15 +451,28 @@ class CurveGrouping(nn.Module):
         self.att = nn.Conv1d(in_channel, 1, kernel_size=1, bias=False)
         self.walk = Walk(in_channel, k, curve_num, curve_length)
 
-    def forward(self, x, xyz, idx):
-        x_att = torch.sigmoid(pw(self.att, x))
-        x = x * x_att
-        # The reference asks for sorted=False (:457): the order of the start points is then unspecified (torch's CPU and
-        # GPU kernels return different ones) — yet the walk's momentum step mixes values of DIFFERENT curves by position
-        # (walk.py:104-105), so the output depends on it. The mirror fixes the order to descending score (a valid
-        # instance of "unsorted"), which makes the forward reproducible and lets fixtures pin it.
-        _, start_index = torch.topk(x_att, self.curve_num, dim=2, sorted=True)
-        return self.walk(xyz, x, idx, start_index.squeeze(1).unsqueeze(2))       # [B,C,cn,cl]
+    def forward(self, x, xyz, idx, cl=False):
+        """Reference layout (default): x [B,C,N], idx [B,N,k] -> curves [B,C,cn,cl]; cl=True: x [B,N,C], idx int32
+        [B,N,k] -> [B,cn,cl,C].
+        The reference asks topk for sorted=False (:457): the order of the start points is then unspecified (torch's CPU
+        and GPU kernels return different ones) — yet the walk's momentum step mixes values of DIFFERENT curves by
+        position (walk.py:104-105), so the output depends on it. The mirror fixes the order to descending score, ties
+        to the lower index (a valid instance of "unsorted"), which makes the forward reproducible and lets fixtures pin
+        it."""
+        if not cl:
+            return self.forward(_cl(x), None, idx.to(torch.int32).contiguous(), cl=True).permute(0, 3, 1, 2)
+        B, N, C = x.shape
+        _, _, w, _ = folded_pw(self.att)
+        if x.is_cuda and C % 4 == 0:
+            xs, att = ops.att_scale(x, w)                          # sigmoid(att(x)) and x * that, one launch
+        else:
+            att = torch.sigmoid(x @ w.reshape(-1))
+            xs = x * att.unsqueeze(-1)
+        if x.is_cuda and N <= ops.TOPK_MAX_N:
+            start = ops.topk_desc(att, self.curve_num)
+        else:
+            start = torch.sort(att.detach(), dim=1, descending=True, stable=True)[1][:, :self.curve_num].to(torch.int32)
+        return self.walk(None, xs, idx, start, cl=True)              # [B,cn,cl,C]
 
 
 class MaskedMaxPool(nn.Module):
@@ -409,6 +484,17 @@ class MaskedMaxPool(nn.Module):
         self.radius = radius
         self.k = k
 
-    def forward(self, xyz, features):
-        sub_xyz, nbr = sample_and_group(self.npoint, self.radius, self.k, xyz, features.transpose(1, 2).contiguous())
-        return sub_xyz, nbr.max(dim=2)[0].transpose(1, 2).contiguous()           # [B,S,3], [B,C,S]
+    def forward(self, xyz, features, cl=False):
+        """Reference layout (default): xyz [B,N,3], features [B,C,N] -> ([B,S,3], [B,C,S]); cl=True: features [B,N,C]
+        -> [B,S,C]. FPS (start index 0, :81) + ball query + max over each ball in one gather-max launch instead of the
+        [B,S,k,C] grouped tensor."""
+        if not cl:
+            sub, y = self.forward(xyz, _cl(features), cl=True)
+            return sub, _cf(y)
+        xyz = xyz.float()
+        B = xyz.shape[0]
+        hold_rng_position(B, xyz.shape[1])
+        fps_idx = ops.fps(xyz, self.npoint, None)
+        sub_xyz = ops.group_gather(xyz, None, fps_idx.view(B, self.npoint, 1)).view(B, self.npoint, 3)
+        idx = ops.ball_query(self.radius, self.k, xyz, sub_xyz)
+        return sub_xyz, ops.gather_max_rows(features, idx)

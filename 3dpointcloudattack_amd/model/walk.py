@@ -55,18 +55,24 @@ class Walk(nn.Module):
         ans = torch.div(dot, divider).squeeze(1)               # [M,k]
         return torch.clamp(1. + ans, 0., 1.0).detach()
 
-    def forward(self, xyz, x, adj, cur):
-        """x [B,C,N] features, adj [B,N,k] neighbour indices (self excluded), cur [B,curve_num,1] start nodes
-        -> curves [B,C,curve_num,curve_length]. One HIP launch per direction (pc3d_curve_walk_*_f32) when the channel
-        count is one the kernel is built for; the step-by-step formulation below otherwise."""
-        B, C, N = x.size()
+    def forward(self, xyz, x, adj, cur, cl=False):
+        """Reference layout (default): x [B,C,N] features, adj [B,N,k] neighbour indices (self excluded), cur
+        [B,curve_num,1] start nodes -> curves [B,C,curve_num,curve_length]. cl=True: x [B,N,C], adj int32 [B,N,k], cur
+        int32 [B,curve_num] -> [B,curve_num,curve_length,C]. One HIP launch per direction (pc3d_curve_walk_*_f32)
+        when the channel count is one the kernel is built for; the step-by-step formulation below otherwise."""
+        C = x.shape[2] if cl else x.shape[1]
+        B = x.shape[0]
         if self.fused and x.is_cuda and C in ops.CURVE_WALK_CHANNELS and adj.shape[2] <= 64:
             from .curvenet_util import folded_pw
             _, _, aw, ab = folded_pw(self.agent_mlp)
             _, _, mw, mb = folded_pw(self.momentum_mlp)
-            curves = ops.curve_walk(x.transpose(1, 2).contiguous().float(), adj.to(torch.int32),
-                                    cur.reshape(B, self.curve_num).to(torch.int32), aw, ab, mw, mb, self.curve_length)
-            return curves.permute(0, 3, 1, 2)                  # [B,cn,L,C] -> [B,C,cn,L]
+            feats = x.float().contiguous() if cl else x.transpose(1, 2).contiguous().float()
+            curves = ops.curve_walk(feats, adj.to(torch.int32), cur.reshape(B, self.curve_num).to(torch.int32), aw, ab,
+                                    mw, mb, self.curve_length)
+            return curves if cl else curves.permute(0, 3, 1, 2)    # [B,cn,L,C] (-> [B,C,cn,L])
+        if cl:
+            cf = self.forward_steps(xyz, x.transpose(1, 2), adj.long(), cur.long().reshape(B, self.curve_num, 1))
+            return cf.permute(0, 2, 3, 1).contiguous()
         return self.forward_steps(xyz, x, adj, cur)
 
     def forward_steps(self, xyz, x, adj, cur):

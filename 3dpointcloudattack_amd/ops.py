@@ -1028,6 +1028,224 @@ def curve_agg_kv(curves, w_att, Wa, Wb, Wn, Wl, Wc, Wd, bd):
 
 
 # ------------------------------------------------------------------------------------------------------
+# K19: channels-last glue of a CurveNet CIC block
+# ------------------------------------------------------------------------------------------------------
+def gate(g, y, slope):
+    """y > 0 ? g : slope * g (one launch): the (Leaky)ReLU derivative taken from the activation's output."""
+    g, y = g.contiguous(), y.contiguous()
+    out = torch.empty_like(g)
+    with torch.cuda.device(g.device):
+        _lib.call("pc3d_gate_f32", g.data_ptr(), y.data_ptr(), g.numel(), float(slope), out.data_ptr(), _stream())
+    return out
+
+
+class _LinearResActFn(torch.autograd.Function):
+    """act(x @ w.T + b + r): the residual tail of a block in one launch; backward = gate + one GEMM on W^T."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, r, act, slope):
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        if x2.stride(1) != 1:
+            x2 = x2.contiguous()
+        N = w.shape[0]
+        r2 = r.reshape(-1, N)
+        if r2.stride(1) != 1:
+            r2 = r2.contiguous()
+        M, K = x2.shape
+        y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.call("pc3d_gemm_nt_res_f32", x2.data_ptr(), x2.stride(0), w.data_ptr(), _ptr(b), r2.data_ptr(),
+                      r2.stride(0), M, N, K, _ACTS[act], float(slope), y.data_ptr(), y.stride(0), _stream())
+        ctx.act, ctx.slope, ctx.shp, ctx.rshp = act, slope, shp, r.shape
+        ctx.save_for_backward(y if act in ("relu", "leaky") else None, w)
+        return y.view(*shp[:-1], N)
+
+    @staticmethod
+    def backward(ctx, gy):
+        y, w = ctx.saved_tensors
+        g2 = gy.reshape(-1, gy.shape[-1])
+        if y is not None:
+            g2 = gate(g2, y, ctx.slope if ctx.act == "leaky" else 0.0)
+        elif not g2.is_contiguous():
+            g2 = g2.contiguous()
+        gx = gemm_nt(g2, _w_transposed(w)) if ctx.needs_input_grad[0] else None
+        return (gx.view(ctx.shp) if gx is not None else None), None, None, g2.view(ctx.rshp), None, None
+
+
+def linear_res_act(x, w, b, r, act=None, slope=0.0):
+    """[..., K] -> [..., N]: act(x @ w.T + b + r) with r [..., N]; frozen (w, b), differentiable in x and r."""
+    _check(x, "x"), _check(r, "r")
+    w = w.detach()
+    if not w.is_contiguous():
+        w = w.contiguous()
+    return _LinearResActFn.apply(x, w, b.detach() if b is not None else None, r, act, float(slope))
+
+
+class _GatherMaxRowsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, P, idx):
+        B, N, C = P.shape
+        S, K = idx.shape[1], idx.shape[2]
+        out = torch.empty((B, S, C), dtype=torch.float32, device=P.device)
+        arg = torch.empty((B, S, C), dtype=torch.int32, device=P.device)
+        with torch.cuda.device(P.device):
+            _lib.call("pc3d_gather_max_rows_f32", P.data_ptr(), idx.data_ptr(), B, N, S, C, K, out.data_ptr(),
+                      arg.data_ptr(), _stream())
+        ctx.save_for_backward(arg)
+        ctx.N = N
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (arg,) = ctx.saved_tensors
+        g = g.contiguous()
+        B, S, C = g.shape
+        gP = torch.empty((B, ctx.N, C), dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            _lib.call("pc3d_gather_max_rows_bwd_f32", g.data_ptr(), arg.data_ptr(), B, ctx.N, S, C, gP.data_ptr(), _stream())
+        return gP, None
+
+
+def gather_max_rows(P, idx):
+    """out[b,s,c] = max_j P[b, idx[b,s,j], c] for P [B,N,C], idx [B,S,K] int32 (clamped to [0,N-1]) -> [B,S,C]."""
+    _check(P, "P")
+    if idx.dtype != torch.int32 or idx.dim() != 3 or idx.shape[0] != P.shape[0]:
+        raise ValueError("gather_max_rows: idx must be int32 [B,S,K]")
+    return _GatherMaxRowsFn.apply(P.contiguous(), idx.contiguous())
+
+
+class _AttScaleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w):
+        C = x.shape[-1]
+        M = x.numel() // C
+        xs = torch.empty_like(x)
+        att = torch.empty(x.shape[:-1], dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.call("pc3d_att_scale_f32", x.data_ptr(), w.data_ptr(), M, C, xs.data_ptr(), att.data_ptr(), _stream())
+        ctx.save_for_backward(x, w, att)
+        ctx.mark_non_differentiable(att)
+        return xs, att
+
+    @staticmethod
+    def backward(ctx, g, _gatt):
+        x, w, att = ctx.saved_tensors
+        C = x.shape[-1]
+        g = g.contiguous()
+        gx = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.call("pc3d_att_scale_bwd_f32", g.data_ptr(), x.data_ptr(), att.data_ptr(), w.data_ptr(), x.numel() // C,
+                      C, gx.data_ptr(), _stream())
+        return gx, None
+
+
+def att_scale(x, w):
+    """(x * att, att) with att = sigmoid(x @ w) for x [..., C] (C % 4 == 0) and a frozen w [C]; the scaled features
+    are differentiable in x, att is returned for the (non-differentiable) start-point selection only."""
+    _check(x, "x")
+    if x.shape[-1] % 4 or w.numel() != x.shape[-1]:
+        raise ValueError("att_scale: x [..., C] with C % 4 == 0 and w [C] expected")
+    return _AttScaleFn.apply(x.contiguous(), w.detach().reshape(-1).contiguous().float())
+
+
+TOPK_MAX_N = 8192
+
+
+def topk_desc(score, K):
+    """score [B,N] fp32 (N <= 8192) -> int32 [B,K]: indices of the K largest, descending, ties to the lower index."""
+    _check(score, "score")
+    score = score.detach().contiguous()
+    B, N = score.shape
+    idx = torch.empty((B, K), dtype=torch.int32, device=score.device)
+    with torch.cuda.device(score.device):
+        _lib.call("pc3d_topk_desc_f32", score.data_ptr(), B, N, int(K), idx.data_ptr(), _stream())
+    return idx
+
+
+CURVE_ATTN_CHANNELS = (8, 16, 32, 64)
+CURVE_ATTN_MAX_R = 128
+
+
+class _CurveAttnFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, Kp, Vp, cn, slope):
+        B, N, C = x.shape
+        R = Kp.shape[2]
+        out = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.call("pc3d_curve_attn_f32", x.data_ptr(), Kp.data_ptr(), Vp.data_ptr(), B, N, C, cn, R - cn, float(slope),
+                      out.data_ptr(), _stream())
+        ctx.save_for_backward(x, Kp, Vp, out)
+        ctx.cn, ctx.slope = cn, float(slope)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, Kp, Vp, out = ctx.saved_tensors
+        B, N, C = x.shape
+        R = Kp.shape[2]
+        g = g.contiguous()
+        gx, gKp, gVp = torch.empty_like(x), torch.empty_like(Kp), torch.empty_like(Vp)
+        ws = torch.empty(int(_lib.load().pc3d_curve_attn_bwd_ws_floats(B, N, C, ctx.cn, R - ctx.cn)), dtype=torch.float32,
+                         device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.call("pc3d_curve_attn_bwd_f32", g.data_ptr(), out.data_ptr(), x.data_ptr(), Kp.data_ptr(), Vp.data_ptr(),
+                      B, N, C, ctx.cn, R - ctx.cn, ctx.slope, gx.data_ptr(), gKp.data_ptr(), gVp.data_ptr(), ws.data_ptr(),
+                      _stream())
+        return gx, gKp, gVp, None, None
+
+
+def curve_attn(x, Kp, Vp, cn, slope=0.2):
+    """leaky(x + softmax(x Kp[:, :, :cn]) Vp[:, :cn] + softmax(x Kp[:, :, cn:]) Vp[:, cn:]) for x [B,N,C], Kp [B,C,R],
+    Vp [B,R,C] in one launch; differentiable in all three."""
+    _check(x, "x"), _check(Kp, "Kp"), _check(Vp, "Vp")
+    B, N, C = x.shape
+    R = Kp.shape[2]
+    if C not in CURVE_ATTN_CHANNELS or R > CURVE_ATTN_MAX_R or Kp.shape != (B, C, R) or Vp.shape != (B, R, C) or not 0 <= cn <= R:
+        raise ValueError("curve_attn: x [B,N,C] (C in 8/16/32/64), Kp [B,C,R], Vp [B,R,C] with R <= 128 expected")
+    return _CurveAttnFn.apply(x.contiguous(), Kp.contiguous(), Vp.contiguous(), int(cn), slope)
+
+
+class _LpfaPrepFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, pts, G1, G2, t):
+        C = x.shape[-1]
+        M = x.numel() // C
+        A, Bc = torch.empty_like(x), torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.call("pc3d_lpfa_prep_f32", x.data_ptr(), pts.data_ptr(), G1.data_ptr(), G2.data_ptr(), t.data_ptr(), M, C,
+                      A.data_ptr(), Bc.data_ptr(), _stream())
+        ctx.save_for_backward(G1, G2)
+        ctx.pshape = pts.shape
+        return A, Bc
+
+    @staticmethod
+    def backward(ctx, gA, gBc):
+        G1, G2 = ctx.saved_tensors
+        gA, gBc = gA.contiguous(), gBc.contiguous()
+        C = gA.shape[-1]
+        M = gA.numel() // C
+        gx = torch.empty_like(gA)
+        gp = torch.empty(ctx.pshape, dtype=torch.float32, device=gA.device)
+        with torch.cuda.device(gA.device):
+            _lib.call("pc3d_lpfa_prep_bwd_f32", gA.data_ptr(), gBc.data_ptr(), G1.data_ptr(), G2.data_ptr(), M, C,
+                      gx.data_ptr(), gp.data_ptr(), _stream())
+        return gx, gp, None, None, None
+
+
+def lpfa_prep(x, pts, G1, G2, t):
+    """(A, Bc) = (x + pts @ G1.T, pts @ G2.T + t - x) for x [..., C] (C % 4 == 0), pts [..., 3], frozen G1, G2 [C,3] and
+    t [C]; differentiable in x and pts."""
+    _check(x, "x"), _check(pts, "pts")
+    C = x.shape[-1]
+    if C % 4 or pts.shape[-1] != 3 or pts.shape[:-1] != x.shape[:-1] or G1.shape != (C, 3) or G2.shape != (C, 3):
+        raise ValueError("lpfa_prep: x [..., C] (C % 4 == 0), pts [..., 3], G1, G2 [C,3] expected")
+    f = lambda w: w.detach().contiguous().float()          # noqa: E731
+    return _LpfaPrepFn.apply(x.contiguous(), pts.contiguous(), f(G1), f(G2), f(t))
+
+
+# ------------------------------------------------------------------------------------------------------
 # K16: CurveNet guided walk
 # ------------------------------------------------------------------------------------------------------
 CURVE_WALK_CHANNELS = (8, 16, 32, 64)

@@ -84,6 +84,14 @@ int pc3d_nn_bidir_shared_f32(const float* a, int64_t a_bs, int64_t a_ps, int64_t
  * ------------------------------------------------------------------------------------------------------- */
 int pc3d_gemm_nt_f32(const float* X, int64_t ldx, const float* W, const float* bias, const float* gate, int64_t ldg,
                      float gate_slope, int M, int N, int K, int act, float slope, float* Y, int64_t ldy, void* stream);
+/* The same layer with a residual branch summed in before the activation:  Y = act(X . W^T + bias + R)  — the tail
+ * of a CurveNet CIC block, relu(conv2(..) + shortcut) (model/curvenet_util.py:372-376). R: [M,N] row stride ldr.
+ * Its backward: G = pc3d_gate_f32(dY, Y) once, then dR = G and dX = pc3d_gemm_nt_f32(G, W^T). */
+int pc3d_gemm_nt_res_f32(const float* X, int64_t ldx, const float* W, const float* bias, const float* R, int64_t ldr,
+                         int M, int N, int K, int act, float slope, float* Y, int64_t ldy, void* stream);
+/* out[i] = y[i] > 0 ? g[i] : slope * g[i] over n contiguous floats (16-byte aligned buffers): the derivative of a
+ * (Leaky)ReLU taken from its OUTPUT's sign, for layers whose pre-activation had more than one producer. */
+int pc3d_gate_f32(const float* g, const float* y, int64_t n, float slope, float* out, void* stream);
 
 /* Point normals from the k-NN covariance (attack/GeoA3/utility.py:43-92 estimate_normal): eigenvector of the smallest
  * eigenvalue of the 3 x 3 covariance of the k neighbours (closed form, double arithmetic), sign fixed against the
@@ -333,6 +341,13 @@ int pc3d_knn_feat_f32(const float* x, int B, int N, int C, int K, int32_t* idx, 
 int pc3d_gather_max_f32(const float* P, const int32_t* idx, const float* sign, int B, int N, int C, int K,
                         float* out, int32_t* arg, void* stream);
 int pc3d_gather_max_bwd_f32(const float* g, const int32_t* arg, int B, int N, int C, float* gP, void* stream);
+/* The same reduction for S query rows over N source points (idx, out, arg, g: [B,S,..]; P, gP: [B,N,C]; indices are
+ * clamped to [0,N-1]): CurveNet's MaskedMaxPool, max over the ball-query neighbours of every FPS centroid
+ * (model/curvenet_util.py:469-484). */
+int pc3d_gather_max_rows_f32(const float* P, const int32_t* idx, int B, int N, int S, int C, int K, float* out,
+                             int32_t* arg, void* stream);
+int pc3d_gather_max_rows_bwd_f32(const float* g, const int32_t* arg, int B, int N, int S, int C, float* gP,
+                                 void* stream);
 /* One EdgeConv layer's epilogue (model/dgcnn.py:299-313): PQ [B,N,2C] = [P | Q] from ONE GEMM against [U;V];
  * out[b,i,c] = leaky_slope(max_j P[b,idx[b,i,j],c] + Q[b,i,c]), arg = the winning j. C % 4 == 0.
  * Backward: gPQ [B,N,2C] overwritten: dQ = g * leaky'(out), dP scattered to arg (float atomics). */
@@ -394,6 +409,33 @@ int pc3d_curve_agg_kv_bwd_f32(const float* gKp, const float* gVp, const float* c
                               const float* Wa, const float* Wb, const float* Wn, const float* Wl, const float* Wc,
                               const float* Wd, const float* bd, int B, int cn, int cl, int C, int mid, float* gcurves,
                               void* stream);
+
+/* K19  channels-last glue of a CurveNet CIC block (csrc/curvenet_cl.hip); all tensors fp32, C % 4 == 0.
+ *   att_scale (model/curvenet_util.py:452-455, CurveGrouping): att[p] = sigmoid(x[p,:] . w), xs[p,:] = x[p,:] att[p]
+ *     for M rows; backward to x of a gradient on xs (att itself only feeds the top-k selection).
+ *   topk_desc (:457): indices of the K largest scores of every cloud, descending, ties to the lower index (the
+ *     reference asks torch.topk for sorted=False, whose order is device dependent — DESIGN.md A-15). N <= 8192.
+ *   curve_attn (:425-437, CurveAggregation's per-point half): with the keys Kp [B,C,R] / values Vp [B,R,C] of
+ *     pc3d_curve_agg_kv_f32 (R = cn + cl),  out = LeakyReLU_slope(x + softmax(x Kp[:, :cn]) Vp[:cn] + softmax(x Kp[:, cn:])
+ *     Vp[cn:]).  C in {8,16,32,64}, R <= 128. Backward: gx [B,N,C], gKp, gVp (overwritten); ws = device scratch of
+ *     pc3d_curve_attn_bwd_ws_floats(..) floats.
+ *   lpfa_prep (:204-236, LPFA): A = x + p G1^T, Bc = p G2^T + t - x for M rows (x [M,C], p [M,3], G1, G2 [C,3], t [C]),
+ *     the two per-point terms of leaky((x_j - x_i) + xyz2feature([p_i; p_j; p_j - p_i])) = leaky(A_j + Bc_i); backward
+ *     gx = gA - gBc, gp = gA G1 + gBc G2. */
+int pc3d_att_scale_f32(const float* x, const float* w, int64_t M, int C, float* xs, float* att, void* stream);
+int pc3d_att_scale_bwd_f32(const float* g, const float* x, const float* att, const float* w, int64_t M, int C, float* gx,
+                           void* stream);
+int pc3d_topk_desc_f32(const float* score, int B, int N, int K, int32_t* idx, void* stream);
+int pc3d_curve_attn_f32(const float* x, const float* Kp, const float* Vp, int B, int N, int C, int cn, int cl,
+                        float slope, float* out, void* stream);
+int64_t pc3d_curve_attn_bwd_ws_floats(int B, int N, int C, int cn, int cl);
+int pc3d_curve_attn_bwd_f32(const float* gout, const float* out, const float* x, const float* Kp, const float* Vp, int B,
+                            int N, int C, int cn, int cl, float slope, float* gx, float* gKp, float* gVp, float* ws,
+                            void* stream);
+int pc3d_lpfa_prep_f32(const float* x, const float* pts, const float* G1, const float* G2, const float* t, int64_t M,
+                       int C, float* A, float* Bc, void* stream);
+int pc3d_lpfa_prep_bwd_f32(const float* gA, const float* gBc, const float* G1, const float* G2, int64_t M, int C,
+                           float* gx, float* gpts, void* stream);
 
 /* K12  dense graph Laplacian L = D - A of the symmetrised kNN graph with Gaussian weights A_ij = exp(-|pi-pj|^2)
  * (attack/AOF/TAOF_attack.py:31-52, attack/AOF/Eval_AOF.py:72-93). idx [B,N,K] from pc3d_knn_f32 (self included, as

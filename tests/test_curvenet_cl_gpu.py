@@ -1,0 +1,121 @@
+"""GPU parity of the channels-last CurveNet block kernels (csrc/curvenet_cl.hip, the residual epilogue of gemm_nt,
+gather_max over S != N rows) against plain torch (float64) formulations of the same reference lines
+(model/curvenet_util.py:372-376, :425-437, :452-457, :469-484, :204-236): values and every gradient."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = a.detach().double(), b.detach().double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.mark.parametrize("M,N,K,act", [(1000, 64, 32, "leaky"), (4096, 128, 16, "relu"), (300, 40, 24, None), (70, 512, 256, "leaky")])
+def test_linear_res_act(ops, dev, M, N, K, act):
+    g = torch.Generator().manual_seed(M + N)
+    x, r = torch.randn(M, K, generator=g).to(dev), torch.randn(M, N, generator=g).to(dev)
+    w, b = (0.2 * torch.randn(N, K, generator=g)).to(dev), torch.randn(N, generator=g).to(dev)
+    up = torch.randn(M, N, generator=g).to(dev)
+    xa, ra = x.clone().requires_grad_(), r.clone().requires_grad_()
+    y = ops.linear_res_act(xa, w, b, ra, act, 0.2)
+    (y * up).sum().backward()
+    xd, rd = x.double().requires_grad_(), r.double().requires_grad_()
+    pre = xd @ w.double().t() + b.double() + rd
+    yr = F.leaky_relu(pre, 0.2) if act == "leaky" else (F.relu(pre) if act == "relu" else pre)
+    (yr * up.double()).sum().backward()
+    assert _rel(y, yr) < 1e-6
+    assert _rel(xa.grad, xd.grad) < 1e-5 and _rel(ra.grad, rd.grad) < 1e-6
+
+
+def test_gate(ops, dev):
+    g = torch.randn(5, 1027, device=dev)
+    y = torch.randn(5, 1027, device=dev)
+    out = ops.gate(g, y, 0.2)
+    assert torch.equal(out, torch.where(y > 0, g, 0.2 * g))
+
+
+@pytest.mark.parametrize("B,N,S,K,C", [(2, 100, 30, 7, 16), (3, 513, 128, 20, 64), (1, 64, 64, 5, 6)])
+def test_gather_max_rows(ops, dev, B, N, S, K, C):
+    g = torch.Generator().manual_seed(N)
+    P = torch.randn(B, N, C, generator=g).to(dev)
+    idx = torch.randint(0, N, (B, S, K), generator=g).int().to(dev)
+    up = torch.randn(B, S, C, generator=g).to(dev)
+    Pa = P.clone().requires_grad_()
+    out = ops.gather_max_rows(Pa, idx)
+    (out * up).sum().backward()
+    Pr = P.clone().requires_grad_()
+    nb = torch.gather(Pr[:, None].expand(-1, S, -1, -1), 2, idx.long()[..., None].expand(-1, -1, -1, C))
+    ref = nb.max(dim=2)[0]
+    (ref * up).sum().backward()
+    assert torch.equal(out, ref)
+    torch.testing.assert_close(Pa.grad, Pr.grad, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("B,N,C", [(2, 300, 16), (3, 1024, 32), (1, 77, 8)])
+def test_att_scale(ops, dev, B, N, C):
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn(B, N, C, generator=g).to(dev)
+    w = torch.randn(C, generator=g).to(dev)
+    up = torch.randn(B, N, C, generator=g).to(dev)
+    xa = x.clone().requires_grad_()
+    xs, att = ops.att_scale(xa, w)
+    (xs * up).sum().backward()
+    xd = x.double().requires_grad_()
+    ad = torch.sigmoid(xd @ w.double())
+    xr = xd * ad[..., None]
+    (xr * up.double()).sum().backward()
+    assert _rel(att, ad) < 1e-6 and _rel(xs, xr) < 1e-6 and _rel(xa.grad, xd.grad) < 1e-5
+
+
+@pytest.mark.parametrize("B,N,K", [(3, 1024, 100), (2, 4096, 100), (2, 77, 10), (1, 8192, 64), (2, 5, 5)])
+def test_topk_desc(ops, dev, B, N, K):
+    g = torch.Generator().manual_seed(N)
+    s = torch.rand(B, N, generator=g)
+    s[0] = (s[0] * 50).floor() / 50          # many exact ties in the first cloud
+    s[-1, N // 2] = 1.0                       # sigmoid saturates at exactly 1.0 for a few points
+    s[-1, 0] = 1.0
+    s = s.to(dev)
+    idx = ops.topk_desc(s, K).long()
+    # expected: stable descending order (ties to the lower index)
+    order = torch.sort(s.double().cpu(), dim=1, descending=True, stable=True)[1][:, :K]
+    assert torch.equal(idx.cpu(), order)
+
+
+@pytest.mark.parametrize("B,N,C,cn,cl", [(2, 300, 16, 100, 5), (3, 1024, 32, 100, 5), (1, 70, 8, 10, 30), (2, 257, 64, 100, 5)])
+def test_curve_attn(ops, dev, B, N, C, cn, cl):
+    g = torch.Generator().manual_seed(N + C)
+    R = cn + cl
+    x = torch.randn(B, N, C, generator=g).to(dev)
+    Kp = (0.5 * torch.randn(B, C, R, generator=g)).to(dev)
+    Vp = torch.randn(B, R, C, generator=g).to(dev)
+    up = torch.randn(B, N, C, generator=g).to(dev)
+    xa, Ka, Va = x.clone().requires_grad_(), Kp.clone().requires_grad_(), Vp.clone().requires_grad_()
+    out = ops.curve_attn(xa, Ka, Va, cn, 0.2)
+    (out * up).sum().backward()
+    xd, Kd, Vd = x.double().requires_grad_(), Kp.double().requires_grad_(), Vp.double().requires_grad_()
+    s = torch.bmm(xd, Kd)
+    w = torch.cat((F.softmax(s[:, :, :cn], dim=-1), F.softmax(s[:, :, cn:], dim=-1)), dim=-1)
+    ref = F.leaky_relu(xd + torch.bmm(w, Vd), 0.2)
+    (ref * up.double()).sum().backward()
+    assert _rel(out, ref) < 2e-6
+    assert _rel(xa.grad, xd.grad) < 1e-5 and _rel(Ka.grad, Kd.grad) < 1e-5 and _rel(Va.grad, Vd.grad) < 1e-5
+
+
+@pytest.mark.parametrize("B,N,C", [(2, 300, 16), (3, 1024, 32), (1, 50, 128)])
+def test_lpfa_prep(ops, dev, B, N, C):
+    g = torch.Generator().manual_seed(C + N)
+    x, p = torch.randn(B, N, C, generator=g).to(dev), torch.randn(B, N, 3, generator=g).to(dev)
+    G1, G2, t = torch.randn(C, 3, generator=g).to(dev), torch.randn(C, 3, generator=g).to(dev), torch.randn(C, generator=g).to(dev)
+    ua, ub = torch.randn(B, N, C, generator=g).to(dev), torch.randn(B, N, C, generator=g).to(dev)
+    xa, pa = x.clone().requires_grad_(), p.clone().requires_grad_()
+    A, Bc = ops.lpfa_prep(xa, pa, G1, G2, t)
+    ((A * ua).sum() + (Bc * ub).sum()).backward()
+    xd, pd = x.double().requires_grad_(), p.double().requires_grad_()
+    Ar = xd + pd @ G1.double().t()
+    Br = pd @ G2.double().t() + t.double() - xd
+    ((Ar * ua.double()).sum() + (Br * ub.double()).sum()).backward()
+    assert _rel(A, Ar) < 1e-6 and _rel(Bc, Br) < 1e-6
+    assert _rel(xa.grad, xd.grad) < 1e-6 and _rel(pa.grad, pd.grad) < 1e-5

@@ -255,8 +255,13 @@ def test_curvenet_stage_trace_vs_reference(dev):
     got = {}
 
     def keep(name, idx=None):
-        def fn(mod, inp, out):
-            got[name] = out
+        def fn(mod, inp, out):      # CurveNet.forward runs its blocks channels-last: back to the reference layout
+            if isinstance(out, tuple):
+                got[name] = (out[0].transpose(1, 2), out[1].transpose(1, 2))
+            elif out.dim() == 4:
+                got[name] = out.permute(0, 3, 1, 2)
+            else:
+                got[name] = out.transpose(1, 2)
         return fn
 
     hooks = [getattr(m, nm).register_forward_hook(keep(nm)) for nm in fx["stages"] if nm != "conv0"]
