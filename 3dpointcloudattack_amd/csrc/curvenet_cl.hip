@@ -160,9 +160,11 @@ __global__ __launch_bounds__(256) void lpfa_prep_bwd_kernel(const float* __restr
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// curve_attn: one thread per point; the cloud's keys (transposed to [R][C]) and values [R][C] sit in LDS and are read
-// as wave-uniform float4 (broadcast, one ds_read_b128 per four FMAs). Scores are recomputed per pass instead of being
-// stored (R = cn + cl ~ 105 of them per point): 3 C R FMAs per point forward.
+// curve_attn: FOUR lanes per point (a quad), each owning every fourth key — with B*N ~ 32 k points a thread per
+// point would leave the chip at one wave per SIMD or less, and the kernel is a chain of dependent FMAs. The cloud's
+// keys (transposed to [R][C+4]) and values [R][C+4] sit in LDS (the +4 keeps the four rows a quad reads in different
+// banks); scores are recomputed per pass instead of being stored (R = cn + cl ~ 105 per point): 3 C R FMAs per point
+// forward. Quad reductions are two DPP quad_perm steps.
 // ---------------------------------------------------------------------------------------------------------
 struct CurveAttnArgs {
   const float* x;    // [B,N,C]
@@ -178,6 +180,19 @@ struct CurveAttnArgs {
   float* Wt;         // [B,N,R]  softmax weights
   float* G;          // [B,N,C]  gated upstream gradient
 };
+
+constexpr int CA_PPW = 64;   // points per workgroup (256 threads, 4 lanes per point)
+
+__device__ __forceinline__ float quad_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));  // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));  // quad_perm [2,3,0,1]
+  return v;
+}
+__device__ __forceinline__ float quad_max(float v) {
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false)));
+  return v;
+}
 
 template <int C>
 __device__ __forceinline__ float ca_dot(const float (&v)[C], const float* __restrict__ row) {
@@ -195,11 +210,12 @@ __device__ __forceinline__ float ca_dot(const float (&v)[C], const float* __rest
 
 template <int C>
 __device__ __forceinline__ void ca_stage(const CurveAttnArgs& a, int b, float* KT, float* V) {
+  constexpr int CP = C + 4;
   const int R = a.R;
   for (int e = threadIdx.x; e < R * C; e += 256) {
     const int j = e / C, c = e - j * C;
-    KT[e] = a.Kp[((int64_t)b * C + c) * R + j];
-    V[e] = a.Vp[(int64_t)b * R * C + e];
+    KT[j * CP + c] = a.Kp[((int64_t)b * C + c) * R + j];
+    V[j * CP + c] = a.Vp[(int64_t)b * R * C + e];
   }
   __syncthreads();
 }
@@ -207,11 +223,13 @@ __device__ __forceinline__ void ca_stage(const CurveAttnArgs& a, int b, float* K
 template <int C>
 __global__ __launch_bounds__(256) void curve_attn_fwd_kernel(CurveAttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float ca_lds[];
+  constexpr int CP = C + 4;
   float* KT = ca_lds;
-  float* V = ca_lds + a.R * C;
+  float* V = ca_lds + a.R * CP;
   const int b = blockIdx.y;
   ca_stage<C>(a, b, KT, V);
-  const int p = blockIdx.x * 256 + threadIdx.x;
+  const int q = threadIdx.x & 3;
+  const int p = blockIdx.x * CA_PPW + (threadIdx.x >> 2);
   const bool valid = p < a.N;
   const float* xr = a.x + ((int64_t)b * a.N + (valid ? p : a.N - 1)) * C;
   float x[C];
@@ -221,11 +239,12 @@ __global__ __launch_bounds__(256) void curve_attn_fwd_kernel(CurveAttnArgs a) {
     x[c] = v.x, x[c + 1] = v.y, x[c + 2] = v.z, x[c + 3] = v.w;
   }
   float m[2] = {-INFINITY, -INFINITY};
-  for (int j = 0; j < a.R; ++j) {
-    const float s = ca_dot<C>(x, KT + j * C);
+  for (int j = q; j < a.R; j += 4) {
+    const float s = ca_dot<C>(x, KT + j * CP);
     if (j < a.cn) m[0] = fmaxf(m[0], s);
     else m[1] = fmaxf(m[1], s);
   }
+  m[0] = quad_max(m[0]), m[1] = quad_max(m[1]);
   float o[C];
 #pragma unroll
   for (int c = 0; c < C; ++c) o[c] = x[c];
@@ -237,26 +256,27 @@ __global__ __launch_bounds__(256) void curve_attn_fwd_kernel(CurveAttnArgs a) {
     float acc[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) acc[c] = 0.f;
-    for (int j = j0; j < j1; ++j) {
-      const float e = expf(ca_dot<C>(x, KT + j * C) - m[seg]);
+    for (int j = j0 + q; j < j1; j += 4) {
+      const float e = expf(ca_dot<C>(x, KT + j * CP) - m[seg]);
       den += e;
 #pragma unroll
       for (int c = 0; c < C; c += 4) {
-        const float4 v = *reinterpret_cast<const float4*>(V + j * C + c);
+        const float4 v = *reinterpret_cast<const float4*>(V + j * CP + c);
         acc[c] += e * v.x, acc[c + 1] += e * v.y, acc[c + 2] += e * v.z, acc[c + 3] += e * v.w;
       }
     }
-    const float inv = 1.f / den;
+    const float inv = 1.f / quad_sum(den);
 #pragma unroll
-    for (int c = 0; c < C; ++c) o[c] += acc[c] * inv;
+    for (int c = 0; c < C; ++c) o[c] += quad_sum(acc[c]) * inv;
   }
   if (!valid) return;
   float* orow = a.out + ((int64_t)b * a.N + p) * C;
 #pragma unroll
   for (int c = 0; c < C; c += 4)
-    *reinterpret_cast<float4*>(orow + c) =
-        make_float4(o[c] > 0.f ? o[c] : a.slope * o[c], o[c + 1] > 0.f ? o[c + 1] : a.slope * o[c + 1],
-                    o[c + 2] > 0.f ? o[c + 2] : a.slope * o[c + 2], o[c + 3] > 0.f ? o[c + 3] : a.slope * o[c + 3]);
+    if (((c >> 2) & 3) == q)     // the quad shares the row's float4 stores
+      *reinterpret_cast<float4*>(orow + c) =
+          make_float4(o[c] > 0.f ? o[c] : a.slope * o[c], o[c + 1] > 0.f ? o[c + 1] : a.slope * o[c + 1],
+                      o[c + 2] > 0.f ? o[c + 2] : a.slope * o[c + 2], o[c + 3] > 0.f ? o[c + 3] : a.slope * o[c + 3]);
 }
 
 // backward, per-point half: gx and, for the per-cloud reductions of the second kernel, dS / softmax weights / the gated
@@ -265,11 +285,13 @@ __global__ __launch_bounds__(256) void curve_attn_fwd_kernel(CurveAttnArgs a) {
 template <int C>
 __global__ __launch_bounds__(256) void curve_attn_bwd_point_kernel(CurveAttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float ca_lds[];
+  constexpr int CP = C + 4;
   float* KT = ca_lds;
-  float* V = ca_lds + a.R * C;
+  float* V = ca_lds + a.R * CP;
   const int b = blockIdx.y;
   ca_stage<C>(a, b, KT, V);
-  const int p = blockIdx.x * 256 + threadIdx.x;
+  const int q = threadIdx.x & 3;
+  const int p = blockIdx.x * CA_PPW + (threadIdx.x >> 2);
   const bool valid = p < a.N;
   const int64_t row = (int64_t)b * a.N + (valid ? p : a.N - 1);
   float x[C], G[C];
@@ -283,52 +305,62 @@ __global__ __launch_bounds__(256) void curve_attn_bwd_point_kernel(CurveAttnArgs
     G[c + 2] = o.z > 0.f ? g.z : a.slope * g.z, G[c + 3] = o.w > 0.f ? g.w : a.slope * g.w;
   }
   float m[2] = {-INFINITY, -INFINITY};
-  for (int j = 0; j < a.R; ++j) {
-    const float s = ca_dot<C>(x, KT + j * C);
+  for (int j = q; j < a.R; j += 4) {
+    const float s = ca_dot<C>(x, KT + j * CP);
     if (j < a.cn) m[0] = fmaxf(m[0], s);
     else m[1] = fmaxf(m[1], s);
   }
+  m[0] = quad_max(m[0]), m[1] = quad_max(m[1]);
   float den[2] = {0.f, 0.f}, u[2] = {0.f, 0.f};
-  for (int j = 0; j < a.R; ++j) {
+  for (int j = q; j < a.R; j += 4) {
     const int seg = j < a.cn ? 0 : 1;
-    const float e = expf(ca_dot<C>(x, KT + j * C) - m[seg]);
+    const float e = expf(ca_dot<C>(x, KT + j * CP) - m[seg]);
     den[seg] += e;
-    u[seg] += e * ca_dot<C>(G, V + j * C);
+    u[seg] += e * ca_dot<C>(G, V + j * CP);
   }
-  const float inv[2] = {den[0] > 0.f ? 1.f / den[0] : 0.f, den[1] > 0.f ? 1.f / den[1] : 0.f};
-  const float t[2] = {u[0] * inv[0], u[1] * inv[1]};
+  float inv[2], t[2];
+#pragma unroll
+  for (int seg = 0; seg < 2; ++seg) {
+    const float d = quad_sum(den[seg]);
+    inv[seg] = d > 0.f ? 1.f / d : 0.f;
+    t[seg] = quad_sum(u[seg]) * inv[seg];
+  }
   float dx[C];
 #pragma unroll
-  for (int c = 0; c < C; ++c) dx[c] = G[c];
+  for (int c = 0; c < C; ++c) dx[c] = 0.f;
   float* dsr = a.dS + row * a.R;
   float* wr = a.Wt + row * a.R;
-  for (int j = 0; j < a.R; ++j) {
+  for (int j = q; j < a.R; j += 4) {
     const int seg = j < a.cn ? 0 : 1;
-    const float w = expf(ca_dot<C>(x, KT + j * C) - m[seg]) * inv[seg];
-    const float ds = w * (ca_dot<C>(G, V + j * C) - t[seg]);
+    const float w = expf(ca_dot<C>(x, KT + j * CP) - m[seg]) * inv[seg];
+    const float ds = w * (ca_dot<C>(G, V + j * CP) - t[seg]);
 #pragma unroll
     for (int c = 0; c < C; c += 4) {
-      const float4 k = *reinterpret_cast<const float4*>(KT + j * C + c);
+      const float4 k = *reinterpret_cast<const float4*>(KT + j * CP + c);
       dx[c] += ds * k.x, dx[c + 1] += ds * k.y, dx[c + 2] += ds * k.z, dx[c + 3] += ds * k.w;
     }
     if (valid) dsr[j] = ds, wr[j] = w;
   }
+#pragma unroll
+  for (int c = 0; c < C; ++c) dx[c] = G[c] + quad_sum(dx[c]);
   if (!valid) return;
 #pragma unroll
-  for (int c = 0; c < C; c += 4) {
-    *reinterpret_cast<float4*>(a.gx + row * C + c) = make_float4(dx[c], dx[c + 1], dx[c + 2], dx[c + 3]);
-    *reinterpret_cast<float4*>(a.G + row * C + c) = make_float4(G[c], G[c + 1], G[c + 2], G[c + 3]);
-  }
+  for (int c = 0; c < C; c += 4)
+    if (((c >> 2) & 3) == q) {
+      *reinterpret_cast<float4*>(a.gx + row * C + c) = make_float4(dx[c], dx[c + 1], dx[c + 2], dx[c + 3]);
+      *reinterpret_cast<float4*>(a.G + row * C + c) = make_float4(G[c], G[c + 1], G[c + 2], G[c + 3]);
+    }
 }
 
 // backward, per-cloud half: gKp[c][j] = sum_p x[p][c] dS[p][j],  gVp[j][c] = sum_p w[p][j] G[p][c]  over the points of
-// one slice of a cloud; tiles of 32 points through LDS, each thread accumulates 4 x 4 blocks of both products, partial
-// sums leave through (row-contiguous) float atomics into the zero-filled outputs.
+// one slice of a cloud; tiles of 32 points through LDS, each thread accumulates 4 x 4 blocks of both products. The
+// slices' partial sums are plain stores into part[b][slice][2 C R] (no float atomics: deterministic), folded by
+// curve_attn_fold_kernel.
 constexpr int CA_PT = 32;   // points per LDS tile
 
 template <int C>
-__global__ __launch_bounds__(256) void curve_attn_bwd_cloud_kernel(CurveAttnArgs a, float* __restrict__ gKp,
-                                                                   float* __restrict__ gVp, int per_split) {
+__global__ __launch_bounds__(256) void curve_attn_bwd_cloud_kernel(CurveAttnArgs a, float* __restrict__ part,
+                                                                   int per_split) {
   extern __shared__ __attribute__((aligned(16))) float ca_lds[];
   const int R = a.R, R4 = (R + 3) / 4, Rp = 4 * R4;
   float* Xt = ca_lds;               // [CA_PT][C]
@@ -347,11 +379,12 @@ __global__ __launch_bounds__(256) void curve_attn_bwd_cloud_kernel(CurveAttnArgs
   for (int q0 = p0; q0 < p1; q0 += CA_PT) {
     const int np = min(CA_PT, p1 - q0);
     __syncthreads();
-    for (int e = threadIdx.x; e < CA_PT * C; e += 256) {
-      const int q = e / C;
-      const int64_t src = ((int64_t)b * a.N + q0 + q) * C + (e - q * C);
-      Xt[e] = q < np ? a.x[src] : 0.f;
-      Gt[e] = q < np ? a.G[src] : 0.f;
+    for (int e = threadIdx.x; e < CA_PT * (C / 4); e += 256) {      // rows of x / G are contiguous: float4 copies
+      const int q = e / (C / 4), c4 = e - q * (C / 4);
+      const int64_t src = ((int64_t)b * a.N + q0 + q) * C + 4 * c4;
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(Xt + q * C + 4 * c4) = q < np ? *reinterpret_cast<const float4*>(a.x + src) : z;
+      *reinterpret_cast<float4*>(Gt + q * C + 4 * c4) = q < np ? *reinterpret_cast<const float4*>(a.G + src) : z;
     }
     for (int e = threadIdx.x; e < CA_PT * Rp; e += 256) {
       const int q = e / Rp, j = e - q * Rp;
@@ -383,6 +416,8 @@ __global__ __launch_bounds__(256) void curve_attn_bwd_cloud_kernel(CurveAttnArgs
       }
     }
   }
+  float* pk = part + ((int64_t)b * gridDim.x + blockIdx.x) * 2 * C * R;   // [C][R] then [R][C]
+  float* pv = pk + C * R;
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int it = threadIdx.x + 256 * u;
@@ -394,11 +429,24 @@ __global__ __launch_bounds__(256) void curve_attn_bwd_cloud_kernel(CurveAttnArgs
       for (int ji = 0; ji < 4; ++ji) {
         const int c = 4 * cg + ci, j = 4 * jg + ji;
         if (j < R) {
-          atomicAdd(gKp + ((int64_t)b * C + c) * R + j, accK[u][ci * 4 + ji]);
-          atomicAdd(gVp + ((int64_t)b * R + j) * C + c, accV[u][ji * 4 + ci]);
+          pk[c * R + j] = accK[u][ci * 4 + ji];
+          pv[j * C + c] = accV[u][ji * 4 + ci];
         }
       }
   }
+}
+
+// gKp[b] | gVp[b] = sum over the slices (fixed order) of part[b][slice]
+__global__ __launch_bounds__(256) void curve_attn_fold_kernel(const float* __restrict__ part, int nsplit, int CR,
+                                                              float* __restrict__ gKp, float* __restrict__ gVp) {
+  const int b = blockIdx.y;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= 2 * CR) return;
+  const float* src = part + (int64_t)b * nsplit * 2 * CR + e;
+  float s = 0.f;
+  for (int k = 0; k < nsplit; ++k) s += src[(int64_t)k * 2 * CR];
+  if (e < CR) gKp[(int64_t)b * CR + e] = s;
+  else gVp[(int64_t)b * CR + e - CR] = s;
 }
 
 }  // namespace pc3d
@@ -496,14 +544,24 @@ extern "C" int pc3d_curve_attn_f32(const float* x, const float* Kp, const float*
   PC3D_REQUIRE(x && Kp && Vp && out, "pc3d_curve_attn_f32: null pointer");
   CurveAttnArgs a{};
   a.x = x, a.Kp = Kp, a.Vp = Vp, a.N = N, a.cn = cn, a.R = cn + cl, a.slope = slope, a.out = out;
-  const size_t lds = (size_t)2 * a.R * C * sizeof(float);
-  PC3D_CA_DISPATCH(C, curve_attn_fwd_kernel, dim3(cdiv(N, 256), B), dim3(256), lds, as_stream(stream), a);
+  const size_t lds = (size_t)2 * a.R * (C + 4) * sizeof(float);
+  PC3D_CA_DISPATCH(C, curve_attn_fwd_kernel, dim3(cdiv(N, CA_PPW), B), dim3(256), lds, as_stream(stream), a);
   PC3D_LAUNCH_CHECK("pc3d_curve_attn_f32");
   return PC3D_OK;
 }
 
+// slices of a cloud for the per-cloud half of the backward: ~128 points each, at least one LDS tile, enough of them
+// that B * nsplit covers the chip
+static int curve_attn_per_split(int B, int N) {
+  int per_split = 128;
+  while (per_split > CA_PT && (int64_t)B * cdiv(N, per_split) < 512) per_split /= 2;
+  return per_split;
+}
+
 extern "C" int64_t pc3d_curve_attn_bwd_ws_floats(int B, int N, int C, int cn, int cl) {
-  return (int64_t)B * N * (2 * (int64_t)(cn + cl) + C);
+  if (B <= 0 || N <= 0) return 0;
+  const int64_t R = cn + cl;
+  return (int64_t)B * N * (2 * R + C) + (int64_t)B * cdiv(N, curve_attn_per_split(B, N)) * 2 * C * R;
 }
 
 extern "C" int pc3d_curve_attn_bwd_f32(const float* gout, const float* out, const float* x, const float* Kp,
@@ -519,21 +577,16 @@ extern "C" int pc3d_curve_attn_bwd_f32(const float* gout, const float* out, cons
   a.gout = gout, a.gx = gx;
   a.dS = ws, a.Wt = ws + (int64_t)B * N * R, a.G = ws + 2 * (int64_t)B * N * R;
   hipStream_t st = as_stream(stream);
-  hipError_t e = zero_async(gKp, (size_t)B * C * R, st);
-  if (e == hipSuccess) e = zero_async(gVp, (size_t)B * C * R, st);
-  if (e != hipSuccess) {
-    set_error("pc3d_curve_attn_bwd_f32: zero fill failed: %s", hipGetErrorString(e));
-    return (int)e;
-  }
-  const size_t lds = (size_t)2 * R * C * sizeof(float);
-  PC3D_CA_DISPATCH(C, curve_attn_bwd_point_kernel, dim3(cdiv(N, 256), B), dim3(256), lds, st, a);
+  const size_t lds = (size_t)2 * R * (C + 4) * sizeof(float);
+  PC3D_CA_DISPATCH(C, curve_attn_bwd_point_kernel, dim3(cdiv(N, CA_PPW), B), dim3(256), lds, st, a);
   PC3D_LAUNCH_CHECK("pc3d_curve_attn_bwd_f32/point");
-  // slices of ~128 points per workgroup (at least one LDS tile), so that B * nsplit covers the chip
-  int per_split = 128;
-  while (per_split > CA_PT && (int64_t)B * cdiv(N, per_split) < 512) per_split /= 2;
+  const int per_split = curve_attn_per_split(B, N), nsplit = cdiv(N, per_split);
+  float* part = ws + (int64_t)B * N * (2 * R + C);
   const int Rp = 4 * ((R + 3) / 4);
   const size_t lds2 = (size_t)(2 * CA_PT * C + 2 * CA_PT * Rp) * sizeof(float);
-  PC3D_CA_DISPATCH(C, curve_attn_bwd_cloud_kernel, dim3(cdiv(N, per_split), B), dim3(256), lds2, st, a, gKp, gVp, per_split);
+  PC3D_CA_DISPATCH(C, curve_attn_bwd_cloud_kernel, dim3(nsplit, B), dim3(256), lds2, st, a, part, per_split);
   PC3D_LAUNCH_CHECK("pc3d_curve_attn_bwd_f32/cloud");
+  hipLaunchKernelGGL(curve_attn_fold_kernel, dim3(cdiv(2 * C * R, 256), B), dim3(256), 0, st, part, nsplit, C * R, gKp, gVp);
+  PC3D_LAUNCH_CHECK("pc3d_curve_attn_bwd_f32/fold");
   return PC3D_OK;
 }
