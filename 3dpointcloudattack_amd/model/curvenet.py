@@ -1,5 +1,6 @@
 """CurveNet classifier — MI355X mirror of model/curvenet.py:11-73 (same module tree / state_dict keys; returns RAW
 logits three times like the reference)."""
+import torch
 import torch.nn as nn
 
 from .. import ops
@@ -16,6 +17,7 @@ class CurveNet(_FrozenFusedMixin, nn.Module):
     # forward is a pure function of its input: attack loops may share / replay it. Its only RNG use is the discarded
     # FPS start draw (curvenet_util.hold_rng_position), which a hipGraph replay re-issues through consume_forward_rng.
     deterministic_forward = True
+    geometry_stream = True      # FPS / ball queries / kNN graphs on a side stream beside the feature path
 
     def _blocks(self):
         return (self.cic11, self.cic12, self.cic21, self.cic22, self.cic31, self.cic32, self.cic41, self.cic42)
@@ -51,21 +53,53 @@ class CurveNet(_FrozenFusedMixin, nn.Module):
         self.dp1 = nn.Dropout(p=0.5)
         self._folded_cache = None
 
+    def _geometry(self, pos):
+        """Everything in a forward that depends on the COORDINATES only — the FPS chain, the ball queries of the
+        down-sampling blocks and the kNN graph of every resolution (curvenet_util.py:69-113, :10-17) — for detached
+        pos [B,N,3], on the current stream: one (pool, graph, event) entry per block. FPS is a chain of npoint dependent
+        arg-max steps on one workgroup per cloud (0.9 ms for 4096 -> 1024 at B=32, on 32 of 256 CUs): forward() runs
+        this on a side stream beside the feature path, which waits for each level's event where it needs it."""
+        B = pos.shape[0]
+        levels, graphs, pts = [], {}, pos
+        for blk in self._blocks():
+            pool = None
+            if pts.shape[1] != blk.npoint:
+                hold_rng_position(B, pts.shape[1])
+                fps_idx = ops.fps(pts, blk.npoint, None)
+                sub = ops.group_gather(pts, None, fps_idx.view(B, blk.npoint, 1)).view(B, blk.npoint, 3)
+                pool = (fps_idx, ops.ball_query(blk.radius, blk.k, pts, sub))
+                pts = sub
+            key = (pts.shape[1], blk.k)
+            if key not in graphs:
+                idx = ops.knn_raw(pts, pts, blk.k + 1)[1]
+                graphs[key] = (idx, idx[:, :, 1:].contiguous(), idx[:, :, :blk.k].contiguous())
+            ev = torch.cuda.Event()
+            ev.record()
+            levels.append((pool, graphs[key], ev))
+        return levels
+
     def forward(self, xyz):
         self._require_fused(xyz)
         # channels-last from here on: every block is a chain of this library's launches on [B,N,C] rows
         pos = xyz.float().transpose(1, 2).contiguous()
-        feats = self.lpfa(None, pos, None, cl=True)
         blocks = self._blocks()
-        graphs = {}                                  # kNN graphs of THIS forward, shared by blocks at one resolution
-        for blk in blocks:
-            object.__setattr__(blk, "_graph_cache", graphs)
-        try:
-            for blk in blocks:
-                pos, feats = blk(pos, feats, cl=True)
-        finally:
-            for blk in blocks:
-                object.__setattr__(blk, "_graph_cache", None)
+        cur = torch.cuda.current_stream()
+        with torch.no_grad():
+            if self.geometry_stream:
+                side = self.__dict__.get("_side_stream")
+                if side is None or side.device != pos.device:
+                    side = torch.cuda.Stream(device=pos.device)
+                    object.__setattr__(self, "_side_stream", side)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    levels = self._geometry(pos.detach())
+            else:
+                levels = self._geometry(pos.detach())
+        feats = self.lpfa(None, pos, None, cl=True)
+        for blk, geo in zip(blocks, levels):
+            pos, feats = blk(pos, feats, cl=True, geo=geo)
+        if self.geometry_stream:
+            cur.wait_stream(side)          # join (every event above has been waited for; keeps captures well-formed)
         # conv0's ReLU is applied inside the pooling launch: [max_i relu(y) | mean_i relu(y)] (:66-68)
         x = ops.act_maxmean_pool(pw_cl(self.conv0, feats, act=(None, 0.0)), 0.0)
         x = pw_cl(self.conv1, x, bn=self.bn1, act=("relu", 0.0))

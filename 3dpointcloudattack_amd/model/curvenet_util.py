@@ -342,11 +342,12 @@ class CIC(nn.Module):
         self.maxpool = MaskedMaxPool(npoint, radius, k)
         self.lpfa = LPFA(planes, planes, k, mlp_num=mlp_num, initial=False)
 
-    def forward(self, xyz, x, cl=False):
+    def forward(self, xyz, x, cl=False, geo=None):
         """Reference layout (default): xyz [B,3,N], x [B,C,N] -> (xyz' [B,3,N'], [B,C',N']). cl=True: channels-last
-        xyz [B,N,3], x [B,N,C] -> ([B,N',3], [B,N',C']); the block itself always runs channels-last."""
+        xyz [B,N,3], x [B,N,C] -> ([B,N',3], [B,N',C']); the block itself always runs channels-last. geo: this block's
+        entry of CurveNet._geometry (sampling / ball-query / graph indices computed ahead on another stream)."""
         if cl:
-            return self._forward_cl(xyz, x)
+            return self._forward_cl(xyz, x, geo)
         pts, y = self._forward_cl(_cl(xyz), _cl(x))
         return (xyz if pts.shape[1] == xyz.shape[2] else _cf(pts)), _cf(y)
 
@@ -365,12 +366,16 @@ class CIC(nn.Module):
             cache[(id(pts), self.k)] = (pts, g)
         return g
 
-    def _forward_cl(self, pts, x):
+    def _forward_cl(self, pts, x, geo=None):
+        pool = graph = None
+        if geo is not None:
+            pool, graph, ready = geo
+            torch.cuda.current_stream().wait_event(ready)
         if pts.shape[1] != self.npoint:                            # FPS + ball-query max-pool down-sampling
-            pts, x = self.maxpool(pts, x, cl=True)
+            pts, x = self.maxpool(pts, x, cl=True, geo=pool)
         shortcut = x
         x = pw_cl(self.conv1, x)
-        _, adj, nbr = self._graph(pts)
+        _, adj, nbr = graph if graph is not None else self._graph(pts)
         if self.use_curve:
             curves = self.curvegrouping(x, pts, adj, cl=True)      # adj: no self-loops
             x = self.curveaggregation(x, curves, cl=True)
@@ -484,17 +489,21 @@ class MaskedMaxPool(nn.Module):
         self.radius = radius
         self.k = k
 
-    def forward(self, xyz, features, cl=False):
+    def forward(self, xyz, features, cl=False, geo=None):
         """Reference layout (default): xyz [B,N,3], features [B,C,N] -> ([B,S,3], [B,C,S]); cl=True: features [B,N,C]
         -> [B,S,C]. FPS (start index 0, :81) + ball query + max over each ball in one gather-max launch instead of the
-        [B,S,k,C] grouped tensor."""
+        [B,S,k,C] grouped tensor. geo = (fps_idx, ball-query idx) when CurveNet._geometry has computed them ahead."""
         if not cl:
             sub, y = self.forward(xyz, _cl(features), cl=True)
             return sub, _cf(y)
         xyz = xyz.float()
         B = xyz.shape[0]
-        hold_rng_position(B, xyz.shape[1])
-        fps_idx = ops.fps(xyz, self.npoint, None)
+        if geo is None:
+            hold_rng_position(B, xyz.shape[1])
+            fps_idx = ops.fps(xyz, self.npoint, None)
+        else:
+            fps_idx, idx = geo
         sub_xyz = ops.group_gather(xyz, None, fps_idx.view(B, self.npoint, 1)).view(B, self.npoint, 3)
-        idx = ops.ball_query(self.radius, self.k, xyz, sub_xyz)
+        if geo is None:
+            idx = ops.ball_query(self.radius, self.k, xyz, sub_xyz)
         return sub_xyz, ops.gather_max_rows(features, idx)

@@ -300,3 +300,29 @@ def test_curvenet_stage_trace_vs_reference(dev):
     errs = dict((r[0], r[1]) for r in report)
     assert errs["lpfa"] < 1e-5
     assert max(errs.values()) < 5e-2, report
+
+
+def test_geometry_side_stream_equals_inline(dev):
+    """CurveNet.forward computes the FPS chain / ball queries / kNN graphs on a side stream beside the feature path
+    (CurveNet._geometry): same logits bit for bit as the inline order, same input gradient up to the float-atomic
+    order noise of the scatter kernels, and the CPU generator advances identically (the discarded FPS start draws)."""
+    cn = importlib.import_module("3dpointcloudattack_amd.model.curvenet")
+    m = cn.CurveNet(num_classes=40)
+    m.load_state_dict(ort.seeded_state_dict(m, 9))
+    m = m.eval().to(dev)
+    g = torch.Generator().manual_seed(4)
+    x0 = (torch.rand(3, 3, 2048, generator=g) - 0.5).to(dev)
+    up = torch.randn(3, 40, generator=g).to(dev)
+    res = []
+    for side in (True, False, True):
+        m.geometry_stream = side
+        torch.manual_seed(11)
+        x = x0.clone().requires_grad_()
+        logits = m(x)[0]
+        (logits * up).sum().backward()
+        res.append((logits.detach().clone(), x.grad.clone(), torch.rand(1).item()))
+    m.geometry_stream = True
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][0], res[2][0])
+    assert res[0][2] == res[1][2]
+    for a in (res[1][1], res[2][1]):
+        assert float((a - res[0][1]).norm() / res[0][1].norm()) < 1e-4
