@@ -130,9 +130,10 @@ __global__ __launch_bounds__(KF_T) void knn_feat_kernel(KnnFeatArgs a) {
       if (blk == 0 && s == 0) {
 #pragma unroll
         for (int u = 0; u < KF_QW; ++u) {      // seed: sort the first 64 candidates
-          float sd = (d[u] == d[u]) ? d[u] : __builtin_inff();
+          int sk = knn_ord((d[u] == d[u]) ? d[u] : __builtin_inff());
           int si = lane;
-          wave_sort_pairs(sd, si, lane);
+          wave_sort_pairs_dpp(sk, si, lane);
+          const float sd = knn_unord(sk);
           ld[u] = sd, li[u] = si;
           thr[u] = readlane_f(sd, K - 1);
         }

@@ -27,6 +27,70 @@ __device__ __forceinline__ void wave_sort_pairs(float& d, int& i, int lane) {
   }
 }
 
+// ---- the same sort without a single LDS round trip (ds_bpermute + s_waitcnt per exchange made the seed sorts of the
+// kNN kernels cost as much as their MFMA work): partners through DPP (quad_perm / row_half_mirror / row_mirror /
+// row_ror / bank-masked row shifts) and v_permlane{16,32}_swap, keys compared as ONE signed 64-bit integer
+// (order-preserving distance bits : index), and the bitonic network in its uniform-direction form (first exchange of
+// every merge against lane ^ (k-1), the rest against lane ^ j: the LOWER lane always keeps the minimum), so the
+// "who takes" predicate is the compare mask XNOR a constant: v_cmp_lt_i64, two s_xor_b32, two v_cndmask per exchange.
+__device__ __forceinline__ int knn_ord(float f) {   // monotone float <-> signed int, an involution
+  const int b = __builtin_bit_cast(int, f);
+  return b ^ ((b >> 31) & 0x7fffffff);
+}
+__device__ __forceinline__ float knn_unord(int i) { return __builtin_bit_cast(float, i ^ ((i >> 31) & 0x7fffffff)); }
+
+using knn_u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+
+template <int M>
+__device__ __forceinline__ int lane_xor(int x, int lane) {   // value of lane ^ M
+  if constexpr (M == 1) return __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xf, 0xf, false);        // quad_perm [1,0,3,2]
+  else if constexpr (M == 2) return __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+  else if constexpr (M == 3) return __builtin_amdgcn_update_dpp(x, x, 0x1B, 0xf, 0xf, false);   // quad_perm [3,2,1,0]
+  else if constexpr (M == 4) {
+    const int t = __builtin_amdgcn_update_dpp(x, x, 0x104, 0xf, 0x5, false);                    // row_shl:4, banks 0, 2
+    return __builtin_amdgcn_update_dpp(t, x, 0x114, 0xf, 0xa, false);                           // row_shr:4, banks 1, 3
+  } else if constexpr (M == 7) return __builtin_amdgcn_update_dpp(x, x, 0x141, 0xf, 0xf, false);   // row_half_mirror
+  else if constexpr (M == 8) return __builtin_amdgcn_update_dpp(x, x, 0x128, 0xf, 0xf, false);     // row_ror:8
+  else if constexpr (M == 15) return __builtin_amdgcn_update_dpp(x, x, 0x140, 0xf, 0xf, false);    // row_mirror
+  else if constexpr (M == 16) {
+    const knn_u32x2 r = __builtin_amdgcn_permlane16_swap((unsigned)x, (unsigned)x, false, false);
+    const unsigned r0 = r[0], r1 = r[1];     // (copied to scalars first: a swizzle fed to a cast reads element 0)
+    return (int)((lane & 16) ? r0 : r1);
+  } else if constexpr (M == 32) {
+    const knn_u32x2 r = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false);
+    const unsigned r0 = r[0], r1 = r[1];
+    return (int)((lane & 32) ? r0 : r1);
+  } else if constexpr (M == 31) return lane_xor<16>(lane_xor<15>(x, lane), lane);
+  else {
+    static_assert(M == 63, "lane_xor: unsupported mask");
+    return lane_xor<32>(lane_xor<16>(lane_xor<15>(x, lane), lane), lane);
+  }
+}
+
+template <int M, unsigned long long LOWER>
+__device__ __forceinline__ void knn_cmpx(int& key, int& idx, int lane) {
+  const int ok = lane_xor<M>(key, lane), oi = lane_xor<M>(idx, lane);
+  const long long self = ((long long)key << 32) | (unsigned)idx, other = ((long long)ok << 32) | (unsigned)oi;
+  const unsigned long long less = __builtin_amdgcn_ballot_w64(other < self);
+  const bool take = __builtin_amdgcn_inverse_ballot_w64(~(less ^ LOWER));   // lower lane: other < self; upper: other > self
+  key = take ? ok : key;
+  idx = take ? oi : idx;
+}
+
+// ascending (key, idx) over the lanes; idx >= 0 and all (key, idx) pairs distinct
+__device__ __forceinline__ void wave_sort_pairs_dpp(int& key, int& idx, int lane) {
+  constexpr unsigned long long L1 = 0x5555555555555555ull, L2 = 0x3333333333333333ull, L4 = 0x0f0f0f0f0f0f0f0full,
+                               L8 = 0x00ff00ff00ff00ffull, L16 = 0x0000ffff0000ffffull, L32 = 0x00000000ffffffffull;
+  knn_cmpx<1, L1>(key, idx, lane);
+  knn_cmpx<3, L2>(key, idx, lane), knn_cmpx<1, L1>(key, idx, lane);
+  knn_cmpx<7, L4>(key, idx, lane), knn_cmpx<2, L2>(key, idx, lane), knn_cmpx<1, L1>(key, idx, lane);
+  knn_cmpx<15, L8>(key, idx, lane), knn_cmpx<4, L4>(key, idx, lane), knn_cmpx<2, L2>(key, idx, lane), knn_cmpx<1, L1>(key, idx, lane);
+  knn_cmpx<31, L16>(key, idx, lane), knn_cmpx<8, L8>(key, idx, lane), knn_cmpx<4, L4>(key, idx, lane);
+  knn_cmpx<2, L2>(key, idx, lane), knn_cmpx<1, L1>(key, idx, lane);
+  knn_cmpx<63, L32>(key, idx, lane), knn_cmpx<16, L16>(key, idx, lane), knn_cmpx<8, L8>(key, idx, lane);
+  knn_cmpx<4, L4>(key, idx, lane), knn_cmpx<2, L2>(key, idx, lane), knn_cmpx<1, L1>(key, idx, lane);
+}
+
 // wave-wide minimum of one float per lane (DPP row shifts + row broadcasts; min is idempotent, so overlapping
 // contributions are harmless); the result is returned as a wave-uniform value
 __device__ __forceinline__ float wave_min_dpp(float v) {
@@ -51,6 +115,9 @@ extern "C" __device__ int knn_writelane(int value, int lane, int old) __asm("llv
 // distances keep the lower index first); the entry in lane 63 falls off. The list is sorted, so the lanes with
 // ld <= dc are exactly the lanes below the insertion point: the compare's 64-bit mask IS the "keep" predicate of the
 // shift (one v_cmp, two DPP moves, two v_cndmask on that mask, two v_writelane for the new entry — 7 VALU).
+// (Round 2, measured: a 5-VALU form — EXEC narrowed to the lanes above the candidate, in-place DPP shifts, v_writelane —
+// in inline assembly changed neither kNN kernel's time: the insertions are bound by the latency of their
+// VALU -> SALU -> VALU hops and taken branches, not by VALU issue.)
 __device__ __forceinline__ void knn_list_insert(float& ld, int& li, float dc, int ic, int lane) {
   const bool k = ld <= dc;
   const int pos = __builtin_popcountll(__builtin_amdgcn_ballot_w64(k));
