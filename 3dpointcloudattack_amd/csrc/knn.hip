@@ -101,9 +101,10 @@ __global__ __launch_bounds__(kKwWaves * 64) void knn_wave_kernel(KnnArgs a) {
           if (K > 10) {                             // larger K: one bitonic sort per query is cheaper than K rounds
 #pragma unroll
             for (int u = 0; u < kKwQPW; ++u) {
-              float sd = rem[u];
+              int sk = knn_ord(rem[u]);
               int si = lane;
-              wave_sort_pairs(sd, si, lane);
+              wave_sort_pairs_dpp(sk, si, lane);   // no LDS round trips (knn_list.h)
+              const float sd = knn_unord(sk);
               ld[p][u] = sd, li[p][u] = si;
               thr[p][u] = readlane_f(sd, K - 1);
             }
