@@ -126,9 +126,12 @@ __global__ __launch_bounds__(WAVES * 64) void nn_kernel(NNArgs args, int mt_cap)
 
   // merge the four waves' candidates (ascending wave = ascending reference index inside a tile; across
   // tiles compare indices explicitly so the lowest index wins ties)
+  // (the merge area sits BEHIND the staged tile: when the whole reference cloud fitted one tile it is still there,
+  // and the arg-min below is resolved from LDS instead of eight dependent global loads per query)
   __syncthreads();
-  float* cd = lds;                                        // [kNNWaves][64*Q]
-  int* ci = reinterpret_cast<int*>(lds + kNNWaves * kWave * Q);
+  float* cd = lds + 3 * mt_pad;                           // [kNNWaves][64*Q]
+  int* ci = reinterpret_cast<int*>(cd + kNNWaves * kWave * Q);
+  const bool resident = M <= mt;
 #pragma unroll
   for (int k = 0; k < Q; ++k) {
     cd[wave * (kWave * Q) + k * kWave + lane] = best[k];
@@ -156,12 +159,18 @@ __global__ __launch_bounds__(WAVES * 64) void nn_kernel(NNArgs args, int mt_cap)
         const float* qp = qb + (int64_t)qi * D.q.ps;
         const float x = qp[0], y = qp[D.q.cs], z = qp[2 * D.q.cs];
         int arg = bi;
+        if (resident) {        // bi is a multiple of 8 inside the staged (padded with far sentinels) tile
 #pragma unroll
-        for (int e = kNNChunk - 1; e >= 0; --e) {
-          const int m = bi + e;
-          if (m < M) {
-            const float* rp = rb + (int64_t)m * D.r.ps;
-            if (nn_dist(rp[0], rp[D.r.cs], rp[2 * D.r.cs], x, y, z) == bd) arg = m;
+          for (int e = kNNChunk - 1; e >= 0; --e)
+            if (nn_dist(sx[bi + e], sy[bi + e], sz[bi + e], x, y, z) == bd) arg = bi + e;
+        } else {
+#pragma unroll
+          for (int e = kNNChunk - 1; e >= 0; --e) {
+            const int m = bi + e;
+            if (m < M) {
+              const float* rp = rb + (int64_t)m * D.r.ps;
+              if (nn_dist(rp[0], rp[D.r.cs], rp[2 * D.r.cs], x, y, z) == bd) arg = m;
+            }
           }
         }
         D.i[(int64_t)b * N + qi] = arg;
@@ -536,7 +545,7 @@ static size_t nn_lds_bytes(int M, int Q, int waves, int* mt_cap_out) {
   const size_t tile = (size_t)3 * slice * waves * sizeof(float);
   const size_t merge = (size_t)waves * kWave * Q * 8;
   *mt_cap_out = cap;
-  return tile > merge ? tile : merge;
+  return tile + merge;
 }
 
 static int nn_launch(const NNArgs& a, int ndir, int B, hipStream_t st) {
@@ -553,6 +562,7 @@ static int nn_launch(const NNArgs& a, int ndir, int B, hipStream_t st) {
   if (q_total / (kWave * 2) < 1024) Q = 1;
   // Small problems are bound by each workgroup's latency chain (stage the tile, scan it, merge), not by issue rate:
   // eight waves split the staged tile instead of four, halving the scan each wave walks.
+  // (sixteen waves per workgroup measured no better: 16.4 against 14.4 us for both directions at B=32, N=1024)
   const int waves = (Q == 1 && maxM >= 512) ? 8 : 4;
   int mt_cap;
   const size_t lds = nn_lds_bytes(maxM, Q, waves, &mt_cap);
@@ -578,12 +588,16 @@ static NNSharedPlan nn_shared_plan(int B, int N, int M) {
   p.Q = N > 2 * kWave ? 4 : (N > kWave ? 2 : 1);
   p.tileA = kWave * p.Q;
   p.tilesA = cdiv(N, p.tileA);
-  // Eight workgroups per CU's worth of grid (measured at B=32: N=4096 106 -> 97 us, N=2048 30.6 -> 29.9 against four),
-  // but at least two butterflies of B per wave: below that the per-workgroup prologue / merge dominates (N=1024).
+  // Sixteen workgroups per CU's worth of grid, in slices of at least two butterflies of B per wave — one butterfly
+  // where the grid would otherwise stay under four workgroups per CU. Measured inside replayed graphs at B=32
+  // (tools/exp/tune_nn_shared.py; values only / with indices, us): target 2048 workgroups N=1024 12.3 / 14.7,
+  // N=2048 27.4 / 31.9, N=4096 90.4 / 110.4; this rule 10.9 / 13.1, 26.5 / 31.0, 87.1 / 100.3. (Q = 2 instead of 4:
+  // 12-20 % slower at every size.)
   const long wgs = (long)p.tilesA * (B > 0 ? B : 1);
-  int ns = (int)((2048 + wgs - 1) / wgs);
+  int ns = (int)((4096 + wgs - 1) / wgs);
   const int gran = kNNWaves * kNNTree;
-  const int max_ns = cdiv(M, 2 * gran);
+  int max_ns = cdiv(M, 2 * gran);
+  if (wgs * (ns < max_ns ? ns : max_ns) < 1024) max_ns = cdiv(M, gran);
   if (ns > max_ns) ns = max_ns;
   if (ns < 1) ns = 1;
   p.per_split = cdiv(cdiv(M, ns), gran) * gran;

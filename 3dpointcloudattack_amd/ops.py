@@ -79,8 +79,10 @@ def _nn_workspace(dev, nbytes):
 _NN_KEEP = []
 
 
-NN_SHARED_MIN_PAIRS = 1 << 26    # B*N*M from which the shared-evaluation search wins (measured, MI355X: at B=32 the
-                                 # two-scan kernel takes 16.8 us at N=1024 against 20.1; 43.8 against 28.5 at N=2048)
+NN_SHARED_MIN_PAIRS = 1 << 25    # B*N*M from which the shared-evaluation search wins. Measured on MI355X inside replayed
+                                 # hipGraphs (tools/bench_nn_small.py; eager calls at these sizes time the host): B=32,
+                                 # N=1024 (2^25 pairs) 14.2 us with indices / 11.8 values only against 14.4 for the two-scan
+                                 # kernel; B=32, N=512 8.8 against 5.9; B=8, N=1024 8.9 against 6.4
 
 
 def nn_bidir_raw(a, b, a_cf=False, b_cf=False, want_idx=True, two_scan=None):

@@ -68,7 +68,14 @@ def chamfer_cpu_baseline():
     from oracle import ref_numpy as orn
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     torch.set_num_threads(max(1, min(16, ncpu)))
-    res = {"numpy_f64_ms_per_pair": {}, "torch_cpu_ms_per_pair": {}, "cores": torch.get_num_threads(), "kind": "port"}
+    res = {"numpy_f64_ms_per_pair": {}, "torch_cpu_ms_per_pair": {}, "c_scalar_ms_per_pair": {},
+           "cores": torch.get_num_threads(), "c_scalar_cores": 1, "kind": "port"}
+    clib = None
+    cso = os.path.join(ROOT, "oracle", "_build", "libref_c.so")      # the plain-C restatement (oracle/ref_c.c), one thread
+    if os.path.exists(cso):
+        import ctypes
+        clib = ctypes.CDLL(cso)
+        clib.refc_chamfer.restype = ctypes.c_double
     for n in (1024, 2048, 4096):
         rs = np.random.default_rng(99 + n)
         a = unit_cloud(rs, n)
@@ -78,7 +85,13 @@ def chamfer_cpu_baseline():
         def torch_path():
             m = torch.cdist(ta, tb, p=2)
             return float(m.min(dim=2)[0].mean() + m.min(dim=1)[0].mean())
-        for key, fn in (("numpy_f64_ms_per_pair", lambda: orn.chamfer(a, b)), ("torch_cpu_ms_per_pair", torch_path)):
+        paths = [("numpy_f64_ms_per_pair", lambda: orn.chamfer(a, b)), ("torch_cpu_ms_per_pair", torch_path)]
+        if clib is not None:
+            w1, w2 = np.empty(n), np.empty(n)
+            i1, i2 = np.empty(n, np.int64), np.empty(n, np.int64)
+            ptr = lambda x: x.ctypes.data_as(ctypes.c_void_p)                      # noqa: E731
+            paths.append(("c_scalar_ms_per_pair", lambda: clib.refc_chamfer(ptr(a), n, ptr(b), n, ptr(w1), ptr(i1), ptr(w2), ptr(i2))))
+        for key, fn in paths:
             fn(), fn()
             ts = []
             for _ in range(3):
@@ -163,6 +176,7 @@ def main():
     dist_utils = M("3dpointcloudattack_amd.attack.CW.CW_utils.dist_utils")
     clip_utils = M("3dpointcloudattack_amd.attack.CW.CW_utils.clip_utils")
     sharding = M("3dpointcloudattack_amd.sharding")
+    graphed = M("3dpointcloudattack_amd.graphed")
 
     # frozen victim weights: built on rank 0, one RCCL broadcast of the flattened blob, never touched again
     model = PointNetCls(k=NCLS, feature_transform=False)
@@ -229,10 +243,114 @@ def main():
     ms_per_step = elapsed * 1e3 / args.steps
     iters_per_s = world * args.steps / elapsed     # whole job: every rank advances its own batch each step
 
+    stream = torch.cuda.current_stream()
+    # ---- kernel-level measurements on rank 0, right after the headline loop (same clocks / thermal state; the sweep
+    # below runs several seconds of other work first otherwise)
+    roofline = chamfer = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel: the fused per-point MLP + max forward (fp32 MFMA)
+        x = st["adv"].detach()
+        tower = model.feat.folded()
+        flops = 2.0 * B * NPTS * (3 * 64 + 64 * 128 + 128 * 1024)   # DESIGN.md: algorithmic flops per launch
+        for _ in range(5):
+            ops.pointmlp3_max_fwd_raw(x, tower, False, fold=False)
+        k_ms = ev_ms(lambda: ops.pointmlp3_max_fwd_raw(x, tower, False, fold=False), 50, stream)
+        ach = flops / (k_ms * 1e-3) / 1e12
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r02_pmc_hbm_counters.json")
+        if os.path.exists(pmc):
+            # HBM bytes per launch from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE
+            # runs of this same command at this round's kernels, KiB units). gfx950 correction (MI355X_MICROARCH.md
+            # §HBM): FETCH_SIZE counts 64 B per 128-B request for 16-B-per-lane reads -> doubled; WRITE_SIZE is exact.
+            # (PMC collection needs the rocprofv3 wrapper, so it cannot run inside this process; the file is regenerated
+            # by tools/prof_pmc.sh whenever a kernel on this line changes.)
+            pj = json.load(open(pmc))
+            c = pj.get("pc3d::pointmlp3_max_fwd_kernel|grid=131072|run=0")
+            if c and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                traffic = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+        roofline = {"kernel": "pointmlp3_max_fwd_kernel", "bound": "mfma", "achieved": ach,
+                    "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS,
+                    "traffic": traffic, "launch_us": k_ms * 1e3, "launches_per_step": 2}
+        # ---- the Chamfer kernel at N=4096 (north_star's second figure): VALU-bound, HBM share reported too.
+        # Three timings per size: `values` = what Chamfer / Hausdorff VALUES need (utils/dis_utils_*.py, the metric's
+        # kernel: scan + fold launches, no arg-min), `with_idx` = values + both arg-min index arrays (what the
+        # backward of the distance functors needs), `two_scan` = the round-1 kernel (one scan per direction).
+        pmc_all = {}
+        pmc2 = os.path.join(ROOT, "profiles", "r02_pmc_hbm_counters.json")
+        if os.path.exists(pmc2):
+            pmc_all = json.load(open(pmc2))
+
+        def counter_bytes(keys):
+            """HBM bytes per call (sum over the launches of one call) from the committed PMC passes of THIS bench
+            command (tools/prof_pmc.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs, mean per dispatch; KiB units;
+            FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note for 16-B-per-lane reads), or None when a kernel of
+            the call is not covered. keys: "kernel name|grid=<work-items>|run=<k>" as that script writes them (run k = the
+            k-th change of that kernel's grid in dispatch order: this function's call order below fixes it)."""
+            tot = 0.0
+            for k in keys:
+                c = pmc_all.get(k)
+                if not c or "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+                    return None
+                tot += (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+            return tot
+
+        def graph_ms(fn, per=10, reps=20):
+            """ms per call of fn, timed as `per` calls captured into ONE hipGraph and replayed `reps` times (HIP events
+            on the replay stream). At N <= 2048 an eager Python call costs more host time than these kernels run, so
+            event timing around eager calls measures the host; the attack loops replay graphs as well."""
+            side = torch.cuda.Stream()
+            g = torch.cuda.CUDAGraph()
+            with graphed.capture_guard(), torch.cuda.stream(side):
+                fn()
+                side.synchronize()
+                with torch.cuda.graph(g, stream=side):
+                    for _ in range(per):
+                        fn()
+                g.replay()
+                side.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(side)
+                for _ in range(reps):
+                    g.replay()
+                e1.record(side)
+                e1.synchronize()
+            return e0.elapsed_time(e1) / (per * reps)
+
+        def chamfer_point(Nc):
+            a = torch.randn(B, Nc, 3, device=dev)
+            b = a + 0.01 * torch.randn_like(a)
+            res = {}
+            for tag, kw in (("values", {"want_idx": False, "two_scan": False}), ("with_idx", {"two_scan": False}),
+                            ("two_scan", {"two_scan": True})):
+                res[tag] = graph_ms(lambda: ops.nn_bidir_raw(a, b, **kw))
+            c_ms = res["values"]
+            alg_bytes = B * (2 * Nc * 12 + 2 * Nc * 8)          # 40*N bytes per cloud pair (SURVEY §8(d))
+            alg_ops = 10.0 * B * Nc * Nc                         # SURVEY §8(d): 8 (shared distance) + 2 (running mins) per pair
+            issued_ops = 8.4 * B * Nc * Nc                       # DESIGN.md §3: instructions the shared-evaluation scan issues per pair
+            return {"kernel": "nn_shared_kernel + nn_shared_finalize_kernel", "config": f"B={B} N=M={Nc} bidirectional",
+                    "timing": "10 calls per replayed hipGraph, HIP events around 20 replays",
+                    "launch_us": c_ms * 1e3, "with_idx_us": res["with_idx"] * 1e3, "two_scan_us": res["two_scan"] * 1e3,
+                    "hbm_alg_GBps": alg_bytes / (c_ms * 1e-3) / 1e9,
+                    "hbm_frac": alg_bytes / (c_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "valu_frac": alg_ops / (c_ms * 1e-3) / VALU_LANE_OPS_PEAK,
+                    "valu_frac_with_idx": alg_ops / (res["with_idx"] * 1e-3) / VALU_LANE_OPS_PEAK,
+                    "valu_frac_two_scan": alg_ops / (res["two_scan"] * 1e-3) / VALU_LANE_OPS_PEAK,
+                    "valu_issue_frac": issued_ops / (c_ms * 1e-3) / VALU_LANE_OPS_PEAK, "bound": "valu"}
+        chamfer = chamfer_point(4096)
+        # B=32, N=M=4096 is the FIRST Chamfer point measured (run 0): scan grid 16 tiles x 32 clouds x 4 splits of 256
+        # threads, fold grid 16 x 32 x 2 of 256
+        cb = counter_bytes(("void pc3d::nn_shared_kernel<4, false>|grid=524288|run=0",
+                            "pc3d::nn_shared_finalize_kernel|grid=262144|run=0"))
+        chamfer["hbm_counter_bytes"] = cb                      # FETCH+WRITE of the values path's launches, per call
+        chamfer["hbm_counter_GBps"] = (cb / (chamfer["launch_us"] * 1e-6) / 1e9) if cb else None
+        chamfer["other_sizes"] = {f"N{n}": {k: v for k, v in chamfer_point(n).items()
+                                            if k in ("launch_us", "with_idx_us", "two_scan_us", "hbm_alg_GBps", "valu_frac", "timing",
+                                                     "valu_frac_with_idx", "valu_frac_two_scan")}
+                                  for n in (1024, 2048)}
+
     # ---- the other shapes of the same path, on EVERY rank (the collectives inside line up): north_star's N = 2048 /
     # 4096 clouds, the reference's default L2 regulariser, and one GPU's share of BASELINE configs[4] (CW on CurveNet,
     # 32 of the 256 clouds, N=4096). Reported as whole-job rates over the slowest rank, with the per-rank times.
-    stream = torch.cuda.current_stream()
     sweep = None
     if not args.no_sweep:
         sweep = {}
@@ -282,84 +400,6 @@ def main():
 
     out = None
     if rank == 0:
-        # ---- roofline of the dominant kernel: the fused per-point MLP + max forward (fp32 MFMA)
-        x = st["adv"].detach()
-        tower = model.feat.folded()
-        flops = 2.0 * B * NPTS * (3 * 64 + 64 * 128 + 128 * 1024)   # DESIGN.md: algorithmic flops per launch
-        for _ in range(5):
-            ops.pointmlp3_max_fwd_raw(x, tower, False, fold=False)
-        k_ms = ev_ms(lambda: ops.pointmlp3_max_fwd_raw(x, tower, False, fold=False), 50, stream)
-        ach = flops / (k_ms * 1e-3) / 1e12
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r02_pmc_hbm_counters.json")
-        if os.path.exists(pmc):
-            # HBM bytes per launch from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE
-            # runs of this same command at this round's kernels, KiB units). gfx950 correction (MI355X_MICROARCH.md
-            # §HBM): FETCH_SIZE counts 64 B per 128-B request for 16-B-per-lane reads -> doubled; WRITE_SIZE is exact.
-            # (PMC collection needs the rocprofv3 wrapper, so it cannot run inside this process; the file is regenerated
-            # by tools/prof_pmc.sh whenever a kernel on this line changes.)
-            pj = json.load(open(pmc))
-            c = pj.get("pc3d::pointmlp3_max_fwd_kernel|grid=131072|run=0")
-            if c and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-                traffic = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
-        roofline = {"kernel": "pointmlp3_max_fwd_kernel", "bound": "mfma", "achieved": ach,
-                    "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS,
-                    "traffic": traffic, "launch_us": k_ms * 1e3, "launches_per_step": 2}
-        # ---- the Chamfer kernel at N=4096 (north_star's second figure): VALU-bound, HBM share reported too.
-        # Three timings per size: `values` = what Chamfer / Hausdorff VALUES need (utils/dis_utils_*.py, the metric's
-        # kernel: scan + fold launches, no arg-min), `with_idx` = values + both arg-min index arrays (what the
-        # backward of the distance functors needs), `two_scan` = the round-1 kernel (one scan per direction).
-        pmc_all = {}
-        pmc2 = os.path.join(ROOT, "profiles", "r02_pmc_hbm_counters.json")
-        if os.path.exists(pmc2):
-            pmc_all = json.load(open(pmc2))
-
-        def counter_bytes(keys):
-            """HBM bytes per call (sum over the launches of one call) from the committed PMC passes of THIS bench
-            command (tools/prof_pmc.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs, mean per dispatch; KiB units;
-            FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note for 16-B-per-lane reads), or None when a kernel of
-            the call is not covered. keys: "kernel name|grid=<work-items>|run=<k>" as that script writes them (run k = the
-            k-th change of that kernel's grid in dispatch order: this function's call order below fixes it)."""
-            tot = 0.0
-            for k in keys:
-                c = pmc_all.get(k)
-                if not c or "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
-                    return None
-                tot += (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
-            return tot
-
-        def chamfer_point(Nc):
-            a = torch.randn(B, Nc, 3, device=dev)
-            b = a + 0.01 * torch.randn_like(a)
-            res = {}
-            for tag, kw in (("values", {"want_idx": False, "two_scan": False}), ("with_idx", {"two_scan": False}),
-                            ("two_scan", {"two_scan": True})):
-                for _ in range(3):
-                    ops.nn_bidir_raw(a, b, **kw)
-                res[tag] = ev_ms(lambda: ops.nn_bidir_raw(a, b, **kw), 20, stream)
-            c_ms = res["values"]
-            alg_bytes = B * (2 * Nc * 12 + 2 * Nc * 8)          # 40*N bytes per cloud pair (SURVEY §8(d))
-            alg_ops = 10.0 * B * Nc * Nc                         # SURVEY §8(d): 8 (shared distance) + 2 (running mins) per pair
-            issued_ops = 8.4 * B * Nc * Nc                       # DESIGN.md §3: instructions the shared-evaluation scan issues per pair
-            return {"kernel": "nn_shared_kernel + nn_shared_finalize_kernel", "config": f"B={B} N=M={Nc} bidirectional",
-                    "launch_us": c_ms * 1e3, "with_idx_us": res["with_idx"] * 1e3, "two_scan_us": res["two_scan"] * 1e3,
-                    "hbm_alg_GBps": alg_bytes / (c_ms * 1e-3) / 1e9,
-                    "hbm_frac": alg_bytes / (c_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    "valu_frac": alg_ops / (c_ms * 1e-3) / VALU_LANE_OPS_PEAK,
-                    "valu_frac_with_idx": alg_ops / (res["with_idx"] * 1e-3) / VALU_LANE_OPS_PEAK,
-                    "valu_frac_two_scan": alg_ops / (res["two_scan"] * 1e-3) / VALU_LANE_OPS_PEAK,
-                    "valu_issue_frac": issued_ops / (c_ms * 1e-3) / VALU_LANE_OPS_PEAK, "bound": "valu"}
-        chamfer = chamfer_point(4096)
-        # B=32, N=M=4096 is the FIRST Chamfer point measured (run 0): scan grid 16 tiles x 32 clouds x 4 splits of 256
-        # threads, fold grid 16 x 32 x 2 of 256
-        cb = counter_bytes(("void pc3d::nn_shared_kernel<4, false>|grid=524288|run=0",
-                            "pc3d::nn_shared_finalize_kernel|grid=262144|run=0"))
-        chamfer["hbm_counter_bytes"] = cb                      # FETCH+WRITE of the values path's launches, per call
-        chamfer["hbm_counter_GBps"] = (cb / (chamfer["launch_us"] * 1e-6) / 1e9) if cb else None
-        chamfer["other_sizes"] = {f"N{n}": {k: v for k, v in chamfer_point(n).items()
-                                            if k in ("launch_us", "with_idx_us", "two_scan_us", "hbm_alg_GBps", "valu_frac",
-                                                     "valu_frac_with_idx", "valu_frac_two_scan")}
-                                  for n in (1024, 2048)}
         out = {
             "metric": "attack iters/s (B=32, N=1024, PointNet) + Chamfer HBM GB/s vs peak",
             "value": iters_per_s, "unit": "iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
