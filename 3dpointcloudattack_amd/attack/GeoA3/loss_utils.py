@@ -41,6 +41,14 @@ def hausdorff_loss(adv_pc, ori_pc, nn_ao=None):
 
 
 def _kappa(pc, normal, k):
+    """mean_j |<normalize(p_j - p_i), n_i>| over the k nearest neighbours (:63-70, :83-90). On the GPU: one neighbour
+    search + one launch (pc3d_kappa_f32, with its own backward) instead of the [b,3,n,k] tensors; the step-by-step
+    form below is kept for normals that need a gradient."""
+    if pc.is_cuda and not normal.requires_grad and pc.dtype == torch.float32 and normal.dtype == torch.float32:
+        from ... import ops
+        pd = pc.detach()
+        idx = ops.knn_raw(pd, pd, k + 1, q_cf=True, r_cf=True)[1]
+        return ops.kappa(pc, normal.detach(), idx, cf=True)
     pts = pc.permute(0, 2, 1).contiguous()
     inter_KNN = knn_points(pts, pts, K=k + 1)
     nn_pts = knn_gather(pts, inter_KNN.idx).permute(0, 3, 1, 2)[:, :, :, 1:].contiguous()  # [b,3,n,k]

@@ -79,6 +79,75 @@ __global__ __launch_bounds__(256) void estimate_normal_kernel(NormalArgs a) {
   o[0] = (float)(sg * nx), o[a.out.cs] = (float)(sg * ny), o[2 * a.out.cs] = (float)(sg * nz);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Curvature proxy of GeoA3 (attack/GeoA3/loss_utils.py:60-90, _get_kappa_ori / _get_kappa_adv):
+//   kappa_i = mean over the k neighbours j of | <(p_j - p_i) / max(|p_j - p_i|, 1e-12), n_i> |
+// for neighbour lists idx [B,N,K1] whose FIRST entry is the point itself (dropped, :66 / :86), and its backward to the
+// points (the normals are gathered constants). The reference builds [b,3,n,k] tensors for this (gather, permute,
+// slice, subtract, norm, clamp, divide, multiply, sum, abs, mean: eleven launches forward, ~twenty backward, one of
+// them the scatter of the gather); here one launch each way, a thread per point.
+// ---------------------------------------------------------------------------------------------------------
+struct KappaArgs {
+  PtsView x, nrm;
+  const int32_t* idx;   // [B,N,K1]
+  int N, K1;
+  float* out;           // [B,N]
+  const float* gout;    // [B,N]   (backward)
+  float* gx;            // [B,N,3] (backward; zero-filled by the entry point, float atomics)
+};
+
+__global__ __launch_bounds__(256) void kappa_fwd_kernel(KappaArgs a) {
+  const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.N) return;
+  const float* xb = a.x.p + (int64_t)b * a.x.bs;
+  const float* pi = xb + (int64_t)i * a.x.ps;
+  const float* ni = a.nrm.p + (int64_t)b * a.nrm.bs + (int64_t)i * a.nrm.ps;
+  const float px = pi[0], py = pi[a.x.cs], pz = pi[2 * a.x.cs];
+  const float nx = ni[0], ny = ni[a.nrm.cs], nz = ni[2 * a.nrm.cs];
+  const int32_t* nb = a.idx + ((int64_t)b * a.N + i) * a.K1;
+  float s = 0.f;
+  for (int k = 1; k < a.K1; ++k) {
+    const int j = min(max(nb[k], 0), a.N - 1);
+    const float* pj = xb + (int64_t)j * a.x.ps;
+    const float dx = pj[0] - px, dy = pj[a.x.cs] - py, dz = pj[2 * a.x.cs] - pz;
+    const float len = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-12f);
+    s += fabsf((dx / len) * nx + (dy / len) * ny + (dz / len) * nz);
+  }
+  a.out[(int64_t)b * a.N + i] = s / (float)(a.K1 - 1);
+}
+
+// d kappa_i / d d_ij = sign(<v,n>) (n - v <v,n>) / |d| / k  for |d| above the clamp (below it: sign n / 1e-12 / k, the
+// norm's own gradient being cut by the clamp); +g to p_j, -g to p_i.
+__global__ __launch_bounds__(256) void kappa_bwd_kernel(KappaArgs a) {
+  const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.N) return;
+  const float* xb = a.x.p + (int64_t)b * a.x.bs;
+  const float* pi = xb + (int64_t)i * a.x.ps;
+  const float* ni = a.nrm.p + (int64_t)b * a.nrm.bs + (int64_t)i * a.nrm.ps;
+  const float px = pi[0], py = pi[a.x.cs], pz = pi[2 * a.x.cs];
+  const float nx = ni[0], ny = ni[a.nrm.cs], nz = ni[2 * a.nrm.cs];
+  const int32_t* nb = a.idx + ((int64_t)b * a.N + i) * a.K1;
+  const float g = a.gout[(int64_t)b * a.N + i] / (float)(a.K1 - 1);
+  float* gb = a.gx + (int64_t)b * a.N * 3;
+  float sx = 0.f, sy = 0.f, sz = 0.f;
+  for (int k = 1; k < a.K1; ++k) {
+    const int j = min(max(nb[k], 0), a.N - 1);
+    const float* pj = xb + (int64_t)j * a.x.ps;
+    const float dx = pj[0] - px, dy = pj[a.x.cs] - py, dz = pj[2 * a.x.cs] - pz;
+    const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
+    const bool clamped = !(nrm > 1e-12f);
+    const float len = clamped ? 1e-12f : nrm;
+    const float vx = dx / len, vy = dy / len, vz = dz / len;
+    const float dot = vx * nx + vy * ny + vz * nz;
+    const float sg = dot > 0.f ? g : (dot < 0.f ? -g : 0.f);
+    const float c = clamped ? 0.f : dot;                    // the -v <v,n> term comes from d|d|/dd, which the clamp cuts
+    const float gxk = sg * (nx - vx * c) / len, gyk = sg * (ny - vy * c) / len, gzk = sg * (nz - vz * c) / len;
+    sx += gxk, sy += gyk, sz += gzk;
+    atomicAdd(gb + 3 * j, gxk), atomicAdd(gb + 3 * j + 1, gyk), atomicAdd(gb + 3 * j + 2, gzk);
+  }
+  atomicAdd(gb + 3 * i, -sx), atomicAdd(gb + 3 * i + 1, -sy), atomicAdd(gb + 3 * i + 2, -sz);
+}
+
 }  // namespace pc3d
 
 using namespace pc3d;
@@ -93,5 +162,37 @@ extern "C" int pc3d_estimate_normal_f32(const float* x, int64_t x_bs, int64_t x_
   NormalArgs a{{x, x_bs, x_ps, x_cs}, idx, N, K1, {out, o_bs, o_ps, o_cs}};
   hipLaunchKernelGGL(estimate_normal_kernel, dim3(cdiv(N, 256), B), dim3(256), 0, as_stream(stream), a);
   PC3D_LAUNCH_CHECK("pc3d_estimate_normal_f32");
+  return PC3D_OK;
+}
+
+extern "C" int pc3d_kappa_f32(const float* x, int64_t x_bs, int64_t x_ps, int64_t x_cs, const float* nrm, int64_t n_bs,
+                              int64_t n_ps, int64_t n_cs, const int32_t* idx, int B, int N, int K1, float* out,
+                              void* stream) {
+  PC3D_REQUIRE(B >= 0 && N >= 1 && K1 >= 2, "pc3d_kappa_f32: bad sizes B=%d N=%d K1=%d (self + >= 1 neighbour)", B, N, K1);
+  PC3D_REQUIRE(B <= 65535, "pc3d_kappa_f32: B=%d exceeds grid.y limit", B);
+  if (B == 0) return PC3D_OK;
+  PC3D_REQUIRE(x && nrm && idx && out, "pc3d_kappa_f32: null pointer");
+  KappaArgs a{{x, x_bs, x_ps, x_cs}, {nrm, n_bs, n_ps, n_cs}, idx, N, K1, out, nullptr, nullptr};
+  hipLaunchKernelGGL(kappa_fwd_kernel, dim3(cdiv(N, 256), B), dim3(256), 0, as_stream(stream), a);
+  PC3D_LAUNCH_CHECK("pc3d_kappa_f32");
+  return PC3D_OK;
+}
+
+extern "C" int pc3d_kappa_bwd_f32(const float* x, int64_t x_bs, int64_t x_ps, int64_t x_cs, const float* nrm,
+                                  int64_t n_bs, int64_t n_ps, int64_t n_cs, const int32_t* idx, const float* gout, int B,
+                                  int N, int K1, float* gx, void* stream) {
+  PC3D_REQUIRE(B >= 0 && N >= 1 && K1 >= 2, "pc3d_kappa_bwd_f32: bad sizes B=%d N=%d K1=%d", B, N, K1);
+  PC3D_REQUIRE(B <= 65535, "pc3d_kappa_bwd_f32: B=%d exceeds grid.y limit", B);
+  if (B == 0) return PC3D_OK;
+  PC3D_REQUIRE(x && nrm && idx && gout && gx, "pc3d_kappa_bwd_f32: null pointer");
+  hipStream_t st = as_stream(stream);
+  hipError_t e = zero_async(gx, (size_t)B * N * 3, st);
+  if (e != hipSuccess) {
+    set_error("pc3d_kappa_bwd_f32: zero fill failed: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  KappaArgs a{{x, x_bs, x_ps, x_cs}, {nrm, n_bs, n_ps, n_cs}, idx, N, K1, nullptr, gout, gx};
+  hipLaunchKernelGGL(kappa_bwd_kernel, dim3(cdiv(N, 256), B), dim3(256), 0, st, a);
+  PC3D_LAUNCH_CHECK("pc3d_kappa_bwd_f32");
   return PC3D_OK;
 }

@@ -586,6 +586,42 @@ def estimate_normal(pts, idx, cf=False):
     return out
 
 
+class _KappaFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pts, normal, idx, cf):
+        p, bs, ps, cs, B, N = _pts(pts, cf, "pts")
+        n, nbs, nps, ncs, _, _ = _pts(normal, cf, "normal")
+        out = torch.empty((B, N), dtype=torch.float32, device=pts.device)
+        with torch.cuda.device(pts.device):
+            _lib.call("pc3d_kappa_f32", p, bs, ps, cs, n, nbs, nps, ncs, idx.data_ptr(), B, N, idx.shape[2],
+                      out.data_ptr(), _stream())
+        ctx.save_for_backward(pts, normal, idx)
+        ctx.cf = cf
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        pts, normal, idx = ctx.saved_tensors
+        p, bs, ps, cs, B, N = _pts(pts, ctx.cf, "pts")
+        n, nbs, nps, ncs, _, _ = _pts(normal, ctx.cf, "normal")
+        g = g.contiguous()
+        gx = torch.empty((B, N, 3), dtype=torch.float32, device=pts.device)
+        with torch.cuda.device(pts.device):
+            _lib.call("pc3d_kappa_bwd_f32", p, bs, ps, cs, n, nbs, nps, ncs, idx.data_ptr(), g.data_ptr(), B, N,
+                      idx.shape[2], gx.data_ptr(), _stream())
+        return (gx.transpose(1, 2) if ctx.cf else gx), None, None, None
+
+
+def kappa(pts, normal, idx, cf=False):
+    """GeoA3's curvature proxy: mean_j |<normalize(p_j - p_i), n_i>| over idx[b,i,1:] (the first entry is the point
+    itself) -> [B,N]; differentiable in pts ([B,N,3], or [B,3,N] with cf), normal is a constant."""
+    if normal.requires_grad:
+        raise NotImplementedError("kappa: no gradient to the normals (they are gathered constants on the attack path)")
+    if idx.dtype != torch.int32 or idx.dim() != 3 or idx.shape[2] < 2:
+        raise ValueError("kappa: idx must be int32 [B,N,K+1] (self first)")
+    return _KappaFn.apply(pts, normal, idx.contiguous(), cf)
+
+
 # ------------------------------------------------------------------------------------------------------
 # K8b: point-wise dense layers (frozen weights) on the fp32-MFMA GEMM
 # ------------------------------------------------------------------------------------------------------

@@ -100,6 +100,15 @@ int pc3d_gate_f32(const float* g, const float* y, int64_t n, float slope, float*
  * as pc3d_knn_f32 returns them for a self-query); out: [B,N] normals (element strides). */
 int pc3d_estimate_normal_f32(const float* x, int64_t x_bs, int64_t x_ps, int64_t x_cs, const int32_t* idx,
                              int B, int N, int K1, float* out, int64_t o_bs, int64_t o_ps, int64_t o_cs, void* stream);
+/* GeoA3's curvature proxy (attack/GeoA3/loss_utils.py:60-90): kappa[b,i] = mean over the k = K1 - 1 neighbours j
+ * (idx[b,i,1:], the first entry is the point itself) of |<(p_j - p_i) / max(|p_j - p_i|, 1e-12), n_i>|, and its
+ * backward to the points (gx [B,N,3] contiguous, overwritten; float atomics). x, nrm: [B,N] points / normals with
+ * element strides; idx [B,N,K1] int32. One launch each way instead of ~30. */
+int pc3d_kappa_f32(const float* x, int64_t x_bs, int64_t x_ps, int64_t x_cs, const float* nrm, int64_t n_bs, int64_t n_ps,
+                   int64_t n_cs, const int32_t* idx, int B, int N, int K1, float* out, void* stream);
+int pc3d_kappa_bwd_f32(const float* x, int64_t x_bs, int64_t x_ps, int64_t x_cs, const float* nrm, int64_t n_bs,
+                       int64_t n_ps, int64_t n_cs, const int32_t* idx, const float* gout, int B, int N, int K1, float* gx,
+                       void* stream);
 
 /* First layer of a set-abstraction MLP without the grouped input tensor (model/pointnet2_utils.py:118-135,190-197): the
  * layer is linear in [x_j - c_s ; f_j], so  W1 [x_j - c_s ; f_j] + b1 = P[idx[s,j]] + Bc[s]  with P = [x | f] W1^T per

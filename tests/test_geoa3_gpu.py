@@ -136,3 +136,35 @@ def test_estimate_normal_closed_form_vs_eigh(dev, k):
     cosang = (got * ref).sum(2).abs()
     assert float(separated.float().mean()) > (0.5 if k == 3 else 0.9)
     assert float(cosang[separated].min()) > 1 - 1e-4, float(cosang[separated].min())
+
+
+@pytest.mark.parametrize("B,N,k,cf", [(2, 300, 16, True), (3, 1024, 2, False), (1, 40, 5, True)])
+def test_kappa_kernel_vs_reference_formulation(dev, B, N, k, cf):
+    """pc3d_kappa_f32 / _bwd_f32 against the step-by-step tensors of attack/GeoA3/loss_utils.py:60-90 in float64 (the
+    same neighbour lists): values and the gradient to the points, including coincident points (clamped norm)."""
+    ops = importlib.import_module("3dpointcloudattack_amd.ops")
+    g = torch.Generator().manual_seed(N + k)
+    pts = torch.rand(B, N, 3, generator=g) - 0.5
+    pts[:, 7] = pts[:, 3]                                   # an exact duplicate: |p_j - p_i| = 0 is clamped to 1e-12
+    nrm = torch.nn.functional.normalize(torch.randn(B, N, 3, generator=g), dim=2)
+    idx = ops.knn_raw(pts.to(dev), pts.to(dev), k + 1)[1]
+    up = torch.randn(B, N, generator=g)
+    x = (pts.transpose(1, 2).contiguous() if cf else pts.clone()).to(dev).requires_grad_()
+    n = (nrm.transpose(1, 2).contiguous() if cf else nrm.clone()).to(dev)
+    out = ops.kappa(x, n, idx, cf=cf)
+    (out * up.to(dev)).sum().backward()
+    xd = pts.double().requires_grad_()
+    nb = torch.gather(xd[:, None].expand(-1, N, -1, -1), 2, idx.cpu().long()[..., None].expand(-1, -1, -1, 3))[:, :, 1:]
+    vec = nb - xd[:, :, None, :]
+    vec = vec / vec.norm(2, 3, keepdim=True).clamp(min=1e-12)
+    ref = (vec * nrm.double()[:, :, None, :]).sum(3).abs().mean(2)
+    (ref * up.double()).sum().backward()
+    torch.testing.assert_close(out.cpu().double(), ref.detach(), rtol=1e-5, atol=1e-6)
+    got = (x.grad.transpose(1, 2) if cf else x.grad).cpu().double()
+    # rows next to the duplicate pair carry 1e12-scaled terms in both formulations: compare the others
+    ok = torch.ones(N, dtype=torch.bool)
+    near = (idx.cpu()[:, :, 1:] == 3) | (idx.cpu()[:, :, 1:] == 7)
+    ok &= ~near.any(2).any(0)
+    ok[3] = ok[7] = False
+    assert float((got[:, ok] - xd.grad[:, ok]).norm() / xd.grad[:, ok].norm()) < 1e-4
+    assert torch.isfinite(got).all()
