@@ -337,9 +337,9 @@ def main():
                     "valu_frac_two_scan": alg_ops / (res["two_scan"] * 1e-3) / VALU_LANE_OPS_PEAK,
                     "valu_issue_frac": issued_ops / (c_ms * 1e-3) / VALU_LANE_OPS_PEAK, "bound": "valu"}
         chamfer = chamfer_point(4096)
-        # B=32, N=M=4096 is the FIRST Chamfer point measured (run 0): scan grid 16 tiles x 32 clouds x 4 splits of 256
-        # threads, fold grid 16 x 32 x 2 of 256
-        cb = counter_bytes(("void pc3d::nn_shared_kernel<4, false>|grid=524288|run=0",
+        # B=32, N=M=4096 is the FIRST Chamfer point measured (run 0): scan grid 16 tiles x 32 clouds x 8 splits of 256
+        # threads, fold grid 16 x 32 x 2 of 256 (the fold's counters average its values-only and with-index calls)
+        cb = counter_bytes(("void pc3d::nn_shared_kernel<4, false>|grid=1048576|run=0",
                             "pc3d::nn_shared_finalize_kernel|grid=262144|run=0"))
         chamfer["hbm_counter_bytes"] = cb                      # FETCH+WRITE of the values path's launches, per call
         chamfer["hbm_counter_GBps"] = (cb / (chamfer["launch_us"] * 1e-6) / 1e9) if cb else None

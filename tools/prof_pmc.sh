@@ -25,7 +25,7 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         if r["Counter_Name"] != ctr:
             continue
         name = r["Kernel_Name"].split("(")[0]
-        if last_grid.get(name) not in (None, r["Grid_Size"]):
+        if "nn_" in name and last_grid.get(name) not in (None, r["Grid_Size"]):   # (only the search kernels share grids)
             run_of[name] += 1
         last_grid[name] = r["Grid_Size"]
         acc[f"{name}|grid={r['Grid_Size']}|run={run_of[name]}"].append(float(r["Counter_Value"]))
