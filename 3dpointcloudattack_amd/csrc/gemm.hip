@@ -37,6 +37,11 @@ struct GemmArgs {
   int M, N, K;
   int act;             // 0 none, 1 ReLU, 2 LeakyReLU(slope)
   float slope, gslope;
+  // group-max epilogue (gm_ns > 0): rows are groups of gm_ns consecutive rows (32, 64 or 128; M a multiple of it);
+  // instead of Y the kernel writes gm_out[g][n] = relu(max_rows(acc) + bias[n]) and the winning row inside the group
+  int gm_ns;
+  float* gm_out;       // [M / gm_ns, N]
+  int64_t* gm_arg;     // [M / gm_ns, N]
 };
 
 __device__ __forceinline__ float4 gm_load4(const float* p, int k, int K, bool row_ok) {
@@ -160,6 +165,53 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_nt_kernel(GemmArgs a) 
     }
   }
 
+  if (a.gm_ns) {
+    // ---- group-max epilogue (the last layer of a set-abstraction MLP, model/pointnet2_utils.py:190-197: conv + BN + ReLU
+    // + max over the group, without the [M,N] activation). ReLU and the bias are monotone: max first, then bias + ReLU.
+    // Per 32-row MFMA tile and column: in-lane over the 16 accumulator rows (ascending in e: strict > keeps the lowest
+    // row), across the two lane halves (rows interleave: compare (value, row)), then the tiles of one group through LDS.
+    __syncthreads();                                   // the operand tiles are dead: reuse their LDS
+    float* pv = gm_lds;                                // [BM / 32][BN] partial maxima
+    int* pi = reinterpret_cast<int*>(gm_lds + (BM / 32) * BN);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        float best = -__builtin_inff();
+        int bi = wm + i * 32;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int rl = wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (m0 + rl < a.M && acc[i][j][e] > best) best = acc[i][j][e], bi = rl;
+        }
+        const float ov = __shfl_xor(best, 32, 64);
+        const int oi = __shfl_xor(bi, 32, 64);
+        if (ov > best || (ov == best && oi < bi)) best = ov, bi = oi;
+        if (h == 0) {
+          pv[((wm >> 5) + i) * BN + wn + j * 32 + r] = best;
+          pi[((wm >> 5) + i) * BN + wn + j * 32 + r] = bi;
+        }
+      }
+    __syncthreads();
+    const int tpg = a.gm_ns / 32;                      // 32-row tiles per group
+    for (int t = tid; t < (BM / a.gm_ns) * BN; t += NT) {
+      const int g = t / BN, col = t - g * BN;
+      float best = pv[g * tpg * BN + col];
+      int bi = pi[g * tpg * BN + col];
+      for (int w = 1; w < tpg; ++w) {                  // ascending tile = ascending rows: strict >
+        const float v = pv[(g * tpg + w) * BN + col];
+        if (v > best) best = v, bi = pi[(g * tpg + w) * BN + col];
+      }
+      const int64_t grp = (int64_t)(m0 / a.gm_ns) + g;
+      if ((int64_t)m0 + (int64_t)g * a.gm_ns < a.M && n0 + col < a.N) {
+        const float bj = a.bias ? a.bias[n0 + col] : 0.f;
+        a.gm_out[grp * a.N + n0 + col] = fmaxf(best + bj, 0.f);
+        a.gm_arg[grp * a.N + n0 + col] = bi - g * a.gm_ns;
+      }
+    }
+    return;
+  }
+
   // epilogue: D[row = sample][col = output]: lane holds column r, rows (e & 3) + 8 (e >> 2) + 4 h of each 32 x 32 tile
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
@@ -194,16 +246,18 @@ extern "C" int pc3d_gemm_nt_tune(int variant) {   // tuning hook (tools/bench_ge
 
 static int gemm_nt_launch(const float* X, int64_t ldx, const float* W, const float* bias, const float* gate, int64_t ldg,
                           float gate_slope, const float* R, int64_t ldr, int M, int N, int K, int act, float slope,
-                          float* Y, int64_t ldy, void* stream) {
+                          float* Y, int64_t ldy, void* stream, int gm_ns = 0, float* gm_out = nullptr,
+                          int64_t* gm_arg = nullptr) {
   PC3D_REQUIRE(M >= 0 && N >= 1 && K >= 1, "pc3d_gemm_nt_f32: bad sizes M=%d N=%d K=%d", M, N, K);
   PC3D_REQUIRE(act >= 0 && act <= 2, "pc3d_gemm_nt_f32: bad activation %d", act);
   if (M == 0) return PC3D_OK;
-  PC3D_REQUIRE(X && W && Y, "pc3d_gemm_nt_f32: null pointer");
+  PC3D_REQUIRE(X && W && (Y || gm_ns), "pc3d_gemm_nt_f32: null pointer");
   PC3D_REQUIRE(ldx >= K && ldy >= N && (!gate || ldg >= K) && (!R || ldr >= N),
                "pc3d_gemm_nt_f32: row stride smaller than the row");
   GemmArgs a{};
   a.X = X, a.W = W, a.bias = bias, a.gate = gate, a.res = R, a.Y = Y, a.ldx = ldx, a.ldg = ldg, a.ldy = ldy, a.ldr = ldr;
   a.M = M, a.N = N, a.K = K, a.act = act, a.slope = slope, a.gslope = gate_slope;
+  a.gm_ns = gm_ns, a.gm_out = gm_out, a.gm_arg = gm_arg;
   // Tile shapes, measured on MI355X (tools/bench_gemm.py, us; hipBLASLt beside them):
   //   layer [M,N,K]                 0: 128x128 DB   2: 128x64   4: 64x128   5: 128x128/8 waves   hipBLASLt
   //   DGCNN conv5 [32768,1024,512]       387           361         350            320               275
@@ -214,9 +268,12 @@ static int gemm_nt_launch(const float* X, int64_t ldx, const float* W, const flo
   // (2-16 steps), so what counts is how many workgroups a CU holds to cover the load -> MFMA -> store latency of each.
   //   0 / 1: 128x128, 4 waves of 64x64, double / single buffered     2: 128x64, 4 waves of 32x64 (N <= 64)
   //   3: 256x64, 4 waves of 64x64, double buffered                    4: 64x128, 4 waves of 32x64
-  //   5 / 6: 128x128, 8 waves of 32x64, single / double buffered
+  //   5 / 6: 128x128, 8 waves of 32x64, single / double buffered       8: as 5 with four workgroups per CU (<= 64 VGPRs)
   int v = g_gemm_variant;
   if (v < 0) v = (N <= 64) ? 2 : 5;
+  // the group-max epilogue is written for 128-row tiles of 32-row wave tiles; with K <= 64 (two K steps per tile) four
+  // workgroups per CU instead of two hide the tile prologue better: 221 -> 203 us on SSG's SA1 (no change at K = 128)
+  if (gm_ns) v = (K <= 64) ? 8 : 5;
   int bm, bn, db;
   switch (v) {
     case 1: bm = 128, bn = 128, db = 0; break;
@@ -225,13 +282,14 @@ static int gemm_nt_launch(const float* X, int64_t ldx, const float* W, const flo
     case 4: bm = 64, bn = 128, db = 0; break;
     case 5: bm = 128, bn = 128, db = 0; break;
     case 6: bm = 128, bn = 128, db = 1; break;
+    case 8: bm = 128, bn = 128, db = 0; break;
     default: bm = 128, bn = 128, db = 1; break;
   }
   const long tiles = (long)cdiv(M, bm) * cdiv(N, bn);
   PC3D_REQUIRE(tiles <= 0x7fffff00L, "pc3d_gemm_nt_f32: too many tiles (%ld)", tiles);
   const int per = (int)((tiles + 7) / 8);
   const size_t lds = (size_t)(db ? 2 : 1) * (bm + bn) * GM_LD * sizeof(float);
-  const dim3 grid(per * 8), block(v == 5 || v == 6 ? 512 : GM_T);
+  const dim3 grid(per * 8), block(v == 5 || v == 6 || v == 8 ? 512 : GM_T);
   hipStream_t st = as_stream(stream);
   switch (v) {
     case 1: hipLaunchKernelGGL((gemm_nt_kernel<2, 2, 2, 2, false, 3>), grid, block, lds, st, a); break;
@@ -240,11 +298,20 @@ static int gemm_nt_launch(const float* X, int64_t ldx, const float* W, const flo
     case 4: hipLaunchKernelGGL((gemm_nt_kernel<2, 2, 1, 2, false, 4>), grid, block, lds, st, a); break;
     case 5: hipLaunchKernelGGL((gemm_nt_kernel<4, 2, 1, 2, false, 2>), grid, block, lds, st, a); break;
     case 6: hipLaunchKernelGGL((gemm_nt_kernel<4, 2, 1, 2, true, 2>), grid, block, lds, st, a); break;
+    case 8: hipLaunchKernelGGL((gemm_nt_kernel<4, 2, 1, 2, false, 4>), grid, block, lds, st, a); break;
     default: hipLaunchKernelGGL((gemm_nt_kernel<2, 2, 2, 2, true, 2>), grid, block, lds, st, a); break;
   }
   PC3D_LAUNCH_CHECK("pc3d_gemm_nt_f32");
   return PC3D_OK;
 }
+
+// internal (not part of the ABI): pc3d_group_linear_max_f32 on the GEMM main loop for groups of 32 / 64 / 128 rows
+namespace pc3d {
+int gemm_nt_groupmax(const float* X, const float* W, const float* bias, int G, int ns, int K, int N, float* out, int64_t* arg,
+                     void* stream) {
+  return gemm_nt_launch(X, K, W, bias, nullptr, 0, 0.f, nullptr, 0, G * ns, N, K, 0, 0.f, nullptr, N, stream, ns, out, arg);
+}
+}  // namespace pc3d
 
 extern "C" int pc3d_gemm_nt_f32(const float* X, int64_t ldx, const float* W, const float* bias, const float* gate,
                                 int64_t ldg, float gate_slope, int M, int N, int K, int act, float slope, float* Y,

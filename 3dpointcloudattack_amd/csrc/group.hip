@@ -631,6 +631,12 @@ extern "C" int pc3d_group_act_bwd_f32(const float* gH, const float* H, const int
   return PC3D_OK;
 }
 
+static int g_glm_gemm = 1;
+extern "C" int pc3d_glm_tune(int use_gemm) {   // timing experiments (tools/bench_glm.py), not part of the ABI
+  g_glm_gemm = use_gemm;
+  return 0;
+}
+
 extern "C" int pc3d_group_linear_max_f32(const float* x, const float* W, const float* b, int G, int ns, int C2, int C3,
                                          float* out, int64_t* arg, void* stream) {
   PC3D_REQUIRE(G >= 0 && ns >= 1 && ns <= 128 && C2 >= 8 && C2 <= 128 && C2 % 8 == 0 && C3 >= 32 && C3 % 32 == 0 && C3 <= 4096,
@@ -638,6 +644,10 @@ extern "C" int pc3d_group_linear_max_f32(const float* x, const float* W, const f
                ns, C2, C3);
   if (G == 0) return PC3D_OK;
   PC3D_REQUIRE(x && W && b && out && arg, "pc3d_group_linear_max_f32: null pointer");
+  // groups of 32 / 64 / 128 rows: the tiled GEMM main loop (operands through LDS, 128 rows share a weight tile) with a
+  // group-max epilogue — measured against the one-workgroup-per-group kernel below in tools/bench_glm.py
+  if (g_glm_gemm && (ns == 32 || ns == 64 || ns == 128) && (int64_t)G * ns <= 0x7fffffff)
+    return gemm_nt_groupmax(x, W, b, G, ns, C2, C3, out, arg, stream);
   GroupLinMaxArgs a{x, W, b, ns, C2, C3, out, arg};
   const int nw = cdiv(ns, 32);
   const size_t lds = nw > 1 ? (size_t)2 * nw * C3 * sizeof(float) : 0;

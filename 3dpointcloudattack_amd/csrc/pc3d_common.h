@@ -9,6 +9,10 @@ namespace pc3d {
 
 void set_error(const char* fmt, ...);
 
+// gemm.hip: the group-max form of the point-wise GEMM (rows in groups of 32 / 64 / 128; see GemmArgs::gm_ns)
+int gemm_nt_groupmax(const float* X, const float* W, const float* bias, int G, int ns, int K, int N, float* out, int64_t* arg,
+                     void* stream);
+
 // Element strides of a [B, n_points, 3] fp32 point set in caller memory.
 struct PtsView {
   const float* p;
