@@ -525,7 +525,8 @@ extern "C" int pc3d_lpfa_prep_bwd_f32(const float* gA, const float* gBc, const f
 
 static bool curve_attn_ok(int B, int N, int C, int cn, int cl) {
   return B >= 0 && B <= 65535 && N >= 1 && cn >= 0 && cl >= 0 && cn + cl >= 1 && cn + cl <= 128 &&
-         (C == 8 || C == 16 || C == 32 || C == 64);
+         (C == 8 || C == 16 || C == 32 || C == 64) &&
+         (size_t)2 * (cn + cl) * (C + 4) * sizeof(float) <= 64 * 1024;   // keys + values of one cloud in LDS
 }
 
 #define PC3D_CA_DISPATCH(C_, KERNEL, ...)                                   \
@@ -539,7 +540,7 @@ static bool curve_attn_ok(int B, int N, int C, int cn, int cl) {
 extern "C" int pc3d_curve_attn_f32(const float* x, const float* Kp, const float* Vp, int B, int N, int C, int cn, int cl,
                                    float slope, float* out, void* stream) {
   PC3D_REQUIRE(curve_attn_ok(B, N, C, cn, cl),
-               "pc3d_curve_attn_f32: bad sizes B=%d N=%d C=%d cn=%d cl=%d (C in {8,16,32,64}, cn + cl <= 128)", B, N, C, cn, cl);
+               "pc3d_curve_attn_f32: bad sizes B=%d N=%d C=%d cn=%d cl=%d (C in {8,16,32,64}, cn + cl <= 128, 8 (cn + cl)(C + 4) bytes <= 64 KiB)", B, N, C, cn, cl);
   if (B == 0) return PC3D_OK;
   PC3D_REQUIRE(x && Kp && Vp && out, "pc3d_curve_attn_f32: null pointer");
   CurveAttnArgs a{};
@@ -568,7 +569,7 @@ extern "C" int pc3d_curve_attn_bwd_f32(const float* gout, const float* out, cons
                                        const float* Vp, int B, int N, int C, int cn, int cl, float slope, float* gx,
                                        float* gKp, float* gVp, float* ws, void* stream) {
   PC3D_REQUIRE(curve_attn_ok(B, N, C, cn, cl),
-               "pc3d_curve_attn_bwd_f32: bad sizes B=%d N=%d C=%d cn=%d cl=%d (C in {8,16,32,64}, cn + cl <= 128)", B, N, C, cn, cl);
+               "pc3d_curve_attn_bwd_f32: bad sizes B=%d N=%d C=%d cn=%d cl=%d (C in {8,16,32,64}, cn + cl <= 128, 8 (cn + cl)(C + 4) bytes <= 64 KiB)", B, N, C, cn, cl);
   if (B == 0) return PC3D_OK;
   PC3D_REQUIRE(gout && out && x && Kp && Vp && gx && gKp && gVp && ws, "pc3d_curve_attn_bwd_f32: null pointer");
   const int R = cn + cl;

@@ -403,7 +403,7 @@ class CurveAggregation(nn.Module):
         self.fused = True
 
     def _kernel_form(self, x, cn, cl, C):
-        return (self.fused and x.is_cuda and C in ops.CURVE_ATTN_CHANNELS and cn + cl <= ops.CURVE_ATTN_MAX_R
+        return (self.fused and x.is_cuda and ops.curve_attn_supported(C, cn + cl)
                 and ops.curve_agg_lds_bytes(cn, cl, C, C // 2) <= 64 * 1024)
 
     def forward(self, x, curves, cl=False):

@@ -1205,6 +1205,11 @@ CURVE_ATTN_CHANNELS = (8, 16, 32, 64)
 CURVE_ATTN_MAX_R = 128
 
 
+def curve_attn_supported(C, R):
+    """Shapes pc3d_curve_attn_f32 takes: the keys and values of one cloud (2 R (C+4) floats) must fit 64 KiB of LDS."""
+    return C in CURVE_ATTN_CHANNELS and 1 <= R <= CURVE_ATTN_MAX_R and 8 * R * (C + 4) <= 64 * 1024
+
+
 class _CurveAttnFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, Kp, Vp, cn, slope):
@@ -1240,7 +1245,7 @@ def curve_attn(x, Kp, Vp, cn, slope=0.2):
     _check(x, "x"), _check(Kp, "Kp"), _check(Vp, "Vp")
     B, N, C = x.shape
     R = Kp.shape[2]
-    if C not in CURVE_ATTN_CHANNELS or R > CURVE_ATTN_MAX_R or Kp.shape != (B, C, R) or Vp.shape != (B, R, C) or not 0 <= cn <= R:
+    if not curve_attn_supported(C, R) or Kp.shape != (B, C, R) or Vp.shape != (B, R, C) or not 0 <= cn <= R:
         raise ValueError("curve_attn: x [B,N,C] (C in 8/16/32/64), Kp [B,C,R], Vp [B,R,C] with R <= 128 expected")
     return _CurveAttnFn.apply(x.contiguous(), Kp.contiguous(), Vp.contiguous(), int(cn), slope)
 
