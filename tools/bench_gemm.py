@@ -29,7 +29,7 @@ for name, M, N, K in shapes:
     b = torch.randn(N, device=dev)
     lib = importlib.import_module("3dpointcloudattack_amd._lib").load()
     tv = {}
-    for v in (0, 2, 4, 5, 6):
+    for v in (0, 2, 4, 5, 6, 8):
         if v in (2, 3) and N > 64 * 64:
             continue
         lib.pc3d_gemm_nt_tune(v)
