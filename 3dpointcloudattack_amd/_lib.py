@@ -86,6 +86,8 @@ SIGNATURES = {
     "pc3d_pairwise_f32": _PTS + _PTS + [_I, _I, _I, _I, _P, _P],
     "pc3d_pointmlp3_tile_points": [],
     "pc3d_pointmlp3_max_fwd_f32": _PTS + [_I, _I] + [_P] * 7 + [_I, _I, _I, _I] + [_P] * 6 + [_P],
+    "pc3d_pointmlp3_max_fwd_th_f32": _PTS + [_I, _I] + [_P, _P, _P, _I, _P] + [_P] * 6 + [_I, _I, _I, _I] + [_P] * 6 + [_P],
+    "pc3d_linear_pre_f32": [_P, _I, _I, _I, _P, _P, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P],
     "pc3d_pointmlp3_max_bwd_f32": _PTS + [_I, _I] + [_P] * 7 + [_I, _I, _I] + [_P, _P, _P, _P] + _PTS + [_P, _I, _P],
     "pc3d_pointmlp3_bwd_tile_points": [],
     "pc3d_linear_f32": [_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _P, _I, _P],

@@ -196,6 +196,99 @@ __global__ __launch_bounds__(LN_T) void linear16_kernel(LinArgs a) {
   }
 }
 
+// The same 32 x 16 tiling with the X operand produced on the fly by a tiny PRE-layer:
+//     X[b,k] = gate_pre[b,k] > 0 ? sum_{j<J} S[b,j] Wp[j,k] : 0,      S[b,j] = sum_p parts[b,p,j]
+// — the backward of STN3d's fc3 (9 -> 256, model/pointnet.py:45) folded into the launch of fc2's backward
+// (256 -> 512): `parts` are the per-tile dL/dT partials of the trunk's backward, Wp = fc3's weight [9,256], gate_pre
+// = fc2's ReLU output. J <= 16, K <= 16 * 8 * 8 = 1024.
+struct LinPreArgs {
+  const float* parts;    // [B, P, Jp] (Jp >= J floats per slab, J used)
+  int P, Jp, J;
+  const float* Wp;       // [J, K] row-major
+  const float* gate_pre; // [B, K]
+  int ldgp;
+  const float* W;        // [O, K]
+  const float* gate;     // [B, O] or null
+  int ldg;
+  float* Y;              // [B, O]
+  int ldy;
+  int B, K, O;
+};
+
+__global__ __launch_bounds__(LN_T) void linear16_pre_kernel(LinPreArgs a) {
+  __shared__ float red[LN_W][32][17];
+  __shared__ float S[32][16];
+  const int o0 = blockIdx.x * 16, b0 = blockIdx.y * 32;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  {   // S: 32 rows x 16 columns = 512 threads, one element each, slabs summed in ascending order
+    const int row = threadIdx.x >> 4, j = threadIdx.x & 15;
+    const int bb = (b0 + row < a.B) ? b0 + row : a.B - 1;
+    float sacc = 0.f;
+    if (j < a.J) {
+      const float* pp = a.parts + (int64_t)bb * a.P * a.Jp + j;
+      int p = 0;
+      for (; p + 8 <= a.P; p += 8) {       // eight slabs in flight; summed in ascending order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = pp[(int64_t)(p + u) * a.Jp];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sacc += v[u];
+      }
+      for (; p < a.P; ++p) sacc += pp[(int64_t)p * a.Jp];
+    }
+    S[row][j] = sacc;
+  }
+  __syncthreads();
+  const int xb0 = (b0 + r < a.B) ? b0 + r : a.B - 1;
+  const int xb1 = (b0 + 16 + r < a.B) ? b0 + 16 + r : a.B - 1;
+  const int wo = (o0 + r < a.O) ? o0 + r : a.O - 1;
+  const float* wr = a.W + (int64_t)wo * a.K + 4 * q;
+  const int nchunk = a.K / 16;
+  using f32x4 = __attribute__((ext_vector_type(4))) float;
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  for (int c = wave; c < nchunk; c += LN_W) {
+    const int k0 = 16 * c + 4 * q;
+    float x0[4] = {0.f, 0.f, 0.f, 0.f}, x1[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < a.J; ++j) {
+      const float4 wp = *reinterpret_cast<const float4*>(a.Wp + (int64_t)j * a.K + k0);
+      const float s0 = S[r][j], s1 = S[16 + r][j];
+      x0[0] = __builtin_fmaf(s0, wp.x, x0[0]), x0[1] = __builtin_fmaf(s0, wp.y, x0[1]);
+      x0[2] = __builtin_fmaf(s0, wp.z, x0[2]), x0[3] = __builtin_fmaf(s0, wp.w, x0[3]);
+      x1[0] = __builtin_fmaf(s1, wp.x, x1[0]), x1[1] = __builtin_fmaf(s1, wp.y, x1[1]);
+      x1[2] = __builtin_fmaf(s1, wp.z, x1[2]), x1[3] = __builtin_fmaf(s1, wp.w, x1[3]);
+    }
+    const float4 g0 = *reinterpret_cast<const float4*>(a.gate_pre + (int64_t)xb0 * a.ldgp + k0);
+    const float4 g1 = *reinterpret_cast<const float4*>(a.gate_pre + (int64_t)xb1 * a.ldgp + k0);
+    const float ge0[4] = {g0.x, g0.y, g0.z, g0.w}, ge1[4] = {g1.x, g1.y, g1.z, g1.w};
+    const float4 wv = *reinterpret_cast<const float4*>(wr + 16 * c);
+    const float we[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float v0 = ge0[e] > 0.f ? x0[e] : 0.f, v1 = ge1[e] > 0.f ? x1[e] : 0.f;
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v0, we[e], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v1, we[e], acc1, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    red[wave][4 * q + e][r] = acc0[e];
+    red[wave][16 + 4 * q + e][r] = acc1[e];
+  }
+  __syncthreads();
+  {
+    const int row = threadIdx.x >> 4, col = threadIdx.x & 15;
+    float sum = red[0][row][col];
+#pragma unroll
+    for (int w = 1; w < LN_W; ++w) sum += red[w][row][col];
+    const int b = b0 + row, o = o0 + col;
+    if (b < a.B && o < a.O) {
+      if (a.gate && !(a.gate[(int64_t)b * a.ldg + o] > 0.f)) sum = 0.f;
+      a.Y[(int64_t)b * a.ldy + o] = sum;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // log_softmax + prediction + adversarial loss and its gradient w.r.t. the LOGITS (pre-softmax), one wave per sample.
 //   kind 0: UntargetedLogitsAdvLoss  mean_b max(real - other + kappa, 0)     (adv_utils.py:64-80)
@@ -441,5 +534,19 @@ extern "C" int pc3d_cls_loss_f32(const float* logits, int ld, int B, int ncls, c
   hipLaunchKernelGGL(cls_loss_kernel, dim3(B), dim3(64), 0, as_stream(stream), logits, ld, ncls, target, kind, kappa,
                      scale, logp, pred, loss, g_logits);
   PC3D_LAUNCH_CHECK("pc3d_cls_loss_f32");
+  return PC3D_OK;
+}
+
+extern "C" int pc3d_linear_pre_f32(const float* parts, int P, int Jp, int J, const float* Wp, const float* gate_pre,
+                                   int ldgp, int B, int K, const float* W, int O, const float* gate, int ldg, float* Y,
+                                   int ldy, void* stream) {
+  PC3D_REQUIRE(B >= 0 && P >= 1 && J >= 1 && J <= 16 && Jp >= J && K >= 16 && K % 16 == 0 && O >= 1,
+               "pc3d_linear_pre_f32: bad sizes B=%d P=%d J=%d Jp=%d K=%d O=%d (J <= 16, K %% 16 == 0)", B, P, J, Jp, K, O);
+  if (B == 0) return PC3D_OK;
+  PC3D_REQUIRE(parts && Wp && gate_pre && W && Y && ldgp >= K && ldy >= O && (!gate || ldg >= O),
+               "pc3d_linear_pre_f32: null pointer or row stride smaller than the row");
+  LinPreArgs a{parts, P, Jp, J, Wp, gate_pre, ldgp, W, gate, ldg, Y, ldy, B, K, O};
+  hipLaunchKernelGGL(linear16_pre_kernel, dim3(cdiv(O, 16), cdiv(B, 32)), dim3(LN_T), 0, as_stream(stream), a);
+  PC3D_LAUNCH_CHECK("pc3d_linear_pre_f32");
   return PC3D_OK;
 }

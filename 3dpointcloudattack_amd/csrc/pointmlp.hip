@@ -39,8 +39,15 @@ struct PMFwdArgs {
   int32_t* part_idx;  // [B, ntiles, C3]
   uint64_t* mask1;    // [B,N]    bit c  = (layer-1 output c of the point > 0), or null
   uint32_t* mask2;    // [B,N,4]  word j bit r = (layer-2 output 32j+r of the point > 0), or null
+  // optional "transform head" (T == null): T[b] = th_W [9,th_K] . th_in[b] + th_b — STN3d's fc3 (+ identity folded
+  // into th_b, model/pointnet.py:45-47) evaluated in this kernel's prologue instead of a launch of its own; tile 0 of
+  // every cloud also writes it to th_out [B,9] for the backward
+  const float *th_in, *th_W, *th_b;
+  int th_K;
+  float* th_out;
 };
 
+// T: the 3 x 3 transform of THIS cloud (or null)
 __device__ __forceinline__ void load_point(const PtsView& x, const float* T, int b, int n, int N, float& px,
                                            float& py, float& pz) {
   px = py = pz = 0.f;
@@ -48,7 +55,7 @@ __device__ __forceinline__ void load_point(const PtsView& x, const float* T, int
     const float* p = x.p + (int64_t)b * x.bs + (int64_t)n * x.ps;
     const float x0 = p[0], x1 = p[x.cs], x2 = p[2 * x.cs];
     if (T) {
-      const float* t = T + (int64_t)b * 9;
+      const float* t = T;
       px = __builtin_fmaf(x2, t[6], __builtin_fmaf(x1, t[3], x0 * t[0]));
       py = __builtin_fmaf(x2, t[7], __builtin_fmaf(x1, t[4], x0 * t[1]));
       pz = __builtin_fmaf(x2, t[8], __builtin_fmaf(x1, t[5], x0 * t[2]));
@@ -95,9 +102,44 @@ __global__ __launch_bounds__(PM_FT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
 
+  const float* Tb = a.T ? a.T + (int64_t)b * 9 : nullptr;
+  // raw coordinates first (their load latency overlaps the transform head's), the transform is applied afterwards
+  float px = 0.f, py = 0.f, pz = 0.f;
+  if (threadIdx.x < PM_TP) load_point(a.x, nullptr, b, n0 + threadIdx.x, a.N, px, py, pz);
+  if (a.th_in) {   // 9 outputs x th_K: 32 lanes per output, strided partial sums + a half-wave reduction
+    __shared__ float Ts[9];
+    if (threadIdx.x < 9 * 32) {
+      const int j = threadIdx.x >> 5, l = threadIdx.x & 31;
+      const float* in = a.th_in + (int64_t)b * a.th_K;
+      const float* w = a.th_W + (int64_t)j * a.th_K;
+      float sacc = 0.f;
+      if (a.th_K == 256) {      // STN3d: all eight operand pairs in flight at once
+        float iv[8], wv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) iv[u] = in[l + 32 * u], wv[u] = w[l + 32 * u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sacc = __builtin_fmaf(iv[u], wv[u], sacc);
+      } else {
+        for (int k = l; k < a.th_K; k += 32) sacc = __builtin_fmaf(in[k], w[k], sacc);
+      }
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o, 32);
+      if (l == 0) {
+        const float t = sacc + a.th_b[j];
+        Ts[j] = t;
+        if (tile == 0) a.th_out[(int64_t)b * 9 + j] = t;
+      }
+    }
+    __syncthreads();
+    Tb = Ts;
+  }
   if (threadIdx.x < PM_TP) {
-    float px, py, pz;
-    load_point(a.x, a.T, b, n0 + threadIdx.x, a.N, px, py, pz);
+    if (Tb) {   // x' = x @ T (model/pointnet.py:106-109)
+      const float x0 = px, x1 = py, x2 = pz;
+      px = __builtin_fmaf(x2, Tb[6], __builtin_fmaf(x1, Tb[3], x0 * Tb[0]));
+      py = __builtin_fmaf(x2, Tb[7], __builtin_fmaf(x1, Tb[4], x0 * Tb[1]));
+      pz = __builtin_fmaf(x2, Tb[8], __builtin_fmaf(x1, Tb[5], x0 * Tb[2]));
+    }
     xs[threadIdx.x] = px;
     xs[PM_TP + threadIdx.x] = py;
     xs[2 * PM_TP + threadIdx.x] = pz;
@@ -529,12 +571,11 @@ using namespace pc3d;
 extern "C" int pc3d_pointmlp3_tile_points(void) { return PM_TP; }
 extern "C" int pc3d_pointmlp3_bwd_tile_points(void) { return PM_BTP; }
 
-extern "C" int pc3d_pointmlp3_max_fwd_f32(const float* x, int64_t x_bs, int64_t x_ps, int64_t x_cs, int B, int N,
-                                          const float* T, const float* W1, const float* b1, const float* W2,
-                                          const float* b2, const float* W3, const float* b3, int C1, int C2,
-                                          int C3, int relu_last, float* part_val, int32_t* part_idx,
-                                          float* pooled, int32_t* argidx, uint64_t* mask1, uint32_t* mask2,
-                                          void* stream) {
+static int pm_fwd_launch(const float* x, int64_t x_bs, int64_t x_ps, int64_t x_cs, int B, int N, const float* T,
+                         const float* th_in, const float* th_W, const float* th_b, int th_K, float* th_out,
+                         const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
+                         const float* b3, int C1, int C2, int C3, int relu_last, float* part_val, int32_t* part_idx,
+                         float* pooled, int32_t* argidx, uint64_t* mask1, uint32_t* mask2, void* stream) {
   PC3D_REQUIRE(B >= 0 && N >= 1, "pc3d_pointmlp3_max_fwd_f32: bad sizes B=%d N=%d", B, N);
   PC3D_REQUIRE(C1 == PM_C1 && C2 == PM_C2 && C3 >= 32 && C3 % 32 == 0 && C3 <= PM_MAXC3F,
                "pc3d_pointmlp3_max_fwd_f32: unsupported widths %d/%d/%d (need 64/128/multiple of 32 <= 1024)", C1, C2, C3);
@@ -547,7 +588,8 @@ extern "C" int pc3d_pointmlp3_max_fwd_f32(const float* x, int64_t x_bs, int64_t 
   PC3D_REQUIRE((mask1 == nullptr) == (mask2 == nullptr),
                "pc3d_pointmlp3_max_fwd_f32: mask1 and mask2 must both be given or both be NULL");
   const int ntiles = cdiv(N, PM_TP);
-  PMFwdArgs a{{x, x_bs, x_ps, x_cs}, N, C3, ntiles, T, W1, b1, W2, b2, W3, b3, part_val, part_idx, mask1, mask2};
+  PMFwdArgs a{{x, x_bs, x_ps, x_cs}, N, C3, ntiles, T, W1, b1, W2, b2, W3, b3, part_val, part_idx, mask1, mask2,
+              th_in, th_W, th_b, th_K, th_out};
   hipStream_t st = as_stream(stream);
   hipLaunchKernelGGL(pointmlp3_max_fwd_kernel, dim3(ntiles, B), dim3(PM_FT), 0, st, a);
   PC3D_LAUNCH_CHECK("pc3d_pointmlp3_max_fwd_f32");
@@ -557,6 +599,28 @@ extern "C" int pc3d_pointmlp3_max_fwd_f32(const float* x, int64_t x_bs, int64_t 
     PC3D_LAUNCH_CHECK("pc3d_pointmlp3_max_fwd_f32/fold");
   }
   return PC3D_OK;
+}
+
+extern "C" int pc3d_pointmlp3_max_fwd_f32(const float* x, int64_t x_bs, int64_t x_ps, int64_t x_cs, int B, int N,
+                                          const float* T, const float* W1, const float* b1, const float* W2,
+                                          const float* b2, const float* W3, const float* b3, int C1, int C2,
+                                          int C3, int relu_last, float* part_val, int32_t* part_idx,
+                                          float* pooled, int32_t* argidx, uint64_t* mask1, uint32_t* mask2,
+                                          void* stream) {
+  return pm_fwd_launch(x, x_bs, x_ps, x_cs, B, N, T, nullptr, nullptr, nullptr, 0, nullptr, W1, b1, W2, b2, W3, b3, C1, C2,
+                       C3, relu_last, part_val, part_idx, pooled, argidx, mask1, mask2, stream);
+}
+
+extern "C" int pc3d_pointmlp3_max_fwd_th_f32(const float* x, int64_t x_bs, int64_t x_ps, int64_t x_cs, int B, int N,
+                                             const float* th_in, const float* th_W, const float* th_b, int th_K,
+                                             float* T_out, const float* W1, const float* b1, const float* W2,
+                                             const float* b2, const float* W3, const float* b3, int C1, int C2, int C3,
+                                             int relu_last, float* part_val, int32_t* part_idx, float* pooled,
+                                             int32_t* argidx, uint64_t* mask1, uint32_t* mask2, void* stream) {
+  PC3D_REQUIRE(th_in && th_W && th_b && T_out && th_K >= 1,
+               "pc3d_pointmlp3_max_fwd_th_f32: the transform head needs its input, weights [9,K], bias [9] and T_out");
+  return pm_fwd_launch(x, x_bs, x_ps, x_cs, B, N, nullptr, th_in, th_W, th_b, th_K, T_out, W1, b1, W2, b2, W3, b3, C1, C2,
+                       C3, relu_last, part_val, part_idx, pooled, argidx, mask1, mask2, stream);
 }
 
 extern "C" int pc3d_pointmlp3_max_bwd_f32(const float* x, int64_t x_bs, int64_t x_ps, int64_t x_cs, int B, int N,

@@ -232,7 +232,7 @@ def _fused_pack(model):
 
 
 def fused_forward(model, x, tail=True):
-    """Launch-minimal forward of PointNetCls: 2 tower launches (+2 folds) + 6 head launches, no autograd graph.
+    """Launch-minimal forward of PointNetCls: 2 tower launches (+2 folds) + 5 head launches, no autograd graph.
     Returns (logits [B,k] PRE-softmax, ctx) — ctx feeds fused_input_grad."""
     model._require_fused(x)
     pk = fused_pack(model)
@@ -241,8 +241,8 @@ def fused_forward(model, x, tail=True):
     pooled_s, idx_s, masks_s = ops.pointmlp3_max_fwd_raw(x, pk["tower_s"], True, want_masks=True)
     a1 = ops.linear(pooled_s, w1s, b1s, relu=True)
     a2 = ops.linear(a1, w2s, b2s, relu=True)
-    trans = ops.linear(a2, w3s, b3s)                                   # [B,9] incl. the identity
-    pooled, idx, masks = ops.pointmlp3_max_fwd_raw(x, pk["tower_c"], False, T=trans, want_masks=True)
+    # the transform (STN fc3 + identity, [B,9]) is computed in the trunk tower's prologue: no launch of its own
+    pooled, idx, masks, trans = ops.pointmlp3_max_fwd_raw(x, pk["tower_c"], False, want_masks=True, T_head=(a2, w3s, b3s))
     c1 = ops.linear(pooled, w1c, b1c, relu=True)
     c2 = ops.linear(c1, w2c, b2c, relu=True)
     logits = ops.linear(c2, w3c, b3c) if tail else None
@@ -250,7 +250,7 @@ def fused_forward(model, x, tail=True):
 
 
 def fused_input_grad(ctx, g_logits, out=None, g_c2=None):
-    """Backward-to-input of fused_forward for an upstream gradient on the logits: 6 head launches + 2 tower launches."""
+    """Backward-to-input of fused_forward for an upstream gradient on the logits: 5 head launches + 2 tower launches."""
     x, pk, pooled_s, idx_s, a1, a2, trans, idx, c1, c2, masks_s, masks = ctx
     w1c_t, w2c_t, w3c_t = pk["c_t"]
     w1s_t, w2s_t, w3s_t = pk["s_t"]
@@ -259,8 +259,8 @@ def fused_input_grad(ctx, g_logits, out=None, g_c2=None):
     g_c1 = ops.linear(g_c2, w2c_t, gate=c1)
     g_pooled = ops.linear(g_c1, w1c_t)
     gx, part_gT = ops.pointmlp3_max_bwd_raw(x, pk["tower_c"], idx, g_pooled, masks, T=trans, want_gT=True, out=out)
-    g_a2 = ops.linear(part_gT, w3s_t, gate=a2, parts=part_gT.shape[1])  # sums the per-tile dL/dT partials on load
-    g_a1 = ops.linear(g_a2, w2s_t, gate=a1)
+    # fc3's backward (dL/dT partials summed, 9 -> 256, ReLU mask of a2) runs inside the launch of fc2's backward
+    g_a1 = ops.linear_pre(part_gT, 9, pk["s"][4], a2, w2s_t, gate=a1)
     g_pooled_s = ops.linear(g_a1, w1s_t, gate=pooled_s)                 # ReLU after the STN max-pool
     ops.pointmlp3_max_bwd_raw(x, pk["tower_s"], idx_s, g_pooled_s, masks_s, out=gx, accumulate=True)
     return gx

@@ -247,10 +247,12 @@ def _pm_tile():
     return _PM_TILE
 
 
-def pointmlp3_max_fwd_raw(x, weights, relu_last, T=None, x_cf=True, fold=True, want_masks=False):
+def pointmlp3_max_fwd_raw(x, weights, relu_last, T=None, x_cf=True, fold=True, want_masks=False, T_head=None):
     """x [B,3,N] (x_cf) or [B,N,3]; weights = (W1[64,3], b1, W2[128,64], b2, W3[C3,128], b3) with eval-BN folded.
     Returns (pooled [B,C3] f32, argidx [B,C3] i32) and, with want_masks, a third item (mask1 [B,N] i64, mask2 [B,N,4]
-    i32): the per-point ReLU decisions of layers 1 and 2 as bit masks, which pointmlp3_max_bwd_raw consumes."""
+    i32): the per-point ReLU decisions of layers 1 and 2 as bit masks, which pointmlp3_max_bwd_raw consumes.
+    T_head = (h [B,K], W [9,K], b [9]): the input transform T = h @ W.T + b is computed in the launch's prologue
+    (no launch of its own) and returned as a last extra item [B,9]."""
     xp, xbs, xps, xcs, B, N = _pts(x, x_cf, "x")
     W1, b1, W2, b2, W3, b3 = weights[:6]
     for w in weights:
@@ -270,15 +272,27 @@ def pointmlp3_max_fwd_raw(x, weights, relu_last, T=None, x_cf=True, fold=True, w
     masks = None
     if want_masks:
         masks = (torch.empty((B, N), dtype=torch.int64, device=dev), torch.empty((B, N, 4), dtype=torch.int32, device=dev))
+    tail = (W1.data_ptr(), b1.data_ptr(), W2.data_ptr(), b2.data_ptr(), W3.data_ptr(), b3.data_ptr(),
+            C1, C2, C3, 1 if relu_last else 0, part_val.data_ptr(), part_idx.data_ptr(),
+            pooled.data_ptr() if fold else 0, argidx.data_ptr() if fold else 0,
+            masks[0].data_ptr() if masks else 0, masks[1].data_ptr() if masks else 0, _stream())
+    T_out = None
     with torch.cuda.device(dev):
-        _lib.call("pc3d_pointmlp3_max_fwd_f32", xp, xbs, xps, xcs, B, N, _ptr(T),
-                  W1.data_ptr(), b1.data_ptr(), W2.data_ptr(), b2.data_ptr(), W3.data_ptr(), b3.data_ptr(),
-                  C1, C2, C3, 1 if relu_last else 0, part_val.data_ptr(), part_idx.data_ptr(),
-                  pooled.data_ptr() if fold else 0, argidx.data_ptr() if fold else 0,
-                  masks[0].data_ptr() if masks else 0, masks[1].data_ptr() if masks else 0, _stream())
+        if T_head is not None:
+            if T is not None:
+                raise ValueError("pointmlp3_max_fwd_raw: give T or T_head, not both")
+            h, Wt, bt = T_head
+            if h.shape[0] != B or Wt.shape != (9, h.shape[1]) or bt.numel() != 9 or not (h.is_contiguous() and Wt.is_contiguous()):
+                raise ValueError("pointmlp3_max_fwd_raw: T_head = (h [B,K], W [9,K], b [9]) contiguous expected")
+            T_out = torch.empty((B, 9), dtype=torch.float32, device=dev)
+            _lib.call("pc3d_pointmlp3_max_fwd_th_f32", xp, xbs, xps, xcs, B, N, h.data_ptr(), Wt.data_ptr(), bt.data_ptr(),
+                      h.shape[1], T_out.data_ptr(), *tail)
+        else:
+            _lib.call("pc3d_pointmlp3_max_fwd_f32", xp, xbs, xps, xcs, B, N, _ptr(T), *tail)
     if not fold:
-        return part_val, part_idx
-    return (pooled, argidx, masks) if want_masks else (pooled, argidx)
+        return (part_val, part_idx) if T_out is None else (part_val, part_idx, T_out)
+    res = (pooled, argidx, masks) if want_masks else (pooled, argidx)
+    return res if T_out is None else res + (T_out,)
 
 
 def pointmlp3_max_bwd_raw(x, weights, argidx, g_pooled, masks, T=None, x_cf=True, out=None, accumulate=False,
@@ -476,6 +490,23 @@ def linear(X, W, bias=None, relu=False, gate=None, parts=1, out=None):
     with torch.cuda.device(X.device):
         _lib.call("pc3d_linear_f32", X.data_ptr(), ldx, parts, B, K, W.data_ptr(), _ptr(bias), O, 1 if relu else 0,
                   _ptr(gate), gate.stride(0) if gate is not None else 0, Y.data_ptr(), Y.stride(0), _stream())
+    return Y
+
+
+def linear_pre(parts, J, Wp, gate_pre, W, gate=None):
+    """Y = gate(X @ W.T) with X[b,k] = gate_pre[b,k] > 0 ? sum_{j<J} (sum_p parts[b,p,j]) Wp[j,k] : 0 in ONE launch
+    (pc3d_linear_pre_f32): parts [B,P,Jp] contiguous, Wp [J,K], gate_pre [B,K], W [O,K], gate [B,O] or None."""
+    _check(parts, "parts"), _check(Wp, "Wp"), _check(gate_pre, "gate_pre"), _check(W, "W")
+    B, P, Jp = parts.shape
+    K, O = Wp.shape[1], W.shape[0]
+    if not (parts.is_contiguous() and Wp.is_contiguous() and W.is_contiguous()) or Wp.shape[0] < J or W.shape[1] != K \
+            or gate_pre.shape != (B, K) or gate_pre.stride(1) != 1 or K % 16:
+        raise ValueError("linear_pre: parts [B,P,Jp], Wp [>=J,K], gate_pre [B,K], W [O,K] (K % 16 == 0) expected")
+    Y = torch.empty((B, O), dtype=torch.float32, device=parts.device)
+    with torch.cuda.device(parts.device):
+        _lib.call("pc3d_linear_pre_f32", parts.data_ptr(), P, Jp, int(J), Wp.data_ptr(), gate_pre.data_ptr(),
+                  gate_pre.stride(0), B, K, W.data_ptr(), O, _ptr(gate), gate.stride(0) if gate is not None else 0,
+                  Y.data_ptr(), Y.stride(0), _stream())
     return Y
 
 

@@ -169,6 +169,15 @@ int pc3d_pointmlp3_max_fwd_f32(const float* x, int64_t x_bs, int64_t x_ps, int64
                                const float* b2, const float* W3, const float* b3, int C1, int C2, int C3,
                                int relu_last, float* part_val, int32_t* part_idx,
                                float* pooled, int32_t* argidx, uint64_t* mask1, uint32_t* mask2, void* stream);
+/* The same launch with the input transform computed in its prologue: T[b] = th_W [9,th_K] . th_in[b] + th_b — the
+ * last layer of STN3d (model/pointnet.py:45-47: fc3, with the flattened identity added into th_b) — instead of a
+ * launch of its own between the two towers; T_out [B,9] receives it (the backward launch reads it as its T). */
+int pc3d_pointmlp3_max_fwd_th_f32(const float* x, int64_t x_bs, int64_t x_ps, int64_t x_cs, int B, int N,
+                                  const float* th_in, const float* th_W, const float* th_b, int th_K, float* T_out,
+                                  const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
+                                  const float* b3, int C1, int C2, int C3, int relu_last, float* part_val,
+                                  int32_t* part_idx, float* pooled, int32_t* argidx, uint64_t* mask1, uint32_t* mask2,
+                                  void* stream);
 
 /* Backward-to-input of the above (weights are frozen during an attack: no weight gradients, SURVEY A-14).
  * g_pooled [B,C3] is the upstream gradient on `pooled`; with relu_last the caller zeroes it where pooled <= 0.
@@ -197,6 +206,12 @@ int pc3d_pointmlp3_max_bwd_f32(const float* x, int64_t x_bs, int64_t x_ps, int64
  * ------------------------------------------------------------------------------------------------------- */
 int pc3d_linear_f32(const float* X, int ldx, int P, int B, int K, const float* W, const float* bias, int O,
                     int relu, const float* gate, int ldg, float* Y, int ldy, void* stream);
+/* The same layer with its X operand produced on the fly by a tiny pre-layer (the backward of STN3d's fc3, 9 -> 256,
+ * folded into the launch of fc2's backward, model/pointnet.py:44-45 and their autograd):
+ *   X[b,k] = gate_pre[b,k] > 0 ? sum_{j<J} (sum_p parts[b,p,j]) Wp[j,k] : 0 ;   Y[b,o] = gate(sum_k X[b,k] W[o,k])
+ * parts [B,P,Jp] (J <= Jp columns used, J <= 16), Wp [J,K] row-major, gate_pre [B,K] (row stride ldgp), K % 16 == 0. */
+int pc3d_linear_pre_f32(const float* parts, int P, int Jp, int J, const float* Wp, const float* gate_pre, int ldgp, int B,
+                        int K, const float* W, int O, const float* gate, int ldg, float* Y, int ldy, void* stream);
 
 /* log_softmax (model/pointnet.py:148) + argmax + adversarial loss on the log-probabilities and its gradient w.r.t.
  * the LOGITS, one launch. kind 0 = UntargetedLogitsAdvLoss, 1 = LogitsAdvLoss, 2 = CrossEntropyAdvLoss
