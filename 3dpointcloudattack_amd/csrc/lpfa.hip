@@ -108,6 +108,136 @@ static int lpfa_grid(int64_t total, unsigned* blocks, const char* nm) {
   return PC3D_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The whole LPFA block (one 1x1-conv layer, C -> C) in ONE launch each way — no [B,N,k,C] tensor at all:
+//     out[b,i,:] = mean_j leaky_s2( W . leaky_s1(A[b,idx[b,i,j],:] + Bc[b,i,:]) + bias )
+// (edge_act + the point-wise GEMM + act_mean above move 3 x 84 MB at B=32, N=1024, k=20, C=32 and are bound by that).
+// A workgroup owns P = 256 / C points: their k activated edge rows are gathered once into LDS (20 KB at k = 20), then
+// thread (point, output channel) keeps its weight row in registers and walks the edges with broadcast ds_read_b128.
+// Backward: the edges and pre-activations are recomputed, dZ goes through LDS, thread (point, INPUT channel) forms
+// dE = W^T dZ, applies the first activation's mask and scatters into gA (row-contiguous float atomics, as
+// edge_act_bwd_kernel) / sums into gBc.
+// ---------------------------------------------------------------------------------------------------------
+struct LpfaFusedArgs {
+  const float* A;      // [B,N,C]
+  const float* Bc;     // [B,N,C]
+  const int* idx;      // [B,N,K]
+  const float* W;      // [C,C] (out, in)
+  const float* Wt;     // [C,C] transposed (backward)
+  const float* bias;   // [C]
+  int N, K;
+  float s1, s2;
+  float* out;          // [B,N,C]
+  const float* gout;   // [B,N,C]
+  float* gA;           // [B,N,C] zero-filled by the entry point
+  float* gBc;          // [B,N,C]
+};
+
+template <int C>
+__device__ __forceinline__ void lpfa_stage_edges(const LpfaFusedArgs& a, int b, int i0, float* E, int* nbr) {
+  constexpr int P = 256 / C, C4 = C / 4;
+  const int K = a.K;
+  for (int t = threadIdx.x; t < P * K; t += 256) {
+    const int p = t / K, j = t - p * K, i = i0 + p;
+    nbr[t] = i < a.N ? min(max(a.idx[((int64_t)b * a.N + i) * K + j], 0), a.N - 1) : 0;
+  }
+  __syncthreads();
+  for (int f = threadIdx.x; f < P * K * C4; f += 256) {
+    const int c4 = f % C4, pj = f / C4;
+    const int p = pj / K, i = i0 + p;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < a.N) {
+      const float4 x = *reinterpret_cast<const float4*>(a.A + ((int64_t)b * a.N + nbr[pj]) * C + 4 * c4);
+      const float4 y = *reinterpret_cast<const float4*>(a.Bc + ((int64_t)b * a.N + i) * C + 4 * c4);
+      v = leaky4(make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w), a.s1);
+    }
+    *reinterpret_cast<float4*>(E + (int64_t)pj * C + 4 * c4) = v;
+  }
+  __syncthreads();
+}
+
+template <int C>
+__device__ __forceinline__ float lpfa_dot(const float (&w)[C], const float* __restrict__ row) {
+  float z = 0.f;
+#pragma unroll
+  for (int c = 0; c < C; c += 4) {
+    const float4 e = *reinterpret_cast<const float4*>(row + c);
+    z = __builtin_fmaf(w[c], e.x, z);
+    z = __builtin_fmaf(w[c + 1], e.y, z);
+    z = __builtin_fmaf(w[c + 2], e.z, z);
+    z = __builtin_fmaf(w[c + 3], e.w, z);
+  }
+  return z;
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void lpfa_fused_fwd_kernel(LpfaFusedArgs a) {
+  constexpr int P = 256 / C;
+  extern __shared__ __attribute__((aligned(16))) float lf_lds[];
+  float* E = lf_lds;                                        // [P][K][C]
+  int* nbr = reinterpret_cast<int*>(lf_lds + P * a.K * C);   // [P][K]
+  const int b = blockIdx.y, i0 = blockIdx.x * P;
+  lpfa_stage_edges<C>(a, b, i0, E, nbr);
+  const int p = threadIdx.x / C, c = threadIdx.x - p * C, i = i0 + p;
+  float w[C];
+#pragma unroll
+  for (int k = 0; k < C; k += 4) {
+    const float4 v = *reinterpret_cast<const float4*>(a.W + (int64_t)c * C + k);
+    w[k] = v.x, w[k + 1] = v.y, w[k + 2] = v.z, w[k + 3] = v.w;
+  }
+  const float bias = a.bias ? a.bias[c] : 0.f;
+  float acc = 0.f;
+  for (int j = 0; j < a.K; ++j) {
+    const float z = lpfa_dot<C>(w, E + (int64_t)(p * a.K + j) * C) + bias;
+    acc += z > 0.f ? z : a.s2 * z;
+  }
+  if (i < a.N) a.out[((int64_t)b * a.N + i) * C + c] = acc * (1.f / (float)a.K);
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void lpfa_fused_bwd_kernel(LpfaFusedArgs a) {
+  constexpr int P = 256 / C;
+  extern __shared__ __attribute__((aligned(16))) float lf_lds[];
+  float* E = lf_lds;                                        // [P][K][C]
+  float* dZ = lf_lds + P * a.K * C;                          // [P][K][C]
+  int* nbr = reinterpret_cast<int*>(lf_lds + 2 * P * a.K * C);
+  const int b = blockIdx.y, i0 = blockIdx.x * P;
+  lpfa_stage_edges<C>(a, b, i0, E, nbr);
+  const int p = threadIdx.x / C, c = threadIdx.x - p * C, i = i0 + p;
+  float w[C];
+  {   // phase 1: thread (point, OUTPUT channel): dZ_j = g / K * leaky'(z_j)
+#pragma unroll
+    for (int k = 0; k < C; k += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(a.W + (int64_t)c * C + k);
+      w[k] = v.x, w[k + 1] = v.y, w[k + 2] = v.z, w[k + 3] = v.w;
+    }
+    const float bias = a.bias ? a.bias[c] : 0.f;
+    const float gk = i < a.N ? a.gout[((int64_t)b * a.N + i) * C + c] * (1.f / (float)a.K) : 0.f;
+    for (int j = 0; j < a.K; ++j) {
+      const float z = lpfa_dot<C>(w, E + (int64_t)(p * a.K + j) * C) + bias;
+      dZ[(int64_t)(p * a.K + j) * C + c] = z > 0.f ? gk : a.s2 * gk;
+    }
+  }
+  __syncthreads();
+  {   // phase 2: thread (point, INPUT channel): dE_j = W^T dZ_j, first activation's mask, scatter / sum
+#pragma unroll
+    for (int k = 0; k < C; k += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(a.Wt + (int64_t)c * C + k);
+      w[k] = v.x, w[k + 1] = v.y, w[k + 2] = v.z, w[k + 3] = v.w;
+    }
+    float sum = 0.f;
+    float* ga = a.gA + (int64_t)b * a.N * C + c;
+    for (int j = 0; j < a.K; ++j) {
+      const float dE = lpfa_dot<C>(w, dZ + (int64_t)(p * a.K + j) * C);
+      const float e = E[(int64_t)(p * a.K + j) * C + c];
+      const float dpre = e > 0.f ? dE : a.s1 * dE;
+      sum += dpre;
+      if (i < a.N) atomicAdd(ga + (int64_t)nbr[p * a.K + j] * C, dpre);
+    }
+    if (i < a.N) a.gBc[((int64_t)b * a.N + i) * C + c] = sum;
+  }
+}
+
 }  // namespace pc3d
 
 using namespace pc3d;
@@ -165,5 +295,50 @@ extern "C" int pc3d_act_mean_bwd_f32(const float* Z, const float* gout, int B, i
   hipLaunchKernelGGL(act_mean_bwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), (const float4*)Z,
                      (const float4*)gout, K, C / 4, slope, (float4*)gZ, total);
   PC3D_LAUNCH_CHECK("pc3d_act_mean_bwd_f32");
+  return PC3D_OK;
+}
+
+static bool lpfa_fused_ok(int B, int N, int K, int C) {
+  return B >= 0 && B <= 65535 && N >= 1 && K >= 1 && K <= 30 && (C == 16 || C == 32 || C == 64 || C == 128);   // 2 x 1 KiB x K of LDS (backward)
+}
+#define PC3D_LF_DISPATCH(KERNEL, ...)                                         \
+  switch (C) {                                                                \
+    case 16: hipLaunchKernelGGL((KERNEL<16>), __VA_ARGS__); break;            \
+    case 32: hipLaunchKernelGGL((KERNEL<32>), __VA_ARGS__); break;            \
+    case 64: hipLaunchKernelGGL((KERNEL<64>), __VA_ARGS__); break;            \
+    default: hipLaunchKernelGGL((KERNEL<128>), __VA_ARGS__); break;           \
+  }
+
+extern "C" int pc3d_lpfa_fused_f32(const float* A, const float* Bc, const int32_t* idx, const float* W, const float* bias,
+                                   int B, int N, int K, int C, float slope1, float slope2, float* out, void* stream) {
+  PC3D_REQUIRE(lpfa_fused_ok(B, N, K, C), "pc3d_lpfa_fused_f32: bad sizes B=%d N=%d K=%d C=%d (C in {16,32,64,128}, K <= 30)",
+               B, N, K, C);
+  if (B == 0) return PC3D_OK;
+  PC3D_REQUIRE(A && Bc && idx && W && out, "pc3d_lpfa_fused_f32: null pointer");
+  LpfaFusedArgs a{A, Bc, idx, W, nullptr, bias, N, K, slope1, slope2, out, nullptr, nullptr, nullptr};
+  const int P = 256 / C;
+  const size_t lds = (size_t)P * K * C * sizeof(float) + (size_t)P * K * sizeof(int);
+  PC3D_LF_DISPATCH(lpfa_fused_fwd_kernel, dim3(cdiv(N, P), B), dim3(256), lds, as_stream(stream), a);
+  PC3D_LAUNCH_CHECK("pc3d_lpfa_fused_f32");
+  return PC3D_OK;
+}
+
+extern "C" int pc3d_lpfa_fused_bwd_f32(const float* gout, const float* A, const float* Bc, const int32_t* idx,
+                                       const float* W, const float* Wt, const float* bias, int B, int N, int K, int C,
+                                       float slope1, float slope2, float* gA, float* gBc, void* stream) {
+  PC3D_REQUIRE(lpfa_fused_ok(B, N, K, C),
+               "pc3d_lpfa_fused_bwd_f32: bad sizes B=%d N=%d K=%d C=%d (C in {16,32,64,128}, K <= 30)", B, N, K, C);
+  if (B == 0) return PC3D_OK;
+  PC3D_REQUIRE(gout && A && Bc && idx && W && Wt && gA && gBc, "pc3d_lpfa_fused_bwd_f32: null pointer");
+  hipStream_t st = as_stream(stream);
+  if (hipError_t e = zero_async(gA, (size_t)B * N * C, st); e != hipSuccess) {
+    set_error("pc3d_lpfa_fused_bwd_f32: zero fill failed: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  LpfaFusedArgs a{A, Bc, idx, W, Wt, bias, N, K, slope1, slope2, nullptr, gout, gA, gBc};
+  const int P = 256 / C;
+  const size_t lds = (size_t)2 * P * K * C * sizeof(float) + (size_t)P * K * sizeof(int);
+  PC3D_LF_DISPATCH(lpfa_fused_bwd_kernel, dim3(cdiv(N, P), B), dim3(256), lds, st, a);
+  PC3D_LAUNCH_CHECK("pc3d_lpfa_fused_bwd_f32");
   return PC3D_OK;
 }

@@ -254,6 +254,12 @@ class LPFA(nn.Module):
         _, _, g, t = folded_pw(self.xyz2feature)
         g1, g2 = self._derived("_geo_w", g, lambda: ((g[:, 3:6] + g[:, 6:9]).contiguous(), (g[:, 0:3] - g[:, 6:9]).contiguous()))
         A, Bc = ops.lpfa_prep(x, pts, g1, g2, t)
+        if len(self.mlp) == 1:
+            _, act, w, b = folded_pw(self.mlp[0])
+            if b is not None and ops.lpfa_fused_supported(A.shape[2], w.shape[0], idx32.shape[2]):
+                # one layer of equal width (every CIC block of the classifier): gather, activation, 1x1 conv,
+                # activation and neighbour mean in ONE launch each way, no [B,N,k,C] tensor
+                return ops.lpfa_fused(A, Bc, idx32, w, b, 0.2, act.negative_slope)
         E = ops.edge_act(A, Bc, idx32, 0.2)                                    # [B,N,k,C]
         for li, layer in enumerate(self.mlp):
             _, act, w, b = folded_pw(layer)

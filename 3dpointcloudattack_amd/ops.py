@@ -1033,6 +1033,53 @@ def act_mean(Z, slope=0.2):
     return _ActMeanFn.apply(Z.contiguous(), slope)
 
 
+LPFA_FUSED_CHANNELS = (16, 32, 64, 128)
+LPFA_FUSED_MAX_K = 30
+
+
+class _LpfaFusedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, A, Bc, idx, W, b, s1, s2):
+        B, N, C = A.shape
+        out = torch.empty_like(A)
+        with torch.cuda.device(A.device):
+            _lib.call("pc3d_lpfa_fused_f32", A.data_ptr(), Bc.data_ptr(), idx.data_ptr(), W.data_ptr(), _ptr(b), B, N,
+                      idx.shape[2], C, float(s1), float(s2), out.data_ptr(), _stream())
+        ctx.save_for_backward(A, Bc, idx, W, b)
+        ctx.slopes = (float(s1), float(s2))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        A, Bc, idx, W, b = ctx.saved_tensors
+        B, N, C = A.shape
+        g = g.contiguous()
+        gA, gBc = torch.empty_like(A), torch.empty_like(A)
+        with torch.cuda.device(A.device):
+            _lib.call("pc3d_lpfa_fused_bwd_f32", g.data_ptr(), A.data_ptr(), Bc.data_ptr(), idx.data_ptr(), W.data_ptr(),
+                      _w_transposed(W).data_ptr(), _ptr(b), B, N, idx.shape[2], C, ctx.slopes[0], ctx.slopes[1],
+                      gA.data_ptr(), gBc.data_ptr(), _stream())
+        return gA, gBc, None, None, None, None, None
+
+
+def lpfa_fused_supported(C, Cout, K):
+    return C == Cout and C in LPFA_FUSED_CHANNELS and 1 <= K <= LPFA_FUSED_MAX_K
+
+
+def lpfa_fused(A, Bc, idx, W, b, slope1=0.2, slope2=0.2):
+    """mean_j leaky_s2(leaky_s1(A[idx[:, :, j]] + Bc) @ W.T + b) for A, Bc [B,N,C], idx [B,N,K] int32, frozen W [C,C] /
+    b [C]: CurveNet's LPFA block with one MLP layer in one launch each way (no [B,N,K,C] tensor); differentiable in A
+    and Bc."""
+    _check(A, "A"), _check(Bc, "Bc")
+    B, N, C = A.shape
+    if A.shape != Bc.shape or idx.dtype != torch.int32 or idx.shape[:2] != (B, N) or not lpfa_fused_supported(C, W.shape[0], idx.shape[2]) \
+            or W.shape != (C, C):
+        raise ValueError("lpfa_fused: A, Bc [B,N,C] (C in 16/32/64/128), idx int32 [B,N,K<=30], W [C,C] expected")
+    W = W.detach().contiguous().float()
+    return _LpfaFusedFn.apply(A.contiguous(), Bc.contiguous(), idx.contiguous(), W,
+                              b.detach().contiguous().float() if b is not None else None, slope1, slope2)
+
+
 def h2d(t, device, dtype=None):
     """Host tensor -> device WITHOUT stalling the launch queue. A plain `.to(device)` of a pageable host tensor is a
     synchronous copy that first waits for everything already queued on the stream, so one such call per iteration

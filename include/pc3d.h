@@ -418,6 +418,16 @@ int pc3d_edge_act_bwd_f32(const float* gE, const float* E, const int32_t* idx, i
 int pc3d_act_mean_f32(const float* Z, int B, int N, int K, int C, float slope, float* out, void* stream);
 int pc3d_act_mean_bwd_f32(const float* Z, const float* gout, int B, int N, int K, int C, float slope, float* gZ,
                           void* stream);
+/* The whole LPFA block for ONE 1x1-conv layer of equal width (model/curvenet_util.py:204-236 with mlp_num = 1, what every
+ * CIC block of the classifier uses) in one launch each way, without any [B,N,K,C] tensor:
+ *   out[b,i,:] = mean_j LeakyReLU_s2( W . LeakyReLU_s1(A[b,idx[b,i,j],:] + Bc[b,i,:]) + bias )
+ * A, Bc, out, gout, gA, gBc [B,N,C]; idx [B,N,K] int32 (clamped); W [C,C] (out, in), Wt its transpose; C in
+ * {16,32,64,128}, K <= 30. Backward: gA, gBc overwritten (gA through float atomics). */
+int pc3d_lpfa_fused_f32(const float* A, const float* Bc, const int32_t* idx, const float* W, const float* bias, int B,
+                        int N, int K, int C, float slope1, float slope2, float* out, void* stream);
+int pc3d_lpfa_fused_bwd_f32(const float* gout, const float* A, const float* Bc, const int32_t* idx, const float* W,
+                            const float* Wt, const float* bias, int B, int N, int K, int C, float slope1, float slope2,
+                            float* gA, float* gBc, void* stream);
 
 /* K18  per-cloud half of CurveNet's curve aggregation (model/curvenet_util.py:379-437 `CurveAggregation.forward`):
  * curves [B,cn,cl,C] (channels-last) -> attention keys Kp [B,C,R] and values Vp [B,R,C], R = cn + cl, such that the

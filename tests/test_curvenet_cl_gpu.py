@@ -119,3 +119,23 @@ def test_lpfa_prep(ops, dev, B, N, C):
     ((Ar * ua.double()).sum() + (Br * ub.double()).sum()).backward()
     assert _rel(A, Ar) < 1e-6 and _rel(Bc, Br) < 1e-6
     assert _rel(xa.grad, xd.grad) < 1e-6 and _rel(pa.grad, pd.grad) < 1e-5
+
+
+@pytest.mark.parametrize("B,N,K,C", [(2, 300, 20, 32), (3, 1024, 20, 16), (1, 70, 7, 64), (2, 33, 30, 128)])
+def test_lpfa_fused(ops, dev, B, N, K, C):
+    """pc3d_lpfa_fused_f32 / _bwd_f32 against the three-launch form (edge_act, point-wise GEMM, act_mean) in float64."""
+    g = torch.Generator().manual_seed(N + C)
+    A, Bc = torch.randn(B, N, C, generator=g).to(dev), torch.randn(B, N, C, generator=g).to(dev)
+    idx = torch.randint(0, N, (B, N, K), generator=g).int().to(dev)
+    W, b = (torch.randn(C, C, generator=g) / C ** 0.5).to(dev), torch.randn(C, generator=g).to(dev)
+    up = torch.randn(B, N, C, generator=g).to(dev)
+    Aa, Ba = A.clone().requires_grad_(), Bc.clone().requires_grad_()
+    out = ops.lpfa_fused(Aa, Ba, idx, W, b, 0.2, 0.1)
+    (out * up).sum().backward()
+    Ad, Bd = A.double().requires_grad_(), Bc.double().requires_grad_()
+    nb = torch.gather(Ad[:, None].expand(-1, N, -1, -1), 2, idx.long()[..., None].expand(-1, -1, -1, C))
+    E = F.leaky_relu(nb + Bd[:, :, None, :], 0.2)
+    ref = F.leaky_relu(E @ W.double().t() + b.double(), 0.1).mean(2)
+    (ref * up.double()).sum().backward()
+    assert _rel(out, ref) < 2e-6
+    assert _rel(Aa.grad, Ad.grad) < 1e-5 and _rel(Ba.grad, Bd.grad) < 1e-5
