@@ -114,6 +114,9 @@ static int lpfa_grid(int64_t total, unsigned* blocks, const char* nm) {
 // (edge_act + the point-wise GEMM + act_mean above move 3 x 84 MB at B=32, N=1024, k=20, C=32 and are bound by that).
 // A workgroup owns P = 256 / C points: their k activated edge rows are gathered once into LDS (20 KB at k = 20), then
 // thread (point, output channel) keeps its weight row in registers and walks the edges with broadcast ds_read_b128.
+// (Two output channels per thread — half the LDS reads per FMA, 40 KB tiles — measured SLOWER: 36 -> 51 us forward,
+// 124 -> 168 backward at B=32, N=1024, C=32: the kernels are bound by the latency of the staged gather, which more,
+// smaller workgroups hide better, not by LDS bandwidth.)
 // Backward: the edges and pre-activations are recomputed, dZ goes through LDS, thread (point, INPUT channel) forms
 // dE = W^T dZ, applies the first activation's mask and scatters into gA (row-contiguous float atomics, as
 // edge_act_bwd_kernel) / sums into gBc.
