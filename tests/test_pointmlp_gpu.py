@@ -107,3 +107,41 @@ def test_forward_relu_masks_match_torch(ops, dev, B, N):
         sure = zt.abs() > 1e-5
         assert torch.equal(bits[sure], (zt > 0)[sure])
         assert sure.float().mean() > 0.999
+
+
+@pytest.mark.parametrize("B,N,K", [(3, 200, 256), (2, 1024, 256), (1, 70, 64)])
+def test_transform_head_in_prologue(ops, dev, B, N, K):
+    """pc3d_pointmlp3_max_fwd_th_f32: the input transform T = h @ W.T + b (STN3d's fc3 + identity, model/pointnet.py:45-47)
+    evaluated in the launch's prologue == the two-launch form (linear, then the tower with T given): T to fp32 rounding
+    of a different summation order, pooled values accordingly, and the same arg-max points."""
+    g = torch.Generator().manual_seed(K + N)
+    x = (torch.randn(B, 3, N, generator=g) * 0.5).to(dev)
+    w = _weights(dev, 256, 2)
+    h = torch.randn(B, K, generator=g).to(dev)
+    Wt = (torch.randn(9, K, generator=g) / K ** 0.5).to(dev)
+    bt = (torch.randn(9, generator=g) * 0.1 + torch.eye(3).reshape(-1)).to(dev)
+    pooled, idx, masks, T = ops.pointmlp3_max_fwd_raw(x, w, False, want_masks=True, T_head=(h, Wt, bt))
+    T_ref = (h.double() @ Wt.double().t() + bt.double()).float()
+    torch.testing.assert_close(T, T_ref, rtol=1e-5, atol=1e-6)
+    pooled2, idx2, masks2 = ops.pointmlp3_max_fwd_raw(x, w, False, T=T.view(B, 3, 3), want_masks=True)
+    assert torch.equal(pooled, pooled2) and torch.equal(idx, idx2)            # same T -> bit-identical tower
+    assert torch.equal(masks[0], masks2[0]) and torch.equal(masks[1], masks2[1])
+
+
+@pytest.mark.parametrize("B,P,K,O", [(32, 32, 256, 512), (5, 3, 64, 40), (33, 8, 128, 17)])
+def test_linear_pre_matches_two_launches(ops, dev, B, P, K, O):
+    """pc3d_linear_pre_f32 (the backward of STN3d's fc3 folded into the launch of fc2's backward) against plain torch:
+    X = relu'(gate_pre) * (sum_p parts[:, p, :9] @ Wp), Y = relu'(gate) * (X @ W.T)."""
+    g = torch.Generator().manual_seed(B + K)
+    parts = torch.randn(B, P, 16, generator=g).to(dev)
+    Wp = torch.randn(9, K, generator=g).to(dev)
+    gate_pre = torch.randn(B, K, generator=g).to(dev)
+    W = (torch.randn(O, K, generator=g) / K ** 0.5).to(dev)
+    gate = torch.randn(B, O, generator=g).to(dev)
+    Y = ops.linear_pre(parts, 9, Wp, gate_pre, W, gate=gate)
+    S = parts.double().sum(1)[:, :9]
+    X = torch.where(gate_pre > 0, S @ Wp.double(), torch.zeros((), dtype=torch.float64, device=dev))
+    ref = torch.where(gate > 0, X @ W.double().t(), torch.zeros((), dtype=torch.float64, device=dev))
+    torch.testing.assert_close(Y.double(), ref, rtol=1e-4, atol=1e-4)
+    Y0 = ops.linear_pre(parts, 9, Wp, gate_pre, W)                            # no output gate
+    torch.testing.assert_close(Y0.double(), X @ W.double().t(), rtol=1e-4, atol=1e-4)
