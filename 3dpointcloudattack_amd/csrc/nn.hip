@@ -590,7 +590,7 @@ static NNSharedPlan nn_shared_plan(int B, int N, int M) {
   p.tilesA = cdiv(N, p.tileA);
   // Sixteen workgroups per CU's worth of grid, in slices of at least two butterflies of B per wave — one butterfly
   // where the grid would otherwise stay under four workgroups per CU. Measured inside replayed graphs at B=32
-  // (tools/exp/tune_nn_shared.py; values only / with indices, us): target 2048 workgroups N=1024 12.3 / 14.7,
+  // (tools/bench_nn_small.py with the rule varied; values only / with indices, us): target 2048 workgroups N=1024 12.3 / 14.7,
   // N=2048 27.4 / 31.9, N=4096 90.4 / 110.4; this rule 10.9 / 13.1, 26.5 / 31.0, 87.1 / 100.3. (Q = 2 instead of 4:
   // 12-20 % slower at every size.)
   const long wgs = (long)p.tilesA * (B > 0 ? B : 1);
