@@ -25,3 +25,18 @@ for g, name, its in [(run.graphs[n], "g%d" % n, n) for n in sorted(run.graphs)]:
     for _ in range(20): g.replay()
     torch.cuda.synchronize(); tot = (time.perf_counter() - t0) / 20
     print(name, "iterations", its, "host us per launch (GPU idle)", round(np.median(hs) * 1e6, 1), "steady us per launch", round(tot * 1e6, 1))
+
+# where the fixed cost of a short timed region comes from: 20 iterations, host clock vs GPU events
+for trial in range(3):
+    for _ in range(5): run()
+    run.flush(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(20): run()
+    run.flush()
+    e1.record()
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print("20 iterations: host enqueue ms", round((t1 - t0) * 1e3, 3), "host total ms", round((t2 - t0) * 1e3, 3), "GPU events ms", round(e0.elapsed_time(e1), 3))
