@@ -112,6 +112,31 @@ def _forward_step(net, pc_ori, input_curr_iter, normal_ori, ori_kappa, target, s
     else:
         assert False, 'Not support such clssification loss'
 
+    scale_const = scale_const.float().to(dev)
+    if input_curr_iter.is_cuda and cfg.dis_loss_type == 'CD' and cfg.uniform_loss_weight == 0:
+        # The default configuration's terms (:139-181) assembled by ONE launch each way (pc3d_geoa3_terms_f32) from the
+        # search kernels' outputs, instead of ~15 reductions / scalings and their ~20 backward launches.
+        from ... import ops
+        adv_t, ori_t = input_curr_iter.permute(0, 2, 1), pc_ori.permute(0, 2, 1)
+        nn_ao = knn_points(adv_t, ori_t, K=1)
+        d_oa = None if cfg.is_cd_single_side else knn_points(ori_t, adv_t, K=1).dists.squeeze(-1)
+        if cfg.curv_loss_weight != 0:
+            adv_kappa, normal_curr_iter = _get_kappa_adv(input_curr_iter, pc_ori, normal_ori, cfg.curv_loss_knn, nn_ao)
+        else:
+            adv_kappa, normal_curr_iter = None, torch.zeros(b, 3, n, device=dev)
+        terms = ops.geoa3_terms(nn_ao.dists.squeeze(-1), d_oa, adv_kappa, ori_kappa, nn_ao.idx.squeeze(-1),
+                                cls_loss.float().contiguous(), scale_const, cfg.dis_loss_weight, cfg.hd_loss_weight,
+                                cfg.curv_loss_weight)
+        dis_loss, hd_loss, curv_loss, constrain_loss, loss_n = terms.unbind(0)
+        if cfg.hd_loss_weight == 0:
+            hd_loss = 0
+        if cfg.curv_loss_weight == 0:
+            curv_loss = 0
+        gb = getattr(cfg, "global_batch", None)
+        loss = loss_n.sum() / float(gb) if gb else loss_n.mean()
+        return (output_curr_iter, normal_curr_iter, loss, loss_n, cls_loss, dis_loss, hd_loss, curv_loss, constrain_loss,
+                '')
+
     # one adv -> ori nearest-neighbour search for every term that needs it
     need_nn = (cfg.dis_loss_type == 'CD') or cfg.hd_loss_weight != 0 or cfg.curv_loss_weight != 0
     nn_ao = knn_points(input_curr_iter.permute(0, 2, 1), pc_ori.permute(0, 2, 1), K=1) if need_nn else None
@@ -150,7 +175,6 @@ def _forward_step(net, pc_ori, input_curr_iter, normal_ori, ori_kappa, target, s
         uniform = uniform_loss(input_curr_iter)
         constrain_loss = constrain_loss + cfg.uniform_loss_weight * uniform
 
-    scale_const = scale_const.float().to(dev)
     loss_n = cls_loss + scale_const * constrain_loss
     # cfg.global_batch: this batch is a shard of a larger one — divide by the GLOBAL size so every sample's gradient
     # (and with it Adam's eps-sensitive step) is what the unsharded run computes

@@ -653,6 +653,62 @@ def kappa(pts, normal, idx, cf=False):
     return _KappaFn.apply(pts, normal, idx.contiguous(), cf)
 
 
+class _GeoTermsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, d_ao, d_oa, k_adv, k_ori, idx_ao, cls, scale, w):
+        B, N = d_ao.shape
+        M = d_oa.shape[1] if d_oa is not None else (k_ori.shape[1] if k_ori is not None else N)
+        dev = d_ao.device
+        out = torch.empty((5, B), dtype=torch.float32, device=dev)
+        hd_arg = torch.empty((B,), dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call("pc3d_geoa3_terms_f32", d_ao.data_ptr(), _ptr(d_oa), _ptr(k_adv), _ptr(k_ori), _ptr(idx_ao),
+                      cls.data_ptr(), scale.data_ptr(), B, N, M, w[0], w[1], w[2], out.data_ptr(), hd_arg.data_ptr(),
+                      _stream())
+        ctx.save_for_backward(k_adv, k_ori, idx_ao, scale, hd_arg)
+        ctx.dims, ctx.w, ctx.has_oa = (B, N, M), w, d_oa is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        k_adv, k_ori, idx_ao, scale, hd_arg = ctx.saved_tensors
+        B, N, M = ctx.dims
+        dev = g.device
+        g = g.contiguous()
+        g_ao = torch.empty((B, N), dtype=torch.float32, device=dev)
+        g_oa = torch.empty((B, M), dtype=torch.float32, device=dev) if ctx.has_oa else None
+        g_k = torch.empty((B, N), dtype=torch.float32, device=dev) if k_adv is not None else None
+        g_cls = torch.empty((B,), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call("pc3d_geoa3_terms_bwd_f32", g.data_ptr(), _ptr(k_adv), _ptr(k_ori), _ptr(idx_ao), scale.data_ptr(),
+                      hd_arg.data_ptr(), B, N, M, ctx.w[0], ctx.w[1], ctx.w[2], g_ao.data_ptr(), _ptr(g_oa), _ptr(g_k),
+                      g_cls.data_ptr(), _stream())
+        return g_ao, g_oa, g_k, None, None, g_cls, None, None
+
+
+def geoa3_terms(d_ao, d_oa, k_adv, k_ori, idx_ao, cls, scale, w_dis, w_hd, w_curv):
+    """GeoA3's loss assembly in one launch (pc3d_geoa3_terms_f32): returns [5,B] = (dis, hd, curv, constrain, loss_n)
+    rows; differentiable in d_ao, d_oa, k_adv and cls. d_oa None = pseudo-Chamfer, k_adv None = no curvature term."""
+    for nm, t in (("d_ao", d_ao), ("d_oa", d_oa), ("k_adv", k_adv), ("k_ori", k_ori), ("cls", cls), ("scale", scale)):
+        if t is not None:
+            _check(t, nm)
+            if not t.is_contiguous():
+                raise ValueError(f"geoa3_terms: {nm} must be contiguous")
+    B, N = d_ao.shape
+    if cls.shape != (B,) or scale.shape != (B,) or (d_oa is not None and d_oa.shape[0] != B):
+        raise ValueError("geoa3_terms: cls / scale / d_oa do not match d_ao's batch")
+    if k_adv is not None:
+        if k_ori is None or idx_ao is None or idx_ao.dtype != torch.int64 or not idx_ao.is_contiguous():
+            raise ValueError("geoa3_terms: the curvature term needs k_ori and a contiguous int64 idx_ao")
+        if k_adv.shape != (B, N) or idx_ao.shape != (B, N) or (d_oa is not None and k_ori.shape != d_oa.shape):
+            raise ValueError("geoa3_terms: k_adv / idx_ao / k_ori shapes do not match the distances")
+        if k_ori.requires_grad:
+            raise NotImplementedError("geoa3_terms: k_ori is a constant of the attack")
+    else:
+        k_ori = idx_ao = None
+    return _GeoTermsFn.apply(d_ao, d_oa, k_adv, k_ori, idx_ao, cls, scale, (float(w_dis), float(w_hd), float(w_curv)))
+
+
 # ------------------------------------------------------------------------------------------------------
 # K8b: point-wise dense layers (frozen weights) on the fp32-MFMA GEMM
 # ------------------------------------------------------------------------------------------------------

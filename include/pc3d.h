@@ -110,6 +110,22 @@ int pc3d_kappa_bwd_f32(const float* x, int64_t x_bs, int64_t x_ps, int64_t x_cs,
                        int64_t n_ps, int64_t n_cs, const int32_t* idx, const float* gout, int B, int N, int K1, float* gx,
                        void* stream);
 
+/* GeoA3's per-sample loss assembly as one launch each way (attack/GeoA3/GeoA3_attack.py:139-181 on top of
+ * loss_utils.py:36-58,92-105): from the adv->ori nearest-neighbour squared distances d_ao [B,N] (and indices idx_ao
+ * [B,N] int64), the ori->adv distances d_oa [B,M] (NULL = pseudo-Chamfer), the curvature proxies k_adv [B,N] / k_ori
+ * [B,M] (both NULL = no curvature term), the classification loss cls [B] and the trade-off constants scale [B]:
+ *   out[0,b] dis  = mean d_ao (+ mean d_oa)     out[1,b] hd = max d_ao     out[2,b] curv = mean (k_adv - k_ori[idx_ao])^2
+ *   out[3,b] constrain = w_dis dis + w_hd hd + w_curv curv                 out[4,b] loss_n = cls + scale constrain
+ * out [5,B]; hd_arg [B] int32 = first arg-max of d_ao (where torch.max routes the gradient). The backward takes the
+ * upstream gradients of all five outputs (g_out [5,B]) and overwrites g_d_ao [B,N], g_d_oa [B,M] (may be NULL),
+ * g_k_adv [B,N] (may be NULL) and g_cls [B]. */
+int pc3d_geoa3_terms_f32(const float* d_ao, const float* d_oa, const float* k_adv, const float* k_ori,
+                         const int64_t* idx_ao, const float* cls, const float* scale, int B, int N, int M, float w_dis,
+                         float w_hd, float w_curv, float* out, int32_t* hd_arg, void* stream);
+int pc3d_geoa3_terms_bwd_f32(const float* g_out, const float* k_adv, const float* k_ori, const int64_t* idx_ao,
+                             const float* scale, const int32_t* hd_arg, int B, int N, int M, float w_dis, float w_hd,
+                             float w_curv, float* g_d_ao, float* g_d_oa, float* g_k_adv, float* g_cls, void* stream);
+
 /* First layer of a set-abstraction MLP without the grouped input tensor (model/pointnet2_utils.py:118-135,190-197): the
  * layer is linear in [x_j - c_s ; f_j], so  W1 [x_j - c_s ; f_j] + b1 = P[idx[s,j]] + Bc[s]  with P = [x | f] W1^T per
  * POINT (B*NA rows, pc3d_gemm_nt_f32) and Bc[s] = b1 - (Wx x)[centroid s].

@@ -138,7 +138,7 @@ def test_estimate_normal_closed_form_vs_eigh(dev, k):
     assert float(cosang[separated].min()) > 1 - 1e-4, float(cosang[separated].min())
 
 
-@pytest.mark.parametrize("B,N,k,cf", [(2, 300, 16, True), (3, 1024, 2, False), (1, 40, 5, True)])
+@pytest.mark.parametrize("B,N,k,cf", [(2, 300, 16, True), (3, 1024, 2, False), (1, 40, 5, True), (1, 4500, 3, True)])
 def test_kappa_kernel_vs_reference_formulation(dev, B, N, k, cf):
     """pc3d_kappa_f32 / _bwd_f32 against the step-by-step tensors of attack/GeoA3/loss_utils.py:60-90 in float64 (the
     same neighbour lists): values and the gradient to the points, including coincident points (clamped norm)."""
@@ -168,3 +168,40 @@ def test_kappa_kernel_vs_reference_formulation(dev, B, N, k, cf):
     ok[3] = ok[7] = False
     assert float((got[:, ok] - xd.grad[:, ok]).norm() / xd.grad[:, ok].norm()) < 1e-4
     assert torch.isfinite(got).all()
+
+
+@pytest.mark.parametrize("B,N,M,both,curv", [(3, 1024, 1024, True, True), (2, 300, 257, False, True),
+                                             (4, 77, 77, True, False), (1, 5, 9, False, False)])
+def test_geoa3_terms_vs_reference_formulation(dev, B, N, M, both, curv):
+    """pc3d_geoa3_terms_f32 / _bwd_f32 against the tensor formulation of attack/GeoA3/GeoA3_attack.py:139-181 (Chamfer or
+    pseudo-Chamfer, Hausdorff, curvature, weighting, scale) in float64: the five outputs and every gradient, with a tie
+    in the Hausdorff maximum (torch.max routes the gradient to the first)."""
+    ops = importlib.import_module("3dpointcloudattack_amd.ops")
+    g = torch.Generator().manual_seed(N + M)
+    d_ao, d_oa = torch.rand(B, N, generator=g), torch.rand(B, M, generator=g)
+    d_ao[0, N // 2] = d_ao[0, 1] = 2.0                      # tie for the maximum
+    k_adv, k_ori = torch.rand(B, N, generator=g), torch.rand(B, M, generator=g)
+    idx = torch.randint(0, M, (B, N), generator=g)
+    cls, scale = torch.randn(B, generator=g), torch.rand(B, generator=g) * 50
+    w = (1.0, 0.1, 1.0)
+    up = torch.randn(5, B, generator=g)
+
+    def leaf(t, dt):
+        return t.to(dt).clone().requires_grad_()
+    a = [leaf(t.to(dev), torch.float32) for t in (d_ao, d_oa, k_adv, cls)]
+    out = ops.geoa3_terms(a[0], a[1] if both else None, a[2] if curv else None, k_ori.to(dev) if curv else None,
+                          idx.to(dev) if curv else None, a[3], scale.to(dev), *w)
+    (out * up.to(dev)).sum().backward()
+    r = [leaf(t, torch.float64) for t in (d_ao, d_oa, k_adv, cls)]
+    dis = r[0].mean(-1) + (r[1].mean(-1) if both else 0)
+    hd = r[0].max(-1)[0]
+    cv = ((r[2] - torch.gather(k_ori.double(), 1, idx)) ** 2).mean(-1) if curv else torch.zeros(B, dtype=torch.float64)
+    con = w[0] * dis + w[1] * hd + w[2] * cv
+    ref = torch.stack([dis, hd, cv, con, r[3] + scale.double() * con])
+    (ref * up.double()).sum().backward()
+    torch.testing.assert_close(out.cpu().double(), ref.detach(), rtol=2e-6, atol=1e-6)
+    for got, want, used in zip(a, r, (True, both, curv, True)):
+        if used:
+            torch.testing.assert_close(got.grad.cpu().double(), want.grad, rtol=2e-5, atol=1e-7)
+        else:
+            assert got.grad is None
