@@ -37,12 +37,21 @@ struct KnnFeatArgs {
 // Register diet on purpose (~80 VGPRs -> 4+ waves per SIMD): the insertions are chains of dependent VALU/SALU
 // hops, and only other resident waves hide them. So the A operand (the 32 query rows) sits in LDS, the B operand is
 // streamed from global memory a few float4 ahead, and nothing but the accumulator tile and the lists stays live.
-constexpr int KF_PF = 4;              // float4 of the B operand in flight per lane
+// NT = C / 8 when it is known at compile time (8: C = 64), 0 = any C. With a run-time trip count the compiler drains the
+// load queue (s_waitcnt vmcnt(0)) inside the product loop, so the "4 float4 ahead" are in flight for one MFMA group at
+// most. With NT static the loop is straight-line code: all 8 float4 of a row slice in flight with graded waits, and the
+// 8 of the NEXT block are requested before this block's strip write and scan (133 -> 129 us at B=32, N=1024, C=64, K=20;
+// products + strip alone 61 -> 57 us against 31 us of matrix-pipe work: the rest is the strip write's VALU work and the
+// two barriers per block, which four lock-stepped workgroups per CU do not hide). C = 128 stays on the run-time form:
+// static, it needs 136 (4 ahead) or 152 (8 ahead) VGPRs = 3 waves per SIMD, and took 195 us against 171.
+constexpr int KF_PF = 4;              // float4 of the B operand in flight per lane (run-time C)
+constexpr int KF_PFS = 8;             // ... with a static C
 
+template <int NT>
 __global__ __launch_bounds__(KF_T) void knn_feat_kernel(KnnFeatArgs a) {
   extern __shared__ __attribute__((aligned(16))) float kf_lds[];
   const int ldq = a.C + 4;                                  // row stride of the query block (16-byte aligned rows)
-  float (*strip)[KF_LD] = reinterpret_cast<float (*)[KF_LD]>(kf_lds);          // [32][132] distance block
+  int (*strip)[KF_LD] = reinterpret_cast<int (*)[KF_LD]>(kf_lds);              // [32][132] block of distance KEYS (knn_key)
   float* qs = kf_lds + KF_Q * KF_LD;                                             // [32][C+4] query rows
   float* qn = qs + KF_Q * ldq;                                                   // [32] squared norms
   const int b = blockIdx.y, q0 = blockIdx.x * KF_Q;
@@ -50,7 +59,7 @@ __global__ __launch_bounds__(KF_T) void knn_feat_kernel(KnnFeatArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 31, h = lane >> 5;
   const float* xb = a.x + (int64_t)b * a.N * a.C;
-  const int nt = a.C / 8;
+  const int nt = NT ? NT : a.C / 8;
   const int K = a.K;
   // stage the query rows (clamped at the cloud's end) and their squared norms
   {
@@ -72,43 +81,59 @@ __global__ __launch_bounds__(KF_T) void knn_feat_kernel(KnnFeatArgs a) {
     }
   }
   // K-lists of this wave's queries (8*wave .. +7), across the lanes
-  float ld[KF_QW], thr[KF_QW];
+  int lk[KF_QW], thr[KF_QW];
   int li[KF_QW];
 #pragma unroll
-  for (int u = 0; u < KF_QW; ++u) ld[u] = __builtin_inff(), li[u] = 0x7fffffff, thr[u] = __builtin_inff();
+  for (int u = 0; u < KF_QW; ++u) lk[u] = kKnnInfKey, li[u] = 0x7fffffff, thr[u] = kKnnInfKey;
 
   const int nblk = (a.N + KF_BLK - 1) / KF_BLK;
+  constexpr int PF = NT ? KF_PFS : KF_PF;
+  float4 bv[PF];            // B operand in flight, carried across blocks
+  const float* rp_next;
+  auto first_rows = [&](int blk) {
+    const int rrow0 = blk * KF_BLK + 32 * wave + r;
+    rp_next = xb + (int64_t)(rrow0 < a.N ? rrow0 : a.N - 1) * a.C + 4 * h;
+#pragma unroll
+    for (int t = 0; t < PF; ++t) bv[t] = (t < nt) ? *reinterpret_cast<const float4*>(rp_next + 8 * t) : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  first_rows(0);
   __syncthreads();   // qn visible
   for (int blk = 0; blk < nblk; ++blk) {
-    float (*st)[KF_LD] = strip;
+    int (*st)[KF_LD] = strip;
     // ---- phase 1: this wave's 32 x 32 tile of the block on MFMA (this IS a dense contraction over C)
     {
-      const int rrow0 = blk * KF_BLK + 32 * wave + r;
-      const int rrow = rrow0 < a.N ? rrow0 : a.N - 1;
-      const float* rp = xb + (int64_t)rrow * a.C + 4 * h;
       f32x16 acc;
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[e] = 0.f;
       float rn = 0.f;
-      float4 bv[KF_PF];
+      const float* rp = rp_next;               // this block's row (its first PF float4 are already in flight)
+      auto step = [&](const float4 v, int t) {
+        const float4 q = *reinterpret_cast<const float4*>(qs + r * ldq + 8 * t + 4 * h);
+        rn += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q.x, v.x, acc, 0, 0, 0);   // D[row = query][col = reference]
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q.y, v.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q.z, v.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q.w, v.w, acc, 0, 0, 0);
+      };
+      if constexpr (NT != 0) {
 #pragma unroll
-      for (int t = 0; t < KF_PF; ++t) bv[t] = (t < nt) ? *reinterpret_cast<const float4*>(rp + 8 * t) : make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int t0 = 0; t0 < nt; t0 += KF_PF) {
+        for (int t = 0; t < NT; ++t) {
+          const float4 v = bv[t % PF];
+          if (t + PF < NT) bv[t % PF] = *reinterpret_cast<const float4*>(rp + 8 * (t + PF));
+          step(v, t);
+        }
+      } else {
+        for (int t0 = 0; t0 < nt; t0 += PF) {
 #pragma unroll
-        for (int tt = 0; tt < KF_PF; ++tt) {
-          const int t = t0 + tt;
-          const float4 v = bv[tt];
-          if (t + KF_PF < nt) bv[tt] = *reinterpret_cast<const float4*>(rp + 8 * (t + KF_PF));
-          if (t < nt) {
-            const float4 q = *reinterpret_cast<const float4*>(qs + r * ldq + 8 * t + 4 * h);
-            rn += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q.x, v.x, acc, 0, 0, 0);   // D[row = query][col = reference]
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q.y, v.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q.z, v.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q.w, v.w, acc, 0, 0, 0);
+          for (int tt = 0; tt < PF; ++tt) {
+            const int t = t0 + tt;
+            const float4 v = bv[tt];
+            if (t + PF < nt) bv[tt] = *reinterpret_cast<const float4*>(rp + 8 * (t + PF));
+            if (t < nt) step(v, t);
           }
         }
       }
+      if (blk + 1 < nblk) first_rows(blk + 1);
       rn += __shfl_xor(rn, 32, 64);            // |r_j|^2 for column j = r
       const bool valid = (blk * KF_BLK + 32 * wave + r) < a.N;
 #pragma unroll
@@ -116,7 +141,7 @@ __global__ __launch_bounds__(KF_T) void knn_feat_kernel(KnnFeatArgs a) {
         const int qi = (e & 3) + 8 * (e >> 2) + 4 * h;
         // model/dgcnn.py:195-197 ranks by 2 q.r - |q|^2 - |r|^2 (largest first); its exact negation is stored, so
         // "smallest first" here is the same order with the same ties
-        st[qi][32 * wave + r] = valid ? -(2.f * acc[e] - qn[qi] - rn) : __builtin_inff();
+        st[qi][32 * wave + r] = valid ? knn_key(-(2.f * acc[e] - qn[qi] - rn)) : kKnnInfKey;
       }
     }
     __syncthreads();
@@ -124,33 +149,21 @@ __global__ __launch_bounds__(KF_T) void knn_feat_kernel(KnnFeatArgs a) {
 #pragma unroll
     for (int s = 0; s < KF_BLK / 64; ++s) {
       const int jbase = blk * KF_BLK + 64 * s;
-      float d[KF_QW];
+      int d[KF_QW];
 #pragma unroll
       for (int u = 0; u < KF_QW; ++u) d[u] = st[KF_QW * wave + u][64 * s + lane];
       if (blk == 0 && s == 0) {
 #pragma unroll
         for (int u = 0; u < KF_QW; ++u) {      // seed: sort the first 64 candidates
-          int sk = knn_ord((d[u] == d[u]) ? d[u] : __builtin_inff());
-          int si = lane;
+          int sk = d[u], si = lane;
           wave_sort_pairs_dpp(sk, si, lane);
-          const float sd = knn_unord(sk);
-          ld[u] = sd, li[u] = si;
-          thr[u] = readlane_f(sd, K - 1);
+          lk[u] = sk, li[u] = si;
+          thr[u] = __builtin_amdgcn_readlane(sk, K - 1);
         }
         continue;
       }
 #pragma unroll
-      for (int u = 0; u < KF_QW; ++u) {
-        unsigned long long mask = __builtin_amdgcn_ballot_w64(d[u] < thr[u]);
-        while (mask) {
-          const int c = __builtin_ctzll(mask);
-          mask &= mask - 1;
-          const float dc = readlane_f(d[u], c);
-          if (!(dc < thr[u])) continue;
-          knn_list_insert(ld[u], li[u], dc, jbase + c, lane);
-          thr[u] = readlane_f(ld[u], K - 1);
-        }
-      }
+      for (int u = 0; u < KF_QW; ++u) knn_scan_insert(lk[u], li[u], thr[u], d[u], jbase, K);
     }
     __syncthreads();   // the block is consumed before the next one overwrites it (single buffer: LDS buys residency)
   }
@@ -432,7 +445,8 @@ extern "C" int pc3d_knn_feat_f32(const float* x, int B, int N, int C, int K, int
   PC3D_REQUIRE(x && idx, "pc3d_knn_feat_f32: null pointer");
   KnnFeatArgs a{x, N, C, K, idx};
   const size_t lds = (size_t)(KF_Q * KF_LD + KF_Q * (C + 4) + KF_Q) * sizeof(float);   // 25.7 KiB (C=64) / 33.9 KiB (C=128)
-  hipLaunchKernelGGL(knn_feat_kernel, dim3(cdiv(N, KF_Q), B), dim3(KF_T), lds, as_stream(stream), a);
+  auto* kern = C == 64 ? knn_feat_kernel<8> : knn_feat_kernel<0>;
+  hipLaunchKernelGGL(kern, dim3(cdiv(N, KF_Q), B), dim3(KF_T), lds, as_stream(stream), a);
   PC3D_LAUNCH_CHECK("pc3d_knn_feat_f32");
   return PC3D_OK;
 }

@@ -49,8 +49,11 @@ __global__ __launch_bounds__(kKwWaves * 64) void knn_wave_kernel(KnnArgs a) {
   float* sz = lds + 2 * kKwTile;
 
   // per-query state, statically indexed: [pass][u]
-  float ld[kKwPasses][kKwQPW], thr[kKwPasses][kKwQPW], qx[kKwPasses][kKwQPW], qy[kKwPasses][kKwQPW], qz[kKwPasses][kKwQPW];
-  int li[kKwPasses][kKwQPW];
+  // The lists hold distance KEYS: a squared distance is >= +0 or NaN, so its bit pattern with the sign cleared is already
+  // an order-preserving integer (NaN above +inf: never below a threshold) — thresholds then live in SGPRs and the
+  // re-check of a candidate is a scalar compare (knn_list.h).
+  float qx[kKwPasses][kKwQPW], qy[kKwPasses][kKwQPW], qz[kKwPasses][kKwQPW];
+  int lk[kKwPasses][kKwQPW], thr[kKwPasses][kKwQPW], li[kKwPasses][kKwQPW];
 #pragma unroll
   for (int p = 0; p < kKwPasses; ++p)
 #pragma unroll
@@ -59,9 +62,9 @@ __global__ __launch_bounds__(kKwWaves * 64) void knn_wave_kernel(KnnArgs a) {
       if (qi >= N) qi = N - 1;
       const float* qp = a.q.p + (int64_t)b * a.q.bs + (int64_t)qi * a.q.ps;   // wave-uniform address
       qx[p][u] = qp[0], qy[p][u] = qp[a.q.cs], qz[p][u] = qp[2 * a.q.cs];
-      ld[p][u] = __builtin_inff();
+      lk[p][u] = kKnnInfKey;
       li[p][u] = 0x7fffffff;
-      thr[p][u] = __builtin_inff();
+      thr[p][u] = kKnnInfKey;
     }
 
   const float* rb = a.r.p + (int64_t)b * a.r.bs;
@@ -101,12 +104,11 @@ __global__ __launch_bounds__(kKwWaves * 64) void knn_wave_kernel(KnnArgs a) {
           if (K > 10) {                             // larger K: one bitonic sort per query is cheaper than K rounds
 #pragma unroll
             for (int u = 0; u < kKwQPW; ++u) {
-              int sk = knn_ord(rem[u]);
+              int sk = __builtin_bit_cast(int, rem[u]);
               int si = lane;
               wave_sort_pairs_dpp(sk, si, lane);   // no LDS round trips (knn_list.h)
-              const float sd = knn_unord(sk);
-              ld[p][u] = sd, li[p][u] = si;
-              thr[p][u] = readlane_f(sd, K - 1);
+              lk[p][u] = sk, li[p][u] = si;
+              thr[p][u] = __builtin_amdgcn_readlane(sk, K - 1);
             }
             continue;
           }
@@ -115,28 +117,18 @@ __global__ __launch_bounds__(kKwWaves * 64) void knn_wave_kernel(KnnArgs a) {
             for (int u = 0; u < kKwQPW; ++u) {      // four independent chains hide the DPP / readlane latencies
               m[u] = wave_min_dpp(rem[u]);
               const int c = __builtin_ctzll(__builtin_amdgcn_ballot_w64(rem[u] == m[u]) | (1ull << 63));
-              ld[p][u] = (lane == t) ? m[u] : ld[p][u];
+              lk[p][u] = (lane == t) ? __builtin_bit_cast(int, m[u]) : lk[p][u];
               li[p][u] = (lane == t) ? c : li[p][u];
               rem[u] = (lane == c) ? __builtin_inff() : rem[u];
             }
           }
 #pragma unroll
-          for (int u = 0; u < kKwQPW; ++u) thr[p][u] = m[u];
+          for (int u = 0; u < kKwQPW; ++u) thr[p][u] = __builtin_bit_cast(int, m[u]);
           continue;
         }
 #pragma unroll
-        for (int u = 0; u < kKwQPW; ++u) {
-          unsigned long long mask = __builtin_amdgcn_ballot_w64(d[u] < thr[p][u]);
-          while (mask) {
-            const int c = __builtin_ctzll(mask);
-            mask &= mask - 1;
-            const float dc = readlane_f(d[u], c);
-            if (!(dc < thr[p][u])) continue;        // the threshold tightened since the ballot
-            const int ic = m0 + j0 + c;
-            knn_list_insert(ld[p][u], li[p][u], dc, ic, lane);
-            thr[p][u] = readlane_f(ld[p][u], K - 1);
-          }
-        }
+        for (int u = 0; u < kKwQPW; ++u)
+          knn_scan_insert(lk[p][u], li[p][u], thr[p][u], __builtin_bit_cast(int, d[u]) & 0x7fffffff, m0 + j0, K);
       }
     }
   }
@@ -146,7 +138,7 @@ __global__ __launch_bounds__(kKwWaves * 64) void knn_wave_kernel(KnnArgs a) {
     for (int u = 0; u < kKwQPW; ++u) {
       const int qi = qbase + p * kKwQPW + u;
       if (qi < N && lane < K) {
-        if (a.d) a.d[((int64_t)b * N + qi) * K + lane] = ld[p][u];
+        if (a.d) a.d[((int64_t)b * N + qi) * K + lane] = __builtin_bit_cast(float, lk[p][u]);
         if (a.i) a.i[((int64_t)b * N + qi) * K + lane] = li[p][u];
       }
     }

@@ -132,4 +132,55 @@ __device__ __forceinline__ void knn_list_insert(float& ld, int& li, float dc, in
   }
 }
 
+// ---- the same list on INTEGER keys (knn_ord of the distance). With float distances the "still below the threshold?"
+// re-check of a candidate is a VALU compare of two wave-uniform values -> VCC -> branch, and the threshold lives in a
+// VGPR; gfx950 has no scalar float compare. On keys it is s_cmp_lt_i32 on two SGPRs, the threshold is the SGPR that
+// v_readlane returned, and the "position < 64" guard goes (a candidate below entry K-1 lands at a position < K).
+constexpr int kKnnInfKey = 0x7f800000;   // knn_ord(+inf)
+// total order on distances: NaN -> +inf (never a neighbour), -0 -> +0
+__device__ __forceinline__ int knn_key(float d) { return knn_ord(fminf(d, __builtin_inff()) + 0.f); }
+
+// One candidate of a 64-candidate step: lane c's key is read into an SGPR, the list lanes with lk <= kc keep their entry,
+// the others take their lower neighbour's (select and wave_shr:1 shift are ONE v_cndmask_b32_dpp per array: lane 0 has no
+// source lane and keeps its own) and the new entry goes to lane popcount(keep) (< K, since kc is below the key of lane
+// K-1). Nine instructions, hand-written: the compiler's form of the same step took 13 (v_mov_b32_dpp + v_cndmask_b32
+// pairs, three SALU instructions for mask &= mask - 1), and at four waves per SIMD these loops are bound by instruction
+// issue — 27 -> 22 -> 18 -> 15 instructions per insertion moved knn_wave_kernel 82 -> 74 -> 66 -> 6x us (B=32, N=1024,
+// K=20) and knn_feat_kernel 141 -> 133 -> 121 -> 1xx us.
+// Hazards (inline code is not seen by the compiler's hazard recogniser), gfx950:
+//   * VALU-written SGPR (kc, from v_readlane) read by a VALU: 2 wait states — the two SALU instructions in between;
+//   * VALU-written VGPR read through DPP: 2 wait states — lk / li were last written by the v_writelane of an earlier
+//     step or by the seed sort, and the step's first three instructions separate them in any case;
+//   * M0 is written by SALU (no hazard before v_writelane) and is CLOBBERED: v_writelane takes an SGPR value only with
+//     M0 as the lane select (one-SGPR constant-bus rule). It cannot be named in the clobber list (reserved); the
+//     compiler never keeps a value in M0 across other code.
+__device__ __forceinline__ void knn_list_step(int& lk, int& li, unsigned long long& mask, int key, int c, int jbase) {
+  int kc, ic;
+  asm volatile(
+      "v_readlane_b32 %[kc], %[key], %[c]\n\t"
+      "s_add_i32 %[ic], %[jb], %[c]\n\t"
+      "s_bitset0_b64 %[mask], %[c]\n\t"
+      "v_cmp_ge_i32_e32 vcc, %[kc], %[lk]\n\t"
+      "v_cndmask_b32_dpp %[lk], %[lk], %[lk], vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %[li], %[li], %[li], vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "s_bcnt1_i32_b64 m0, vcc\n\t"
+      "v_writelane_b32 %[lk], %[kc], m0\n\t"
+      "v_writelane_b32 %[li], %[ic], m0"
+      : [lk] "+v"(lk), [li] "+v"(li), [mask] "+s"(mask), [kc] "=&s"(kc), [ic] "=&s"(ic)
+      : [key] "v"(key), [c] "s"(c), [jb] "s"(jbase)
+      : "vcc", "scc");
+}
+
+// 64 candidates (one key per lane, index jbase + lane) against one list; thr = key of entry K-1, kept in an SGPR.
+// Candidates are taken in ascending lane order; after every insertion the remaining ones are re-filtered against the
+// tightened threshold (one v_cmp + s_and), so no iteration is spent on a candidate that no longer qualifies.
+__device__ __forceinline__ void knn_scan_insert(int& lk, int& li, int& thr, int key, int jbase, int K) {
+  unsigned long long mask = __builtin_amdgcn_ballot_w64(key < thr);
+  while (mask) {
+    knn_list_step(lk, li, mask, key, __builtin_ctzll(mask), jbase);
+    thr = __builtin_amdgcn_readlane(lk, K - 1);
+    mask &= __builtin_amdgcn_ballot_w64(key < thr);
+  }
+}
+
 }  // namespace pc3d
