@@ -47,7 +47,7 @@ struct KnnFeatArgs {
 constexpr int KF_PF = 4;              // float4 of the B operand in flight per lane (run-time C)
 constexpr int KF_PFS = 8;             // ... with a static C
 
-template <int NT>
+template <int NT, bool KGE2>
 __global__ __launch_bounds__(KF_T) void knn_feat_kernel(KnnFeatArgs a) {
   extern __shared__ __attribute__((aligned(16))) float kf_lds[];
   const int ldq = a.C + 4;                                  // row stride of the query block (16-byte aligned rows)
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(KF_T) void knn_feat_kernel(KnnFeatArgs a) {
         continue;
       }
 #pragma unroll
-      for (int u = 0; u < KF_QW; ++u) knn_scan_insert(lk[u], li[u], thr[u], d[u], jbase, K);
+      for (int u = 0; u < KF_QW; ++u) knn_scan_insert<KGE2>(lk[u], li[u], thr[u], d[u], jbase, K);
     }
     __syncthreads();   // the block is consumed before the next one overwrites it (single buffer: LDS buys residency)
   }
@@ -445,7 +445,8 @@ extern "C" int pc3d_knn_feat_f32(const float* x, int B, int N, int C, int K, int
   PC3D_REQUIRE(x && idx, "pc3d_knn_feat_f32: null pointer");
   KnnFeatArgs a{x, N, C, K, idx};
   const size_t lds = (size_t)(KF_Q * KF_LD + KF_Q * (C + 4) + KF_Q) * sizeof(float);   // 25.7 KiB (C=64) / 33.9 KiB (C=128)
-  auto* kern = C == 64 ? knn_feat_kernel<8> : knn_feat_kernel<0>;
+  auto* kern = C == 64 ? (K >= 2 ? knn_feat_kernel<8, true> : knn_feat_kernel<8, false>)
+                       : (K >= 2 ? knn_feat_kernel<0, true> : knn_feat_kernel<0, false>);
   hipLaunchKernelGGL(kern, dim3(cdiv(N, KF_Q), B), dim3(KF_T), lds, as_stream(stream), a);
   PC3D_LAUNCH_CHECK("pc3d_knn_feat_f32");
   return PC3D_OK;

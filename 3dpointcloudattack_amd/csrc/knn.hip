@@ -34,7 +34,7 @@ struct KnnArgs {
 constexpr int kKwQPW = 4;          // queries scanned together by a wave
 constexpr int kKwTile = 2048;      // reference points per LDS tile (24 KiB SoA)
 
-template <int kKwWaves>    // waves per workgroup: a workgroup serves 4 * kKwWaves queries from one staged copy of the cloud
+template <int kKwWaves, bool KGE2>    // waves per workgroup: a workgroup serves 4 * kKwWaves queries from one staged copy of the cloud
 __global__ __launch_bounds__(kKwWaves * 64) void knn_wave_kernel(KnnArgs a) {
   constexpr int kKwPasses = 1;
   constexpr int kKwThreads = kKwWaves * 64;
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(kKwWaves * 64) void knn_wave_kernel(KnnArgs a) {
         }
 #pragma unroll
         for (int u = 0; u < kKwQPW; ++u)
-          knn_scan_insert(lk[p][u], li[p][u], thr[p][u], __builtin_bit_cast(int, d[u]) & 0x7fffffff, m0 + j0, K);
+          knn_scan_insert<KGE2>(lk[p][u], li[p][u], thr[p][u], __builtin_bit_cast(int, d[u]) & 0x7fffffff, m0 + j0, K);
       }
     }
   }
@@ -280,7 +280,8 @@ extern "C" int pc3d_knn_f32(const float* q, int64_t q_bs, int64_t q_ps, int64_t 
   KnnArgs a{{q, q_bs, q_ps, q_cs}, {r, r_bs, r_ps, r_cs}, N, M, K, dists, idx};
   hipStream_t st = as_stream(stream);
   // 4 waves (16 queries) per workgroup: measured best of {2,4,8,16} — larger workgroups wait at the staging barriers
-  hipLaunchKernelGGL(knn_wave_kernel<4>, dim3(cdiv(N, 16), B), dim3(256), 0, st, a);
+  if (K >= 2) hipLaunchKernelGGL((knn_wave_kernel<4, true>), dim3(cdiv(N, 16), B), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((knn_wave_kernel<4, false>), dim3(cdiv(N, 16), B), dim3(256), 0, st, a);
   PC3D_LAUNCH_CHECK("pc3d_knn_f32");
   return PC3D_OK;
 }

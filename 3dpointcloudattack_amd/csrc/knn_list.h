@@ -171,15 +171,50 @@ __device__ __forceinline__ void knn_list_step(int& lk, int& li, unsigned long lo
       : "vcc", "scc");
 }
 
+// The same step for K >= 2 with the re-filter folded in and no wait states: the list is sorted, so the threshold AFTER
+// the insertion is max(kc, key of entry K-2 before it) — two v_readlane up front, one s_max, and the compare that
+// re-filters the remaining candidates issues under the insertion instead of behind a v_writelane -> v_readlane ->
+// (2 wait states) -> v_cmp chain. 14 instructions; with s_ff1 and the loop branch 17 issue slots per insertion
+// against 20 (18 + 2 s_nop) for knn_list_step + v_readlane + v_cmp + s_and.
+// Hazards as above; additionally: SALU reads of VALU-written SGPRs (s_max on kc / t2, s_bcnt1 / s_and on VCC) are
+// interlocked in hardware; v_readlane of lk follows the previous step's v_writelane by >= 4 instructions.
+__device__ __forceinline__ void knn_list_step_refilter(int& lk, int& li, unsigned long long& mask, int& thr, int key, int c,
+                                                       int jbase, int km2) {
+  int kc, ic, t2;
+  asm volatile(
+      "v_readlane_b32 %[kc], %[key], %[c]\n\t"
+      "v_readlane_b32 %[t2], %[lk], %[km2]\n\t"
+      "s_bitset0_b64 %[mask], %[c]\n\t"
+      "s_add_i32 %[ic], %[jb], %[c]\n\t"
+      "s_max_i32 %[thr], %[kc], %[t2]\n\t"
+      "v_cmp_ge_i32_e32 vcc, %[kc], %[lk]\n\t"
+      "v_cndmask_b32_dpp %[lk], %[lk], %[lk], vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %[li], %[li], %[li], vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "s_bcnt1_i32_b64 m0, vcc\n\t"
+      "v_cmp_gt_i32_e32 vcc, %[thr], %[key]\n\t"
+      "s_and_b64 %[mask], vcc, %[mask]\n\t"
+      "v_writelane_b32 %[lk], %[kc], m0\n\t"
+      "v_writelane_b32 %[li], %[ic], m0"
+      : [lk] "+v"(lk), [li] "+v"(li), [mask] "+s"(mask), [thr] "=&s"(thr), [kc] "=&s"(kc), [ic] "=&s"(ic), [t2] "=&s"(t2)
+      : [key] "v"(key), [c] "s"(c), [jb] "s"(jbase), [km2] "s"(km2)
+      : "vcc", "scc");
+}
+
 // 64 candidates (one key per lane, index jbase + lane) against one list; thr = key of entry K-1, kept in an SGPR.
 // Candidates are taken in ascending lane order; after every insertion the remaining ones are re-filtered against the
-// tightened threshold (one v_cmp + s_and), so no iteration is spent on a candidate that no longer qualifies.
+// tightened threshold, so no iteration is spent on a candidate that no longer qualifies.
+template <bool KGE2>   // K >= 2 (decided per kernel instantiation: a run-time branch here doubles every unrolled call site)
 __device__ __forceinline__ void knn_scan_insert(int& lk, int& li, int& thr, int key, int jbase, int K) {
   unsigned long long mask = __builtin_amdgcn_ballot_w64(key < thr);
-  while (mask) {
-    knn_list_step(lk, li, mask, key, __builtin_ctzll(mask), jbase);
-    thr = __builtin_amdgcn_readlane(lk, K - 1);
-    mask &= __builtin_amdgcn_ballot_w64(key < thr);
+  if constexpr (KGE2) {
+    const int km2 = K - 2;
+    while (mask) knn_list_step_refilter(lk, li, mask, thr, key, __builtin_ctzll(mask), jbase, km2);
+  } else {
+    while (mask) {
+      knn_list_step(lk, li, mask, key, __builtin_ctzll(mask), jbase);
+      thr = __builtin_amdgcn_readlane(lk, K - 1);
+      mask &= __builtin_amdgcn_ballot_w64(key < thr);
+    }
   }
 }
 
