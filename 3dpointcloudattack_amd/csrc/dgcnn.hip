@@ -53,7 +53,6 @@ __global__ __launch_bounds__(KF_T) void knn_feat_kernel(KnnFeatArgs a) {
   const int ldq = a.C + 4;                                  // row stride of the query block (16-byte aligned rows)
   int (*strip)[KF_LD] = reinterpret_cast<int (*)[KF_LD]>(kf_lds);              // [32][132] block of distance KEYS (knn_key)
   float* qs = kf_lds + KF_Q * KF_LD;                                             // [32][C+4] query rows
-  float* qn = qs + KF_Q * ldq;                                                   // [32] squared norms
   const int b = blockIdx.y, q0 = blockIdx.x * KF_Q;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -61,23 +60,13 @@ __global__ __launch_bounds__(KF_T) void knn_feat_kernel(KnnFeatArgs a) {
   const float* xb = a.x + (int64_t)b * a.N * a.C;
   const int nt = NT ? NT : a.C / 8;
   const int K = a.K;
-  // stage the query rows (clamped at the cloud's end) and their squared norms
+  // stage the query rows (clamped at the cloud's end)
   {
     const int cq = a.C / 4;   // float4 per row
     for (int i = threadIdx.x; i < KF_Q * cq; i += KF_T) {
       const int row = i / cq, c4 = i - row * cq;
       const int qrow = (q0 + row < a.N) ? q0 + row : a.N - 1;
       *reinterpret_cast<float4*>(qs + row * ldq + 4 * c4) = *reinterpret_cast<const float4*>(xb + (int64_t)qrow * a.C + 4 * c4);
-    }
-    __syncthreads();
-    if (wave == 0) {   // lane (r,h) sums the float4s 8t+4h of row r — the same partition and order as the reference rows below
-      float s = 0.f;
-      for (int t = 0; t < nt; ++t) {
-        const float4 v = *reinterpret_cast<const float4*>(qs + r * ldq + 8 * t + 4 * h);
-        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-      }
-      s += __shfl_xor(s, 32, 64);
-      if (h == 0) qn[r] = s;
     }
   }
   // K-lists of this wave's queries (8*wave .. +7), across the lanes
@@ -97,7 +86,7 @@ __global__ __launch_bounds__(KF_T) void knn_feat_kernel(KnnFeatArgs a) {
     for (int t = 0; t < PF; ++t) bv[t] = (t < nt) ? *reinterpret_cast<const float4*>(rp_next + 8 * t) : make_float4(0.f, 0.f, 0.f, 0.f);
   };
   first_rows(0);
-  __syncthreads();   // qn visible
+  __syncthreads();   // query rows visible
   for (int blk = 0; blk < nblk; ++blk) {
     int (*st)[KF_LD] = strip;
     // ---- phase 1: this wave's 32 x 32 tile of the block on MFMA (this IS a dense contraction over C)
@@ -109,7 +98,7 @@ __global__ __launch_bounds__(KF_T) void knn_feat_kernel(KnnFeatArgs a) {
       const float* rp = rp_next;               // this block's row (its first PF float4 are already in flight)
       auto step = [&](const float4 v, int t) {
         const float4 q = *reinterpret_cast<const float4*>(qs + r * ldq + 8 * t + 4 * h);
-        rn += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        rn = __builtin_fmaf(v.w, v.w, __builtin_fmaf(v.z, v.z, __builtin_fmaf(v.y, v.y, __builtin_fmaf(v.x, v.x, rn))));   // 4 VALU, not 8
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q.x, v.x, acc, 0, 0, 0);   // D[row = query][col = reference]
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q.y, v.y, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q.z, v.z, acc, 0, 0, 0);
@@ -135,13 +124,22 @@ __global__ __launch_bounds__(KF_T) void knn_feat_kernel(KnnFeatArgs a) {
       }
       if (blk + 1 < nblk) first_rows(blk + 1);
       rn += __shfl_xor(rn, 32, 64);            // |r_j|^2 for column j = r
-      const bool valid = (blk * KF_BLK + 32 * wave + r) < a.N;
+      // model/dgcnn.py:195-197 ranks the references of a query by 2 q.r - |q|^2 - |r|^2, largest first. |q|^2 is the
+      // same for every candidate of a query, so the key is that of |r|^2 - 2 q.r, smallest first (never -0: x - x is +0;
+      // NaN -> +inf by v_min_f32, which returns its other operand for a quiet NaN): 6 VALU per element instead of 10 and
+      // no |q|^2 read — this write is ~2/3 of the phase's VALU work.
+      auto key_of = [&](float accv) {
+        float d = rn - (accv + accv);
+        asm("v_min_f32_e32 %0, 0x7f800000, %0" : "+v"(d));
+        return knn_ord(d);
+      };
+      if (__builtin_expect((blk + 1) * KF_BLK > a.N, 0)) {          // ragged last block: columns beyond the cloud never rank
+        const bool valid = (blk * KF_BLK + 32 * wave + r) < a.N;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int qi = (e & 3) + 8 * (e >> 2) + 4 * h;
-        // model/dgcnn.py:195-197 ranks by 2 q.r - |q|^2 - |r|^2 (largest first); its exact negation is stored, so
-        // "smallest first" here is the same order with the same ties
-        st[qi][32 * wave + r] = valid ? knn_key(-(2.f * acc[e] - qn[qi] - rn)) : kKnnInfKey;
+        for (int e = 0; e < 16; ++e) st[(e & 3) + 8 * (e >> 2) + 4 * h][32 * wave + r] = valid ? key_of(acc[e]) : kKnnInfKey;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) st[(e & 3) + 8 * (e >> 2) + 4 * h][32 * wave + r] = key_of(acc[e]);
       }
     }
     __syncthreads();
@@ -444,7 +442,7 @@ extern "C" int pc3d_knn_feat_f32(const float* x, int B, int N, int C, int K, int
   if (B == 0) return PC3D_OK;
   PC3D_REQUIRE(x && idx, "pc3d_knn_feat_f32: null pointer");
   KnnFeatArgs a{x, N, C, K, idx};
-  const size_t lds = (size_t)(KF_Q * KF_LD + KF_Q * (C + 4) + KF_Q) * sizeof(float);   // 25.7 KiB (C=64) / 33.9 KiB (C=128)
+  const size_t lds = (size_t)(KF_Q * KF_LD + KF_Q * (C + 4)) * sizeof(float);   // 25.6 KiB (C=64) / 33.8 KiB (C=128)
   auto* kern = C == 64 ? (K >= 2 ? knn_feat_kernel<8, true> : knn_feat_kernel<8, false>)
                        : (K >= 2 ? knn_feat_kernel<0, true> : knn_feat_kernel<0, false>);
   hipLaunchKernelGGL(kern, dim3(cdiv(N, KF_Q), B), dim3(KF_T), lds, as_stream(stream), a);
