@@ -121,11 +121,23 @@ class CWKNN:
             exp_avg, exp_avg_sq = torch.zeros_like(adv_data), torch.zeros_like(adv_data)
         ori_t = ori_data.transpose(1, 2).contiguous()
 
+        # The distance term does not depend on the victim: its searches (kNN + Chamfer) run on a side stream beside the
+        # victim's forward, whose first kernels (farthest-point sampling: one workgroup per cloud) leave most of the
+        # chip idle. Autograd runs each node's backward on its forward's stream, so the two backwards overlap as well.
+        cur = torch.cuda.current_stream(dev) if adv_data.is_cuda else None
+        side = torch.cuda.Stream(device=dev) if cur is not None and getattr(self, "dist_stream", True) else None
         for iteration in range(self.num_iter):
+            if side is not None:
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    # in the official tensorflow code they use sum instead of mean, hence * K (:119-123)
+                    dist_loss = self.dist_func(adv_data.transpose(1, 2).contiguous(), ori_t).mean() * K
             logits = _logits_of(self.model(adv_data))  # [B, num_classes]
             adv_loss = self.adv_func(logits, target).mean()
-            # in the official tensorflow code they use sum instead of mean, hence * K (:119-123)
-            dist_loss = self.dist_func(adv_data.transpose(1, 2).contiguous(), ori_t).mean() * K
+            if side is not None:
+                cur.wait_stream(side)
+            else:
+                dist_loss = self.dist_func(adv_data.transpose(1, 2).contiguous(), ori_t).mean() * K
             loss = adv_loss + dist_loss
             if fc is None:
                 opt.zero_grad()

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(KF_T) void knn_feat_kernel(KnnFeatArgs a) {
       const float* rp = rp_next;               // this block's row (its first PF float4 are already in flight)
       auto step = [&](const float4 v, int t) {
         const float4 q = *reinterpret_cast<const float4*>(qs + r * ldq + 8 * t + 4 * h);
-        rn = __builtin_fmaf(v.w, v.w, __builtin_fmaf(v.z, v.z, __builtin_fmaf(v.y, v.y, __builtin_fmaf(v.x, v.x, rn))));   // 4 VALU, not 8
+        rn += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;   // squares summed, then added: the reference's xx = sum(x ** 2)
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q.x, v.x, acc, 0, 0, 0);   // D[row = query][col = reference]
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q.y, v.y, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q.z, v.z, acc, 0, 0, 0);
