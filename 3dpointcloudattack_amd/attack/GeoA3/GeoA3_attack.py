@@ -105,8 +105,13 @@ def _forward_step(net, pc_ori, input_curr_iter, normal_ori, ori_kappa, target, s
         else:
             cls_loss = torch.clamp(fake - other + cfg.confidence, min=0.)
     elif cfg.cls_loss_type == 'CE':
-        ce = nn.CrossEntropyLoss(reduction='none')(output_curr_iter, target.long())
-        cls_loss = ce if targeted else -ce
+        if output_curr_iter.is_cuda and output_curr_iter.dtype == torch.float32 and output_curr_iter.dim() == 2 \
+                and output_curr_iter.stride(1) == 1:
+            from ... import ops     # log-softmax + NLL (+ sign) and their backward: one launch each way instead of 3 + 3
+            cls_loss = ops.cross_entropy(output_curr_iter, target.long(), 1.0 if targeted else -1.0)
+        else:
+            ce = nn.CrossEntropyLoss(reduction='none')(output_curr_iter, target.long())
+            cls_loss = ce if targeted else -ce
     elif cfg.cls_loss_type == 'None':
         cls_loss = torch.zeros(b, device=dev)
     else:
@@ -320,8 +325,18 @@ def geoA3_attack(net, pt_model, ptm_model, pts_model, dgcnn_model, cur_model, pc
                 _forward_step(net, pc_ori, input_curr_iter, normal_ori, kappa_ori, target, scale_dev, cfg, targeted)
             if share_forward:
                 with torch.no_grad():   # input_all still holds this iteration's iterate: the optimiser steps below
-                    output_label = torch.argmax(logits_curr.detach(), dim=1)
-                    record(output_label, _compare(output_label, target, gt_target, targeted), prev_constrain.detach())
+                    lg, it_ = logits_curr.detach(), input_all.detach()
+                    if (lg.is_cuda and lg.dtype == torch.float32 and lg.dim() == 2 and lg.stride(1) == 1
+                            and isinstance(prev_constrain, torch.Tensor) and prev_constrain.shape == (b,)
+                            and prev_constrain.dtype == torch.float32 and it_.is_contiguous()):
+                        from ... import ops     # arg-max, success test and the six conditional updates: one launch
+                        output_label = ops.geoa3_record(lg, target if targeted else gt_target, targeted,
+                                                        prev_constrain.detach().contiguous(), it_, search_step, step,
+                                                        best_loss, best_attack, best_attack_BS_idx, best_attack_step,
+                                                        iter_best_loss, iter_best_score)
+                    else:
+                        output_label = torch.argmax(lg, dim=1)
+                        record(output_label, _compare(output_label, target, gt_target, targeted), prev_constrain.detach())
             loss_curves.append(loss_n.detach())
 
             optimizer.zero_grad()

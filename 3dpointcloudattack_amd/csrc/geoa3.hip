@@ -106,9 +106,85 @@ __global__ __launch_bounds__(256) void geoa3_terms_bwd_kernel(GeoTermsArgs a, in
   if (a.g_d_oa && i < a.M) a.g_d_oa[(int64_t)b * a.M + i] = g_dis / (float)a.M;
 }
 
+// Best-attack bookkeeping of one GeoA3 iteration (attack/GeoA3/GeoA3_attack.py:307-330): predicted label of the iterate
+// (first arg-max of the logits, NaN counts as the maximum like torch.argmax), success test, and the conditional updates
+// of the running bests — ~25 ATen launches (argmax, compares, full_like, where x6 incl. one over the whole cloud) as one.
+struct GeoRecordArgs {
+  const float* logits;    // [B,ncls], row stride ld
+  int ld, ncls;
+  const int64_t* target;  // [B] label compared against (the attack target when targeted, else the ground truth)
+  int targeted;
+  const float* metric;    // [B]
+  const float* iterate;   // [B,3N] contiguous
+  int n3;
+  int64_t search_step, step;
+  float* best_loss;       // [B]
+  float* best_attack;     // [B,3N]
+  int64_t* best_bs;       // [B]
+  int64_t* best_step;     // [B]
+  float* iter_best_loss;  // [B]
+  int64_t* iter_best_score;  // [B]
+  int64_t* label_out;     // [B]
+};
+
+__global__ __launch_bounds__(256) void geoa3_record_kernel(GeoRecordArgs a) {
+  __shared__ int s_upd;
+  const int b = blockIdx.x;
+  if (threadIdx.x < 64) {
+    const float* lg = a.logits + (int64_t)b * a.ld;
+    float bv = -__builtin_inff();
+    int bi = 0x7fffffff;
+    bool bnan = false;
+    for (int c = threadIdx.x; c < a.ncls; c += 64) {   // ascending c within a lane: strict > keeps the first maximum
+      const float v = lg[c];
+      const bool vnan = v != v;
+      if (bi == 0x7fffffff || (!bnan && (vnan || v > bv))) bv = v, bi = c, bnan = vnan;
+    }
+    // wave arg-max: NaN beats everything, then the larger value, then the lower index
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      const bool on = ov != ov;
+      const bool take = oi != 0x7fffffff && (bi == 0x7fffffff || (on && !bnan) || (on == bnan && (on ? oi < bi : (ov > bv || (ov == bv && oi < bi)))));
+      if (take) bv = ov, bi = oi, bnan = on;
+    }
+    if (threadIdx.x == 0) {
+      const int64_t lab = bi;
+      a.label_out[b] = lab;
+      const bool ok = a.targeted ? (lab == a.target[b]) : (lab != a.target[b]);
+      const float m = a.metric[b];
+      const bool upd = ok && m < a.best_loss[b];
+      if (upd) a.best_loss[b] = m, a.best_bs[b] = a.search_step, a.best_step[b] = a.step;
+      if (ok && m < a.iter_best_loss[b]) a.iter_best_loss[b] = m, a.iter_best_score[b] = lab;
+      s_upd = upd;
+    }
+  }
+  __syncthreads();
+  if (!s_upd) return;
+  const float* src = a.iterate + (int64_t)b * a.n3;
+  float* dst = a.best_attack + (int64_t)b * a.n3;
+  for (int t = threadIdx.x; t < a.n3; t += 256) dst[t] = src[t];
+}
+
 }  // namespace pc3d
 
 using namespace pc3d;
+
+extern "C" int pc3d_geoa3_record_f32(const float* logits, int ld, int B, int ncls, const int64_t* target, int targeted,
+                                     const float* metric, const float* iterate, int n3, int64_t search_step, int64_t step,
+                                     float* best_loss, float* best_attack, int64_t* best_bs, int64_t* best_step,
+                                     float* iter_best_loss, int64_t* iter_best_score, int64_t* label_out, void* stream) {
+  PC3D_REQUIRE(B >= 0 && ncls >= 1 && ld >= ncls && n3 >= 1, "pc3d_geoa3_record_f32: bad sizes B=%d ncls=%d ld=%d n3=%d", B, ncls, ld, n3);
+  if (B == 0) return PC3D_OK;
+  PC3D_REQUIRE(logits && target && metric && iterate && best_loss && best_attack && best_bs && best_step && iter_best_loss &&
+                   iter_best_score && label_out, "pc3d_geoa3_record_f32: null pointer");
+  GeoRecordArgs a{logits, ld, ncls, target, targeted, metric, iterate, n3, search_step, step, best_loss, best_attack,
+                  best_bs, best_step, iter_best_loss, iter_best_score, label_out};
+  hipLaunchKernelGGL(geoa3_record_kernel, dim3(B), dim3(256), 0, as_stream(stream), a);
+  PC3D_LAUNCH_CHECK("pc3d_geoa3_record_f32");
+  return PC3D_OK;
+}
 
 extern "C" int pc3d_geoa3_terms_f32(const float* d_ao, const float* d_oa, const float* k_adv, const float* k_ori,
                                     const int64_t* idx_ao, const float* cls, const float* scale, int B, int N, int M,

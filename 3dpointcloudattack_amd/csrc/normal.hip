@@ -94,6 +94,9 @@ struct KappaArgs {
   float* out;           // [B,N]
   const float* gout;    // [B,N]   (backward)
   float* gx;            // [B,N,3] (backward; zero-filled by the entry point, float atomics)
+  const int64_t* nidx = nullptr;   // [B,N] or null: point i takes normal nidx[b,i] of the M source normals (clamped)
+  float* nout = nullptr;           // [B,3,N] the normals used (written when nidx is given)
+  int M = 0;
 };
 
 __global__ __launch_bounds__(256) void kappa_fwd_kernel(KappaArgs a) {
@@ -101,9 +104,18 @@ __global__ __launch_bounds__(256) void kappa_fwd_kernel(KappaArgs a) {
   if (i >= a.N) return;
   const float* xb = a.x.p + (int64_t)b * a.x.bs;
   const float* pi = xb + (int64_t)i * a.x.ps;
-  const float* ni = a.nrm.p + (int64_t)b * a.nrm.bs + (int64_t)i * a.nrm.ps;
+  int64_t ni_ = i;
+  if (a.nidx) {
+    ni_ = a.nidx[(int64_t)b * a.N + i];
+    ni_ = ni_ < 0 ? 0 : (ni_ >= a.M ? a.M - 1 : ni_);
+  }
+  const float* ni = a.nrm.p + (int64_t)b * a.nrm.bs + ni_ * a.nrm.ps;
   const float px = pi[0], py = pi[a.x.cs], pz = pi[2 * a.x.cs];
   const float nx = ni[0], ny = ni[a.nrm.cs], nz = ni[2 * a.nrm.cs];
+  if (a.nout) {
+    float* no = a.nout + (int64_t)b * 3 * a.N + i;
+    no[0] = nx, no[a.N] = ny, no[2 * (int64_t)a.N] = nz;
+  }
   const int32_t* nb = a.idx + ((int64_t)b * a.N + i) * a.K1;
   float s = 0.f;
   for (int k = 1; k < a.K1; ++k) {
@@ -175,6 +187,19 @@ extern "C" int pc3d_kappa_f32(const float* x, int64_t x_bs, int64_t x_ps, int64_
   KappaArgs a{{x, x_bs, x_ps, x_cs}, {nrm, n_bs, n_ps, n_cs}, idx, N, K1, out, nullptr, nullptr};
   hipLaunchKernelGGL(kappa_fwd_kernel, dim3(cdiv(N, 256), B), dim3(256), 0, as_stream(stream), a);
   PC3D_LAUNCH_CHECK("pc3d_kappa_f32");
+  return PC3D_OK;
+}
+
+extern "C" int pc3d_kappa_gather_f32(const float* x, int64_t x_bs, int64_t x_ps, int64_t x_cs, const float* nrm,
+                                     int64_t n_bs, int64_t n_ps, int64_t n_cs, int M, const int64_t* nidx,
+                                     const int32_t* idx, int B, int N, int K1, float* out, float* nout, void* stream) {
+  PC3D_REQUIRE(B >= 0 && N >= 1 && M >= 1 && K1 >= 2, "pc3d_kappa_gather_f32: bad sizes B=%d N=%d M=%d K1=%d", B, N, M, K1);
+  PC3D_REQUIRE(B <= 65535, "pc3d_kappa_gather_f32: B=%d exceeds grid.y limit", B);
+  if (B == 0) return PC3D_OK;
+  PC3D_REQUIRE(x && nrm && nidx && idx && out && nout, "pc3d_kappa_gather_f32: null pointer");
+  KappaArgs a{{x, x_bs, x_ps, x_cs}, {nrm, n_bs, n_ps, n_cs}, idx, N, K1, out, nullptr, nullptr, nidx, nout, M};
+  hipLaunchKernelGGL(kappa_fwd_kernel, dim3(cdiv(N, 256), B), dim3(256), 0, as_stream(stream), a);
+  PC3D_LAUNCH_CHECK("pc3d_kappa_gather_f32");
   return PC3D_OK;
 }
 

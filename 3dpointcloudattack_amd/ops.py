@@ -653,6 +653,88 @@ def kappa(pts, normal, idx, cf=False):
     return _KappaFn.apply(pts, normal, idx.contiguous(), cf)
 
 
+class _KappaGatherFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pts, normal_src, nidx, idx):
+        p, bs, ps, cs, B, N = _pts(pts, True, "pts")
+        n, nbs, nps, ncs, _, M = _pts(normal_src, True, "normal_src")
+        out = torch.empty((B, N), dtype=torch.float32, device=pts.device)
+        nout = torch.empty((B, 3, N), dtype=torch.float32, device=pts.device)
+        with torch.cuda.device(pts.device):
+            _lib.call("pc3d_kappa_gather_f32", p, bs, ps, cs, n, nbs, nps, ncs, M, nidx.data_ptr(), idx.data_ptr(), B, N,
+                      idx.shape[2], out.data_ptr(), nout.data_ptr(), _stream())
+        ctx.save_for_backward(pts, nout, idx)
+        ctx.mark_non_differentiable(nout)
+        return out, nout
+
+    @staticmethod
+    def backward(ctx, g, _g_nout):
+        pts, nout, idx = ctx.saved_tensors
+        p, bs, ps, cs, B, N = _pts(pts, True, "pts")
+        n, nbs, nps, ncs, _, _ = _pts(nout, True, "normal")
+        g = g.contiguous()
+        gx = torch.empty((B, N, 3), dtype=torch.float32, device=pts.device)
+        with torch.cuda.device(pts.device):
+            _lib.call("pc3d_kappa_bwd_f32", p, bs, ps, cs, n, nbs, nps, ncs, idx.data_ptr(), g.data_ptr(), B, N,
+                      idx.shape[2], gx.data_ptr(), _stream())
+        return gx.transpose(1, 2), None, None, None
+
+
+def kappa_gather(pts, normal_src, nidx, idx):
+    """GeoA3's curvature proxy of pts [B,3,N] with point i taking normal_src[:, :, nidx[b,i]] ([B,3,M] constants, nidx
+    int64 [B,N]): (kappa [B,N], the gathered normals [B,3,N]) in one launch; differentiable in pts."""
+    if normal_src.requires_grad:
+        raise NotImplementedError("kappa_gather: no gradient to the normals (constants of the attack)")
+    if nidx.dtype != torch.int64 or nidx.shape != (pts.shape[0], pts.shape[2]) or not nidx.is_contiguous():
+        raise ValueError("kappa_gather: nidx must be a contiguous int64 [B,N]")
+    if idx.dtype != torch.int32 or idx.dim() != 3 or idx.shape[2] < 2:
+        raise ValueError("kappa_gather: idx must be int32 [B,N,K+1] (self first)")
+    return _KappaGatherFn.apply(pts, normal_src, nidx, idx.contiguous())
+
+
+class _CrossEntropyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, sign):
+        _, _, loss, g = cls_loss(logits, target, 2, 0.0, sign, want_grad=True)
+        ctx.save_for_backward(g)
+        return loss * sign if sign != 1.0 else loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        (g,) = ctx.saved_tensors
+        return g * gout[:, None], None, None
+
+
+def cross_entropy(logits, target, sign=1.0):
+    """sign * CrossEntropyLoss(reduction='none')(logits, target) -> [B], one launch each way (pc3d_cls_loss_f32, kind 2)."""
+    if logits.dim() != 2 or logits.stride(1) != 1:
+        raise ValueError("cross_entropy: logits must be [B,k] with unit column stride")
+    return _CrossEntropyFn.apply(logits, target, float(sign))
+
+
+def geoa3_record(logits, target, targeted, metric, iterate, search_step, step, best_loss, best_attack, best_bs, best_step,
+                 iter_best_loss, iter_best_score):
+    """One GeoA3 iteration's best-attack bookkeeping in place (pc3d_geoa3_record_f32); returns the predicted labels [B]."""
+    _check(logits, "logits"), _check(metric, "metric"), _check(iterate, "iterate")
+    B, ncls = logits.shape
+    for nm, t, dt in (("target", target, torch.int64), ("best_loss", best_loss, torch.float32),
+                      ("best_bs", best_bs, torch.int64), ("best_step", best_step, torch.int64),
+                      ("iter_best_loss", iter_best_loss, torch.float32), ("iter_best_score", iter_best_score, torch.int64),
+                      ("metric", metric, torch.float32)):
+        if t.dtype != dt or t.shape != (B,) or not t.is_contiguous() or not t.is_cuda:
+            raise ValueError(f"geoa3_record: {nm} must be a contiguous {dt} GPU tensor of shape [{B}]")
+    if logits.stride(1) != 1 or not iterate.is_contiguous() or best_attack.shape != iterate.shape \
+            or not best_attack.is_contiguous() or best_attack.dtype != torch.float32:
+        raise ValueError("geoa3_record: logits rows / iterate / best_attack must be contiguous float32 of matching shapes")
+    label = torch.empty((B,), dtype=torch.int64, device=logits.device)
+    with torch.cuda.device(logits.device):
+        _lib.call("pc3d_geoa3_record_f32", logits.data_ptr(), logits.stride(0), B, ncls, target.data_ptr(),
+                  1 if targeted else 0, metric.data_ptr(), iterate.data_ptr(), iterate[0].numel(), int(search_step),
+                  int(step), best_loss.data_ptr(), best_attack.data_ptr(), best_bs.data_ptr(), best_step.data_ptr(),
+                  iter_best_loss.data_ptr(), iter_best_score.data_ptr(), label.data_ptr(), _stream())
+    return label
+
+
 class _GeoTermsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, d_ao, d_oa, k_adv, k_ori, idx_ao, cls, scale, w):

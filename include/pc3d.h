@@ -106,6 +106,12 @@ int pc3d_estimate_normal_f32(const float* x, int64_t x_bs, int64_t x_ps, int64_t
  * element strides; idx [B,N,K1] int32. One launch each way instead of ~30. */
 int pc3d_kappa_f32(const float* x, int64_t x_bs, int64_t x_ps, int64_t x_cs, const float* nrm, int64_t n_bs, int64_t n_ps,
                    int64_t n_cs, const int32_t* idx, int B, int N, int K1, float* out, void* stream);
+/* pc3d_kappa_f32 with the normals taken THROUGH an index: point i uses normal nidx[b,i] of the M source normals (nrm
+ * [B,M] with element strides; the reference gathers the nearest original point's normal first, loss_utils.py:72-82) and
+ * the normals used are written to nout [B,3,N] (contiguous, channels first) — what pc3d_kappa_bwd_f32 then takes. */
+int pc3d_kappa_gather_f32(const float* x, int64_t x_bs, int64_t x_ps, int64_t x_cs, const float* nrm, int64_t n_bs,
+                          int64_t n_ps, int64_t n_cs, int M, const int64_t* nidx, const int32_t* idx, int B, int N, int K1,
+                          float* out, float* nout, void* stream);
 int pc3d_kappa_bwd_f32(const float* x, int64_t x_bs, int64_t x_ps, int64_t x_cs, const float* nrm, int64_t n_bs,
                        int64_t n_ps, int64_t n_cs, const int32_t* idx, const float* gout, int B, int N, int K1, float* gx,
                        void* stream);
@@ -125,6 +131,16 @@ int pc3d_geoa3_terms_f32(const float* d_ao, const float* d_oa, const float* k_ad
 int pc3d_geoa3_terms_bwd_f32(const float* g_out, const float* k_adv, const float* k_ori, const int64_t* idx_ao,
                              const float* scale, const int32_t* hd_arg, int B, int N, int M, float w_dis, float w_hd,
                              float w_curv, float* g_d_ao, float* g_d_oa, float* g_k_adv, float* g_cls, void* stream);
+
+/* Best-attack bookkeeping of one GeoA3 iteration in one launch (attack/GeoA3/GeoA3_attack.py:307-330): label_out[b] =
+ * first arg-max of logits[b,:] (NaN counts as the maximum, like torch.argmax); success = (label == target[b]) when
+ * targeted, (label != target[b]) otherwise; where success and metric[b] < best_loss[b]: best_loss, best_bs = search_step,
+ * best_step = step and best_attack[b,:] = iterate[b,:] (n3 floats per sample, contiguous); where success and metric[b] <
+ * iter_best_loss[b]: iter_best_loss and iter_best_score = label. All state is updated in place. */
+int pc3d_geoa3_record_f32(const float* logits, int ld, int B, int ncls, const int64_t* target, int targeted,
+                          const float* metric, const float* iterate, int n3, int64_t search_step, int64_t step,
+                          float* best_loss, float* best_attack, int64_t* best_bs, int64_t* best_step,
+                          float* iter_best_loss, int64_t* iter_best_score, int64_t* label_out, void* stream);
 
 /* First layer of a set-abstraction MLP without the grouped input tensor (model/pointnet2_utils.py:118-135,190-197): the
  * layer is linear in [x_j - c_s ; f_j], so  W1 [x_j - c_s ; f_j] + b1 = P[idx[s,j]] + Bc[s]  with P = [x | f] W1^T per

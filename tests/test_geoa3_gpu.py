@@ -205,3 +205,79 @@ def test_geoa3_terms_vs_reference_formulation(dev, B, N, M, both, curv):
             torch.testing.assert_close(got.grad.cpu().double(), want.grad, rtol=2e-5, atol=1e-7)
         else:
             assert got.grad is None
+
+
+@pytest.mark.parametrize("targeted", [False, True])
+def test_geoa3_record_vs_reference_formulation(dev, targeted):
+    """pc3d_geoa3_record_f32 against the tensor formulation of attack/GeoA3/GeoA3_attack.py:307-330 (arg-max incl. ties and
+    NaN, success test, the six conditional updates), over three consecutive steps on the same state."""
+    ops = importlib.import_module("3dpointcloudattack_amd.ops")
+    g = torch.Generator().manual_seed(5 + targeted)
+    B, ncls, N = 9, 40, 130
+    tgt = torch.randint(0, ncls, (B,), generator=g)
+    st = [torch.full((B,), 1e10), torch.ones(B, 3, N), torch.full((B,), -1, dtype=torch.long),
+          torch.full((B,), -1, dtype=torch.long), torch.full((B,), 1e10), torch.full((B,), -1, dtype=torch.long)]
+    ref = [t.clone() for t in st]
+    dst = [t.to(dev) for t in st]
+    for step in range(3):
+        logits = torch.randn(B, ncls, generator=g)
+        logits[0, 7] = logits[0, 3] = logits[0].max() + 1.0          # tie: the first maximum wins
+        logits[1, 11] = float("nan")                                 # NaN counts as the maximum
+        if targeted:
+            logits[2, tgt[2]] = 50.0                                 # a sure success
+        metric = torch.rand(B, generator=g) * (3 - step)
+        it = torch.randn(B, 3, N, generator=g)
+        lab = ops.geoa3_record(logits.to(dev), tgt.to(dev), targeted, metric.to(dev), it.to(dev), 4, step, *dst)
+        rl = torch.argmax(logits, dim=1)
+        ok = (rl == tgt) if targeted else (rl != tgt)
+        upd = ok & (metric < ref[0])
+        ref[0] = torch.where(upd, metric, ref[0])
+        ref[1] = torch.where(upd[:, None, None], it, ref[1])
+        ref[2] = torch.where(upd, torch.full_like(ref[2], 4), ref[2])
+        ref[3] = torch.where(upd, torch.full_like(ref[3], step), ref[3])
+        upd_i = ok & (metric < ref[4])
+        ref[4] = torch.where(upd_i, metric, ref[4])
+        ref[5] = torch.where(upd_i, rl, ref[5])
+        assert torch.equal(lab.cpu(), rl)
+        for a, r in zip(dst, ref):
+            assert torch.equal(a.cpu(), r)
+    assert bool((ref[0] < 1e10).any())                               # the updates were exercised
+
+
+@pytest.mark.parametrize("sign", [1.0, -1.0])
+def test_cross_entropy_op_vs_torch(dev, sign):
+    ops = importlib.import_module("3dpointcloudattack_amd.ops")
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(17, 40, generator=g) * 3
+    t = torch.randint(0, 40, (17,), generator=g)
+    up = torch.randn(17, generator=g)
+    xa = x.to(dev).requires_grad_()
+    out = ops.cross_entropy(xa, t.to(dev), sign)
+    (out * up.to(dev)).sum().backward()
+    xd = x.double().requires_grad_()
+    ref = sign * torch.nn.CrossEntropyLoss(reduction='none')(xd, t)
+    (ref * up.double()).sum().backward()
+    torch.testing.assert_close(out.cpu().double(), ref.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(xa.grad.cpu().double(), xd.grad, rtol=1e-5, atol=1e-6)
+
+
+def test_kappa_gather_equals_kappa_on_gathered_normals(dev):
+    """pc3d_kappa_gather_f32 (normals taken through the nearest-original-point index inside the kernel) == gather, then
+    pc3d_kappa_f32: values bit for bit, the normals it reports, and the gradient."""
+    ops = importlib.import_module("3dpointcloudattack_amd.ops")
+    g = torch.Generator().manual_seed(9)
+    B, N, M, k = 3, 300, 257, 5
+    pts = (torch.rand(B, 3, N, generator=g) - 0.5).to(dev)
+    nsrc = torch.nn.functional.normalize(torch.randn(B, 3, M, generator=g), dim=1).to(dev)
+    nidx = torch.randint(0, M, (B, N), generator=g).to(dev)
+    idx = ops.knn_raw(pts, pts, k + 1, q_cf=True, r_cf=True)[1]
+    up = torch.randn(B, N, generator=g).to(dev)
+    a = pts.clone().requires_grad_()
+    kap, nrm = ops.kappa_gather(a, nsrc, nidx, idx)
+    (kap * up).sum().backward()
+    gathered = torch.gather(nsrc, 2, nidx[:, None, :].expand(-1, 3, -1)).contiguous()
+    b = pts.clone().requires_grad_()
+    ref = ops.kappa(b, gathered, idx, cf=True)
+    (ref * up).sum().backward()
+    assert torch.equal(nrm, gathered) and torch.equal(kap, ref)
+    torch.testing.assert_close(a.grad, b.grad, rtol=1e-5, atol=1e-6)      # float atomics: order-dependent rounding
