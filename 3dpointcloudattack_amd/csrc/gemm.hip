@@ -42,6 +42,16 @@ struct GemmArgs {
   int gm_ns;
   float* gm_out;       // [M / gm_ns, N]
   int64_t* gm_arg;     // [M / gm_ns, N]
+  // gathered A operand (ga_idx != null): row m = (group g = m / ga_ns, member j) is GENERATED on load as
+  //   act_in(X[(g / ga_S) * ga_NA + ga_idx[m], :] + ga_Bc[g, :])     act_in = LeakyReLU(ga_slope), 0 = ReLU
+  // i.e. the output of a set-abstraction MLP's first layer in its per-point form (group.hip, pc3d_group_act_f32) without
+  // that [M, K] tensor ever existing; an index outside [0, ga_NA) reads as a zero row of X.
+  const int32_t* ga_idx;
+  const float* ga_Bc;  // [M / ga_ns, K]
+  int ga_ns, ga_S, ga_NA;
+  float ga_slope;
+  uint8_t* ga_mask;    // [M, K / 4] or null: bit c % 4 of byte c / 4 of row m = "the generated element (m, c) came from a
+                       // positive pre-activation" — what the backward of act_in needs, 1/32 of the tensor it replaces
 };
 
 __device__ __forceinline__ float4 gm_load4(const float* p, int k, int K, bool row_ok) {
@@ -58,7 +68,7 @@ __device__ __forceinline__ float4 gm_load4(const float* p, int k, int K, bool ro
 
 // WM x WN waves of 64 x 64 outputs each: <2,2> = 128 x 128 tile (wide layers), <4,1> = 256 x 64 (layers with <= 64
 // outputs: no half-empty MFMA tiles, and the kernel is then bound by reading / writing the [M, 64] activations).
-template <int WM, int WN, int TM, int TN, bool DB, int OCC>
+template <int WM, int WN, int TM, int TN, bool DB, int OCC, bool GA = false>   // GA: gathered A operand (GemmArgs::ga_idx)
 __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_nt_kernel(GemmArgs a) {
   constexpr int NT = WM * WN * 64;               // threads
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -96,10 +106,36 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_nt_kernel(GemmArgs a) 
   // => 128 B contiguous per row
   const int lrow = tid >> 3, lk = (tid & 7) * 4;
   float4 xa[QA], wb[QB];
+  // gathered A operand: source row and group of this thread's QA tile rows, resolved once
+  int ga_row[GA ? QA : 1], ga_grp[GA ? QA : 1];
+  if constexpr (GA) {
+#pragma unroll
+    for (int q = 0; q < QA; ++q) {
+      const int gm = m0 + q * RPS + lrow;
+      ga_row[q] = -1, ga_grp[q] = 0;
+      if (gm < a.M) {
+        const int g = gm / a.ga_ns, p = a.ga_idx[gm];
+        ga_grp[q] = g;
+        if ((unsigned)p < (unsigned)a.ga_NA) ga_row[q] = (g / a.ga_S) * a.ga_NA + p;   // < B * NA <= 2^31 (entry point)
+      }
+    }
+  }
   auto fetch = [&](int k0) {
 #pragma unroll
     for (int q = 0; q < QA; ++q) {
       const int gm = m0 + q * RPS + lrow;
+      if constexpr (GA) {
+        float4 v = gm_load4(a.X + (int64_t)ga_row[q] * a.ldx, k0 + lk, a.K, ga_row[q] >= 0);
+        const float4 c = gm_load4(a.ga_Bc + (int64_t)ga_grp[q] * a.K, k0 + lk, a.K, gm < a.M);
+        v.x += c.x, v.y += c.y, v.z += c.z, v.w += c.w;
+        if (a.ga_mask && tn == 0 && gm < a.M && k0 + lk < a.K)
+          a.ga_mask[(int64_t)gm * (a.K >> 2) + ((k0 + lk) >> 2)] =
+              (uint8_t)((v.x > 0.f ? 1 : 0) | (v.y > 0.f ? 2 : 0) | (v.z > 0.f ? 4 : 0) | (v.w > 0.f ? 8 : 0));
+        v.x = v.x > 0.f ? v.x : v.x * a.ga_slope, v.y = v.y > 0.f ? v.y : v.y * a.ga_slope;
+        v.z = v.z > 0.f ? v.z : v.z * a.ga_slope, v.w = v.w > 0.f ? v.w : v.w * a.ga_slope;
+        xa[q] = v;
+        continue;
+      }
       float4 v = gm_load4(a.X + (int64_t)gm * a.ldx, k0 + lk, a.K, gm < a.M);
       if (a.gate) {
         const float4 g = gm_load4(a.gate + (int64_t)gm * a.ldg, k0 + lk, a.K, gm < a.M);
@@ -247,7 +283,8 @@ extern "C" int pc3d_gemm_nt_tune(int variant) {   // tuning hook (tools/bench_ge
 static int gemm_nt_launch(const float* X, int64_t ldx, const float* W, const float* bias, const float* gate, int64_t ldg,
                           float gate_slope, const float* R, int64_t ldr, int M, int N, int K, int act, float slope,
                           float* Y, int64_t ldy, void* stream, int gm_ns = 0, float* gm_out = nullptr,
-                          int64_t* gm_arg = nullptr) {
+                          int64_t* gm_arg = nullptr, const int32_t* ga_idx = nullptr, const float* ga_Bc = nullptr,
+                          int ga_ns = 0, int ga_S = 0, int ga_NA = 0, float ga_slope = 0.f, uint8_t* ga_mask = nullptr) {
   PC3D_REQUIRE(M >= 0 && N >= 1 && K >= 1, "pc3d_gemm_nt_f32: bad sizes M=%d N=%d K=%d", M, N, K);
   PC3D_REQUIRE(act >= 0 && act <= 2, "pc3d_gemm_nt_f32: bad activation %d", act);
   if (M == 0) return PC3D_OK;
@@ -258,6 +295,7 @@ static int gemm_nt_launch(const float* X, int64_t ldx, const float* W, const flo
   a.X = X, a.W = W, a.bias = bias, a.gate = gate, a.res = R, a.Y = Y, a.ldx = ldx, a.ldg = ldg, a.ldy = ldy, a.ldr = ldr;
   a.M = M, a.N = N, a.K = K, a.act = act, a.slope = slope, a.gslope = gate_slope;
   a.gm_ns = gm_ns, a.gm_out = gm_out, a.gm_arg = gm_arg;
+  a.ga_idx = ga_idx, a.ga_Bc = ga_Bc, a.ga_ns = ga_ns, a.ga_S = ga_S, a.ga_NA = ga_NA, a.ga_slope = ga_slope, a.ga_mask = ga_mask;
   // Tile shapes, measured on MI355X (tools/bench_gemm.py, us; hipBLASLt beside them):
   //   layer [M,N,K]                 0: 128x128 DB   2: 128x64   4: 64x128   5: 128x128/8 waves   hipBLASLt
   //   DGCNN conv5 [32768,1024,512]       387           361         350            320               275
@@ -270,7 +308,7 @@ static int gemm_nt_launch(const float* X, int64_t ldx, const float* W, const flo
   //   3: 256x64, 4 waves of 64x64, double buffered                    4: 64x128, 4 waves of 32x64
   //   5 / 6: 128x128, 8 waves of 32x64, single / double buffered       8: as 5 with four workgroups per CU (<= 64 VGPRs)
   int v = g_gemm_variant;
-  if (v < 0) v = (N <= 64) ? 2 : 5;
+  if (v < 0 || ga_idx) v = (N <= 64) ? 2 : 5;
   // the group-max epilogue is written for 128-row tiles of 32-row wave tiles; with K <= 64 (two K steps per tile) four
   // workgroups per CU instead of two hide the tile prologue better: 221 -> 203 us on SSG's SA1 (no change at K = 128)
   if (gm_ns) v = (K <= 64) ? 8 : 5;
@@ -291,6 +329,12 @@ static int gemm_nt_launch(const float* X, int64_t ldx, const float* W, const flo
   const size_t lds = (size_t)(db ? 2 : 1) * (bm + bn) * GM_LD * sizeof(float);
   const dim3 grid(per * 8), block(v == 5 || v == 6 || v == 8 ? 512 : GM_T);
   hipStream_t st = as_stream(stream);
+  if (ga_idx) {
+    if (v == 2) hipLaunchKernelGGL((gemm_nt_kernel<4, 1, 1, 2, false, 4, true>), grid, block, lds, st, a);
+    else hipLaunchKernelGGL((gemm_nt_kernel<4, 2, 1, 2, false, 2, true>), grid, block, lds, st, a);
+    PC3D_LAUNCH_CHECK("pc3d_gemm_nt_gather_f32");
+    return PC3D_OK;
+  }
   switch (v) {
     case 1: hipLaunchKernelGGL((gemm_nt_kernel<2, 2, 2, 2, false, 3>), grid, block, lds, st, a); break;
     case 2: hipLaunchKernelGGL((gemm_nt_kernel<4, 1, 1, 2, false, 4>), grid, block, lds, st, a); break;
@@ -324,4 +368,16 @@ extern "C" int pc3d_gemm_nt_res_f32(const float* X, int64_t ldx, const float* W,
                                     void* stream) {
   PC3D_REQUIRE(R != nullptr, "pc3d_gemm_nt_res_f32: null residual");
   return gemm_nt_launch(X, ldx, W, bias, nullptr, 0, 0.f, R, ldr, M, N, K, act, slope, Y, ldy, stream);
+}
+
+extern "C" int pc3d_gemm_nt_gather_f32(const float* P, int64_t ldp, const float* Bc, const int32_t* idx, int B, int NA, int S,
+                                       int ns, float slope_in, const float* W, const float* bias, int N, int K, int act,
+                                       float slope, float* Y, int64_t ldy, uint8_t* mask, void* stream) {
+  PC3D_REQUIRE(B >= 0 && NA >= 1 && S >= 1 && ns >= 1 && (int64_t)B * S * ns <= 0x7fffffffLL && (int64_t)B * NA <= 0x7fffffffLL,
+               "pc3d_gemm_nt_gather_f32: bad sizes B=%d NA=%d S=%d ns=%d", B, NA, S, ns);
+  if (B == 0) return PC3D_OK;
+  PC3D_REQUIRE(P && Bc && idx, "pc3d_gemm_nt_gather_f32: null pointer");
+  PC3D_REQUIRE(!mask || K % 4 == 0, "pc3d_gemm_nt_gather_f32: the sign mask needs K %% 4 == 0 (K=%d)", K);
+  return gemm_nt_launch(P, ldp, W, bias, nullptr, 0, 0.f, nullptr, 0, B * S * ns, N, K, act, slope, Y, ldy, stream, 0, nullptr,
+                        nullptr, idx, Bc, ns, S, NA, slope_in, mask);
 }

@@ -277,10 +277,14 @@ __global__ __launch_bounds__(256) void group_act_fwd_kernel(const float4* __rest
 
 constexpr int GAB_MAXC = 512;   // channels (<= 8 per lane)
 
+// H == null: the activation's sign comes from the bit mask pc3d_gemm_nt_gather_f32 wrote while it generated the layer-1
+// output on load (that output was never stored): C/4 bytes per row instead of a second [B,S,K,C] stream. (Recomputing
+// the sign from P[idx] + Bc was measured first: 270 us against 179 us with H at SSG's SA1 — the row gather from the
+// 33 MB P misses the L2 where the H stream did not.)
 __global__ __launch_bounds__(256) void group_act_bwd_kernel(const float* __restrict__ gH, const float* __restrict__ H,
                                                             const int* __restrict__ idx, int NA, int S, int K, int C,
                                                             float slope, float* __restrict__ gP,
-                                                            float* __restrict__ gBc) {
+                                                            float* __restrict__ gBc, const uint8_t* __restrict__ mask) {
   extern __shared__ float gab_lds[];            // [2][4][C]: per-wave group sums and padded-tail sums
   const int s = blockIdx.x, b = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -293,15 +297,17 @@ __global__ __launch_bounds__(256) void group_act_bwd_kernel(const float* __restr
   for (int j = wave; j < K; j += 4) {
     const int i = id[j];
     const float* g = gH + (g0 + j) * C;
-    const float* h = H + (g0 + j) * C;
     const bool ok = (unsigned)i < (unsigned)NA;
+    const float* h = H + (g0 + j) * C;
+    const uint8_t* mrow = mask + (g0 + j) * (C >> 2);
     const bool rep = j > 0 && i == i0;          // wave-uniform
     float* dst = gP + ((int64_t)b * NA + (ok ? i : 0)) * C;
 #pragma unroll
     for (int q = 0; q < GAB_MAXC / 64; ++q) {
       const int c = 64 * q + lane;
       if (c < C) {
-        const float v = h[c] > 0.f ? g[c] : g[c] * slope;
+        const bool pos = H ? h[c] > 0.f : ((mrow[c >> 2] >> (c & 3)) & 1) != 0;
+        const float v = pos ? g[c] : g[c] * slope;
         tot[q] += v;
         if (rep) tail[q] += v;
         else if (ok) atomicAdd(dst + c, v);
@@ -626,8 +632,25 @@ extern "C" int pc3d_group_act_bwd_f32(const float* gH, const float* H, const int
     return (int)e;
   }
   hipLaunchKernelGGL(group_act_bwd_kernel, dim3(S, B), dim3(256), (size_t)8 * C * sizeof(float), st, gH, H, idx, NA, S,
-                     K, C, slope, gP, gBc);
+                     K, C, slope, gP, gBc, (const uint8_t*)nullptr);
   PC3D_LAUNCH_CHECK("pc3d_group_act_bwd_f32");
+  return PC3D_OK;
+}
+
+extern "C" int pc3d_group_act_bwd_mask_f32(const float* gH, const uint8_t* mask, const int32_t* idx, int B, int NA, int S,
+                                           int K, int C, float slope, float* gP, float* gBc, void* stream) {
+  PC3D_REQUIRE(B >= 0 && NA >= 1 && S >= 1 && K >= 1 && C >= 4 && C % 4 == 0 && C <= GAB_MAXC, "pc3d_group_act_bwd_mask_f32: bad sizes B=%d NA=%d S=%d K=%d C=%d (C %% 4 == 0, C <= %d)", B, NA, S, K, C, GAB_MAXC);
+  PC3D_REQUIRE(B <= 65535, "pc3d_group_act_bwd_mask_f32: B=%d exceeds grid.y limit", B);
+  if (B == 0) return PC3D_OK;
+  PC3D_REQUIRE(gH && mask && idx && gP && gBc, "pc3d_group_act_bwd_mask_f32: null pointer");
+  hipStream_t st = as_stream(stream);
+  if (hipError_t e = zero_async(gP, (size_t)B * NA * C, st); e != hipSuccess) {
+    set_error("pc3d_group_act_bwd_mask_f32: zero fill failed: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  hipLaunchKernelGGL(group_act_bwd_kernel, dim3(S, B), dim3(256), (size_t)8 * C * sizeof(float), st, gH,
+                     (const float*)nullptr, idx, NA, S, K, C, slope, gP, gBc, mask);
+  PC3D_LAUNCH_CHECK("pc3d_group_act_bwd_mask_f32");
   return PC3D_OK;
 }
 

@@ -35,6 +35,9 @@ def _split_first(layers):
     return w1[:, :3].contiguous(), (w1[:, 3:].contiguous() if w1.shape[1] > 3 else None), b1
 
 
+FUSE_LAYERS_1_2 = True    # layer 1 generated inside layer 2's GEMM (ops.grouped_mlp_max); False: group_act + mlp_relu_max
+
+
 def _grouped_mlp_max(xyz_t, pts, idx, fps_idx, layers, first):
     """The shared MLP + group max of one grouping scale, first layer WITHOUT the grouped input tensor:
     W1 [x_j - c_s ; f_j] + b1 = P[idx[s,j]] + Bc[s], P = Wx x + Wf f per POINT (B*N rows instead of B*S*ns: 16x fewer
@@ -53,6 +56,8 @@ def _grouped_mlp_max(xyz_t, pts, idx, fps_idx, layers, first):
     px = ops.linear_act(xyz_t.contiguous(), wx)                       # [B,N,C1] = Wx x
     P = px if pts is None else px + ops.linear_act(pts, wf)
     Bc = b1 - ops.group_gather(None, px, fps_idx.view(B, S, 1)).view(B, S, C1)
+    if FUSE_LAYERS_1_2 and ops.grouped_mlp_max_supported(C1, idx.shape[2], layers[1:]):
+        return ops.grouped_mlp_max(P, Bc, idx, layers[1:])            # layer 1 generated inside layer 2's GEMM
     h1 = ops.group_act(P, Bc, idx, 0.0)                               # [B,S,ns,C1] = relu(layer 1)
     return ops.mlp_relu_max(h1, layers[1:])
 

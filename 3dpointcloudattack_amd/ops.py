@@ -1657,6 +1657,69 @@ class _MLPReLUMaxFn(torch.autograd.Function):
         return (gx.view(G, ns, C0),) + (None,) * (2 * nl)
 
 
+class _GroupedMLPMaxFn(torch.autograd.Function):
+    """A three-layer set-abstraction MLP + group max from the per-point form of its first layer, WITHOUT the layer-1
+    output: H2 = relu(W2 relu(P[idx] + Bc) + b2) in one launch (pc3d_gemm_nt_gather_f32 generates the rows of its X
+    operand on load), then the last layer + max (pc3d_group_linear_max_f32). Backward: sparse rows through the max,
+    one GEMM on W2^T, and the scatter to P / Bc with the first ReLU's sign from the bit mask the forward GEMM wrote
+    (pc3d_group_act_bwd_mask_f32). One [B,S,ns,C1] write and two reads fewer than group_act + mlp_relu_max."""
+
+    @staticmethod
+    def forward(ctx, P, Bc, idx, w2, b2, w3, b3):
+        B, NA, C1 = P.shape
+        S, ns = idx.shape[1], idx.shape[2]
+        C2 = w2.shape[0]
+        H2 = torch.empty((B * S * ns, C2), dtype=torch.float32, device=P.device)
+        mask = torch.empty((B * S * ns, C1 // 4), dtype=torch.uint8, device=P.device)
+        with torch.cuda.device(P.device):
+            _lib.call("pc3d_gemm_nt_gather_f32", P.data_ptr(), C1, Bc.data_ptr(), idx.data_ptr(), B, NA, S, ns, 0.0,
+                      w2.data_ptr(), b2.data_ptr(), C2, C1, _ACTS["relu"], 0.0, H2.data_ptr(), C2, mask.data_ptr(),
+                      _stream())
+        out, arg = _group_linear_max_fwd(H2.view(B * S, ns, C2), w3, b3)
+        ctx.save_for_backward(out, arg, H2, mask, idx, w2, w3)
+        ctx.dims = (B, NA, C1)
+        return out.view(B, S, -1)
+
+    @staticmethod
+    def backward(ctx, g):
+        out, arg, H2, mask, idx, w2, w3 = ctx.saved_tensors
+        B, NA, C1 = ctx.dims
+        S, ns = idx.shape[1], idx.shape[2]
+        C2 = w2.shape[0]
+        g = g.contiguous()
+        gz = torch.empty((B * S * ns, C2), dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            _lib.call("pc3d_group_max_linear_bwd_f32", g.data_ptr(), out.data_ptr(), arg.data_ptr(), w3.data_ptr(),
+                      B * S, ns, C2, w3.shape[0], H2.data_ptr(), gz.data_ptr(), _stream())
+        gh1 = gemm_nt(gz, _w_transposed(w2))
+        gP = torch.empty((B, NA, C1), dtype=torch.float32, device=g.device)
+        gBc = torch.empty((B, S, C1), dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            _lib.call("pc3d_group_act_bwd_mask_f32", gh1.data_ptr(), mask.data_ptr(), idx.data_ptr(), B, NA, S, ns, C1,
+                      0.0, gP.data_ptr(), gBc.data_ptr(), _stream())
+        return gP, gBc, None, None, None, None, None
+
+
+def grouped_mlp_max_supported(C1, ns, layers):
+    """Shapes pc3d_gemm_nt_gather_f32 + the fused last layer take: [(W2,b2),(W3,b3)] after the per-point first layer."""
+    if len(layers) != 2 or C1 % 4 or C1 > GROUP_ACT_MAX_C or ns > GROUP_MAX_NS:
+        return False
+    C2, C3 = layers[0][0].shape[0], layers[1][0].shape[0]
+    return C2 % 8 == 0 and C2 <= 128 and C3 % 32 == 0 and C3 <= 4096
+
+
+def grouped_mlp_max(P, Bc, idx, layers):
+    """max_j relu(W3 relu(W2 relu(P[b,idx[b,s,j]] + Bc[b,s]) + b2) + b3) -> [B,S,C3]; P [B,NA,C1], Bc [B,S,C1], idx
+    [B,S,ns] int32, layers = [(W2,b2),(W3,b3)] frozen. Differentiable in P and Bc."""
+    _check(P, "P"), _check(Bc, "Bc")
+    if not grouped_mlp_max_supported(P.shape[2], idx.shape[2], layers) or idx.dtype != torch.int32 \
+            or Bc.shape != (P.shape[0], idx.shape[1], P.shape[2]):
+        raise ValueError("grouped_mlp_max: unsupported shapes (see grouped_mlp_max_supported)")
+    (w2, b2), (w3, b3) = layers
+    return _GroupedMLPMaxFn.apply(P.contiguous(), Bc.contiguous(), idx.contiguous(), w2.detach().contiguous(),
+                                  b2.detach().contiguous(), w3.detach().contiguous(), b3.detach().contiguous())
+
+
 def mlp_relu_max(x, layers):
     """x [..., ns, C0], layers [(w, b), ...] frozen -> max over dim -2 of the ReLU MLP's output: [..., C_last]."""
     _check(x, "x")

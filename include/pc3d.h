@@ -154,6 +154,19 @@ int pc3d_group_act_f32(const float* P, const float* Bc, const int32_t* idx, int 
                        float slope, float* H, void* stream);
 int pc3d_group_act_bwd_f32(const float* gH, const float* H, const int32_t* idx, int B, int NA, int S, int K, int C,
                            float slope, float* gP, float* gBc, void* stream);
+/* Layers 1 + 2 of a set-abstraction MLP in one launch, without the [B,S,ns,C1] layer-1 output:
+ *   Y[(b,s,j), :] = act(W act_in(P[b, idx[b,s,j], :] + Bc[b,s,:]) + bias)
+ * = pc3d_group_act_f32 followed by pc3d_gemm_nt_f32, with the rows of the GEMM's X operand generated on load (P [B*NA, K]
+ * with row stride ldp, Bc [B*S, K], idx [B,S,ns] int32, outside [0,NA): zero row of P). act_in = LeakyReLU(slope_in),
+ * 0 = ReLU; act / slope as pc3d_gemm_nt_f32. Y [B*S*ns, N] with row stride ldy. mask (may be NULL; needs K % 4 == 0):
+ * [B*S*ns, K/4] bytes, bit c % 4 of byte c / 4 = "element c of the generated row had a positive pre-activation" — the
+ * only thing the backward of act_in needs from the tensor that is no longer stored:
+ *   pc3d_group_act_bwd_mask_f32 = pc3d_group_act_bwd_f32 reading that mask instead of H. */
+int pc3d_gemm_nt_gather_f32(const float* P, int64_t ldp, const float* Bc, const int32_t* idx, int B, int NA, int S, int ns,
+                            float slope_in, const float* W, const float* bias, int N, int K, int act, float slope, float* Y,
+                            int64_t ldy, uint8_t* mask, void* stream);
+int pc3d_group_act_bwd_mask_f32(const float* gH, const uint8_t* mask, const int32_t* idx, int B, int NA, int S, int K, int C,
+                                float slope, float* gP, float* gBc, void* stream);
 
 /* Row reductions of a [B,N] f32 matrix into out[B].
  *   op:  0 = mean, 1 = max, 2 = sum        pre: 0 = identity, 1 = sqrt(max(x,0)) applied per element first

@@ -296,6 +296,34 @@ def test_group_act_fwd_bwd_vs_torch(dev, B, NA, S, K, C, slope):
     torch.testing.assert_close(Pa.grad.double(), Pr.grad, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("B,NA,S,ns,C1,C2,C3", [(2, 300, 40, 32, 64, 64, 128), (3, 257, 17, 64, 128, 128, 256),
+                                                (1, 90, 5, 16, 32, 48, 64), (2, 128, 9, 128, 12, 24, 32)])
+def test_grouped_mlp_max_equals_group_act_then_mlp(dev, B, NA, S, ns, C1, C2, C3):
+    """pc3d_gemm_nt_gather_f32 (layer 1 generated while loading layer 2's operand) + the bit-mask backward against
+    the two-operator form (pc3d_group_act_f32, then the MLP): outputs bit for bit (same GEMM, same operand values),
+    gradients to P and Bc to float-atomic noise; padded tails and a "no point" index included."""
+    ops = importlib.import_module("3dpointcloudattack_amd.ops")
+    g = torch.Generator().manual_seed(NA + ns)
+    P, Bc = torch.randn(B, NA, C1, generator=g).to(dev), torch.randn(B, S, C1, generator=g).to(dev)
+    idx = torch.randint(0, NA, (B, S, ns), generator=g)
+    idx[:, :, ns // 2:] = idx[:, :, :1]
+    idx[0, 0, 1] = NA
+    idx = idx.int().to(dev)
+    layers = [((torch.randn(C2, C1, generator=g) / C1 ** 0.5).to(dev), torch.randn(C2, generator=g).to(dev)),
+              ((torch.randn(C3, C2, generator=g) / C2 ** 0.5).to(dev), torch.randn(C3, generator=g).to(dev))]
+    up = torch.randn(B, S, C3, generator=g).to(dev)
+    assert ops.grouped_mlp_max_supported(C1, ns, layers)
+    Pa, Ba = P.clone().requires_grad_(), Bc.clone().requires_grad_()
+    out = ops.grouped_mlp_max(Pa, Ba, idx, layers)
+    (out * up).sum().backward()
+    Pr, Br = P.clone().requires_grad_(), Bc.clone().requires_grad_()
+    ref = ops.mlp_relu_max(ops.group_act(Pr, Br, idx, 0.0), layers)
+    (ref * up).sum().backward()
+    assert torch.equal(out, ref)
+    torch.testing.assert_close(Ba.grad, Br.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(Pa.grad, Pr.grad, rtol=1e-4, atol=1e-5)
+
+
 @pytest.mark.parametrize("mlp,in_feat", [([64, 64, 128], 0), ([32, 48, 64], 13), ([30, 40], 5), ([16], 0)])
 def test_set_abstraction_vs_oracle_module(dev, mlp, in_feat):
     """PointNetSetAbstraction end to end (FPS + ball query + the grouped first layer as P[idx] + Bc + the rest of the MLP

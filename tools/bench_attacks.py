@@ -16,6 +16,8 @@ def mk(modname, cls, seed=0, **kw):
 rng = np.random.default_rng(0)
 which = sys.argv[1:] or ["geoa3", "knn", "aof"]
 GRAPH = os.environ.get("PC3D_GRAPH_VICTIM", "1") != "0"
+if os.environ.get("PC3D_FUSE12") == "0":      # A/B switch for the experiment recorded in DESIGN.md
+    M("3dpointcloudattack_amd.model.pointnet2_utils").FUSE_LAYERS_1_2 = False
 res = {}
 if "cw_curvenet" in which:
     B, N, IT = 32, 4096, 30
