@@ -6,7 +6,7 @@ import torch.nn.functional as F
 from .. import ops
 
 from .pointnet import _FrozenFusedMixin, _fold_bn, _plain
-from .pointnet2_utils import PointNetSetAbstraction, PointNetSetAbstractionMsg
+from .pointnet2_utils import PointNetSetAbstraction, PointNetSetAbstractionMsg, geometry_chain, geometry_join
 
 
 class PointNet_Msg(_FrozenFusedMixin, nn.Module):
@@ -39,8 +39,10 @@ class PointNet_Msg(_FrozenFusedMixin, nn.Module):
         else:
             norm = None
         head = self.folded()
-        l1_xyz, l1_points = self.sa1(xyz, norm)
-        l2_xyz, l2_points = self.sa2(l1_xyz, l1_points)
+        geo = geometry_chain(self, xyz, (self.sa1, self.sa2))     # FPS + ball queries of both layers, on a side stream
+        l1_xyz, l1_points = self.sa1(xyz, norm, geo=geo[0])
+        l2_xyz, l2_points = self.sa2(l1_xyz, l1_points, geo=geo[1])
+        geometry_join(self, xyz)
         l3_xyz, l3_points = self.sa3(l2_xyz, l2_points)
         x = l3_points.reshape(B, 1024)
         x = ops.linear_act(x, *head[0], "relu")

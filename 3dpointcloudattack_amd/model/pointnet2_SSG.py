@@ -6,7 +6,7 @@ import torch.nn.functional as F
 from .. import ops
 
 from .pointnet import _FrozenFusedMixin, _fold_bn, _plain
-from .pointnet2_utils import PointNetSetAbstraction
+from .pointnet2_utils import PointNetSetAbstraction, geometry_chain, geometry_join
 
 
 class PointNet_Ssg(_FrozenFusedMixin, nn.Module):
@@ -32,8 +32,10 @@ class PointNet_Ssg(_FrozenFusedMixin, nn.Module):
         self._require_fused(xyz)
         B, _, _ = xyz.shape
         head = self.folded()
-        l1_xyz, l1_points = self.sa1(xyz, None)
-        l2_xyz, l2_points = self.sa2(l1_xyz, l1_points)
+        geo = geometry_chain(self, xyz, (self.sa1, self.sa2))     # FPS + ball queries of both layers, on a side stream
+        l1_xyz, l1_points = self.sa1(xyz, None, geo=geo[0])
+        l2_xyz, l2_points = self.sa2(l1_xyz, l1_points, geo=geo[1])
+        geometry_join(self, xyz)
         l3_xyz, l3_points = self.sa3(l2_xyz, l2_points)
         x = l3_points.reshape(B, 1024)
         x = ops.linear_act(x, *head[0], "relu")      # dropout is identity in eval

@@ -183,8 +183,21 @@ class PointNetSetAbstraction(_FrozenFusedMixin, nn.Module):
         layers = [_fold_bn2d(c, b) for c, b in zip(self.mlp_convs, self.mlp_bns)]
         return layers, _split_first(layers)
 
-    def forward(self, xyz, points):
-        """xyz [B,3,N], points [B,D,N] or None -> new_xyz [B,3,S], new_points [B,D',S]."""
+    def geometry(self, xyz_t):
+        """What this layer derives from the COORDINATES alone, for detached xyz_t [B,N,3] on the current stream: (centre
+        indices [B,S] i32, detached centres [B,S,3], group indices [B,S,ns] i32, event). A classifier runs the whole
+        chain of its layers on a side stream (geometry_chain) beside the MLPs of the previous layer."""
+        B, N, _ = xyz_t.shape
+        fps_idx = ops.fps(xyz_t, self.npoint, _fps_start(B, N, xyz_t.device))                       # [B,S] i32
+        centres = ops.group_gather(xyz_t, None, fps_idx.view(B, self.npoint, 1)).view(B, self.npoint, 3)
+        idx = ops.ball_query(self.radius, self.nsample, xyz_t, centres)                              # [B,S,ns] i32
+        ev = torch.cuda.Event()
+        ev.record()
+        return fps_idx, centres, idx, ev
+
+    def forward(self, xyz, points, geo=None):
+        """xyz [B,3,N], points [B,D,N] or None -> new_xyz [B,3,S], new_points [B,D',S]. geo: this layer's entry of
+        geometry_chain (indices computed ahead on a side stream), or None to sample and group here."""
         self._require_fused(xyz)
         xyz_t = xyz.permute(0, 2, 1).float()      # strided view; the kernels take strides
         pts = _cl(points)
@@ -194,9 +207,14 @@ class PointNetSetAbstraction(_FrozenFusedMixin, nn.Module):
             new_points = _mlp_max(new_points, layers)   # [B,1,D'] channels-last 1x1 convs, no permutes
         else:
             B, N, _ = xyz_t.shape
-            fps_idx = ops.fps(xyz_t, self.npoint, _fps_start(B, N, xyz_t.device))                       # [B,S] i32
-            new_xyz = ops.group_gather(xyz_t, None, fps_idx.view(B, self.npoint, 1)).view(B, self.npoint, 3)
-            idx = ops.ball_query(self.radius, self.nsample, xyz_t, new_xyz)                              # [B,S,ns] i32
+            if geo is not None:
+                fps_idx, _, idx, ev = geo
+                torch.cuda.current_stream(xyz_t.device).wait_event(ev)
+                new_xyz = ops.group_gather(xyz_t, None, fps_idx.view(B, self.npoint, 1)).view(B, self.npoint, 3)
+            else:
+                fps_idx = ops.fps(xyz_t, self.npoint, _fps_start(B, N, xyz_t.device))                   # [B,S] i32
+                new_xyz = ops.group_gather(xyz_t, None, fps_idx.view(B, self.npoint, 1)).view(B, self.npoint, 3)
+                idx = ops.ball_query(self.radius, self.nsample, xyz_t, new_xyz)                          # [B,S,ns] i32
             new_points = _grouped_mlp_max(xyz_t, pts, idx, fps_idx, layers, first)
         return new_xyz.permute(0, 2, 1), new_points.permute(0, 2, 1)
 
@@ -236,20 +254,71 @@ class PointNetSetAbstractionMsg(_FrozenFusedMixin, nn.Module):
             out.append((layers, _split_first(layers)))
         return out
 
-    def forward(self, xyz, points):
+    def geometry(self, xyz_t):
+        """(centre indices, detached centres, [group indices per scale], event) for detached xyz_t [B,N,3]; see
+        PointNetSetAbstraction.geometry."""
+        B, N, _ = xyz_t.shape
+        S = self.npoint
+        fps_idx = ops.fps(xyz_t, S, _fps_start(B, N, xyz_t.device))
+        centres = ops.group_gather(xyz_t, None, fps_idx.view(B, S, 1)).view(B, S, 3)
+        idxs = [ops.ball_query(radius, self.nsample_list[i], xyz_t, centres) for i, radius in enumerate(self.radius_list)]
+        ev = torch.cuda.Event()
+        ev.record()
+        return fps_idx, centres, idxs, ev
+
+    def forward(self, xyz, points, geo=None):
         self._require_fused(xyz)
         xyz_t = xyz.permute(0, 2, 1).float()
         pts = _cl(points)
         B, N, C = xyz_t.shape
         S = self.npoint
-        fps_idx = ops.fps(xyz_t, S, _fps_start(B, N, xyz_t.device))
+        if geo is not None:
+            fps_idx, _, idxs, ev = geo
+            torch.cuda.current_stream(xyz_t.device).wait_event(ev)
+        else:
+            fps_idx = ops.fps(xyz_t, S, _fps_start(B, N, xyz_t.device))
+            idxs = None
         new_xyz = ops.group_gather(xyz_t, None, fps_idx.view(B, S, 1)).view(B, S, 3)
         outs = []
         for i, radius in enumerate(self.radius_list):
-            idx = ops.ball_query(radius, self.nsample_list[i], xyz_t, new_xyz)
+            idx = idxs[i] if idxs is not None else ops.ball_query(radius, self.nsample_list[i], xyz_t, new_xyz)
             layers, first = self.folded()[i]
             outs.append(_grouped_mlp_max(xyz_t, pts, idx, fps_idx, layers, first))
         return new_xyz.permute(0, 2, 1), torch.cat(outs, dim=-1).permute(0, 2, 1)
+
+
+def geometry_chain(owner, xyz, layers):
+    """Sampling and grouping of consecutive set-abstraction layers on a SIDE stream: layer l+1 samples the centres of
+    layer l, so the whole chain depends on the input coordinates only (model/pointnet2_utils.py:158-176 draws and
+    searches inside each layer's forward). Farthest-point sampling is a chain of dependent arg-max steps on one
+    workgroup per cloud; run ahead, the sampling and ball queries of layer l+1 overlap the MLP of layer l. The FPS start
+    indices are drawn from the CPU generator in the same order as in-line. Returns one geometry() entry per layer;
+    `owner.geometry_stream = False` (or a CPU tensor) computes them in-line on the current stream."""
+    if not xyz.is_cuda:
+        return [None] * len(layers)
+    pts = xyz.detach().permute(0, 2, 1).float()
+    cur = torch.cuda.current_stream(xyz.device)
+    side = None
+    if getattr(owner, "geometry_stream", True):
+        side = owner.__dict__.get("_side_stream")
+        if side is None or side.device != xyz.device:
+            side = torch.cuda.Stream(device=xyz.device)
+            object.__setattr__(owner, "_side_stream", side)
+        side.wait_stream(cur)
+    out = []
+    with torch.no_grad(), torch.cuda.stream(side if side is not None else cur):
+        for layer in layers:
+            g = layer.geometry(pts)
+            out.append(g)
+            pts = g[1]
+    return out
+
+
+def geometry_join(owner, xyz):
+    """The forward's last word to the side stream (keeps graph captures well-formed: every fork is joined)."""
+    side = owner.__dict__.get("_side_stream")
+    if xyz.is_cuda and side is not None and getattr(owner, "geometry_stream", True):
+        torch.cuda.current_stream(xyz.device).wait_stream(side)
 
 
 class PointNetFeaturePropagation(_FrozenFusedMixin, nn.Module):

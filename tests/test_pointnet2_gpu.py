@@ -161,6 +161,26 @@ def _hip_model(name, dev):
 
 
 @pytest.mark.parametrize("name", ["ssg", "msg"])
+def test_geometry_side_stream_equals_inline(dev, fx, name):
+    """Sampling + grouping of both set-abstraction layers on the side stream (geometry_chain) against the same forward
+    with everything on one stream: same FPS start draws, so logits and the input gradient are equal bit for bit up to
+    the float atomics of the scatter kernels."""
+    model, _ = _hip_model(name, dev)
+    x0 = torch.from_numpy(fx[f"{name}_x"]).to(dev)
+    res = []
+    for side in (True, False):
+        model.geometry_stream = side
+        x = x0.clone().requires_grad_()
+        torch.manual_seed(21)
+        logp = model(x)[0]
+        logp[:, 3].sum().backward()
+        res.append((logp.detach().clone(), x.grad.clone()))
+    model.geometry_stream = True
+    assert torch.equal(res[0][0], res[1][0])
+    torch.testing.assert_close(res[0][1], res[1][1], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["ssg", "msg"])
 def test_classifier_logits_and_input_grad_vs_reference(dev, fx, name):
     model, sha = _hip_model(name, dev)
     assert sha == str(fx[f"{name}_sha256"])
