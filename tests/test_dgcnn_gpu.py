@@ -148,3 +148,24 @@ def test_act_maxmean_pool_fwd_bwd_vs_torch(ops, dev, B, N, C, slope):
     (ref * w).sum().backward()
     torch.testing.assert_close(g1, Y.grad, rtol=1e-5, atol=1e-7)
     assert torch.equal(ops.act_maxmean_pool(Y, slope), out)          # deterministic
+
+
+@pytest.mark.parametrize("C", [64, 72])          # the static product loop (C = 64) and the run-time one
+def test_knn_feat_nan_rows_are_never_neighbours(ops, dev, C):
+    """A NaN feature row gives NaN distances; as keys they rank as +inf (knn_list.h), so no finite query lists the row
+    and the kernel returns valid indices for the NaN query itself."""
+    torch.manual_seed(C)
+    B, N, K = 2, 300, 20
+    x = torch.randn(B, N, C)
+    x[0, 17] = float("nan")
+    x[1, 255, 3] = float("nan")
+    idx = ops.knn_feat(x.to(dev), K).cpu()
+    assert int(idx.min()) >= 0 and int(idx.max()) < N
+    ok0 = torch.ones(N, dtype=torch.bool); ok0[17] = False
+    ok1 = torch.ones(N, dtype=torch.bool); ok1[255] = False
+    assert not bool((idx[0][ok0] == 17).any()) and not bool((idx[1][ok1] == 255).any())
+    # the finite queries still get their exact neighbours among the finite rows
+    D = torch.cdist(x[0][ok0].double(), x[0][ok0].double(), compute_mode='donot_use_mm_for_euclid_dist') ** 2
+    remap = torch.full((N,), -1, dtype=torch.long); remap[ok0] = torch.arange(int(ok0.sum()))
+    picked = torch.gather(D, 1, remap[idx[0][ok0].long()])
+    torch.testing.assert_close(picked, torch.sort(D, dim=1)[0][:, :K], rtol=1e-4, atol=1e-3)

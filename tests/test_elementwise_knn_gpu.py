@@ -112,6 +112,32 @@ def test_knn_ties_prefer_lower_index(ops, dev):
             assert np.all(np.diff(row[4 * g:4 * g + 4]) == 700)
 
 
+@pytest.mark.parametrize("K", [5, 20])            # the selection-round seed (K <= 10) and the sorted seed
+def test_knn_nan_points_are_never_neighbours(ops, dev, K):
+    """A reference point with a NaN coordinate has NaN distances; their keys rank above +inf (knn_list.h), so it is in
+    no finite query's list, whether it falls in the seed step (index < 64) or a later one; K = 1 goes through the same
+    list code (candidate step without the re-filter)."""
+    rng = np.random.default_rng(K)
+    r = unit_cloud(rng, 500)[None].copy()
+    r[0, 7, 1] = np.nan
+    r[0, 300, 0] = np.nan
+    q = unit_cloud(rng, 120)[None]
+    d, i = ops.knn_raw(torch.from_numpy(q).to(dev), torch.from_numpy(r).to(dev), K)
+    d, i = d.cpu().numpy()[0], i.cpu().numpy()[0]
+    assert np.isfinite(d).all() and not np.isin(i, (7, 300)).any()
+    ok = np.ones(500, dtype=bool); ok[[7, 300]] = False
+    D = ((q[0].astype(np.float64)[:, None] - r[0][ok].astype(np.float64)[None]) ** 2).sum(-1)
+    np.testing.assert_allclose(d, np.sort(D, axis=1)[:, :K], rtol=2e-6, atol=1e-12)
+    # K = 1 straight through the C ABI (ops.knn_raw routes K = 1 to the nearest-neighbour kernel instead)
+    lib = importlib.import_module("3dpointcloudattack_amd._lib")
+    qd, rd = torch.from_numpy(q).to(dev), torch.from_numpy(r).to(dev)
+    d1 = torch.empty(1, 120, 1, device=dev)
+    i1 = torch.empty(1, 120, 1, dtype=torch.int32, device=dev)
+    lib.call("pc3d_knn_f32", qd.data_ptr(), *qd.stride(), rd.data_ptr(), *rd.stride(), 1, 120, 500, 1, d1.data_ptr(),
+             i1.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    np.testing.assert_allclose(d1.cpu().numpy()[0, :, 0], np.sort(D, axis=1)[:, 0], rtol=2e-6, atol=1e-12)
+
+
 @pytest.mark.parametrize("det", [False, True])
 def test_knn_dist_functor_value_and_grad(dev, det):
     dist = importlib.import_module("3dpointcloudattack_amd.attack.CW.CW_utils.dist_utils")
