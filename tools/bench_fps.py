@@ -1,0 +1,15 @@
+"""pc3d_fps_f32 at the shapes of the attack configs: us per call and per sampling step."""
+import importlib, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+ops = importlib.import_module("3dpointcloudattack_amd.ops")
+dev = torch.device("cuda:0")
+for B, N, S in ((32, 4096, 1024), (64, 2048, 512), (64, 512, 128), (32, 1024, 256)):
+    x = torch.rand(B, N, 3, device=dev)
+    for _ in range(3): ops.fps(x, S, None)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10): ops.fps(x, S, None)
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / 10 * 1e3
+    print(f"B={B} N={N} S={S}: {us:.1f} us, {us / S * 1e3:.0f} ns per step", flush=True)
