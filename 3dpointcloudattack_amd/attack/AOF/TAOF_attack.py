@@ -16,6 +16,7 @@ import torch.optim as optim
 
 from ... import graphed as _graphed
 from ... import ops
+from ... import streams as _streams
 from ..CW.CW_utils import adv_utils as _adv_utils
 
 
@@ -201,7 +202,7 @@ class CWTAOF:
             begin_step(adv0)
             if binary_step == 0 and self._capturable() and self.num_iter > 0:
                 # capture once (after eager warm-up passes on a side stream, as torch requires), then rewind the state
-                side = torch.cuda.Stream(device=dev)
+                side = _streams.side_stream(dev, _streams.TERMS)     # ONE per process (streams.py)
                 side.wait_stream(torch.cuda.current_stream(dev))
                 with torch.cuda.stream(side):
                     for _ in range(2):

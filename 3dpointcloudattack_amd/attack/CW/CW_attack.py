@@ -19,6 +19,7 @@ import torch.optim as optim
 
 from ... import graphed as _graphed
 from ... import ops
+from ... import streams as _streams
 from .CW_utils import adv_utils as _adv_utils
 from .CW_utils import clip_utils as _clip_utils
 from .CW_utils import dist_utils as _dist_utils
@@ -318,7 +319,7 @@ class CW:
             return run
         if st["graph"] is not None:
             return st["graph_run"]
-        side = torch.cuda.Stream(device=self.device)
+        side = _streams.side_stream(self.device, _streams.TERMS)     # ONE per process (streams.py)
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):
             for _ in range(warmup):

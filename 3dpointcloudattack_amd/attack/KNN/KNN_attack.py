@@ -13,6 +13,7 @@ import torch.optim as optim
 
 from ... import graphed as _graphed
 from ... import ops
+from ... import streams as _streams
 from ..CW.CW_utils import clip_utils as _clip_utils
 from ..CW.CW_utils import dist_utils as _dist_utils
 
@@ -125,7 +126,8 @@ class CWKNN:
         # victim's forward, whose first kernels (farthest-point sampling: one workgroup per cloud) leave most of the
         # chip idle. Autograd runs each node's backward on its forward's stream, so the two backwards overlap as well.
         cur = torch.cuda.current_stream(dev) if adv_data.is_cuda else None
-        side = torch.cuda.Stream(device=dev) if cur is not None and getattr(self, "dist_stream", True) else None
+        side = (_streams.side_stream(dev, _streams.TERMS) if cur is not None and getattr(self, "dist_stream", True)
+                else None)                      # ONE per process (see streams.py)
         for iteration in range(self.num_iter):
             if side is not None:
                 side.wait_stream(cur)

@@ -22,6 +22,8 @@ import weakref
 import torch
 import torch.nn as nn
 
+from . import streams as _streams
+
 
 @contextlib.contextmanager
 def capture_guard():
@@ -197,7 +199,7 @@ class GraphedVictim(nn.Module):
                                                   num_warmup_iters=self._warmup)
         else:
             static_in = x.detach().clone()
-            side = torch.cuda.Stream(device=x.device)
+            side = _streams.side_stream(x.device, _streams.TERMS)     # warm-up passes; ONE per process (streams.py)
             side.wait_stream(torch.cuda.current_stream(x.device))
             with torch.cuda.stream(side), torch.no_grad():
                 for _ in range(self._warmup):

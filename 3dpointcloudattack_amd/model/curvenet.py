@@ -4,6 +4,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
+from .. import streams as _streams
 from .curvenet_util import CIC, LPFA, hold_rng_position, pw_cl
 from .pointnet import _FrozenFusedMixin
 
@@ -86,10 +87,7 @@ class CurveNet(_FrozenFusedMixin, nn.Module):
         cur = torch.cuda.current_stream()
         with torch.no_grad():
             if self.geometry_stream:
-                side = self.__dict__.get("_side_stream")
-                if side is None or side.device != pos.device:
-                    side = torch.cuda.Stream(device=pos.device)
-                    object.__setattr__(self, "_side_stream", side)
+                side = _streams.side_stream(pos.device, _streams.GEOMETRY)      # ONE per process (see streams.py)
                 side.wait_stream(cur)
                 with torch.cuda.stream(side):
                     levels = self._geometry(pos.detach())

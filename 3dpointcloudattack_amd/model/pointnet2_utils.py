@@ -15,6 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
+from .. import streams as _streams
 from .pointnet import _FrozenFusedMixin
 
 
@@ -300,10 +301,7 @@ def geometry_chain(owner, xyz, layers):
     cur = torch.cuda.current_stream(xyz.device)
     side = None
     if getattr(owner, "geometry_stream", True):
-        side = owner.__dict__.get("_side_stream")
-        if side is None or side.device != xyz.device:
-            side = torch.cuda.Stream(device=xyz.device)
-            object.__setattr__(owner, "_side_stream", side)
+        side = _streams.side_stream(xyz.device, _streams.GEOMETRY)      # ONE per process (see streams.py)
         side.wait_stream(cur)
     out = []
     with torch.no_grad(), torch.cuda.stream(side if side is not None else cur):
@@ -316,9 +314,8 @@ def geometry_chain(owner, xyz, layers):
 
 def geometry_join(owner, xyz):
     """The forward's last word to the side stream (keeps graph captures well-formed: every fork is joined)."""
-    side = owner.__dict__.get("_side_stream")
-    if xyz.is_cuda and side is not None and getattr(owner, "geometry_stream", True):
-        torch.cuda.current_stream(xyz.device).wait_stream(side)
+    if xyz.is_cuda and getattr(owner, "geometry_stream", True):
+        torch.cuda.current_stream(xyz.device).wait_stream(_streams.side_stream(xyz.device, _streams.GEOMETRY))
 
 
 class PointNetFeaturePropagation(_FrozenFusedMixin, nn.Module):
