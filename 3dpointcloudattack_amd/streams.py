@@ -20,5 +20,8 @@ def side_stream(device, slot):
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     st = _STREAMS.get((idx, slot))
     if st is None:
-        st = _STREAMS[(idx, slot)] = torch.cuda.Stream(device=torch.device("cuda", idx))
+        # the geometry chain gates the victim's feature path (its first kernel is a long one-workgroup-per-cloud chain):
+        # high priority, so its workgroups are placed ahead of the bulk kernels of the other two streams
+        st = _STREAMS[(idx, slot)] = torch.cuda.Stream(device=torch.device("cuda", idx),
+                                                       priority=-1 if slot == GEOMETRY else 0)
     return st
