@@ -160,6 +160,56 @@ __global__ __launch_bounds__(256) void kappa_bwd_kernel(KappaArgs a) {
   atomicAdd(gb + 3 * i, -sx), atomicAdd(gb + 3 * i + 1, -sy), atomicAdd(gb + 3 * i + 2, -sz);
 }
 
+// The same backward without global atomics: workgroup (coordinate d, cloud b) keeps the cloud's points and ONE component
+// of its gradient in LDS, a lane walks the neighbours of its point, adds component d of every edge's gradient to the
+// neighbour's slot (ds_add_f32) and keeps its own point's sum in a register. The three workgroups of a cloud repeat the
+// edge arithmetic (cheap) so that each issues a third of the LDS atomics, which are what bounds this form (two earlier
+// one-workgroup-per-cloud variants with all three components took 70 and 150 us against 72 for the kernel above at B=32,
+// N=1024, k=16: LDS float atomics retire about one lane per 1.5-3 clocks). N <= kKappaSlabMaxN (16 N bytes of LDS).
+constexpr int kKappaSlabMaxN = 4096;
+__global__ __launch_bounds__(1024) void kappa_bwd_slab_kernel(KappaArgs a) {
+  extern __shared__ float ks_lds[];
+  float* xs = ks_lds;                 // [3][N]
+  float* acc = ks_lds + 3 * a.N;      // [N]
+  const int d = blockIdx.x, b = blockIdx.y;
+  const float* xb = a.x.p + (int64_t)b * a.x.bs;
+  for (int t = threadIdx.x; t < 3 * a.N; t += 1024) {
+    const int c = t / a.N, i = t - c * a.N;
+    xs[t] = xb[(int64_t)i * a.x.ps + (int64_t)c * a.x.cs];
+  }
+  for (int i = threadIdx.x; i < a.N; i += 1024) acc[i] = 0.f;
+  __syncthreads();
+  const float inv_k = 1.f / (float)(a.K1 - 1);
+  for (int i = threadIdx.x; i < a.N; i += 1024) {
+    const float* ni = a.nrm.p + (int64_t)b * a.nrm.bs + (int64_t)i * a.nrm.ps;
+    const float nx = ni[0], ny = ni[a.nrm.cs], nz = ni[2 * a.nrm.cs];
+    const float nd = d == 0 ? nx : (d == 1 ? ny : nz);
+    const float px = xs[i], py = xs[a.N + i], pz = xs[2 * a.N + i];
+    const int32_t* nb = a.idx + ((int64_t)b * a.N + i) * a.K1;
+    const float g = a.gout[(int64_t)b * a.N + i] * inv_k;
+    float own = 0.f;
+    for (int k = 1; k < a.K1; ++k) {
+      const int j = min(max(nb[k], 0), a.N - 1);
+      const float dx = xs[j] - px, dy = xs[a.N + j] - py, dz = xs[2 * a.N + j] - pz;
+      const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
+      const bool clamped = !(nrm > 1e-12f);
+      const float len = clamped ? 1e-12f : nrm;
+      const float vx = dx / len, vy = dy / len, vz = dz / len;
+      const float dot = vx * nx + vy * ny + vz * nz;
+      const float sg = dot > 0.f ? g : (dot < 0.f ? -g : 0.f);
+      const float c = clamped ? 0.f : dot;
+      const float vd = d == 0 ? vx : (d == 1 ? vy : vz);
+      const float gk = sg * (nd - vd * c) / len;
+      own += gk;
+      atomicAdd(acc + j, gk);
+    }
+    atomicAdd(acc + i, -own);
+  }
+  __syncthreads();
+  float* gb = a.gx + (int64_t)b * a.N * 3 + d;
+  for (int i = threadIdx.x; i < a.N; i += 1024) gb[3 * i] = acc[i];
+}
+
 }  // namespace pc3d
 
 using namespace pc3d;
@@ -211,12 +261,17 @@ extern "C" int pc3d_kappa_bwd_f32(const float* x, int64_t x_bs, int64_t x_ps, in
   if (B == 0) return PC3D_OK;
   PC3D_REQUIRE(x && nrm && idx && gout && gx, "pc3d_kappa_bwd_f32: null pointer");
   hipStream_t st = as_stream(stream);
+  KappaArgs a{{x, x_bs, x_ps, x_cs}, {nrm, n_bs, n_ps, n_cs}, idx, N, K1, nullptr, gout, gx};
+  if (N <= kKappaSlabMaxN) {
+    hipLaunchKernelGGL(kappa_bwd_slab_kernel, dim3(3, B), dim3(1024), (size_t)N * 4 * sizeof(float), st, a);
+    PC3D_LAUNCH_CHECK("pc3d_kappa_bwd_f32");
+    return PC3D_OK;
+  }
   hipError_t e = zero_async(gx, (size_t)B * N * 3, st);
   if (e != hipSuccess) {
     set_error("pc3d_kappa_bwd_f32: zero fill failed: %s", hipGetErrorString(e));
     return (int)e;
   }
-  KappaArgs a{{x, x_bs, x_ps, x_cs}, {nrm, n_bs, n_ps, n_cs}, idx, N, K1, nullptr, gout, gx};
   hipLaunchKernelGGL(kappa_bwd_kernel, dim3(cdiv(N, 256), B), dim3(256), 0, st, a);
   PC3D_LAUNCH_CHECK("pc3d_kappa_bwd_f32");
   return PC3D_OK;
