@@ -48,6 +48,7 @@ SIGNATURES = {
     "pc3d_geoa3_record_f32": [_P, _I, _I, _I, _P, _I, _P, _P, _I, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P],
     "pc3d_group_act_bwd_mask_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P],
     "pc3d_gemm_nt_gather_f32": [_P, _L, _P, _P, _I, _I, _I, _I, _F, _P, _P, _I, _I, _I, _F, _P, _L, _P, _P],
+    "pc3d_gemm_nt_poolbwd_f32": [_P, _L, _P, _P, _I, _I, _F, _P, _I, _I, _P, _L, _P],
     "pc3d_geoa3_terms_f32": [_P] * 7 + [_I, _I, _I, _F, _F, _F, _P, _P, _P],
     "pc3d_geoa3_terms_bwd_f32": [_P] * 6 + [_I, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P],
     "pc3d_lpfa_fused_f32": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _P],

@@ -52,6 +52,14 @@ struct GemmArgs {
   float ga_slope;
   uint8_t* ga_mask;    // [M, K / 4] or null: bit c % 4 of byte c / 4 of row m = "the generated element (m, c) came from a
                        // positive pre-activation" — what the backward of act_in needs, 1/32 of the tensor it replaces
+  // pooled-gradient A operand (pb_g != null): X holds the PRE-activation Y [M, K] of a layer that was followed by
+  // LeakyReLU(pb_slope) and [max | mean] pooling over the pb_N rows of every cloud; row m = (cloud b, point n) is
+  // generated as  dY[m, c] = (Y > 0 ? 1 : pb_slope) * ((pb_arg[b,c] == n ? g[b, c] : 0) + g[b, K + c] / pb_N)
+  // — the backward of that pooling (act_pool_bwd_kernel, dgcnn.hip) without the [M, K] gradient tensor.
+  const float* pb_g;       // [M / pb_N, 2K]
+  const int32_t* pb_arg;   // [M / pb_N, K]
+  int pb_N;
+  float pb_slope;
 };
 
 __device__ __forceinline__ float4 gm_load4(const float* p, int k, int K, bool row_ok) {
@@ -68,7 +76,7 @@ __device__ __forceinline__ float4 gm_load4(const float* p, int k, int K, bool ro
 
 // WM x WN waves of 64 x 64 outputs each: <2,2> = 128 x 128 tile (wide layers), <4,1> = 256 x 64 (layers with <= 64
 // outputs: no half-empty MFMA tiles, and the kernel is then bound by reading / writing the [M, 64] activations).
-template <int WM, int WN, int TM, int TN, bool DB, int OCC, bool GA = false>   // GA: gathered A operand (GemmArgs::ga_idx)
+template <int WM, int WN, int TM, int TN, bool DB, int OCC, int GA = 0>   // GA: generated A operand — 1: GemmArgs::ga_idx, 2: ::pb_g
 __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_nt_kernel(GemmArgs a) {
   constexpr int NT = WM * WN * 64;               // threads
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -108,7 +116,15 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_nt_kernel(GemmArgs a) 
   float4 xa[QA], wb[QB];
   // gathered A operand: source row and group of this thread's QA tile rows, resolved once
   int ga_row[GA ? QA : 1], ga_grp[GA ? QA : 1];
-  if constexpr (GA) {
+  if constexpr (GA == 2) {     // (cloud, point) of this thread's tile rows
+#pragma unroll
+    for (int q = 0; q < QA; ++q) {
+      const int gm = m0 + q * RPS + lrow;
+      ga_grp[q] = gm / a.pb_N;
+      ga_row[q] = gm - ga_grp[q] * a.pb_N;
+    }
+  }
+  if constexpr (GA == 1) {
 #pragma unroll
     for (int q = 0; q < QA; ++q) {
       const int gm = m0 + q * RPS + lrow;
@@ -120,11 +136,37 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_nt_kernel(GemmArgs a) 
       }
     }
   }
+  float4 pb_gx = make_float4(0.f, 0.f, 0.f, 0.f), pb_ge = pb_gx;
+  int4 pb_ar = make_int4(0, 0, 0, 0);
   auto fetch = [&](int k0) {
 #pragma unroll
     for (int q = 0; q < QA; ++q) {
       const int gm = m0 + q * RPS + lrow;
-      if constexpr (GA) {
+      if constexpr (GA == 2) {
+        // a row tile lies inside ONE cloud when pb_N is a multiple of the tile height (the entry point checks it), so the
+        // per-(cloud, channel) operands are those of tile row 0 for every q: loaded once per K step (q == 0)
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gm < a.M && k0 + lk < a.K) {       // K % 4 == 0 (entry point): whole float4s
+          const int k = k0 + lk;
+          const float4 y = *reinterpret_cast<const float4*>(a.X + (int64_t)gm * a.ldx + k);
+          if (q == 0) {
+            const float* gb = a.pb_g + (int64_t)ga_grp[0] * 2 * a.K + k;
+            pb_gx = *reinterpret_cast<const float4*>(gb);
+            pb_ge = *reinterpret_cast<const float4*>(gb + a.K);
+            pb_ar = *reinterpret_cast<const int4*>(a.pb_arg + (int64_t)ga_grp[0] * a.K + k);
+            const float inv = 1.f / (float)a.pb_N;
+            pb_ge.x *= inv, pb_ge.y *= inv, pb_ge.z *= inv, pb_ge.w *= inv;
+          }
+          const int n = ga_row[q];
+          v.x = (y.x > 0.f ? 1.f : a.pb_slope) * ((pb_ar.x == n ? pb_gx.x : 0.f) + pb_ge.x);
+          v.y = (y.y > 0.f ? 1.f : a.pb_slope) * ((pb_ar.y == n ? pb_gx.y : 0.f) + pb_ge.y);
+          v.z = (y.z > 0.f ? 1.f : a.pb_slope) * ((pb_ar.z == n ? pb_gx.z : 0.f) + pb_ge.z);
+          v.w = (y.w > 0.f ? 1.f : a.pb_slope) * ((pb_ar.w == n ? pb_gx.w : 0.f) + pb_ge.w);
+        }
+        xa[q] = v;
+        continue;
+      }
+      if constexpr (GA == 1) {
         float4 v = gm_load4(a.X + (int64_t)ga_row[q] * a.ldx, k0 + lk, a.K, ga_row[q] >= 0);
         const float4 c = gm_load4(a.ga_Bc + (int64_t)ga_grp[q] * a.K, k0 + lk, a.K, gm < a.M);
         v.x += c.x, v.y += c.y, v.z += c.z, v.w += c.w;
@@ -284,7 +326,8 @@ static int gemm_nt_launch(const float* X, int64_t ldx, const float* W, const flo
                           float gate_slope, const float* R, int64_t ldr, int M, int N, int K, int act, float slope,
                           float* Y, int64_t ldy, void* stream, int gm_ns = 0, float* gm_out = nullptr,
                           int64_t* gm_arg = nullptr, const int32_t* ga_idx = nullptr, const float* ga_Bc = nullptr,
-                          int ga_ns = 0, int ga_S = 0, int ga_NA = 0, float ga_slope = 0.f, uint8_t* ga_mask = nullptr) {
+                          int ga_ns = 0, int ga_S = 0, int ga_NA = 0, float ga_slope = 0.f, uint8_t* ga_mask = nullptr,
+                          const float* pb_g = nullptr, const int32_t* pb_arg = nullptr, int pb_N = 0, float pb_slope = 0.f) {
   PC3D_REQUIRE(M >= 0 && N >= 1 && K >= 1, "pc3d_gemm_nt_f32: bad sizes M=%d N=%d K=%d", M, N, K);
   PC3D_REQUIRE(act >= 0 && act <= 2, "pc3d_gemm_nt_f32: bad activation %d", act);
   if (M == 0) return PC3D_OK;
@@ -296,6 +339,7 @@ static int gemm_nt_launch(const float* X, int64_t ldx, const float* W, const flo
   a.M = M, a.N = N, a.K = K, a.act = act, a.slope = slope, a.gslope = gate_slope;
   a.gm_ns = gm_ns, a.gm_out = gm_out, a.gm_arg = gm_arg;
   a.ga_idx = ga_idx, a.ga_Bc = ga_Bc, a.ga_ns = ga_ns, a.ga_S = ga_S, a.ga_NA = ga_NA, a.ga_slope = ga_slope, a.ga_mask = ga_mask;
+  a.pb_g = pb_g, a.pb_arg = pb_arg, a.pb_N = pb_N, a.pb_slope = pb_slope;
   // Tile shapes, measured on MI355X (tools/bench_gemm.py, us; hipBLASLt beside them):
   //   layer [M,N,K]                 0: 128x128 DB   2: 128x64   4: 64x128   5: 128x128/8 waves   hipBLASLt
   //   DGCNN conv5 [32768,1024,512]       387           361         350            320               275
@@ -308,7 +352,7 @@ static int gemm_nt_launch(const float* X, int64_t ldx, const float* W, const flo
   //   3: 256x64, 4 waves of 64x64, double buffered                    4: 64x128, 4 waves of 32x64
   //   5 / 6: 128x128, 8 waves of 32x64, single / double buffered       8: as 5 with four workgroups per CU (<= 64 VGPRs)
   int v = g_gemm_variant;
-  if (v < 0 || ga_idx) v = (N <= 64) ? 2 : 5;
+  if (v < 0 || ga_idx || pb_g) v = (N <= 64) ? 2 : 5;
   // the group-max epilogue is written for 128-row tiles of 32-row wave tiles; with K <= 64 (two K steps per tile) four
   // workgroups per CU instead of two hide the tile prologue better: 221 -> 203 us on SSG's SA1 (no change at K = 128)
   if (gm_ns) v = (K <= 64) ? 8 : 5;
@@ -330,9 +374,17 @@ static int gemm_nt_launch(const float* X, int64_t ldx, const float* W, const flo
   const dim3 grid(per * 8), block(v == 5 || v == 6 || v == 8 ? 512 : GM_T);
   hipStream_t st = as_stream(stream);
   if (ga_idx) {
-    if (v == 2) hipLaunchKernelGGL((gemm_nt_kernel<4, 1, 1, 2, false, 4, true>), grid, block, lds, st, a);
-    else hipLaunchKernelGGL((gemm_nt_kernel<4, 2, 1, 2, false, 2, true>), grid, block, lds, st, a);
+    if (v == 2) hipLaunchKernelGGL((gemm_nt_kernel<4, 1, 1, 2, false, 4, 1>), grid, block, lds, st, a);
+    else hipLaunchKernelGGL((gemm_nt_kernel<4, 2, 1, 2, false, 2, 1>), grid, block, lds, st, a);
     PC3D_LAUNCH_CHECK("pc3d_gemm_nt_gather_f32");
+    return PC3D_OK;
+  }
+  if (pb_g) {
+    // the generated operand costs ~50 VALU instructions per K step between load arrival and the LDS store; with
+    // double-buffered tiles that work overlaps the other waves' MFMAs instead of sitting between two barriers
+    if (v == 2) hipLaunchKernelGGL((gemm_nt_kernel<4, 1, 1, 2, false, 4, 2>), grid, block, lds, st, a);
+    else hipLaunchKernelGGL((gemm_nt_kernel<4, 2, 1, 2, true, 2, 2>), grid, block, 2 * lds, st, a);
+    PC3D_LAUNCH_CHECK("pc3d_gemm_nt_poolbwd_f32");
     return PC3D_OK;
   }
   switch (v) {
@@ -380,4 +432,17 @@ extern "C" int pc3d_gemm_nt_gather_f32(const float* P, int64_t ldp, const float*
   PC3D_REQUIRE(!mask || K % 4 == 0, "pc3d_gemm_nt_gather_f32: the sign mask needs K %% 4 == 0 (K=%d)", K);
   return gemm_nt_launch(P, ldp, W, bias, nullptr, 0, 0.f, nullptr, 0, B * S * ns, N, K, act, slope, Y, ldy, stream, 0, nullptr,
                         nullptr, idx, Bc, ns, S, NA, slope_in, mask);
+}
+
+extern "C" int pc3d_gemm_nt_poolbwd_f32(const float* Y, int64_t ldy_in, const float* g, const int32_t* arg, int B, int Npts,
+                                        float slope_pool, const float* W, int N, int K, float* dX, int64_t ldx_out,
+                                        void* stream) {
+  PC3D_REQUIRE(B >= 0 && Npts >= 1 && K >= 4 && K % 4 == 0 && (int64_t)B * Npts <= 0x7fffffffLL && ldy_in % 4 == 0,
+               "pc3d_gemm_nt_poolbwd_f32: bad sizes B=%d Npts=%d K=%d ldy=%lld (K, ldy multiples of 4)", B, Npts, K,
+               (long long)ldy_in);
+  if (B == 0) return PC3D_OK;
+  PC3D_REQUIRE(Y && g && arg, "pc3d_gemm_nt_poolbwd_f32: null pointer");
+  PC3D_REQUIRE(Npts % 128 == 0, "pc3d_gemm_nt_poolbwd_f32: Npts=%d must be a multiple of the 128-row tile", Npts);
+  return gemm_nt_launch(Y, ldy_in, W, nullptr, nullptr, 0, 0.f, nullptr, 0, B * Npts, N, K, 0, 0.f, dX, ldx_out, stream, 0,
+                        nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0.f, nullptr, g, arg, Npts, slope_pool);
 }

@@ -5,7 +5,7 @@ import torch.nn as nn
 
 from .. import ops
 from .. import streams as _streams
-from .curvenet_util import CIC, LPFA, hold_rng_position, pw_cl
+from .curvenet_util import CIC, LPFA, folded_pw, hold_rng_position, pw_cl
 from .pointnet import _FrozenFusedMixin
 
 curve_config = {
@@ -99,7 +99,8 @@ class CurveNet(_FrozenFusedMixin, nn.Module):
         if self.geometry_stream:
             cur.wait_stream(side)          # join (every event above has been waited for; keeps captures well-formed)
         # conv0's ReLU is applied inside the pooling launch: [max_i relu(y) | mean_i relu(y)] (:66-68)
-        x = ops.act_maxmean_pool(pw_cl(self.conv0, feats, act=(None, 0.0)), 0.0)
+        _, _, w0, b0 = folded_pw(self.conv0, None)
+        x = ops.linear_act_maxmean_pool(feats, w0, b0, 0.0)
         x = pw_cl(self.conv1, x, bn=self.bn1, act=("relu", 0.0))
         x = pw_cl(self.conv2, self.dp1(x))
         return x, x, x

@@ -101,7 +101,8 @@ class DGCNN(_FrozenFusedMixin, nn.Module):
             f = ops.edge_max(PQ, idx, 0.2)                  # leaky(max_j P_j + Q_i) == max_j leaky(bn(conv(e_ij)))
             feats.append(f)
         g = torch.cat(feats, dim=2)                         # [B,N,512]
-        g = ops.act_maxmean_pool(ops.linear_act(g, *c5), 0.2)   # leaky + adaptive max / avg pool over N in one pass
+        g = ops.linear_act_maxmean_pool(g, *c5, 0.2)            # conv5, leaky + adaptive max / avg pool over N (backward:
+                                                                # one GEMM, the pooled gradient generated on load)
         g = ops.linear_act(g, *head[0], "leaky", 0.2)
         g = ops.linear_act(g, *head[1], "leaky", 0.2)
         g = ops.linear_act(g, *head[2])

@@ -1060,6 +1060,49 @@ class _ActPoolFn(torch.autograd.Function):
         return gY, None
 
 
+class _LinearActPoolFn(torch.autograd.Function):
+    """act_maxmean_pool(x @ w.T + b) for a frozen layer: forward = the point-wise GEMM + the pooling launch; backward = ONE
+    GEMM on W^T whose dY operand is generated on load from the saved pre-activation, the upstream [B,2C] gradient and the
+    arg-max rows (pc3d_gemm_nt_poolbwd_f32) — no pooling-backward launch and no [B,N,C] gradient tensor."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, slope):
+        B, N, K = x.shape
+        C = w.shape[0]
+        Y = gemm_nt(x.reshape(B * N, K), w, b)
+        out = torch.empty((B, 2 * C), dtype=torch.float32, device=x.device)
+        arg = torch.empty((B, C), dtype=torch.int32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.call("pc3d_act_pool_f32", Y.data_ptr(), B, N, C, float(slope), out.data_ptr(), arg.data_ptr(), _stream())
+        ctx.save_for_backward(Y, arg, w)
+        ctx.meta = (B, N, K, C, float(slope))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        Y, arg, w = ctx.saved_tensors
+        B, N, K, C, slope = ctx.meta
+        g = g.contiguous()
+        wt = _w_transposed(w)                                   # [K, C]
+        gx = torch.empty((B * N, K), dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            _lib.call("pc3d_gemm_nt_poolbwd_f32", Y.data_ptr(), Y.stride(0), g.data_ptr(), arg.data_ptr(), B, N, slope,
+                      wt.data_ptr(), K, C, gx.data_ptr(), K, _stream())
+        return gx.view(B, N, K), None, None, None
+
+
+def linear_act_maxmean_pool(x, w, b, slope):
+    """[max_n z | mean_n z] of z = leaky_relu(x @ w.T + b, slope) for x [B,N,K] and a frozen (w [C,K], b): [B,2C].
+    Differentiable in x (see _LinearActPoolFn). C % 4 == 0; a handful of rows, or N not a multiple of 128, goes through
+    the two-operator form."""
+    _check(x, "x"), _check(w, "w")
+    if x.dim() != 3 or w.shape[0] % 4 or x.shape[0] * x.shape[1] <= GEMM_SMALL_M or x.shape[1] % 128:
+        return act_maxmean_pool(linear_act(x, w, b), slope)      # (the fused backward wants whole 128-row tiles per cloud)
+    w = w.detach()
+    return _LinearActPoolFn.apply(x.contiguous(), w if w.is_contiguous() else w.contiguous(),
+                                  b.detach() if b is not None else None, slope)
+
+
 def act_maxmean_pool(Y, slope):
     """[max_i z | mean_i z] over dim 1 of z = leaky_relu(Y, slope) (slope 0: ReLU) for Y [B,N,C], C % 4 == 0 -> [B,2C]."""
     _check(Y, "Y")

@@ -168,6 +168,15 @@ int pc3d_gemm_nt_gather_f32(const float* P, int64_t ldp, const float* Bc, const 
 int pc3d_group_act_bwd_mask_f32(const float* gH, const uint8_t* mask, const int32_t* idx, int B, int NA, int S, int K, int C,
                                 float slope, float* gP, float* gBc, void* stream);
 
+/* Backward of  [max_n | mean_n] LeakyReLU(Y[b,n,:], slope)  followed straight by the backward of the layer that produced Y
+ * (model/dgcnn.py:317-320 after conv5, model/curvenet.py:64-67 after conv0), in ONE GEMM: dX = dY W with the rows of dY
+ * generated on load from the pre-activation Y [B*Npts, K] (row stride ldy_in), the upstream gradient g [B, 2K] (max part,
+ * then mean part) and the arg-max rows arg [B, K] of pc3d_act_pool_f32 — pc3d_act_pool_bwd_f32 + pc3d_gemm_nt_f32 without
+ * the [B*Npts, K] gradient tensor. W [N, K] row-major (the producing layer's weight TRANSPOSED, as for any backward on
+ * pc3d_gemm_nt_f32); dX [B*Npts, N] with row stride ldx_out. K % 4 == 0. */
+int pc3d_gemm_nt_poolbwd_f32(const float* Y, int64_t ldy_in, const float* g, const int32_t* arg, int B, int Npts,
+                             float slope_pool, const float* W, int N, int K, float* dX, int64_t ldx_out, void* stream);
+
 /* Row reductions of a [B,N] f32 matrix into out[B].
  *   op:  0 = mean, 1 = max, 2 = sum        pre: 0 = identity, 1 = sqrt(max(x,0)) applied per element first
  * mean/max of squared distances = ChamferDistance/HausdorffDistance (distance.py:44-49,64-69);

@@ -169,3 +169,28 @@ def test_knn_feat_nan_rows_are_never_neighbours(ops, dev, C):
     remap = torch.full((N,), -1, dtype=torch.long); remap[ok0] = torch.arange(int(ok0.sum()))
     picked = torch.gather(D, 1, remap[idx[0][ok0].long()])
     torch.testing.assert_close(picked, torch.sort(D, dim=1)[0][:, :K], rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("B,N,K,C,slope", [(2, 384, 64, 128, 0.2), (3, 1024, 512, 1024, 0.2), (2, 128, 40, 36, 0.0),
+                                           (1, 77, 40, 36, 0.0)])     # the last one: two-operator fallback (N % 128 != 0)
+def test_linear_act_maxmean_pool_backward_in_one_gemm(ops, dev, B, N, K, C, slope):
+    """conv + LeakyReLU + [max | mean] pooling with the pooling's backward generated inside the layer's backward GEMM
+    (pc3d_gemm_nt_poolbwd_f32) against the two-operator form and a float64 torch formulation (model/dgcnn.py:317-320)."""
+    g = torch.Generator().manual_seed(N + C)
+    x = torch.randn(B, N, K, generator=g).to(dev)
+    w, b = (torch.randn(C, K, generator=g) / K ** 0.5).to(dev), torch.randn(C, generator=g).to(dev)
+    up = torch.randn(B, 2 * C, generator=g).to(dev)
+    xa = x.clone().requires_grad_()
+    out = ops.linear_act_maxmean_pool(xa, w, b, slope)
+    (out * up).sum().backward()
+    xb = x.clone().requires_grad_()
+    ref = ops.act_maxmean_pool(ops.linear_act(xb, w, b), slope)
+    (ref * up).sum().backward()
+    assert torch.equal(out, ref)
+    torch.testing.assert_close(xa.grad, xb.grad, rtol=1e-4, atol=1e-5)
+    xd = x.double().requires_grad_()
+    z = torch.nn.functional.leaky_relu(xd @ w.double().t() + b.double(), slope)
+    r64 = torch.cat([z.max(dim=1)[0], z.mean(dim=1)], dim=1)
+    (r64 * up.double()).sum().backward()
+    torch.testing.assert_close(out.double(), r64.detach(), rtol=1e-5, atol=1e-5)
+    assert float((xa.grad.double() - xd.grad).norm() / xd.grad.norm()) < 1e-4
