@@ -37,13 +37,14 @@ struct KnnFeatArgs {
 // Register diet on purpose (~80 VGPRs -> 4+ waves per SIMD): the insertions are chains of dependent VALU/SALU
 // hops, and only other resident waves hide them. So the A operand (the 32 query rows) sits in LDS, the B operand is
 // streamed from global memory a few float4 ahead, and nothing but the accumulator tile and the lists stays live.
-// NT = C / 8 when it is known at compile time (8: C = 64), 0 = any C. With a run-time trip count the compiler drains the
+// NT = C / 8 when it is known at compile time (8: C = 64, 16: C = 128), 0 = any C. With a run-time trip count the compiler drains the
 // load queue (s_waitcnt vmcnt(0)) inside the product loop, so the "4 float4 ahead" are in flight for one MFMA group at
 // most. With NT static the loop is straight-line code: all 8 float4 of a row slice in flight with graded waits, and the
 // 8 of the NEXT block are requested before this block's strip write and scan (133 -> 129 us at B=32, N=1024, C=64, K=20;
 // products + strip alone 61 -> 57 us against 31 us of matrix-pipe work: the rest is the strip write's VALU work and the
-// two barriers per block, which four lock-stepped workgroups per CU do not hide). C = 128 stays on the run-time form:
-// static, it needs 136 (4 ahead) or 152 (8 ahead) VGPRs = 3 waves per SIMD, and took 195 us against 171.
+// two barriers per block, which four lock-stepped workgroups per CU do not hide). C = 128 (NT = 16) is static too, with 4
+// float4 in flight and WITHOUT the cross-block request (the operand would stay live through the scan: 136 or, 8 ahead,
+// 152 VGPRs = 3 waves per SIMD, 195 us): 154 -> 150 us.
 constexpr int KF_PF = 4;              // float4 of the B operand in flight per lane (run-time C)
 constexpr int KF_PFS = 8;             // ... with a static C
 
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(KF_T) void knn_feat_kernel(KnnFeatArgs a) {
   for (int u = 0; u < KF_QW; ++u) lk[u] = kKnnInfKey, li[u] = 0x7fffffff, thr[u] = kKnnInfKey;
 
   const int nblk = (a.N + KF_BLK - 1) / KF_BLK;
-  constexpr int PF = NT ? KF_PFS : KF_PF;
+  constexpr int PF = NT == 8 ? KF_PFS : KF_PF;
   float4 bv[PF];            // B operand in flight, carried across blocks
   const float* rp_next;
   auto first_rows = [&](int blk) {
@@ -95,6 +96,7 @@ __global__ __launch_bounds__(KF_T) void knn_feat_kernel(KnnFeatArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[e] = 0.f;
       float rn = 0.f;
+      if (NT == 16 && blk > 0) first_rows(blk);
       const float* rp = rp_next;               // this block's row (its first PF float4 are already in flight)
       auto step = [&](const float4 v, int t) {
         const float4 q = *reinterpret_cast<const float4*>(qs + r * ldq + 8 * t + 4 * h);
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(KF_T) void knn_feat_kernel(KnnFeatArgs a) {
           }
         }
       }
-      if (blk + 1 < nblk) first_rows(blk + 1);
+      if (NT != 16 && blk + 1 < nblk) first_rows(blk + 1);   // (C = 128: the operand would stay live through the scan: 136 VGPRs)
       rn += __shfl_xor(rn, 32, 64);            // |r_j|^2 for column j = r
       // model/dgcnn.py:195-197 ranks the references of a query by 2 q.r - |q|^2 - |r|^2, largest first. |q|^2 is the
       // same for every candidate of a query, so the key is that of |r|^2 - 2 q.r, smallest first (never -0: x - x is +0;
@@ -444,7 +446,8 @@ extern "C" int pc3d_knn_feat_f32(const float* x, int B, int N, int C, int K, int
   KnnFeatArgs a{x, N, C, K, idx};
   const size_t lds = (size_t)(KF_Q * KF_LD + KF_Q * (C + 4)) * sizeof(float);   // 25.6 KiB (C=64) / 33.8 KiB (C=128)
   auto* kern = C == 64 ? (K >= 2 ? knn_feat_kernel<8, true> : knn_feat_kernel<8, false>)
-                       : (K >= 2 ? knn_feat_kernel<0, true> : knn_feat_kernel<0, false>);
+             : C == 128 ? (K >= 2 ? knn_feat_kernel<16, true> : knn_feat_kernel<16, false>)
+                        : (K >= 2 ? knn_feat_kernel<0, true> : knn_feat_kernel<0, false>);
   hipLaunchKernelGGL(kern, dim3(cdiv(N, KF_Q), B), dim3(KF_T), lds, as_stream(stream), a);
   PC3D_LAUNCH_CHECK("pc3d_knn_feat_f32");
   return PC3D_OK;
