@@ -126,7 +126,11 @@ def _forward_step(net, pc_ori, input_curr_iter, normal_ori, ori_kappa, target, s
         nn_ao = knn_points(adv_t, ori_t, K=1)
         d_oa = None if cfg.is_cd_single_side else knn_points(ori_t, adv_t, K=1).dists.squeeze(-1)
         if cfg.curv_loss_weight != 0:
-            adv_kappa, normal_curr_iter = _get_kappa_adv(input_curr_iter, pc_ori, normal_ori, cfg.curv_loss_knn, nn_ao)
+            # DGCNN and CurveNet build the k = 20 graph of this very cloud in their forward: its first curv_loss_knn + 1
+            # columns ARE the search the curvature proxy needs (same kernel, same tie rule)
+            hint = _graphed.input_knn(net, input_curr_iter, cfg.curv_loss_knn + 1) if getattr(cfg, "share_victim_knn", True) else None
+            adv_kappa, normal_curr_iter = _get_kappa_adv(input_curr_iter, pc_ori, normal_ori, cfg.curv_loss_knn, nn_ao,
+                                                         knn_idx=hint)
         else:
             adv_kappa, normal_curr_iter = None, torch.zeros(b, 3, n, device=dev)
         terms = ops.geoa3_terms(nn_ao.dists.squeeze(-1), d_oa, adv_kappa, ori_kappa, nn_ao.idx.squeeze(-1),

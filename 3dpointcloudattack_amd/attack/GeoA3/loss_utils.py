@@ -61,14 +61,16 @@ def _get_kappa_ori(pc, normal, k=2):
     return _kappa(pc, normal, k)
 
 
-def _get_kappa_adv(adv_pc, ori_pc, ori_normal, k=2, nn_ao=None):
-    """:72-90 — normals of the nearest ori point, curvature proxy from the adv cloud's own k-NN."""
+def _get_kappa_adv(adv_pc, ori_pc, ori_normal, k=2, nn_ao=None, knn_idx=None):
+    """:72-90 — normals of the nearest ori point, curvature proxy from the adv cloud's own k-NN. knn_idx: int32 [B,N,k+1]
+    neighbour lists of adv_pc (self first) when the caller already has them (the victim's own input graph,
+    graphed.input_knn), else they are searched here."""
     intra_KNN = _nn(adv_pc, ori_pc, nn_ao)
     if adv_pc.is_cuda and adv_pc.dtype == torch.float32 and ori_normal.dtype == torch.float32 and not ori_normal.requires_grad:
         # one neighbour search + one launch: the normal gather happens inside the curvature kernel (pc3d_kappa_gather_f32)
         from ... import ops
         pd = adv_pc.detach()
-        idx = ops.knn_raw(pd, pd, k + 1, q_cf=True, r_cf=True)[1]
+        idx = knn_idx if knn_idx is not None else ops.knn_raw(pd, pd, k + 1, q_cf=True, r_cf=True)[1]
         return ops.kappa_gather(adv_pc, ori_normal, intra_KNN.idx.squeeze(-1).contiguous(), idx)
     normal = knn_gather(ori_normal.permute(0, 2, 1).contiguous(), intra_KNN.idx).permute(0, 3, 1, 2).squeeze(3).contiguous()
     return _kappa(adv_pc, normal, k), normal

@@ -84,6 +84,24 @@ class _OwnGrad(torch.autograd.Function):
         return g.clone()
 
 
+def note_input_knn(model, x, idx):
+    """Called by a victim's forward that has built a neighbour graph of its INPUT cloud x [B,3,N]: idx int32 [B,N,K], the K
+    nearest points of every point in ascending distance, itself first. An attack that needs the same graph with fewer
+    columns (GeoA3's curvature term: 17 of DGCNN's / CurveNet's 20) takes it from here instead of searching again."""
+    object.__setattr__(model, "_input_knn", (x.data_ptr(), x._version, tuple(x.shape), idx))
+
+
+def input_knn(net, x, k1):
+    """idx[:, :, :k1] (contiguous int32) of the neighbour graph `net` built for exactly this x in its last forward, or None."""
+    rec = net.__dict__.get("_input_knn") if isinstance(net, nn.Module) else None
+    if rec is None or rec[3] is None or rec[0] != x.data_ptr() or rec[1] != x._version or rec[2] != tuple(x.shape):
+        return None
+    idx = rec[3]
+    if idx.dim() != 3 or idx.shape[0] != x.shape[0] or idx.shape[1] != x.shape[2] or idx.shape[2] < k1 or idx.dtype != torch.int32:
+        return None
+    return idx[:, :, :k1].contiguous()
+
+
 class _Slot:
     def __init__(self, fn):
         self.fn = fn
@@ -215,6 +233,8 @@ class GraphedVictim(nn.Module):
                 return static_out
         slot = _Slot(g)
         slot.where, slot.is_seq = where, is_seq
+        rec = model.__dict__.get("_input_knn")           # the capture pass's neighbour graph: static memory of this capture,
+        slot.input_knn = rec[3] if rec else None         # rewritten by every replay (see note_input_knn)
         # The graphs hold raw pointers to every tensor the forward read, including the victims' folded-weight caches
         # (created lazily, re-folded when weights change): keep those alive with the capture.
         slot.keepalive = _cached_tensors(model)
@@ -225,7 +245,9 @@ class GraphedVictim(nn.Module):
         model = self.model
         if (not torch.is_tensor(x) or not x.is_cuda or model.training or not getattr(model, "deterministic_forward", False)
                 or torch.cuda.is_current_stream_capturing()):
-            return model(x)
+            out = model(x)
+            object.__setattr__(self, "_input_knn", model.__dict__.get("_input_knn"))
+            return out
         with_grad = torch.is_grad_enabled() and x.requires_grad
         key = (tuple(x.shape), x.dtype, x.device, with_grad, self._weights_key())
         slots = self._slots.get(key)
@@ -241,7 +263,9 @@ class GraphedVictim(nn.Module):
             slots.append(slot)
         if slot is None:
             self.stats["eager"] += 1         # every replica still waits for its backward: do not touch their memory
-            return model(x)
+            out = model(x)
+            object.__setattr__(self, "_input_knn", model.__dict__.get("_input_knn"))
+            return out
         self.stats["replayed"] += 1
         hook = getattr(model, "consume_forward_rng", None)
         if hook is not None:
@@ -254,6 +278,7 @@ class GraphedVictim(nn.Module):
             outs = _Guard.apply(slot, slot.ticket, *outs)
         else:
             outs = tuple(o.clone() for o in outs)
+        object.__setattr__(self, "_input_knn", (x.data_ptr(), x._version, tuple(x.shape), slot.input_knn))
         res = tuple(w[1] if isinstance(w, tuple) else outs[w] for w in slot.where)
         return res if slot.is_seq else res[0]
 

@@ -3,6 +3,7 @@ logits three times like the reference)."""
 import torch
 import torch.nn as nn
 
+from .. import graphed as _graphed
 from .. import ops
 from .. import streams as _streams
 from .curvenet_util import CIC, LPFA, folded_pw, hold_rng_position, pw_cl
@@ -94,6 +95,7 @@ class CurveNet(_FrozenFusedMixin, nn.Module):
             else:
                 levels = self._geometry(pos.detach())
         feats = self.lpfa(None, pos, None, cl=True)
+        _graphed.note_input_knn(self, xyz, self.lpfa.__dict__.get("_last_idx"))   # the input cloud's graph: attacks may reuse it
         for blk, geo in zip(blocks, levels):
             pos, feats = blk(pos, feats, cl=True, geo=geo)
         if self.geometry_stream:

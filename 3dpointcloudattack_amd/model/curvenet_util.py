@@ -223,6 +223,10 @@ class LPFA(nn.Module):
     def _forward_cl(self, x, pts, idx32):
         if idx32 is None:
             idx32 = ops.knn_raw(pts.detach(), pts.detach(), self.k)[1]          # the k nearest, self first
+            if self.initial:
+                object.__setattr__(self, "_last_idx", idx32)                    # (CurveNet.forward publishes it)
+        elif self.initial:
+            object.__setattr__(self, "_last_idx", None)
         if not self._kernel_form(0 if x is None else x.shape[2]):
             return _cl(self.forward(None if x is None else _cf(x), _cf(pts), idx32.long()))
         return self._initial_edge_max(pts, idx32) if self.initial else self._edge_act_mean(x, pts, idx32)

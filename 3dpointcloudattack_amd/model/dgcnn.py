@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import graphed as _graphed
 from .. import ops
 from .pointnet import _FrozenFusedMixin, _fold_bn, _plain
 
@@ -97,6 +98,8 @@ class DGCNN(_FrozenFusedMixin, nn.Module):
             with torch.no_grad():                           # graph indices are constants for autograd (topk indices)
                 fd = f.detach()
                 idx = ops.knn_raw(fd, fd, self.k)[1] if li == 0 else ops.knn_feat(fd, self.k)
+                if li == 0:
+                    _graphed.note_input_knn(self, x, idx)       # the graph of the INPUT cloud: attacks may reuse it
             PQ = ops.linear_act(f, UV, tb)                  # [U x | V x + t] in one fp32-MFMA launch
             f = ops.edge_max(PQ, idx, 0.2)                  # leaky(max_j P_j + Q_i) == max_j leaky(bn(conv(e_ij)))
             feats.append(f)
