@@ -298,14 +298,14 @@ __global__ __launch_bounds__(256) void edge_max_kernel(EdgeMaxArgs a, int lpp) {
 }
 
 // backward: one thread per (b, i, c): dQ written, dP scattered with float atomics into the zero-filled P half
-__global__ __launch_bounds__(256) void edge_max_bwd_kernel(const float* g, const float* out, const int32_t* arg, int N,
-                                                           int C, float slope, float* gPQ) {
+__global__ __launch_bounds__(256) void edge_max_bwd_kernel(const float* g, int64_t ldg, const float* out, const int32_t* arg,
+                                                           int N, int C, float slope, float* gPQ) {
   const int b = blockIdx.y;
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= (int64_t)N * C) return;
   const int i = (int)(e / C), c = (int)(e - (int64_t)i * C);
   const int64_t o = (int64_t)b * N * C + e;
-  const float gp = g[o] * (out[o] > 0.f ? 1.f : slope);
+  const float gp = g[((int64_t)b * N + i) * ldg + c] * (out[o] > 0.f ? 1.f : slope);
   float* base = gPQ + (int64_t)b * N * 2 * C;
   base[(int64_t)i * 2 * C + C + c] = gp;
   atomicAdd(base + (int64_t)arg[o] * 2 * C + c, gp);
@@ -316,7 +316,8 @@ __global__ __launch_bounds__(256) void edge_max_bwd_kernel(const float* g, const
 // Each lane's global atomic above lands in a different row (the arg-max neighbour differs per channel), i.e. 64
 // separate L2 transactions per wave instruction: 130 us per call on average in DGCNN's four layers at B=32, N=1024.
 template <int CH>
-__global__ __launch_bounds__(256) void edge_max_bwd_lds_kernel(const float* __restrict__ g, const float* __restrict__ out,
+__global__ __launch_bounds__(256) void edge_max_bwd_lds_kernel(const float* __restrict__ g, int64_t ldg,
+                                                               const float* __restrict__ out,
                                                                const int32_t* __restrict__ arg, int N, int C, float slope,
                                                                float* __restrict__ gPQ) {
   extern __shared__ float emb_acc[];   // [N][CH+1]
@@ -331,7 +332,8 @@ __global__ __launch_bounds__(256) void edge_max_bwd_lds_kernel(const float* __re
     int av[CH];
 #pragma unroll
     for (int q = 0; q < CH; q += 4) {
-      const float4 a = *reinterpret_cast<const float4*>(g + o + q), w = *reinterpret_cast<const float4*>(out + o + q);
+      const float4 a = *reinterpret_cast<const float4*>(g + ((int64_t)b * N + i) * ldg + c0 + q);
+      const float4 w = *reinterpret_cast<const float4*>(out + o + q);
       const int4 r = *reinterpret_cast<const int4*>(arg + o + q);
       gv[q] = a.x, gv[q + 1] = a.y, gv[q + 2] = a.z, gv[q + 3] = a.w;
       ov[q] = w.x, ov[q + 1] = w.y, ov[q + 2] = w.z, ov[q + 3] = w.w;
@@ -521,23 +523,23 @@ extern "C" int pc3d_edge_max_f32(const float* PQ, const int32_t* idx, int B, int
   return PC3D_OK;
 }
 
-extern "C" int pc3d_edge_max_bwd_f32(const float* g, const float* out, const int32_t* arg, int B, int N, int C,
+extern "C" int pc3d_edge_max_bwd_f32(const float* g, int64_t ldg, const float* out, const int32_t* arg, int B, int N, int C,
                                      float slope, float* gPQ, void* stream) {
-  PC3D_REQUIRE(B >= 0 && N >= 1 && C >= 1, "pc3d_edge_max_bwd_f32: bad sizes");
+  PC3D_REQUIRE(B >= 0 && N >= 1 && C >= 1 && ldg >= C, "pc3d_edge_max_bwd_f32: bad sizes (row stride of g smaller than C)");
   PC3D_REQUIRE(B <= 65535, "pc3d_edge_max_bwd_f32: B=%d exceeds grid.y limit", B);
   if (B == 0) return PC3D_OK;
   PC3D_REQUIRE(g && out && arg && gPQ, "pc3d_edge_max_bwd_f32: null pointer");
   hipStream_t st = as_stream(stream);
   const bool al = ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(arg) |
-                    reinterpret_cast<uintptr_t>(gPQ)) & 15) == 0;
+                    reinterpret_cast<uintptr_t>(gPQ)) & 15) == 0 && ldg % 4 == 0;
   if (al && C % 8 == 0 && (size_t)N * 9 * sizeof(float) <= 64 * 1024) {
-    hipLaunchKernelGGL(edge_max_bwd_lds_kernel<8>, dim3(C / 8, B), dim3(256), (size_t)N * 9 * sizeof(float), st, g, out,
+    hipLaunchKernelGGL(edge_max_bwd_lds_kernel<8>, dim3(C / 8, B), dim3(256), (size_t)N * 9 * sizeof(float), st, g, ldg, out,
                        arg, N, C, slope, gPQ);
     PC3D_LAUNCH_CHECK("pc3d_edge_max_bwd_f32");
     return PC3D_OK;
   }
   if (al && C % 4 == 0 && (size_t)N * 5 * sizeof(float) <= 64 * 1024) {
-    hipLaunchKernelGGL(edge_max_bwd_lds_kernel<4>, dim3(C / 4, B), dim3(256), (size_t)N * 5 * sizeof(float), st, g, out,
+    hipLaunchKernelGGL(edge_max_bwd_lds_kernel<4>, dim3(C / 4, B), dim3(256), (size_t)N * 5 * sizeof(float), st, g, ldg, out,
                        arg, N, C, slope, gPQ);
     PC3D_LAUNCH_CHECK("pc3d_edge_max_bwd_f32");
     return PC3D_OK;
@@ -547,7 +549,7 @@ extern "C" int pc3d_edge_max_bwd_f32(const float* g, const float* out, const int
     set_error("pc3d_edge_max_bwd_f32: zero fill failed: %s", hipGetErrorString(e));
     return (int)e;
   }
-  hipLaunchKernelGGL(edge_max_bwd_kernel, dim3((unsigned)(((int64_t)N * C + 255) / 256), B), dim3(256), 0, st, g, out,
+  hipLaunchKernelGGL(edge_max_bwd_kernel, dim3((unsigned)(((int64_t)N * C + 255) / 256), B), dim3(256), 0, st, g, ldg, out,
                      arg, N, C, slope, gPQ);
   PC3D_LAUNCH_CHECK("pc3d_edge_max_bwd_f32");
   return PC3D_OK;

@@ -802,17 +802,21 @@ def F_leaky(y, slope):
     return torch.nn.functional.leaky_relu_(y, slope)
 
 
-_WT_CACHE = {}      # (data_ptr, version, shape) -> (weak owner check, W^T): the backward's operand; weights are frozen
+_WT_CACHE = {}      # (data_ptr, version, shape) -> (w, W^T): the backward's operand; weights are frozen
 
 
 def _w_transposed(w):
+    """W^T (contiguous) of a frozen weight, computed once per (storage address, version, shape). The entry keeps a
+    reference to `w` — an alias is enough — so the storage cannot be freed and its address reused while the entry lives;
+    in-place updates bump the version, re-folded / moved weights have another address. (Until late round 2 the entry
+    held a WEAK reference to the tensor OBJECT; callers pass `w.detach()`, a new object per call, so every backward of
+    every point-wise layer re-transposed its weight: 7 copies per DGCNN backward, ~60 per CurveNet backward.)"""
     key = (w.data_ptr(), w._version, tuple(w.shape))
     hit = _WT_CACHE.get(key)
-    if hit is None or hit[0]() is None:
-        import weakref
+    if hit is None:
         if len(_WT_CACHE) > 512:
             _WT_CACHE.clear()
-        hit = (weakref.ref(w), w.t().contiguous())
+        hit = (w, w.t().contiguous())
         _WT_CACHE[key] = hit
     return hit[1]
 
@@ -1129,11 +1133,13 @@ class _EdgeMaxFn(torch.autograd.Function):
     def backward(ctx, g):
         out, arg = ctx.saved_tensors
         B, N, C = out.shape
-        g = g.contiguous()
+        # a column slice of a wider gradient (torch.cat's backward) is read in place through its row stride
+        if not (g.stride(2) == 1 and g.stride(0) == N * g.stride(1) and g.stride(1) >= C):
+            g = g.contiguous()
         gPQ = torch.empty((B, N, 2 * C), dtype=torch.float32, device=g.device)
         with torch.cuda.device(g.device):
-            _lib.call("pc3d_edge_max_bwd_f32", g.data_ptr(), out.data_ptr(), arg.data_ptr(), B, N, C, ctx.slope,
-                      gPQ.data_ptr(), _stream())
+            _lib.call("pc3d_edge_max_bwd_f32", g.data_ptr(), g.stride(1), out.data_ptr(), arg.data_ptr(), B, N, C,
+                      ctx.slope, gPQ.data_ptr(), _stream())
         return gPQ, None, None
 
 

@@ -437,8 +437,10 @@ int pc3d_edge_max_f32(const float* PQ, const int32_t* idx, int B, int N, int C, 
 int pc3d_act_pool_f32(const float* Y, int B, int N, int C, float slope, float* out, int32_t* arg, void* stream);
 int pc3d_act_pool_bwd_f32(const float* Y, const float* gout, const int32_t* arg, int B, int N, int C, float slope,
                           float* gY, void* stream);
-int pc3d_edge_max_bwd_f32(const float* g, const float* out, const int32_t* arg, int B, int N, int C, float slope,
-                          float* gPQ, void* stream);
+/* g [B,N,C] with row stride ldg >= C floats: the slice of a wider gradient (the backward of DGCNN's torch.cat over the four
+ * EdgeConv outputs hands over [B,N,512] column slices) is read in place. */
+int pc3d_edge_max_bwd_f32(const float* g, int64_t ldg, const float* out, const int32_t* arg, int B, int N, int C,
+                          float slope, float* gPQ, void* stream);
 
 /* K16  guided curve walk of CurveNet (model/walk.py:74-153 `Walk.forward`) in one launch per direction: one
  * wavefront per curve, lane j scores neighbour j. feats [B,N,C] (C in {8,16,32,64}), adj [B,N,k] (k <= 64, self

@@ -131,6 +131,13 @@ def test_edge_max_fwd_bwd_vs_torch(ops, dev, C, N):
     torch.testing.assert_close(out, ref.detach())
     (ref * w).sum().backward()
     torch.testing.assert_close(g1, PQ.grad, rtol=1e-5, atol=1e-6)
+    # the upstream gradient as a column slice of a wider tensor (what torch.cat's backward hands over): read in place
+    # through its row stride (C % 4 == 0) or copied (otherwise) — same result either way
+    PQ.grad = None
+    wide = torch.zeros(B, N, C + 24, device=dev)
+    wide[..., 8:8 + C] = w
+    (ops.edge_max(PQ, idx, 0.2) * 1.0).backward(wide[..., 8:8 + C])
+    torch.testing.assert_close(PQ.grad, g1, rtol=1e-5, atol=1e-6)
 
 
 @pytest.mark.parametrize("B,N,C,slope", [(2, 100, 64, 0.2), (3, 1024, 1024, 0.2), (1, 3, 8, 0.0), (2, 257, 132, 0.0)])

@@ -13,7 +13,7 @@ arg = torch.randint(0, N, (B, N, C), generator=gen).to(dev).to(torch.int32)
 g = torch.randn(B, N, C, generator=gen).to(dev)
 gPQ = torch.full((B, N, 2 * C), 7.0, device=dev)
 def run(stream):
-    _lib.call("pc3d_edge_max_bwd_f32", g.data_ptr(), out.data_ptr(), arg.data_ptr(), B, N, C, 0.2, gPQ.data_ptr(), stream)
+    _lib.call("pc3d_edge_max_bwd_f32", g.data_ptr(), C, out.data_ptr(), arg.data_ptr(), B, N, C, 0.2, gPQ.data_ptr(), stream)
 run(torch.cuda.current_stream().cuda_stream); torch.cuda.synchronize()
 ref = gPQ.clone()
 graph = torch.cuda.CUDAGraph()
