@@ -6,6 +6,17 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+def _kernel_loss(logits, targets, kind, kappa=0.):
+    """The functor on the HIP kernel (pc3d_cls_loss_f32, raw mode: the loss on `logits` as given), or None when the
+    inputs are not what it takes. One launch forward, one backward, instead of ~10 + ~10 ATen launches on [B,k]."""
+    if not (torch.is_tensor(logits) and logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 2
+            and logits.stride(1) == 1 and 2 <= logits.shape[1] <= 64 and torch.is_tensor(targets) and targets.is_cuda
+            and targets.numel() == logits.shape[0]):
+        return None
+    from .... import ops
+    return ops.adv_loss_raw(logits, targets.reshape(-1).long(), kind, kappa).mean()
+
+
 def _real_other(logits, targets):
     B, K = logits.shape
     if len(targets.shape) == 1:
@@ -25,6 +36,9 @@ class LogitsAdvLoss(nn.Module):
         self.kappa = kappa
 
     def forward(self, logits, targets):
+        fast = _kernel_loss(logits, targets, "logits", self.kappa)
+        if fast is not None:
+            return fast
         real, other = _real_other(logits, targets)
         return torch.clamp(other - real + self.kappa, min=0.).mean()
 
@@ -36,6 +50,9 @@ class CrossEntropyAdvLoss(nn.Module):
         super(CrossEntropyAdvLoss, self).__init__()
 
     def forward(self, logits, targets):
+        fast = _kernel_loss(logits, targets, "cross_entropy")
+        if fast is not None:
+            return fast
         return F.nll_loss(logits, targets)
 
 
@@ -47,5 +64,8 @@ class UntargetedLogitsAdvLoss(nn.Module):
         self.kappa = kappa
 
     def forward(self, logits, targets):
+        fast = _kernel_loss(logits, targets, "untargeted_logits", self.kappa)
+        if fast is not None:
+            return fast
         real, other = _real_other(logits, targets)
         return torch.clamp(real - other + self.kappa, min=0.).mean()

@@ -302,6 +302,8 @@ __global__ __launch_bounds__(64) void cls_loss_kernel(const float* logits, int l
                                                       int64_t* pred, float* loss, float* g_logits) {
   const int b = blockIdx.x, lane = threadIdx.x;
   const float* z = logits + (int64_t)b * ld;
+  const bool raw = (kind & 4) != 0;     // the loss is taken on z itself (what the reference's functors do with whatever the
+  kind &= 3;                            // victim returns: log-probabilities or raw logits), not on log_softmax(z)
   float m = -__builtin_inff();
   int am = 0;
   for (int j = lane; j < ncls; j += 64) {
@@ -317,7 +319,7 @@ __global__ __launch_bounds__(64) void cls_loss_kernel(const float* logits, int l
   float se = 0.f;
   for (int j = lane; j < ncls; j += 64) se += expf(z[j] - m);
   se = wave_sum(se);
-  const float lse = m + logf(se);
+  const float lse = raw ? 0.f : m + logf(se);
   const int t = (int)target[b];
   float other = -__builtin_inff();
   int ao = 0;
@@ -356,7 +358,7 @@ __global__ __launch_bounds__(64) void cls_loss_kernel(const float* logits, int l
     const float gsum = gt + ((kind == 2) ? 0.f : go);
     for (int j = lane; j < ncls; j += 64) {
       float g = (j == t ? gt : 0.f) + ((kind != 2 && j == ao) ? go : 0.f);
-      g -= expf(z[j] - lse) * gsum;
+      if (!raw) g -= expf(z[j] - lse) * gsum;
       g_logits[(int64_t)b * ncls + j] = g * scale;
     }
   }
@@ -528,7 +530,7 @@ extern "C" int pc3d_cls_loss_f32(const float* logits, int ld, int B, int ncls, c
                                  float kappa, float scale, float* logp, int64_t* pred, float* loss,
                                  float* g_logits, void* stream) {
   PC3D_REQUIRE(B >= 0 && ncls >= 2 && ld >= ncls, "pc3d_cls_loss_f32: bad sizes B=%d ncls=%d ld=%d", B, ncls, ld);
-  PC3D_REQUIRE(kind >= 0 && kind <= 2, "pc3d_cls_loss_f32: kind=%d not in {0,1,2}", kind);
+  PC3D_REQUIRE(kind >= 0 && kind <= 6 && (kind & 3) != 3, "pc3d_cls_loss_f32: kind=%d not in {0,1,2} (+4)", kind);
   if (B == 0) return PC3D_OK;
   PC3D_REQUIRE(logits && target, "pc3d_cls_loss_f32: null pointer");
   hipLaunchKernelGGL(cls_loss_kernel, dim3(B), dim3(64), 0, as_stream(stream), logits, ld, ncls, target, kind, kappa,

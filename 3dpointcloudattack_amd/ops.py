@@ -705,6 +705,28 @@ class _CrossEntropyFn(torch.autograd.Function):
         return g * gout[:, None], None, None
 
 
+class _AdvLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, kind, kappa):
+        _, _, loss, g = cls_loss(logits, target, kind, kappa, 1.0, want_grad=True)
+        ctx.save_for_backward(g)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        (g,) = ctx.saved_tensors
+        return g * gout[:, None], None, None, None
+
+
+def adv_loss_raw(logits, target, kind, kappa=0.0):
+    """Per-sample adversarial loss [B] of attack/CW/CW_utils/adv_utils.py on `logits` AS GIVEN (no log-softmax): kind
+    "untargeted_logits" / "logits" = clamp(+-(real - other) + kappa, 0), "cross_entropy" = -logits[target]; one launch
+    each way (LOSS_KINDS)."""
+    if logits.dim() != 2 or logits.stride(1) != 1:
+        raise ValueError("adv_loss_raw: logits must be [B,k] with unit column stride")
+    return _AdvLossFn.apply(logits, target, LOSS_KINDS[kind] + 4, float(kappa))
+
+
 def cross_entropy(logits, target, sign=1.0):
     """sign * CrossEntropyLoss(reduction='none')(logits, target) -> [B], one launch each way (pc3d_cls_loss_f32, kind 2)."""
     if logits.dim() != 2 or logits.stride(1) != 1:

@@ -270,7 +270,9 @@ int pc3d_linear_pre_f32(const float* parts, int P, int Jp, int J, const float* W
 /* log_softmax (model/pointnet.py:148) + argmax + adversarial loss on the log-probabilities and its gradient w.r.t.
  * the LOGITS, one launch. kind 0 = UntargetedLogitsAdvLoss, 1 = LogitsAdvLoss, 2 = CrossEntropyAdvLoss
  * (attack/CW/CW_utils/adv_utils.py:64-80, 17-33, 42-51); per-sample loss[b] (before the batch mean), pred[b],
- * logp [B,ncls], g_logits [B,ncls] = scale * dloss_b/dlogits (scale = 1/B reproduces .mean()). Outputs may be NULL. */
+ * logp [B,ncls], g_logits [B,ncls] = scale * dloss_b/dlogits (scale = 1/B reproduces .mean()). Outputs may be NULL.
+ * kind + 4: the loss is taken on `logits` AS GIVEN (no log-softmax) — what the reference's functors compute on whatever the
+ * victim returns, log-probabilities (PointNet, PointNet++, DGCNN) or raw logits (CurveNet); kind 6 is then nll_loss. */
 int pc3d_cls_loss_f32(const float* logits, int ld, int B, int ncls, const int64_t* target, int kind, float kappa,
                       float scale, float* logp, int64_t* pred, float* loss, float* g_logits, void* stream);
 

@@ -190,10 +190,22 @@ def test_cls_loss_kernel_matches_torch(ops, dev, kind):
     tgt = torch.randint(0, k, (B,), device=dev)
     fn = {"untargeted_logits": adv.UntargetedLogitsAdvLoss(2.0), "logits": adv.LogitsAdvLoss(2.0),
           "cross_entropy": adv.CrossEntropyAdvLoss()}[kind]
-    logp_ref = torch.log_softmax(z, dim=1)
-    fn(logp_ref, tgt).mean().backward()
+    # reference: the functors' torch formulation, which is what they run on CPU tensors (on the GPU they use the kernel)
+    zc = z.detach().cpu().requires_grad_()
+    logp_ref = torch.log_softmax(zc, dim=1)
+    fn(logp_ref, tgt.cpu()).mean().backward()
     logp, pred, loss, g = ops.cls_loss(z.detach(), tgt, kind, 2.0, scale=1.0 / B)
-    torch.testing.assert_close(logp, logp_ref.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(logp.cpu(), logp_ref.detach(), rtol=1e-5, atol=1e-6)
     assert torch.equal(pred, z.argmax(1))
-    torch.testing.assert_close(g, z.grad, rtol=1e-5, atol=1e-7)
-    torch.testing.assert_close(loss.mean(), fn(logp_ref.detach(), tgt), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(g.cpu(), zc.grad, rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(loss.mean().cpu(), fn(logp_ref.detach(), tgt.cpu()), rtol=1e-5, atol=1e-6)
+    # raw mode (the loss on the tensor as given — log-probabilities or raw logits), through the functor itself: GPU
+    # (kernel) against CPU (torch formulation), value and gradient, with a tie for the runner-up and [B,1] targets
+    raw = (torch.randn(B, k) * 3)
+    raw[0, 5] = raw[0, 9] = raw[0].max() + 1.0
+    rc, rg = raw.clone().requires_grad_(), raw.clone().to(dev).requires_grad_()
+    fn(rc, tgt.cpu().view(-1, 1) if kind != "cross_entropy" else tgt.cpu()).backward()
+    out = fn(rg, tgt.view(-1, 1) if kind != "cross_entropy" else tgt)
+    out.backward()
+    torch.testing.assert_close(out.cpu(), fn(raw, tgt.cpu().view(-1, 1) if kind != "cross_entropy" else tgt.cpu()), rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(rg.grad.cpu(), rc.grad, rtol=1e-6, atol=1e-8)
