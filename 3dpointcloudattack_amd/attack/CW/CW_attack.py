@@ -267,17 +267,27 @@ class CW:
         # record values (device side; reference :129-153)
         with torch.no_grad():
             cur = adv_data.detach()
-            dist_val = torch.sqrt(torch.sum((cur - ori_data) ** 2, dim=[1, 2]))  # [B]
-            succ = self._success(pred, label)
-            upd = succ & (dist_val < st["bestdist"])
-            st["bestdist"].copy_(torch.where(upd, dist_val, st["bestdist"]))
-            st["bestscore"].copy_(torch.where(upd, pred, st["bestscore"]))
-            upd_o = succ & (dist_val < st["o_bestdist"])
-            st["o_bestdist"].copy_(torch.where(upd_o, dist_val, st["o_bestdist"]))
-            st["o_bestscore"].copy_(torch.where(upd_o, pred, st["o_bestscore"]))
-            st["o_bestattack"].copy_(torch.where(upd_o[:, None, None], cur, st["o_bestattack"]))
-            st["input_val"].copy_(cur)     # the iterate the LAST pass started from (reference :133, :208-209)
-            st["pred"].copy_(pred)
+        if (cur.is_cuda and cur.dtype == torch.float32 and ori_data.dtype == torch.float32 and pred.dtype == torch.int64
+                and cur.dim() == 3 and cur.shape[1] == 3 and st["input_val"] is not None):
+            # the same bookkeeping as ONE launch (pc3d_cw_bookkeep_f32, as on the fused-victim path) instead of ~16
+            with torch.no_grad():
+                ops.cw_bookkeep(cur, ori_data, pred.contiguous(), label, self.attack_method == 'untarget', st["bestdist"],
+                                st["bestscore"], st["o_bestdist"], st["o_bestscore"], st["o_bestattack"],
+                                input_val=st["input_val"], dist_val=st["dist_val"])
+                st["pred"].copy_(pred)
+        else:
+            with torch.no_grad():
+                dist_val = torch.sqrt(torch.sum((cur - ori_data) ** 2, dim=[1, 2]))  # [B]
+                succ = self._success(pred, label)
+                upd = succ & (dist_val < st["bestdist"])
+                st["bestdist"].copy_(torch.where(upd, dist_val, st["bestdist"]))
+                st["bestscore"].copy_(torch.where(upd, pred, st["bestscore"]))
+                upd_o = succ & (dist_val < st["o_bestdist"])
+                st["o_bestdist"].copy_(torch.where(upd_o, dist_val, st["o_bestdist"]))
+                st["o_bestscore"].copy_(torch.where(upd_o, pred, st["o_bestscore"]))
+                st["o_bestattack"].copy_(torch.where(upd_o[:, None, None], cur, st["o_bestattack"]))
+                st["input_val"].copy_(cur)     # the iterate the LAST pass started from (reference :133, :208-209)
+                st["pred"].copy_(pred)
         # compute loss and backward
         dist_loss = self.dist_func(adv_data, ori_data, st["weights"]).mean()
         if gx_model is not None:
