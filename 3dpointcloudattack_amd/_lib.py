@@ -49,6 +49,9 @@ SIGNATURES = {
     "pc3d_group_act_bwd_mask_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P],
     "pc3d_gemm_nt_gather_f32": [_P, _L, _P, _P, _I, _I, _I, _I, _F, _P, _P, _I, _I, _I, _F, _P, _L, _P, _P],
     "pc3d_gemm_nt_poolbwd_f32": [_P, _L, _P, _P, _I, _I, _F, _P, _I, _I, _P, _L, _P],
+    "pc3d_group_reverse_list_len": [_I, _I],
+    "pc3d_group_reverse_i32": [_P, _I, _I, _I, _I, _P, _P, _P, _P],
+    "pc3d_group_act_bwd_rev_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P],
     "pc3d_geoa3_terms_f32": [_P] * 7 + [_I, _I, _I, _F, _F, _F, _P, _P, _P],
     "pc3d_geoa3_terms_bwd_f32": [_P] * 6 + [_I, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P],
     "pc3d_lpfa_fused_f32": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _P],
@@ -104,7 +107,8 @@ SIGNATURES = {
 }
 
 # entry points that do not return a status code
-RESTYPES = {"pc3d_nn_bidir_shared_ws_bytes": c_int64, "pc3d_curve_attn_bwd_ws_floats": c_int64}
+RESTYPES = {"pc3d_nn_bidir_shared_ws_bytes": c_int64, "pc3d_curve_attn_bwd_ws_floats": c_int64,
+            "pc3d_group_reverse_list_len": c_int64}
 
 _lib = None
 

@@ -513,6 +513,195 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// group_act backward WITHOUT float atomics: gather over a reverse index of the grouping.
+// The scatter above costs 270 us per set-abstraction level at SSG's sizes (B=64: 1.05 M rows of 64 / 0.5 M rows of 128
+// channels, one row-wide atomic per non-padded row): 12 % of the KNN-attack iteration. The grouping indices are known as
+// soon as the ball query has run, long before the backward — so the forward's geometry chain also builds, per cloud, the
+// list of rows that reference each point (a counting sort: two passes of integer atomics + a scan, ~30 us on the side
+// stream), and the backward becomes
+//   groups pass : per group, dBc = sum of the masked rows and `tail` = sum of the rows that repeat the group's first
+//                 index (the ball query's padding, 56-65 % of the entries) — sequential reads, no atomics;
+//   points pass : per point, the sum of the masked rows in its list plus the tails of the groups it leads — every dP
+//                 row is written exactly once (no zero fill).
+// List entry codes: s * K + j for row (s, j) of the cloud, S * K + s for the tail of group s.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void group_rev_count_kernel(const int* __restrict__ idx, int NA, int S, int K,
+                                                              int* __restrict__ cnt, int64_t total) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int j = (int)(e % K);
+  const int64_t bs = e / K;
+  const int b = (int)(bs / S);
+  const int i = idx[e], i0 = idx[e - j];
+  if ((unsigned)i >= (unsigned)NA) return;
+  if (j == 0) {
+    atomicAdd(cnt + (int64_t)b * NA + i, K > 1 ? 2 : 1);      // the row itself + the group's tail entry
+  } else if (i != i0) {
+    atomicAdd(cnt + (int64_t)b * NA + i, 1);
+  }
+}
+
+// exclusive scan of one cloud's counters -> off [NA + 1]; the counters are zeroed (they become the fill cursors)
+__global__ __launch_bounds__(256) void group_rev_scan_kernel(int* __restrict__ cnt, int NA, int* __restrict__ off) {
+  __shared__ int part[256];
+  const int b = blockIdx.x, t = threadIdx.x;
+  int* c = cnt + (int64_t)b * NA;
+  int* o = off + (int64_t)b * (NA + 1);
+  const int per = (NA + 255) / 256, lo = t * per, hi = min(lo + per, NA);
+  int s = 0;
+  for (int i = lo; i < hi; ++i) s += c[i];
+  part[t] = s;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {          // Hillis-Steele inclusive scan of the 256 partial sums
+    const int v = t >= d ? part[t - d] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int run = part[t] - s;                        // exclusive prefix of this thread's range
+  for (int i = lo; i < hi; ++i) {
+    const int v = c[i];
+    o[i] = run;
+    run += v;
+    c[i] = 0;
+  }
+  if (t == 255) o[NA] = part[255];
+}
+
+__global__ __launch_bounds__(256) void group_rev_fill_kernel(const int* __restrict__ idx, int NA, int S, int K,
+                                                             int* __restrict__ cur, const int* __restrict__ off,
+                                                             int* __restrict__ lst, int64_t L, int64_t total) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int j = (int)(e % K);
+  const int64_t bs = e / K;
+  const int b = (int)(bs / S), s = (int)(bs - (int64_t)b * S);
+  const int i = idx[e], i0 = idx[e - j];
+  if ((unsigned)i >= (unsigned)NA) return;
+  const int* o = off + (int64_t)b * (NA + 1);
+  int* l = lst + (int64_t)b * L;
+  if (j == 0) {
+    const int slot = atomicAdd(cur + (int64_t)b * NA + i, K > 1 ? 2 : 1);
+    l[o[i] + slot] = s * K;
+    if (K > 1) l[o[i] + slot + 1] = S * K + s;
+  } else if (i != i0) {
+    const int slot = atomicAdd(cur + (int64_t)b * NA + i, 1);
+    l[o[i] + slot] = s * K + j;
+  }
+}
+
+// groups pass: dBc and the padded-tail sums (the scatter kernel above minus its atomics). Q = channels per lane
+// (C <= 64 Q). A WAVE owns a group — no LDS, no barrier — and loads its rows EIGHT AT A TIME before any is used: with one
+// row per loop trip (as in the scatter kernel) every trip waits out a full memory latency, and a workgroup per group of 32
+// rows is 8 KB of work per workgroup; in that form the pass took as long as the scatter with its atomics (228 us), with
+// four rows in flight per wave 159 us.
+template <int Q>
+__global__ __launch_bounds__(256) void group_act_bwd_groups_kernel(const float* __restrict__ gH, const float* __restrict__ H,
+                                                                   const uint8_t* __restrict__ mask,
+                                                                   const int* __restrict__ idx, int S, int K, int C,
+                                                                   float slope, float* __restrict__ gBc,
+                                                                   float* __restrict__ tail_out) {
+  const int b = blockIdx.y, lane = threadIdx.x & 63;
+  const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (s >= S) return;
+  const int64_t g0 = ((int64_t)b * S + s) * K;
+  const int* id = idx + g0;
+  const int i0 = id[0];
+  float tot[Q], tail[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) tot[q] = 0.f, tail[q] = 0.f;
+  constexpr int U = Q == 1 ? 8 : 4;             // rows in flight (Q = 2 with 8: 140 us against 124 at SSG SA2)
+  for (int j0 = 0; j0 < K; j0 += U) {
+    float gv[U][Q];
+    bool pos[U][Q], rep[U], live[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j = j0 + u;
+      live[u] = j < K;
+      const int jj = live[u] ? j : j0;
+      rep[u] = jj > 0 && id[jj] == i0;          // wave-uniform
+      const float* g = gH + (g0 + jj) * C;
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        const int c = 64 * q + lane;
+        gv[u][q] = c < C ? g[c] : 0.f;
+        if (H) pos[u][q] = c < C && H[(g0 + jj) * C + c] > 0.f;
+        else pos[u][q] = c < C && ((mask[(g0 + jj) * (C >> 2) + (c >> 2)] >> (c & 3)) & 1) != 0;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!live[u]) continue;
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        const float v = pos[u][q] ? gv[u][q] : gv[u][q] * slope;
+        tot[q] += v;
+        if (rep[u]) tail[q] += v;
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const int c = 64 * q + lane;
+    if (c < C) {
+      const int64_t o = ((int64_t)b * S + s) * C + c;
+      gBc[o] = tot[q];
+      tail_out[o] = tail[q];
+    }
+  }
+}
+
+// points pass: a wave per point walks the point's list, four entries in flight
+template <int Q>
+__global__ __launch_bounds__(256) void group_act_bwd_points_kernel(const float* __restrict__ gH, const float* __restrict__ H,
+                                                                   const uint8_t* __restrict__ mask,
+                                                                   const float* __restrict__ tail, const int* __restrict__ off,
+                                                                   const int* __restrict__ lst, int64_t L, int NA, int S,
+                                                                   int K, int C, float slope, float* __restrict__ gP) {
+  const int b = blockIdx.y, lane = threadIdx.x & 63;
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= NA) return;
+  const int* o = off + (int64_t)b * (NA + 1);
+  const int* l = lst + (int64_t)b * L;
+  const int t0 = __builtin_amdgcn_readfirstlane(o[p]), t1 = __builtin_amdgcn_readfirstlane(o[p + 1]);
+  const int SK = S * K;
+  float acc[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) acc[q] = 0.f;
+  constexpr int U = 4;
+  for (int t = t0; t < t1; t += U) {
+    float gv[U][Q];
+    bool pos[U][Q];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool live = t + u < t1;
+      const int code = __builtin_amdgcn_readfirstlane(l[live ? t + u : t]);
+      const bool is_tail = code >= SK;
+      const int64_t row = (int64_t)b * SK + (is_tail ? 0 : code);
+      const float* src = is_tail ? tail + ((int64_t)b * S + (code - SK)) * C : gH + row * C;
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        const int c = 64 * q + lane;
+        gv[u][q] = (live && c < C) ? src[c] : 0.f;
+        if (is_tail) pos[u][q] = true;
+        else if (H) pos[u][q] = c < C && H[row * C + c] > 0.f;
+        else pos[u][q] = c < C && ((mask[row * (C >> 2) + (c >> 2)] >> (c & 3)) & 1) != 0;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int q = 0; q < Q; ++q) acc[q] += pos[u][q] ? gv[u][q] : gv[u][q] * slope;
+  }
+  float* dst = gP + ((int64_t)b * NA + p) * C;
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const int c = 64 * q + lane;
+    if (c < C) dst[c] = acc[q];
+  }
+}
+
 }  // namespace pc3d
 
 
@@ -651,6 +840,53 @@ extern "C" int pc3d_group_act_bwd_mask_f32(const float* gH, const uint8_t* mask,
   hipLaunchKernelGGL(group_act_bwd_kernel, dim3(S, B), dim3(256), (size_t)8 * C * sizeof(float), st, gH,
                      (const float*)nullptr, idx, NA, S, K, C, slope, gP, gBc, mask);
   PC3D_LAUNCH_CHECK("pc3d_group_act_bwd_mask_f32");
+  return PC3D_OK;
+}
+
+extern "C" int64_t pc3d_group_reverse_list_len(int S, int K) { return (int64_t)S * K + S; }
+
+extern "C" int pc3d_group_reverse_i32(const int32_t* idx, int B, int NA, int S, int K, int32_t* cnt, int32_t* off,
+                                      int32_t* lst, void* stream) {
+  PC3D_REQUIRE(B >= 0 && NA >= 1 && S >= 1 && K >= 1 && (int64_t)S * K + S <= 0x7fffffffLL,
+               "pc3d_group_reverse_i32: bad sizes B=%d NA=%d S=%d K=%d", B, NA, S, K);
+  if (B == 0) return PC3D_OK;
+  PC3D_REQUIRE(idx && cnt && off && lst, "pc3d_group_reverse_i32: null pointer");
+  hipStream_t st = as_stream(stream);
+  const int64_t total = (int64_t)B * S * K, L = (int64_t)S * K + S;
+  const int64_t nb = (total + 255) / 256;
+  PC3D_REQUIRE(nb <= 0x7fffffffLL, "pc3d_group_reverse_i32: problem too large for one launch");
+  if (hipError_t e = zero_async(reinterpret_cast<float*>(cnt), (size_t)B * NA, st); e != hipSuccess) {   // all-zero bits
+    set_error("pc3d_group_reverse_i32: zero fill failed: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  hipLaunchKernelGGL(group_rev_count_kernel, dim3((unsigned)nb), dim3(256), 0, st, idx, NA, S, K, cnt, total);
+  hipLaunchKernelGGL(group_rev_scan_kernel, dim3(B), dim3(256), 0, st, cnt, NA, off);
+  hipLaunchKernelGGL(group_rev_fill_kernel, dim3((unsigned)nb), dim3(256), 0, st, idx, NA, S, K, cnt, off, lst, L, total);
+  PC3D_LAUNCH_CHECK("pc3d_group_reverse_i32");
+  return PC3D_OK;
+}
+
+extern "C" int pc3d_group_act_bwd_rev_f32(const float* gH, const float* H, const uint8_t* mask, const int32_t* idx,
+                                          const int32_t* off, const int32_t* lst, int B, int NA, int S, int K, int C,
+                                          float slope, float* gP, float* gBc, float* tail, void* stream) {
+  PC3D_REQUIRE(B >= 0 && NA >= 1 && S >= 1 && K >= 1 && C >= 4 && C % 4 == 0 && C <= GAB_MAXC,
+               "pc3d_group_act_bwd_rev_f32: bad sizes B=%d NA=%d S=%d K=%d C=%d (C %% 4 == 0, C <= %d)", B, NA, S, K, C, GAB_MAXC);
+  PC3D_REQUIRE(B <= 65535, "pc3d_group_act_bwd_rev_f32: B=%d exceeds grid.y limit", B);
+  if (B == 0) return PC3D_OK;
+  PC3D_REQUIRE(gH && (H || mask) && idx && off && lst && gP && gBc && tail, "pc3d_group_act_bwd_rev_f32: null pointer");
+  hipStream_t st = as_stream(stream);
+  const size_t lds = 0;
+  const int64_t L = (int64_t)S * K + S;
+  const dim3 gg(cdiv(S, 4), B), gp(cdiv(NA, 4), B), blk(256);
+#define PC3D_GAB_LAUNCH(Q)                                                                                                \
+  hipLaunchKernelGGL(group_act_bwd_groups_kernel<Q>, gg, blk, lds, st, gH, H, mask, idx, S, K, C, slope, gBc, tail);      \
+  hipLaunchKernelGGL(group_act_bwd_points_kernel<Q>, gp, blk, 0, st, gH, H, mask, tail, off, lst, L, NA, S, K, C, slope, gP)
+  if (C <= 64) { PC3D_GAB_LAUNCH(1); }
+  else if (C <= 128) { PC3D_GAB_LAUNCH(2); }
+  else if (C <= 256) { PC3D_GAB_LAUNCH(4); }
+  else { PC3D_GAB_LAUNCH(8); }
+#undef PC3D_GAB_LAUNCH
+  PC3D_LAUNCH_CHECK("pc3d_group_act_bwd_rev_f32");
   return PC3D_OK;
 }
 

@@ -37,9 +37,11 @@ def _split_first(layers):
 
 
 FUSE_LAYERS_1_2 = True    # layer 1 generated inside layer 2's GEMM (ops.grouped_mlp_max); False: group_act + mlp_relu_max
+REVERSE_INDEX = True      # the geometry chain also builds the reverse index of every grouping (ops.group_reverse): layer 1's
+                          # backward gathers through it; False: scatter with float atomics
 
 
-def _grouped_mlp_max(xyz_t, pts, idx, fps_idx, layers, first):
+def _grouped_mlp_max(xyz_t, pts, idx, fps_idx, layers, first, rev=None):
     """The shared MLP + group max of one grouping scale, first layer WITHOUT the grouped input tensor:
     W1 [x_j - c_s ; f_j] + b1 = P[idx[s,j]] + Bc[s], P = Wx x + Wf f per POINT (B*N rows instead of B*S*ns: 16x fewer
     at SSG's second layer), Bc = b1 - (Wx x)[centroid]; pc3d_group_act_f32 gathers P and applies the ReLU, i.e. it
@@ -58,7 +60,7 @@ def _grouped_mlp_max(xyz_t, pts, idx, fps_idx, layers, first):
     P = px if pts is None else px + ops.linear_act(pts, wf)
     Bc = b1 - ops.group_gather(None, px, fps_idx.view(B, S, 1)).view(B, S, C1)
     if FUSE_LAYERS_1_2 and ops.grouped_mlp_max_supported(C1, idx.shape[2], layers[1:]):
-        return ops.grouped_mlp_max(P, Bc, idx, layers[1:])            # layer 1 generated inside layer 2's GEMM
+        return ops.grouped_mlp_max(P, Bc, idx, layers[1:], rev=rev)   # layer 1 generated inside layer 2's GEMM
     h1 = ops.group_act(P, Bc, idx, 0.0)                               # [B,S,ns,C1] = relu(layer 1)
     return ops.mlp_relu_max(h1, layers[1:])
 
@@ -192,9 +194,10 @@ class PointNetSetAbstraction(_FrozenFusedMixin, nn.Module):
         fps_idx = ops.fps(xyz_t, self.npoint, _fps_start(B, N, xyz_t.device))                       # [B,S] i32
         centres = ops.group_gather(xyz_t, None, fps_idx.view(B, self.npoint, 1)).view(B, self.npoint, 3)
         idx = ops.ball_query(self.radius, self.nsample, xyz_t, centres)                              # [B,S,ns] i32
+        rev = ops.group_reverse(idx, N) if REVERSE_INDEX else None      # for the backward of layer 1 (no float atomics)
         ev = torch.cuda.Event()
         ev.record()
-        return fps_idx, centres, idx, ev
+        return fps_idx, centres, idx, ev, rev
 
     def forward(self, xyz, points, geo=None):
         """xyz [B,3,N], points [B,D,N] or None -> new_xyz [B,3,S], new_points [B,D',S]. geo: this layer's entry of
@@ -208,15 +211,16 @@ class PointNetSetAbstraction(_FrozenFusedMixin, nn.Module):
             new_points = _mlp_max(new_points, layers)   # [B,1,D'] channels-last 1x1 convs, no permutes
         else:
             B, N, _ = xyz_t.shape
+            rev = None
             if geo is not None:
-                fps_idx, _, idx, ev = geo
+                fps_idx, _, idx, ev, rev = geo
                 torch.cuda.current_stream(xyz_t.device).wait_event(ev)
                 new_xyz = ops.group_gather(xyz_t, None, fps_idx.view(B, self.npoint, 1)).view(B, self.npoint, 3)
             else:
                 fps_idx = ops.fps(xyz_t, self.npoint, _fps_start(B, N, xyz_t.device))                   # [B,S] i32
                 new_xyz = ops.group_gather(xyz_t, None, fps_idx.view(B, self.npoint, 1)).view(B, self.npoint, 3)
                 idx = ops.ball_query(self.radius, self.nsample, xyz_t, new_xyz)                          # [B,S,ns] i32
-            new_points = _grouped_mlp_max(xyz_t, pts, idx, fps_idx, layers, first)
+            new_points = _grouped_mlp_max(xyz_t, pts, idx, fps_idx, layers, first, rev=rev)
         return new_xyz.permute(0, 2, 1), new_points.permute(0, 2, 1)
 
 
@@ -263,9 +267,10 @@ class PointNetSetAbstractionMsg(_FrozenFusedMixin, nn.Module):
         fps_idx = ops.fps(xyz_t, S, _fps_start(B, N, xyz_t.device))
         centres = ops.group_gather(xyz_t, None, fps_idx.view(B, S, 1)).view(B, S, 3)
         idxs = [ops.ball_query(radius, self.nsample_list[i], xyz_t, centres) for i, radius in enumerate(self.radius_list)]
+        revs = [ops.group_reverse(ix, N) if REVERSE_INDEX else None for ix in idxs]
         ev = torch.cuda.Event()
         ev.record()
-        return fps_idx, centres, idxs, ev
+        return fps_idx, centres, idxs, ev, revs
 
     def forward(self, xyz, points, geo=None):
         self._require_fused(xyz)
@@ -273,8 +278,9 @@ class PointNetSetAbstractionMsg(_FrozenFusedMixin, nn.Module):
         pts = _cl(points)
         B, N, C = xyz_t.shape
         S = self.npoint
+        revs = None
         if geo is not None:
-            fps_idx, _, idxs, ev = geo
+            fps_idx, _, idxs, ev, revs = geo
             torch.cuda.current_stream(xyz_t.device).wait_event(ev)
         else:
             fps_idx = ops.fps(xyz_t, S, _fps_start(B, N, xyz_t.device))
@@ -284,7 +290,7 @@ class PointNetSetAbstractionMsg(_FrozenFusedMixin, nn.Module):
         for i, radius in enumerate(self.radius_list):
             idx = idxs[i] if idxs is not None else ops.ball_query(radius, self.nsample_list[i], xyz_t, new_xyz)
             layers, first = self.folded()[i]
-            outs.append(_grouped_mlp_max(xyz_t, pts, idx, fps_idx, layers, first))
+            outs.append(_grouped_mlp_max(xyz_t, pts, idx, fps_idx, layers, first, rev=revs[i] if revs is not None else None))
         return new_xyz.permute(0, 2, 1), torch.cat(outs, dim=-1).permute(0, 2, 1)
 
 

@@ -1728,6 +1728,41 @@ class _MLPReLUMaxFn(torch.autograd.Function):
         return (gx.view(G, ns, C0),) + (None,) * (2 * nl)
 
 
+def group_reverse(idx, NA):
+    """Reverse index of a grouping idx [B,S,K] int32 over NA points per cloud: (off [B,NA+1], lst [B,S*K+S]) int32 — per
+    point the grouped rows that reference it (pc3d_group_reverse_i32). Depends on idx only; the set-abstraction layers
+    build it once per forward on the geometry stream and their backward gathers through it instead of scattering with
+    float atomics."""
+    if idx.dtype != torch.int32 or idx.dim() != 3 or not idx.is_cuda:
+        raise ValueError("group_reverse: idx must be an int32 [B,S,K] GPU tensor")
+    idx = idx.contiguous()
+    B, S, K = idx.shape
+    dev = idx.device
+    cnt = torch.empty((B, NA), dtype=torch.int32, device=dev)
+    off = torch.empty((B, NA + 1), dtype=torch.int32, device=dev)
+    lst = torch.empty((B, S * K + S), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.call("pc3d_group_reverse_i32", idx.data_ptr(), B, NA, S, K, cnt.data_ptr(), off.data_ptr(), lst.data_ptr(),
+                  _stream())
+    return off, lst
+
+
+def group_act_bwd_rev(gH, H, mask, idx, rev, NA, slope=0.0):
+    """(gP [B,NA,C], gBc [B,S,C]) of group_act through the reverse index rev = group_reverse(idx, NA): no float atomics,
+    every gP row written once. The activation's sign comes from H [B,S,K,C] or, with H None, from the bit mask."""
+    off, lst = rev
+    B, S, K = idx.shape
+    C = gH.shape[-1]
+    gH = gH.contiguous()
+    gP = torch.empty((B, NA, C), dtype=torch.float32, device=gH.device)
+    gBc = torch.empty((B, S, C), dtype=torch.float32, device=gH.device)
+    tail = torch.empty((B, S, C), dtype=torch.float32, device=gH.device)
+    with torch.cuda.device(gH.device):
+        _lib.call("pc3d_group_act_bwd_rev_f32", gH.data_ptr(), _ptr(H), _ptr(mask), idx.data_ptr(), off.data_ptr(),
+                  lst.data_ptr(), B, NA, S, K, C, float(slope), gP.data_ptr(), gBc.data_ptr(), tail.data_ptr(), _stream())
+    return gP, gBc
+
+
 class _GroupedMLPMaxFn(torch.autograd.Function):
     """A three-layer set-abstraction MLP + group max from the per-point form of its first layer, WITHOUT the layer-1
     output: H2 = relu(W2 relu(P[idx] + Bc) + b2) in one launch (pc3d_gemm_nt_gather_f32 generates the rows of its X
@@ -1736,7 +1771,7 @@ class _GroupedMLPMaxFn(torch.autograd.Function):
     (pc3d_group_act_bwd_mask_f32). One [B,S,ns,C1] write and two reads fewer than group_act + mlp_relu_max."""
 
     @staticmethod
-    def forward(ctx, P, Bc, idx, w2, b2, w3, b3):
+    def forward(ctx, P, Bc, idx, w2, b2, w3, b3, rev_off, rev_lst):
         B, NA, C1 = P.shape
         S, ns = idx.shape[1], idx.shape[2]
         C2 = w2.shape[0]
@@ -1747,13 +1782,13 @@ class _GroupedMLPMaxFn(torch.autograd.Function):
                       w2.data_ptr(), b2.data_ptr(), C2, C1, _ACTS["relu"], 0.0, H2.data_ptr(), C2, mask.data_ptr(),
                       _stream())
         out, arg = _group_linear_max_fwd(H2.view(B * S, ns, C2), w3, b3)
-        ctx.save_for_backward(out, arg, H2, mask, idx, w2, w3)
+        ctx.save_for_backward(out, arg, H2, mask, idx, w2, w3, rev_off, rev_lst)
         ctx.dims = (B, NA, C1)
         return out.view(B, S, -1)
 
     @staticmethod
     def backward(ctx, g):
-        out, arg, H2, mask, idx, w2, w3 = ctx.saved_tensors
+        out, arg, H2, mask, idx, w2, w3, rev_off, rev_lst = ctx.saved_tensors
         B, NA, C1 = ctx.dims
         S, ns = idx.shape[1], idx.shape[2]
         C2 = w2.shape[0]
@@ -1763,12 +1798,15 @@ class _GroupedMLPMaxFn(torch.autograd.Function):
             _lib.call("pc3d_group_max_linear_bwd_f32", g.data_ptr(), out.data_ptr(), arg.data_ptr(), w3.data_ptr(),
                       B * S, ns, C2, w3.shape[0], H2.data_ptr(), gz.data_ptr(), _stream())
         gh1 = gemm_nt(gz, _w_transposed(w2))
+        if rev_off is not None:        # gather through the reverse index of the grouping: no float atomics
+            gP, gBc = group_act_bwd_rev(gh1.view(B, S, ns, C1), None, mask, idx, (rev_off, rev_lst), NA, 0.0)
+            return gP, gBc, None, None, None, None, None, None, None
         gP = torch.empty((B, NA, C1), dtype=torch.float32, device=g.device)
         gBc = torch.empty((B, S, C1), dtype=torch.float32, device=g.device)
         with torch.cuda.device(g.device):
             _lib.call("pc3d_group_act_bwd_mask_f32", gh1.data_ptr(), mask.data_ptr(), idx.data_ptr(), B, NA, S, ns, C1,
                       0.0, gP.data_ptr(), gBc.data_ptr(), _stream())
-        return gP, gBc, None, None, None, None, None
+        return gP, gBc, None, None, None, None, None, None, None
 
 
 def grouped_mlp_max_supported(C1, ns, layers):
@@ -1779,16 +1817,18 @@ def grouped_mlp_max_supported(C1, ns, layers):
     return C2 % 8 == 0 and C2 <= 128 and C3 % 32 == 0 and C3 <= 4096
 
 
-def grouped_mlp_max(P, Bc, idx, layers):
+def grouped_mlp_max(P, Bc, idx, layers, rev=None):
     """max_j relu(W3 relu(W2 relu(P[b,idx[b,s,j]] + Bc[b,s]) + b2) + b3) -> [B,S,C3]; P [B,NA,C1], Bc [B,S,C1], idx
-    [B,S,ns] int32, layers = [(W2,b2),(W3,b3)] frozen. Differentiable in P and Bc."""
+    [B,S,ns] int32, layers = [(W2,b2),(W3,b3)] frozen. Differentiable in P and Bc. rev = group_reverse(idx, NA): the
+    backward gathers through it instead of scattering with float atomics."""
     _check(P, "P"), _check(Bc, "Bc")
     if not grouped_mlp_max_supported(P.shape[2], idx.shape[2], layers) or idx.dtype != torch.int32 \
             or Bc.shape != (P.shape[0], idx.shape[1], P.shape[2]):
         raise ValueError("grouped_mlp_max: unsupported shapes (see grouped_mlp_max_supported)")
     (w2, b2), (w3, b3) = layers
+    r0, r1 = rev if rev is not None else (None, None)
     return _GroupedMLPMaxFn.apply(P.contiguous(), Bc.contiguous(), idx.contiguous(), w2.detach().contiguous(),
-                                  b2.detach().contiguous(), w3.detach().contiguous(), b3.detach().contiguous())
+                                  b2.detach().contiguous(), w3.detach().contiguous(), b3.detach().contiguous(), r0, r1)
 
 
 def mlp_relu_max(x, layers):

@@ -168,6 +168,23 @@ int pc3d_gemm_nt_gather_f32(const float* P, int64_t ldp, const float* Bc, const 
 int pc3d_group_act_bwd_mask_f32(const float* gH, const uint8_t* mask, const int32_t* idx, int B, int NA, int S, int K, int C,
                                 float slope, float* gP, float* gBc, void* stream);
 
+/* The same backward WITHOUT float atomics, as a gather over a reverse index of the grouping.
+ * pc3d_group_reverse_i32: per cloud, the list of grouped rows that reference each point (a counting sort on the device:
+ *   two passes of integer atomics + a scan). idx [B,S,K] int32 as above; cnt [B,NA] int32 scratch; off [B,NA+1] int32
+ *   (list of point p = lst[b][off[b,p] .. off[b,p+1])); lst [B, L] int32 with L = pc3d_group_reverse_list_len(S, K) =
+ *   S*K + S. Entry codes: s*K + j = row (s,j) of the cloud; S*K + s = "the sum of the rows of group s that repeat its
+ *   first index" (the ball query's padding), listed under that first index. Entries outside [0,NA) are in no list.
+ *   It depends on idx only: build it once per forward, beside the MLPs.
+ * pc3d_group_act_bwd_rev_f32: gBc and the per-group padded-tail sums in one pass over the groups (tail [B,S,C] scratch),
+ *   then gP[b,p,:] = sum over the list of p — every row of gP written once, no zero fill. The sign of the activation
+ *   comes from H [B,S,K,C] or, when H is NULL, from the bit mask of pc3d_gemm_nt_gather_f32. C % 4 == 0, C <= 512. */
+int64_t pc3d_group_reverse_list_len(int S, int K);
+int pc3d_group_reverse_i32(const int32_t* idx, int B, int NA, int S, int K, int32_t* cnt, int32_t* off, int32_t* lst,
+                           void* stream);
+int pc3d_group_act_bwd_rev_f32(const float* gH, const float* H, const uint8_t* mask, const int32_t* idx, const int32_t* off,
+                               const int32_t* lst, int B, int NA, int S, int K, int C, float slope, float* gP, float* gBc,
+                               float* tail, void* stream);
+
 /* Backward of  [max_n | mean_n] LeakyReLU(Y[b,n,:], slope)  followed straight by the backward of the layer that produced Y
  * (model/dgcnn.py:317-320 after conv5, model/curvenet.py:64-67 after conv0), in ONE GEMM: dX = dY W with the rows of dY
  * generated on load from the pre-activation Y [B*Npts, K] (row stride ldy_in), the upstream gradient g [B, 2K] (max part,
