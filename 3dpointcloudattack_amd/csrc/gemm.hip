@@ -56,6 +56,8 @@ struct GemmArgs {
   // LeakyReLU(pb_slope) and [max | mean] pooling over the pb_N rows of every cloud; row m = (cloud b, point n) is
   // generated as  dY[m, c] = (Y > 0 ? 1 : pb_slope) * ((pb_arg[b,c] == n ? g[b, c] : 0) + g[b, K + c] / pb_N)
   // — the backward of that pooling (act_pool_bwd_kernel, dgcnn.hip) without the [M, K] gradient tensor.
+  uint32_t* ymask;     // [M, N / 32] or null (N % 32 == 0): bit n % 32 of word n / 32 of row m = "Y[m, n] > 0 before the
+                       // activation" — the activation's backward mask, written by the standard epilogue (16 ballots per tile)
   const float* pb_g;       // [M / pb_N, 2K]
   const int32_t* pb_arg;   // [M / pb_N, K]
   int pb_N;
@@ -294,16 +296,22 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_nt_kernel(GemmArgs a) 
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = n0 + wn + j * 32 + r;
-    if (col >= a.N) continue;
-    const float bj = a.bias ? a.bias[col] : 0.f;
+    const bool col_ok = col < a.N;
+    if (!col_ok && !a.ymask) continue;
+    const float bj = (a.bias && col_ok) ? a.bias[col] : 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int row = m0 + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (row < a.M) {
-          float v = acc[i][j][e] + bj;
-          if (a.res) v += a.res[(int64_t)row * a.ldr + col];
+        float v = acc[i][j][e] + bj;
+        if (a.res && row < a.M && col_ok) v += a.res[(int64_t)row * a.ldr + col];
+        if (a.ymask) {     // the 32 columns of this tile as one word per row: lanes 0-31 hold row `row`, lanes 32-63 row + 4
+          const unsigned long long bal = __builtin_amdgcn_ballot_w64(v > 0.f && col_ok);
+          if (r == 0 && row < a.M && n0 + wn + j * 32 < a.N)      // (N % 32 == 0: a 32-column tile is all in or all out)
+            a.ymask[(int64_t)row * (a.N >> 5) + ((n0 + wn + j * 32) >> 5)] = (uint32_t)(h ? (bal >> 32) : bal);
+        }
+        if (row < a.M && col_ok) {
           if (a.act == 1) v = v > 0.f ? v : 0.f;
           else if (a.act == 2) v = v > 0.f ? v : a.slope * v;
           a.Y[(int64_t)row * a.ldy + col] = v;
@@ -327,7 +335,8 @@ static int gemm_nt_launch(const float* X, int64_t ldx, const float* W, const flo
                           float* Y, int64_t ldy, void* stream, int gm_ns = 0, float* gm_out = nullptr,
                           int64_t* gm_arg = nullptr, const int32_t* ga_idx = nullptr, const float* ga_Bc = nullptr,
                           int ga_ns = 0, int ga_S = 0, int ga_NA = 0, float ga_slope = 0.f, uint8_t* ga_mask = nullptr,
-                          const float* pb_g = nullptr, const int32_t* pb_arg = nullptr, int pb_N = 0, float pb_slope = 0.f) {
+                          const float* pb_g = nullptr, const int32_t* pb_arg = nullptr, int pb_N = 0, float pb_slope = 0.f,
+                          uint32_t* ymask = nullptr) {
   PC3D_REQUIRE(M >= 0 && N >= 1 && K >= 1, "pc3d_gemm_nt_f32: bad sizes M=%d N=%d K=%d", M, N, K);
   PC3D_REQUIRE(act >= 0 && act <= 2, "pc3d_gemm_nt_f32: bad activation %d", act);
   if (M == 0) return PC3D_OK;
@@ -339,7 +348,8 @@ static int gemm_nt_launch(const float* X, int64_t ldx, const float* W, const flo
   a.M = M, a.N = N, a.K = K, a.act = act, a.slope = slope, a.gslope = gate_slope;
   a.gm_ns = gm_ns, a.gm_out = gm_out, a.gm_arg = gm_arg;
   a.ga_idx = ga_idx, a.ga_Bc = ga_Bc, a.ga_ns = ga_ns, a.ga_S = ga_S, a.ga_NA = ga_NA, a.ga_slope = ga_slope, a.ga_mask = ga_mask;
-  a.pb_g = pb_g, a.pb_arg = pb_arg, a.pb_N = pb_N, a.pb_slope = pb_slope;
+  a.pb_g = pb_g, a.pb_arg = pb_arg, a.pb_N = pb_N, a.pb_slope = pb_slope, a.ymask = ymask;
+  PC3D_REQUIRE(!ymask || N % 32 == 0, "pc3d_gemm_nt_f32: the output sign mask needs N %% 32 == 0 (N=%d)", N);
   // Tile shapes, measured on MI355X (tools/bench_gemm.py, us; hipBLASLt beside them):
   //   layer [M,N,K]                 0: 128x128 DB   2: 128x64   4: 64x128   5: 128x128/8 waves   hipBLASLt
   //   DGCNN conv5 [32768,1024,512]       387           361         350            320               275
@@ -424,14 +434,14 @@ extern "C" int pc3d_gemm_nt_res_f32(const float* X, int64_t ldx, const float* W,
 
 extern "C" int pc3d_gemm_nt_gather_f32(const float* P, int64_t ldp, const float* Bc, const int32_t* idx, int B, int NA, int S,
                                        int ns, float slope_in, const float* W, const float* bias, int N, int K, int act,
-                                       float slope, float* Y, int64_t ldy, uint8_t* mask, void* stream) {
+                                       float slope, float* Y, int64_t ldy, uint8_t* mask, uint32_t* ymask, void* stream) {
   PC3D_REQUIRE(B >= 0 && NA >= 1 && S >= 1 && ns >= 1 && (int64_t)B * S * ns <= 0x7fffffffLL && (int64_t)B * NA <= 0x7fffffffLL,
                "pc3d_gemm_nt_gather_f32: bad sizes B=%d NA=%d S=%d ns=%d", B, NA, S, ns);
   if (B == 0) return PC3D_OK;
   PC3D_REQUIRE(P && Bc && idx, "pc3d_gemm_nt_gather_f32: null pointer");
   PC3D_REQUIRE(!mask || K % 4 == 0, "pc3d_gemm_nt_gather_f32: the sign mask needs K %% 4 == 0 (K=%d)", K);
   return gemm_nt_launch(P, ldp, W, bias, nullptr, 0, 0.f, nullptr, 0, B * S * ns, N, K, act, slope, Y, ldy, stream, 0, nullptr,
-                        nullptr, idx, Bc, ns, S, NA, slope_in, mask);
+                        nullptr, idx, Bc, ns, S, NA, slope_in, mask, nullptr, nullptr, 0, 0.f, ymask);
 }
 
 extern "C" int pc3d_gemm_nt_poolbwd_f32(const float* Y, int64_t ldy_in, const float* g, const int32_t* arg, int B, int Npts,

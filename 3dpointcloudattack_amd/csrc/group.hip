@@ -349,6 +349,8 @@ struct GroupMaxBwdArgs {
   float* gx;            // [G,ns,C2]
   const float* xin;     // [G,ns,C2] or null: the operator's input when it is itself a ReLU output — gx is then
                         // zeroed where xin <= 0, i.e. the previous layer's ReLU backward is applied on the way out
+  const uint32_t* xmask = nullptr;   // [G*ns, C2/32] or null: the same signs as bits (bit k % 32 of word k / 32 of a row),
+                                     // as pc3d_gemm_nt_gather_f32 writes them — 1/32 of the bytes of xin
 };
 
 // Thread = one input channel k of one group; its NS row accumulators live in REGISTERS and are addressed with the
@@ -411,16 +413,21 @@ __global__ __launch_bounds__(GMB_T) void group_max_linear_bwd_kernel(GroupMaxBwd
   if (live) {
     float* o = a.gx + (int64_t)g * a.ns * a.C2 + k;
     const float* xi = a.xin ? a.xin + (int64_t)g * a.ns * a.C2 + k : nullptr;
+    const uint32_t* xm = a.xmask ? a.xmask + (int64_t)g * a.ns * (a.C2 >> 5) + (k >> 5) : nullptr;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       float m[32];
-      if (xi) {   // all 32 mask loads of this register vector in flight before the first store
+      if (xm) {   // one word per row, shared by the 32 channels of a word (a broadcast load)
+#pragma unroll
+        for (int e = 0; e < 32; ++e)
+          m[e] = (32 * v + e < a.ns && ((xm[(int64_t)(32 * v + e) * (a.C2 >> 5)] >> (k & 31)) & 1u)) ? 1.f : 0.f;
+      } else if (xi) {   // all 32 mask loads of this register vector in flight before the first store
 #pragma unroll
         for (int e = 0; e < 32; ++e) m[e] = (32 * v + e < a.ns) ? xi[(int64_t)(32 * v + e) * a.C2] : 0.f;
       }
 #pragma unroll
       for (int e = 0; e < 32; ++e)
-        if (32 * v + e < a.ns) o[(int64_t)(32 * v + e) * a.C2] = (xi && !(m[e] > 0.f)) ? 0.f : acc[v][e];
+        if (32 * v + e < a.ns) o[(int64_t)(32 * v + e) * a.C2] = ((xi || xm) && !(m[e] > 0.f)) ? 0.f : acc[v][e];
     }
   }
 }
@@ -777,13 +784,14 @@ extern "C" int pc3d_group_gather_bwd_f32(const float* g_out, const int32_t* idx,
   return PC3D_OK;
 }
 
-extern "C" int pc3d_group_max_linear_bwd_f32(const float* gout, const float* out, const int64_t* arg, const float* W,
-                                             int G, int ns, int C2, int C3, const float* xin, float* gx, void* stream) {
+static int group_max_linear_bwd_launch(const float* gout, const float* out, const int64_t* arg, const float* W, int G, int ns,
+                                       int C2, int C3, const float* xin, const uint32_t* xmask, float* gx, void* stream) {
   PC3D_REQUIRE(G >= 0 && ns >= 1 && ns <= GMB_MAXNS && C2 >= 1 && C3 >= 1 && C3 <= 4096,
                "pc3d_group_max_linear_bwd_f32: bad sizes G=%d ns=%d C2=%d C3=%d (ns <= 128, C3 <= 4096)", G, ns, C2, C3);
+  PC3D_REQUIRE(!xmask || C2 % 32 == 0, "pc3d_group_max_linear_bwd_mask_f32: C2=%d must be a multiple of 32", C2);
   if (G == 0) return PC3D_OK;
   PC3D_REQUIRE(gout && out && arg && W && gx, "pc3d_group_max_linear_bwd_f32: null pointer");
-  GroupMaxBwdArgs a{gout, out, arg, W, ns, C2, C3, gx, xin};
+  GroupMaxBwdArgs a{gout, out, arg, W, ns, C2, C3, gx, xin, xmask};
   const int bt = C2 <= 64 ? 64 : GMB_T;          // one wave per group when the layer is narrow
   const dim3 grid(G, cdiv(C2, bt)), block(bt);
   hipStream_t st = as_stream(stream);
@@ -793,6 +801,18 @@ extern "C" int pc3d_group_max_linear_bwd_f32(const float* gout, const float* out
   else hipLaunchKernelGGL(group_max_linear_bwd_kernel<128>, grid, block, lds, st, a);
   PC3D_LAUNCH_CHECK("pc3d_group_max_linear_bwd_f32");
   return PC3D_OK;
+}
+
+extern "C" int pc3d_group_max_linear_bwd_f32(const float* gout, const float* out, const int64_t* arg, const float* W,
+                                             int G, int ns, int C2, int C3, const float* xin, float* gx, void* stream) {
+  return group_max_linear_bwd_launch(gout, out, arg, W, G, ns, C2, C3, xin, nullptr, gx, stream);
+}
+
+extern "C" int pc3d_group_max_linear_bwd_mask_f32(const float* gout, const float* out, const int64_t* arg, const float* W,
+                                                  int G, int ns, int C2, int C3, const uint32_t* xmask, float* gx,
+                                                  void* stream) {
+  PC3D_REQUIRE(xmask != nullptr, "pc3d_group_max_linear_bwd_mask_f32: null mask");
+  return group_max_linear_bwd_launch(gout, out, arg, W, G, ns, C2, C3, nullptr, xmask, gx, stream);
 }
 
 extern "C" int pc3d_group_act_f32(const float* P, const float* Bc, const int32_t* idx, int B, int NA, int S, int K, int C,

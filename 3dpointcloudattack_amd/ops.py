@@ -1777,26 +1777,32 @@ class _GroupedMLPMaxFn(torch.autograd.Function):
         C2 = w2.shape[0]
         H2 = torch.empty((B * S * ns, C2), dtype=torch.float32, device=P.device)
         mask = torch.empty((B * S * ns, C1 // 4), dtype=torch.uint8, device=P.device)
+        # layer 2's own sign bits (C2 % 32 == 0): H2 is then not kept for the backward at all
+        m2 = torch.empty((B * S * ns, C2 // 32), dtype=torch.int32, device=P.device) if C2 % 32 == 0 else None
         with torch.cuda.device(P.device):
             _lib.call("pc3d_gemm_nt_gather_f32", P.data_ptr(), C1, Bc.data_ptr(), idx.data_ptr(), B, NA, S, ns, 0.0,
                       w2.data_ptr(), b2.data_ptr(), C2, C1, _ACTS["relu"], 0.0, H2.data_ptr(), C2, mask.data_ptr(),
-                      _stream())
+                      _ptr(m2), _stream())
         out, arg = _group_linear_max_fwd(H2.view(B * S, ns, C2), w3, b3)
-        ctx.save_for_backward(out, arg, H2, mask, idx, w2, w3, rev_off, rev_lst)
+        ctx.save_for_backward(out, arg, H2 if m2 is None else None, m2, mask, idx, w2, w3, rev_off, rev_lst)
         ctx.dims = (B, NA, C1)
         return out.view(B, S, -1)
 
     @staticmethod
     def backward(ctx, g):
-        out, arg, H2, mask, idx, w2, w3, rev_off, rev_lst = ctx.saved_tensors
+        out, arg, H2, m2, mask, idx, w2, w3, rev_off, rev_lst = ctx.saved_tensors
         B, NA, C1 = ctx.dims
         S, ns = idx.shape[1], idx.shape[2]
         C2 = w2.shape[0]
         g = g.contiguous()
         gz = torch.empty((B * S * ns, C2), dtype=torch.float32, device=g.device)
         with torch.cuda.device(g.device):
-            _lib.call("pc3d_group_max_linear_bwd_f32", g.data_ptr(), out.data_ptr(), arg.data_ptr(), w3.data_ptr(),
-                      B * S, ns, C2, w3.shape[0], H2.data_ptr(), gz.data_ptr(), _stream())
+            if m2 is not None:
+                _lib.call("pc3d_group_max_linear_bwd_mask_f32", g.data_ptr(), out.data_ptr(), arg.data_ptr(),
+                          w3.data_ptr(), B * S, ns, C2, w3.shape[0], m2.data_ptr(), gz.data_ptr(), _stream())
+            else:
+                _lib.call("pc3d_group_max_linear_bwd_f32", g.data_ptr(), out.data_ptr(), arg.data_ptr(), w3.data_ptr(),
+                          B * S, ns, C2, w3.shape[0], H2.data_ptr(), gz.data_ptr(), _stream())
         gh1 = gemm_nt(gz, _w_transposed(w2))
         if rev_off is not None:        # gather through the reverse index of the grouping: no float atomics
             gP, gBc = group_act_bwd_rev(gh1.view(B, S, ns, C1), None, mask, idx, (rev_off, rev_lst), NA, 0.0)

@@ -317,7 +317,8 @@ def test_group_act_fwd_bwd_vs_torch(dev, B, NA, S, K, C, slope):
 
 
 @pytest.mark.parametrize("B,NA,S,ns,C1,C2,C3", [(2, 300, 40, 32, 64, 64, 128), (3, 257, 17, 64, 128, 128, 256),
-                                                (1, 90, 5, 16, 32, 48, 64), (2, 128, 9, 128, 12, 24, 32)])
+                                                (1, 90, 5, 16, 32, 48, 64), (2, 128, 9, 128, 12, 24, 32),
+                                                (2, 200, 11, 128, 64, 96, 128), (2, 150, 20, 16, 32, 32, 64)])   # MSG widths
 def test_grouped_mlp_max_equals_group_act_then_mlp(dev, B, NA, S, ns, C1, C2, C3):
     """pc3d_gemm_nt_gather_f32 (layer 1 generated while loading layer 2's operand) + the bit-mask backward against
     the two-operator form (pc3d_group_act_f32, then the MLP): outputs bit for bit (same GEMM, same operand values),
