@@ -1763,6 +1763,12 @@ def group_act_bwd_rev(gH, H, mask, idx, rev, NA, slope=0.0):
     return gP, gBc
 
 
+# Keep layer 2's sign bits (pc3d_gemm_nt_gather_f32's ymask) instead of its output for the backward? It saves 0.5 GB per
+# forward at SSG's sizes, but pc3d_group_max_linear_bwd_mask_f32 (one broadcast word load per row and thread) runs ~30 us
+# slower per level than the form that reads the stored output coalesced: cfg4 3.56 against 3.48 ms per iteration. Off.
+LAYER2_SIGN_BITS = False
+
+
 class _GroupedMLPMaxFn(torch.autograd.Function):
     """A three-layer set-abstraction MLP + group max from the per-point form of its first layer, WITHOUT the layer-1
     output: H2 = relu(W2 relu(P[idx] + Bc) + b2) in one launch (pc3d_gemm_nt_gather_f32 generates the rows of its X
@@ -1778,7 +1784,7 @@ class _GroupedMLPMaxFn(torch.autograd.Function):
         H2 = torch.empty((B * S * ns, C2), dtype=torch.float32, device=P.device)
         mask = torch.empty((B * S * ns, C1 // 4), dtype=torch.uint8, device=P.device)
         # layer 2's own sign bits (C2 % 32 == 0): H2 is then not kept for the backward at all
-        m2 = torch.empty((B * S * ns, C2 // 32), dtype=torch.int32, device=P.device) if C2 % 32 == 0 else None
+        m2 = torch.empty((B * S * ns, C2 // 32), dtype=torch.int32, device=P.device) if (C2 % 32 == 0 and LAYER2_SIGN_BITS) else None
         with torch.cuda.device(P.device):
             _lib.call("pc3d_gemm_nt_gather_f32", P.data_ptr(), C1, Bc.data_ptr(), idx.data_ptr(), B, NA, S, ns, 0.0,
                       w2.data_ptr(), b2.data_ptr(), C2, C1, _ACTS["relu"], 0.0, H2.data_ptr(), C2, mask.data_ptr(),

@@ -351,13 +351,18 @@ def test_grouped_mlp_max_equals_group_act_then_mlp(dev, B, NA, S, ns, C1, C2, C3
     real = (ic < NA) & ((torch.arange(ns)[None, None, :] == 0) | (ic != ic[:, :, :1]))
     lead = (ic[:, :, 0] < NA).sum(1) if ns > 1 else torch.zeros(B, dtype=torch.long)
     assert torch.equal(off[:, -1].long(), real.sum((1, 2)) + lead)       # every real row once + one tail per led group
-    Pg, Bg = P.clone().requires_grad_(), Bc.clone().requires_grad_()
-    out_g = ops.grouped_mlp_max(Pg, Bg, idx, layers, rev=rev)
-    (out_g * up).sum().backward()
-    assert torch.equal(out_g, ref)
-    torch.testing.assert_close(Bg.grad, Br.grad, rtol=1e-4, atol=1e-5)
-    torch.testing.assert_close(Pg.grad, Pr.grad, rtol=1e-4, atol=1e-5)
-    assert torch.isfinite(Pg.grad).all() and float(Pg.grad[0].abs().sum()) > 0
+    for bits in (False, True):       # ... and with layer 2's sign bits kept instead of its output (ops.LAYER2_SIGN_BITS)
+        ops.LAYER2_SIGN_BITS = bits
+        try:
+            Pg, Bg = P.clone().requires_grad_(), Bc.clone().requires_grad_()
+            out_g = ops.grouped_mlp_max(Pg, Bg, idx, layers, rev=rev)
+            (out_g * up).sum().backward()
+        finally:
+            ops.LAYER2_SIGN_BITS = False
+        assert torch.equal(out_g, ref)
+        torch.testing.assert_close(Bg.grad, Br.grad, rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(Pg.grad, Pr.grad, rtol=1e-4, atol=1e-5)
+        assert torch.isfinite(Pg.grad).all() and float(Pg.grad[0].abs().sum()) > 0
 
 
 @pytest.mark.parametrize("mlp,in_feat", [([64, 64, 128], 0), ([32, 48, 64], 13), ([30, 40], 5), ([16], 0)])

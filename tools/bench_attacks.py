@@ -18,6 +18,8 @@ which = sys.argv[1:] or ["geoa3", "knn", "aof"]
 GRAPH = os.environ.get("PC3D_GRAPH_VICTIM", "1") != "0"
 if os.environ.get("PC3D_FUSE12") == "0":      # A/B switch for the experiment recorded in DESIGN.md
     M("3dpointcloudattack_amd.model.pointnet2_utils").FUSE_LAYERS_1_2 = False
+if os.environ.get("PC3D_L2_BITS") == "0":
+    M("3dpointcloudattack_amd.ops").LAYER2_SIGN_BITS = False
 if os.environ.get("PC3D_REV_INDEX") == "0":
     M("3dpointcloudattack_amd.model.pointnet2_utils").REVERSE_INDEX = False
 res = {}
