@@ -410,24 +410,40 @@ __global__ __launch_bounds__(GMB_T) void group_max_linear_bwd_kernel(GroupMaxBwd
     for (int v = 0; v < NV; ++v)
       if (hi == v) acc[v][lo] = __builtin_fmaf(gv, w, acc[v][lo]);
   }
+  if (a.xmask) {
+    // sign bits instead of the stored activation: the wave's 32 rows x 2 words of a register vector are ONE load (lane l
+    // takes row l & 31, word column l >> 5 of the wave's two), and row e's word reaches every lane through v_readlane —
+    // a thread-per-word load per row (32 broadcast loads per thread) made this kernel 30 us slower than reading xin
+    const int lane = threadIdx.x & 63;
+    const int kw = (blockIdx.y * blockDim.x + (threadIdx.x & ~63)) >> 5;     // first word column of this wave
+    const int wpr = a.C2 >> 5;                                               // words per row
+    float* o = a.gx + (int64_t)g * a.ns * a.C2 + k;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int wrow = 32 * v + (lane & 31), wcol = kw + (lane >> 5);
+      const uint32_t word = (wrow < a.ns && wcol < wpr) ? a.xmask[((int64_t)g * a.ns + wrow) * wpr + wcol] : 0u;
+#pragma unroll
+      for (int e = 0; e < 32; ++e) {
+        const uint32_t lo = __builtin_amdgcn_readlane(word, e), hi = __builtin_amdgcn_readlane(word, 32 + e);
+        const uint32_t w = (lane & 32) ? hi : lo;
+        if (live && 32 * v + e < a.ns) o[(int64_t)(32 * v + e) * a.C2] = ((w >> (k & 31)) & 1u) ? acc[v][e] : 0.f;
+      }
+    }
+    return;
+  }
   if (live) {
     float* o = a.gx + (int64_t)g * a.ns * a.C2 + k;
     const float* xi = a.xin ? a.xin + (int64_t)g * a.ns * a.C2 + k : nullptr;
-    const uint32_t* xm = a.xmask ? a.xmask + (int64_t)g * a.ns * (a.C2 >> 5) + (k >> 5) : nullptr;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       float m[32];
-      if (xm) {   // one word per row, shared by the 32 channels of a word (a broadcast load)
-#pragma unroll
-        for (int e = 0; e < 32; ++e)
-          m[e] = (32 * v + e < a.ns && ((xm[(int64_t)(32 * v + e) * (a.C2 >> 5)] >> (k & 31)) & 1u)) ? 1.f : 0.f;
-      } else if (xi) {   // all 32 mask loads of this register vector in flight before the first store
+      if (xi) {   // all 32 mask loads of this register vector in flight before the first store
 #pragma unroll
         for (int e = 0; e < 32; ++e) m[e] = (32 * v + e < a.ns) ? xi[(int64_t)(32 * v + e) * a.C2] : 0.f;
       }
 #pragma unroll
       for (int e = 0; e < 32; ++e)
-        if (32 * v + e < a.ns) o[(int64_t)(32 * v + e) * a.C2] = ((xi || xm) && !(m[e] > 0.f)) ? 0.f : acc[v][e];
+        if (32 * v + e < a.ns) o[(int64_t)(32 * v + e) * a.C2] = (xi && !(m[e] > 0.f)) ? 0.f : acc[v][e];
     }
   }
 }

@@ -1763,10 +1763,11 @@ def group_act_bwd_rev(gH, H, mask, idx, rev, NA, slope=0.0):
     return gP, gBc
 
 
-# Keep layer 2's sign bits (pc3d_gemm_nt_gather_f32's ymask) instead of its output for the backward? It saves 0.5 GB per
-# forward at SSG's sizes, but pc3d_group_max_linear_bwd_mask_f32 (one broadcast word load per row and thread) runs ~30 us
-# slower per level than the form that reads the stored output coalesced: cfg4 3.56 against 3.48 ms per iteration. Off.
-LAYER2_SIGN_BITS = False
+# Keep layer 2's sign bits (pc3d_gemm_nt_gather_f32's ymask) instead of its output for the backward: 0.5 GB less per
+# forward at SSG's sizes at the same speed (cfg4 3.43 / 3.44 ms per iteration with / without, once
+# pc3d_group_max_linear_bwd_mask_f32 loads a wave's mask words in one go; with a word load per row and thread it was
+# 30 us per level slower).
+LAYER2_SIGN_BITS = True
 
 
 class _GroupedMLPMaxFn(torch.autograd.Function):

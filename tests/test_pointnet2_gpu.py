@@ -358,7 +358,7 @@ def test_grouped_mlp_max_equals_group_act_then_mlp(dev, B, NA, S, ns, C1, C2, C3
             out_g = ops.grouped_mlp_max(Pg, Bg, idx, layers, rev=rev)
             (out_g * up).sum().backward()
         finally:
-            ops.LAYER2_SIGN_BITS = False
+            ops.LAYER2_SIGN_BITS = True
         assert torch.equal(out_g, ref)
         torch.testing.assert_close(Bg.grad, Br.grad, rtol=1e-4, atol=1e-5)
         torch.testing.assert_close(Pg.grad, Pr.grad, rtol=1e-4, atol=1e-5)
