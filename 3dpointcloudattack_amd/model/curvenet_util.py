@@ -414,7 +414,7 @@ class CurveAggregation(nn.Module):
 
     def _kernel_form(self, x, cn, cl, C):
         return (self.fused and x.is_cuda and ops.curve_attn_supported(C, cn + cl)
-                and ops.curve_agg_lds_bytes(cn, cl, C, C // 2) <= 64 * 1024)
+                and ops.curve_agg_lds_bytes(cn, cl, C, C // 2) <= ops.CURVE_AGG_LDS_LIMIT)
 
     def forward(self, x, curves, cl=False):
         """Reference layout (default): x [B,C,N], curves [B,C,cn,cl] -> [B,C,N]; cl=True: x [B,N,C], curves

@@ -1305,9 +1305,11 @@ def h2d(t, device, dtype=None):
 # ------------------------------------------------------------------------------------------------------
 # K18: CurveNet curve aggregation, per-cloud half (attention keys / values from the curves)
 # ------------------------------------------------------------------------------------------------------
+CURVE_AGG_LDS_LIMIT = 160 * 1024      # the CU's whole LDS (csrc/curve_agg.hip raises the kernels' window to it)
+
+
 def curve_agg_lds_bytes(cn, cl, C, mid, backward=True):
-    R = cn + cl
-    return 4 * ((6 if backward else 3) * cn * cl + R * C + 2 * R * mid + (R if backward else 0))
+    return int(_lib.load().pc3d_curve_agg_lds_bytes(int(cn), int(cl), int(C), int(mid), int(bool(backward))))
 
 
 class _CurveAggKVFn(torch.autograd.Function):
@@ -1347,8 +1349,8 @@ def curve_agg_kv(curves, w_att, Wa, Wb, Wn, Wl, Wc, Wd, bd):
     ws = [w.detach().contiguous().float() for w in (w_att.reshape(-1), Wa, Wb, Wn, Wl, Wc, Wd, bd)]
     if any(tuple(w.shape) != sh for w, sh in zip(ws, shapes)):
         raise ValueError(f"curve_agg_kv: weight shapes must be {shapes}")
-    if curve_agg_lds_bytes(cn, cl, C, mid) > 64 * 1024:
-        raise ValueError(f"curve_agg_kv: cn={cn} cl={cl} C={C} mid={mid} does not fit the 64 KB LDS window")
+    if curve_agg_lds_bytes(cn, cl, C, mid) > CURVE_AGG_LDS_LIMIT:
+        raise ValueError(f"curve_agg_kv: cn={cn} cl={cl} C={C} mid={mid} does not fit the CU's 160 KB of LDS")
     return _CurveAggKVFn.apply(curves.contiguous(), *ws)
 
 

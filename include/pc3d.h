@@ -514,8 +514,10 @@ int pc3d_lpfa_fused_bwd_f32(const float* gout, const float* A, const float* Bc, 
  * block's output is leaky(x + softmax_rows(x^T Kp[:, :cn]) Vp[:cn] + softmax_rows(x^T Kp[:, cn:]) Vp[cn:]).
  * w_att [C] (line_conv_att), Wa / Wb / Wc [mid,C] (conva / convb / convc), Wn / Wl [mid,mid] (convn / convl),
  * Wd [C,2 mid] + bd [C] (convd with its eval BatchNorm folded; bd is added to the first cn value rows).
- * LDS-resident: 4 (3 cn cl + R C + 2 R mid) bytes forward, 4 (6 cn cl + R C + 2 R mid + R) backward, <= 64 KB.
- * Backward: gcurves [B,cn,cl,C] overwritten from gKp / gVp; deterministic. */
+ * LDS-resident, weights included: pc3d_curve_agg_lds_bytes(cn, cl, C, mid, backward) bytes, which must not exceed the
+ * CU's 160 KB (error otherwise; the classifier's blocks need 58 / 97 KB). Backward: gcurves [B,cn,cl,C] overwritten
+ * from gKp / gVp; deterministic. */
+int64_t pc3d_curve_agg_lds_bytes(int cn, int cl, int C, int mid, int backward);
 int pc3d_curve_agg_kv_f32(const float* curves, const float* w_att, const float* Wa, const float* Wb, const float* Wn,
                           const float* Wl, const float* Wc, const float* Wd, const float* bd, int B, int cn, int cl,
                           int C, int mid, float* Kp, float* Vp, void* stream);
