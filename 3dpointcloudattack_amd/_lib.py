@@ -81,7 +81,8 @@ SIGNATURES = {
     "pc3d_act_pool_f32": [_P, _I, _I, _I, _F, _P, _P, _P],
     "pc3d_act_pool_bwd_f32": [_P, _P, _P, _I, _I, _I, _F, _P, _P],
     "pc3d_curve_walk_fwd_f32": [_P] * 7 + [_I] * 6 + [_P] * 5 + [_P],
-    "pc3d_curve_walk_bwd_f32": [_P] * 7 + [_I] * 6 + [_P] * 7 + [_P],
+    "pc3d_curve_walk_bwd_f32": [_P] * 7 + [_I] * 6 + [_P] * 8 + [_P],
+    "pc3d_curve_walk_bwd_ws_floats": [_I] * 3,
     "pc3d_curve_agg_lds_bytes": [_I] * 5,
     "pc3d_curve_agg_kv_f32": [_P] * 9 + [_I] * 5 + [_P, _P, _P],
     "pc3d_curve_agg_kv_bwd_f32": [_P] * 11 + [_I] * 5 + [_P, _P],
@@ -110,7 +111,8 @@ SIGNATURES = {
 
 # entry points that do not return a status code
 RESTYPES = {"pc3d_nn_bidir_shared_ws_bytes": c_int64, "pc3d_curve_attn_bwd_ws_floats": c_int64,
-            "pc3d_group_reverse_list_len": c_int64, "pc3d_curve_agg_lds_bytes": c_int64}
+            "pc3d_group_reverse_list_len": c_int64, "pc3d_curve_agg_lds_bytes": c_int64,
+            "pc3d_curve_walk_bwd_ws_floats": c_int64}
 
 _lib = None
 

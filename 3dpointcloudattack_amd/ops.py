@@ -1610,17 +1610,18 @@ class _CurveWalkFn(torch.autograd.Function):
         g = g.contiguous()
         gF = torch.zeros((B, N, C), dtype=torch.float32, device=g.device)
         coef = torch.zeros((B, N), dtype=torch.float32, device=g.device)
+        ws = torch.empty(int(_lib.load().pc3d_curve_walk_bwd_ws_floats(B, cn, C)), dtype=torch.float32, device=g.device)
         with torch.cuda.device(g.device):
             _lib.call("pc3d_curve_walk_bwd_f32", g.data_ptr(), feats.data_ptr(), adj.data_ptr(), aw.data_ptr(),
                       ab.data_ptr(), mw.data_ptr(), mb.data_ptr(), B, N, C, k, cn, ctx.L, curves.data_ptr(),
                       nodes.data_ptr(), pick.data_ptr(), pre.data_ptr(), mom.data_ptr(), gF.data_ptr(),
-                      coef.data_ptr(), _stream())
+                      coef.data_ptr(), ws.data_ptr(), _stream())
         gF.addcmul_(coef.unsqueeze(-1), aw[:C])      # the rank-1 score term: every candidate row gets coef * w_nbr
         return gF, None, None, None, None, None, None, None
 
 
 def curve_walk(feats, adj, start, agent_w, agent_b, mom_w, mom_b, length):
-    """Guided walk of CurveNet (model/walk.py:74-153) in one launch per direction: feats [B,N,C] (C in
+    """Guided walk of CurveNet (model/walk.py:74-153), one launch per step and direction: feats [B,N,C] (C in
     CURVE_WALK_CHANNELS), adj [B,N,k] int32 (k <= 64), start [B,cn] int32, folded agent / momentum weights
     ([2C], [1], [2,2C], [2]) -> curves [B,cn,length,C]; differentiable in feats (weights are frozen)."""
     _check(feats, "feats")

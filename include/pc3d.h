@@ -466,8 +466,8 @@ int pc3d_act_pool_bwd_f32(const float* Y, const float* gout, const int32_t* arg,
 int pc3d_edge_max_bwd_f32(const float* g, int64_t ldg, const float* out, const int32_t* arg, int B, int N, int C,
                           float slope, float* gPQ, void* stream);
 
-/* K16  guided curve walk of CurveNet (model/walk.py:74-153 `Walk.forward`) in one launch per direction: one
- * wavefront per curve, lane j scores neighbour j. feats [B,N,C] (C in {8,16,32,64}), adj [B,N,k] (k <= 64, self
+/* K16  guided curve walk of CurveNet (model/walk.py:74-153 `Walk.forward`), one launch per step and direction: one or
+ * two curves per wavefront, lane j scores neighbour j. feats [B,N,C] (C in {8,16,32,64}), adj [B,N,k] (k <= 64, self
  * excluded), start [B,cn]. agent_w [2C] / agent_b [1]: the 1x1 agent conv + eval BatchNorm folded, neighbour part
  * first (walk.py:128-131); mom_w [2,2C] / mom_b [2]: the momentum conv folded, current-feature columns first
  * (walk.py:104-115). Per step: descriptor blend by the 2-way softmax momentum, neighbour scores damped by
@@ -475,7 +475,8 @@ int pc3d_edge_max_bwd_f32(const float* g, int64_t ldg, const float* out, const i
  * softmax as its straight-through gradient. Outputs: curves [B,cn,L,C] (the reference's [B,C,cn,L] transposed) and,
  * for the backward, nodes / pick [B,cn,L], pre [B,cn,L,C], mom [B,cn,L,2].
  * Backward: gfeats [B,N,C] and coef [B,N] are ACCUMULATED into (zero them first); the full gradient is
- * gfeats + coef (x) agent_w[0:C] (the rank-1 score term is left to the caller as one dense pass). Float atomics. */
+ * gfeats + coef (x) agent_w[0:C] (the rank-1 score term is left to the caller as one dense pass). Float atomics.
+ * ws: pc3d_curve_walk_bwd_ws_floats(B, cn, C) floats of scratch (the gradients that travel from step to step). */
 int pc3d_curve_walk_fwd_f32(const float* feats, const int32_t* adj, const int32_t* start, const float* agent_w,
                             const float* agent_b, const float* mom_w, const float* mom_b, int B, int N, int C, int k,
                             int cn, int L, float* curves, int32_t* nodes, int32_t* pick, float* pre, float* mom,
@@ -483,7 +484,8 @@ int pc3d_curve_walk_fwd_f32(const float* feats, const int32_t* adj, const int32_
 int pc3d_curve_walk_bwd_f32(const float* gcurves, const float* feats, const int32_t* adj, const float* agent_w,
                             const float* agent_b, const float* mom_w, const float* mom_b, int B, int N, int C, int k,
                             int cn, int L, const float* curves, const int32_t* nodes, const int32_t* pick,
-                            const float* pre, const float* mom, float* gfeats, float* coef, void* stream);
+                            const float* pre, const float* mom, float* gfeats, float* coef, float* ws, void* stream);
+int64_t pc3d_curve_walk_bwd_ws_floats(int B, int cn, int C);
 
 /* K17  the two bandwidth-bound halves of CurveNet's local point-feature aggregation (model/curvenet_util.py:199-236,
  * `LPFA.group_feature` / `LPFA.forward`) around its 1x1-conv GEMM; channels-last, C % 4 == 0:
