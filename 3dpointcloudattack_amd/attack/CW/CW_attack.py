@@ -227,6 +227,7 @@ class CW:
         adv_data, ori_data, label = st["adv"], st["ori"], st["label"]
         fml = self._fused_model_loss() if st["budget"] is not None else None
         gx_model = None
+        side = None
         dk = self._fused_dist_kind() if fml is not None else 0
         if dk:
             # launch-minimal pass: victim fwd/bwd (fused heads), bookkeeping, [NN search], one update launch
@@ -262,6 +263,16 @@ class CW:
                 logits, pred, _, gx_model = self.model.fused_loss_and_grad(adv_data.detach(), st["target"], *fml,
                                                                            scale=st["ratio"] / st["B"])
         else:
+            if (adv_data.is_cuda and getattr(self, "dist_stream", True)
+                    and not torch.cuda.is_current_stream_capturing()):
+                # the distance term depends on the iterate only: it runs on the process-wide TERMS stream beside the
+                # victim's forward (whose sampling chain leaves most of the chip idle), and autograd runs its backward
+                # there too (as in attack/KNN/KNN_attack.py)
+                main = torch.cuda.current_stream(adv_data.device)
+                side = _streams.side_stream(adv_data.device, _streams.TERMS)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    dist_loss = self.dist_func(adv_data, ori_data, st["weights"]).mean()
             logits = _logits_of(self.model(adv_data))
             pred = torch.argmax(logits, dim=1)  # [B]
         # record values (device side; reference :129-153)
@@ -289,7 +300,10 @@ class CW:
                 st["input_val"].copy_(cur)     # the iterate the LAST pass started from (reference :133, :208-209)
                 st["pred"].copy_(pred)
         # compute loss and backward
-        dist_loss = self.dist_func(adv_data, ori_data, st["weights"]).mean()
+        if side is not None:
+            main.wait_stream(side)
+        else:
+            dist_loss = self.dist_func(adv_data, ori_data, st["weights"]).mean()
         if gx_model is not None:
             adv_data.grad = None
             dist_loss.backward()

@@ -130,6 +130,85 @@ __global__ __launch_bounds__(256) void ball_query_kernel(BallArgs a) {
   for (int j = found + lane; j < a.ns; j += 64) o[j] = first;
 }
 
+// The same query with the roles turned round: a lane is a CENTRE (64 per workgroup), the four wavefronts of the
+// workgroup each scan a quarter of the cloud in index order, 64 points at a time through a wave-private LDS buffer
+// (the next 64 are in flight meanwhile). The point a wavefront looks at is the same for all its lanes — one broadcast
+// LDS read — so a pair costs nine vector instructions with no cross-lane step, and "the first nsample in index order"
+// is the scan order itself. Each (quarter, centre) keeps its hits in LDS (16-bit indices); the quarters are
+// concatenated, cut at nsample and padded afterwards. Against a wavefront per centre (the kernel above: three strided
+// loads, a ballot and a prefix count per 64 pairs, one trip per load) this is what CurveNet's first pooling level
+// (B=32, N=4096, S=1024, r=0.05) needs: it sits right behind the 4096 -> 1024 sampling chain on the forward's
+// critical path.
+constexpr int BQ_SEG = 4;
+static size_t ball_tile_lds(int ns) {
+  return (size_t)BQ_SEG * 2 * 64 * sizeof(float4) + BQ_SEG * 64 * sizeof(int) + (size_t)BQ_SEG * 64 * ns * sizeof(uint16_t);
+}
+
+__global__ __launch_bounds__(BQ_SEG * 64) void ball_query_tile_kernel(BallArgs a) {
+  extern __shared__ float4 bq_sm4[];
+  float4* const stage = bq_sm4;                                              // [BQ_SEG][2][64] points
+  int* const cnts = reinterpret_cast<int*>(bq_sm4 + BQ_SEG * 2 * 64);        // [BQ_SEG][64]
+  uint16_t* const lists = reinterpret_cast<uint16_t*>(cnts + BQ_SEG * 64);   // [BQ_SEG][64][ns]
+  const int b = blockIdx.y, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int s = blockIdx.x * 64 + lane;
+  const bool live = s < a.S;
+  const float* cp = a.c.p + (int64_t)b * a.c.bs + (int64_t)(live ? s : a.S - 1) * a.c.ps;
+  const float cx = cp[0], cy = cp[a.c.cs], cz = cp[2 * a.c.cs];
+  const float* __restrict__ xb = a.x.p + (int64_t)b * a.x.bs;
+  const int per = (a.N + BQ_SEG - 1) / BQ_SEG, i0 = wave * per, i1 = min(i0 + per, a.N);
+  uint16_t* list = lists + (size_t)(wave * 64 + lane) * a.ns;
+  int cnt = live ? 0 : a.ns;      // a lane without a centre counts as full: it must not hold up the early exit
+  auto fetch = [&](int i) {
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < i1) {
+      const float* p = xb + (int64_t)i * a.x.ps;
+      q.x = p[0], q.y = p[a.x.cs], q.z = p[2 * a.x.cs];
+    }
+    return q;
+  };
+  auto test = [&](const float4 q, int i) {
+    const float dx = q.x - cx, dy = q.y - cy, dz = q.z - cz;
+    if (((dx * dx + dy * dy) + dz * dz) <= a.r2 && cnt < a.ns) list[cnt++] = (uint16_t)i;
+  };
+  float4 nxt = fetch(i0 + lane);
+  for (int ib = i0, k = 0; ib < i1; ib += 64, ++k) {
+    float4* buf = stage + (wave * 2 + (k & 1)) * 64;
+    buf[lane] = nxt;
+    nxt = fetch(ib + 64 + lane);
+    wave_lds_sync();
+    if (__builtin_amdgcn_ballot_w64(cnt < a.ns) == 0) break;   // every centre of this tile has its nsample hits
+    if (ib + 64 <= i1) {
+#pragma unroll 8
+      for (int t = 0; t < 64; ++t) test(buf[t], ib + t);
+    } else {
+      for (int t = 0; t < i1 - ib; ++t) test(buf[t], ib + t);
+    }
+  }
+  cnts[wave * 64 + lane] = live ? cnt : 0;
+  __syncthreads();
+  for (int cc = 0; cc < 64 / BQ_SEG; ++cc) {   // each wavefront writes the rows of 16 centres, slots across the lanes
+    const int c = wave * (64 / BQ_SEG) + cc, s2 = blockIdx.x * 64 + c;
+    if (s2 >= a.S) break;
+    int n[BQ_SEG], first = a.N;
+#pragma unroll
+    for (int q = BQ_SEG - 1; q >= 0; --q) {
+      n[q] = cnts[q * 64 + c];
+      if (n[q] > 0) first = lists[(size_t)(q * 64 + c) * a.ns];
+    }
+    int32_t* o = a.out + ((int64_t)b * a.S + s2) * a.ns;
+    for (int j = lane; j < a.ns; j += 64) {
+      int v = first, r = j;
+#pragma unroll
+      for (int q = 0; q < BQ_SEG; ++q) {
+        if (r >= 0 && r < n[q]) v = lists[(size_t)(q * 64 + c) * a.ns + r];
+        r = r < n[q] ? -1 : r - n[q];
+      }
+      o[j] = v;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Group gather, channels-last: out[b,s,j,0:3] = xyz[b,idx]-center[b,s] (center optional), out[b,s,j,3:3+D] = feat[b,idx]
 // (model/pointnet2_utils.py:41-57,121-131). One thread per output element group of 4 channels.
@@ -750,18 +829,44 @@ extern "C" int pc3d_fps_f32(const float* xyz, int64_t x_bs, int64_t x_ps, int64_
   return PC3D_OK;
 }
 
+// kernel: 0 = choose, 1 = a wavefront per centre, 2 = a centre per lane (error when its limits are exceeded)
+static int ball_query_launch(const char* nm, int kernel, const float* xyz, int64_t x_bs, int64_t x_ps, int64_t x_cs,
+                             const float* centers, int64_t c_bs, int64_t c_ps, int64_t c_cs, int B, int N, int S,
+                             float radius, int nsample, int32_t* out, void* stream) {
+  PC3D_REQUIRE(B >= 0 && N >= 1 && S >= 1 && nsample >= 1, "%s: bad sizes B=%d N=%d S=%d ns=%d", nm, B, N, S, nsample);
+  PC3D_REQUIRE(B <= 65535, "%s: B=%d exceeds grid.y limit", nm, B);
+  const bool tile_ok = N <= 65535 && nsample <= 96;   // 16-bit hit lists of four quarters per centre: <= 57 KB of LDS
+  PC3D_REQUIRE(kernel != 2 || tile_ok, "%s: the centre-per-lane kernel needs N <= 65535 and nsample <= 96 (N=%d ns=%d)", nm,
+               N, nsample);
+  if (B == 0) return PC3D_OK;
+  PC3D_REQUIRE(xyz && centers && out, "%s: null pointer", nm);
+  BallArgs a{{xyz, x_bs, x_ps, x_cs}, {centers, c_bs, c_ps, c_cs}, N, S, nsample, radius * radius, out};
+  // the centre-per-lane kernel runs S/64 x B workgroups: it wins once those fill the chip (measured at B=32/64:
+  // 181 -> 93 us for N=4096, S=1024; 99 -> 56 us for N=2048, S=512; 20 -> 32 us for N=1024, S=256)
+  const bool tile = kernel == 2 || (kernel == 0 && tile_ok && (int64_t)cdiv(S, 64) * B >= 256);
+  if (tile)
+    hipLaunchKernelGGL(ball_query_tile_kernel, dim3(cdiv(S, 64), B), dim3(BQ_SEG * 64), ball_tile_lds(nsample),
+                       as_stream(stream), a);
+  else
+    hipLaunchKernelGGL(ball_query_kernel, dim3(cdiv(S, 4), B), dim3(256), 0, as_stream(stream), a);
+  PC3D_LAUNCH_CHECK(nm);
+  return PC3D_OK;
+}
+
 extern "C" int pc3d_ball_query_f32(const float* xyz, int64_t x_bs, int64_t x_ps, int64_t x_cs,
                                    const float* centers, int64_t c_bs, int64_t c_ps, int64_t c_cs,
                                    int B, int N, int S, float radius, int nsample, int32_t* out, void* stream) {
-  PC3D_REQUIRE(B >= 0 && N >= 1 && S >= 1 && nsample >= 1, "pc3d_ball_query_f32: bad sizes B=%d N=%d S=%d ns=%d", B, N,
-               S, nsample);
-  PC3D_REQUIRE(B <= 65535, "pc3d_ball_query_f32: B=%d exceeds grid.y limit", B);
-  if (B == 0) return PC3D_OK;
-  PC3D_REQUIRE(xyz && centers && out, "pc3d_ball_query_f32: null pointer");
-  BallArgs a{{xyz, x_bs, x_ps, x_cs}, {centers, c_bs, c_ps, c_cs}, N, S, nsample, radius * radius, out};
-  hipLaunchKernelGGL(ball_query_kernel, dim3(cdiv(S, 4), B), dim3(256), 0, as_stream(stream), a);
-  PC3D_LAUNCH_CHECK("pc3d_ball_query_f32");
-  return PC3D_OK;
+  return ball_query_launch("pc3d_ball_query_f32", 0, xyz, x_bs, x_ps, x_cs, centers, c_bs, c_ps, c_cs, B, N, S, radius,
+                           nsample, out, stream);
+}
+
+extern "C" int pc3d_ball_query_kernel_f32(int kernel, const float* xyz, int64_t x_bs, int64_t x_ps, int64_t x_cs,
+                                          const float* centers, int64_t c_bs, int64_t c_ps, int64_t c_cs, int B, int N,
+                                          int S, float radius, int nsample, int32_t* out, void* stream) {
+  PC3D_REQUIRE(kernel == 1 || kernel == 2, "pc3d_ball_query_kernel_f32: kernel=%d (1: wavefront per centre, 2: centre per lane)",
+               kernel);
+  return ball_query_launch("pc3d_ball_query_kernel_f32", kernel, xyz, x_bs, x_ps, x_cs, centers, c_bs, c_ps, c_cs, B, N, S,
+                           radius, nsample, out, stream);
 }
 
 extern "C" int pc3d_group_gather_f32(const float* xyz, int64_t x_bs, int64_t x_ps, int64_t x_cs, const float* feat,

@@ -73,6 +73,14 @@ static inline hipError_t zero_async(float* p, size_t n, hipStream_t st) {
   return hipGetLastError();
 }
 
+// Orders LDS traffic between the lanes of ONE wavefront (LDS operations of a wave complete in issue order; this only
+// stops the compiler from moving them across).
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // Wave-level reductions through DPP/ds_swizzle-backed shuffles (64 lanes).
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll

@@ -46,13 +46,6 @@ struct WalkArgs {
 __device__ __forceinline__ float readlane_f32(float v, int l) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
-// Orders LDS traffic between the lanes of ONE wavefront (LDS operations of a wave complete in issue order; this only
-// stops the compiler from moving them across).
-__device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 template <int C>
 __device__ __forceinline__ void load_row(const float* __restrict__ p, float (&r)[C]) {

@@ -919,14 +919,18 @@ def fps(xyz, npoint, start=None, cf=False):
     return out
 
 
-def ball_query(radius, nsample, xyz, new_xyz, cf=False):
-    """int32 [B,S,nsample]: first nsample in-radius indices in ascending order, padded with the first."""
+def ball_query(radius, nsample, xyz, new_xyz, cf=False, kernel=None):
+    """int32 [B,S,nsample]: first nsample in-radius indices in ascending order, padded with the first. kernel: None (the
+    library chooses by problem size), "wave" (a wavefront per centre) or "lane" (a centre per lane) — same results."""
     p, bs, ps, cs, B, N = _pts(xyz, cf, "xyz")
     c, cbs, cps, ccs, B2, S = _pts(new_xyz, cf, "new_xyz")
     out = torch.empty((B, S, nsample), dtype=torch.int32, device=xyz.device)
+    args = (p, bs, ps, cs, c, cbs, cps, ccs, B, N, S, float(radius), int(nsample), out.data_ptr(), _stream())
     with torch.cuda.device(xyz.device):
-        _lib.call("pc3d_ball_query_f32", p, bs, ps, cs, c, cbs, cps, ccs, B, N, S, float(radius), int(nsample),
-                  out.data_ptr(), _stream())
+        if kernel is None:
+            _lib.call("pc3d_ball_query_f32", *args)
+        else:
+            _lib.call("pc3d_ball_query_kernel_f32", {"wave": 1, "lane": 2}[kernel], *args)
     return out
 
 

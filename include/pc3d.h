@@ -400,6 +400,12 @@ int pc3d_fps_f32(const float* xyz, int64_t x_bs, int64_t x_ps, int64_t x_cs, int
 int pc3d_ball_query_f32(const float* xyz, int64_t x_bs, int64_t x_ps, int64_t x_cs,
                         const float* centers, int64_t c_bs, int64_t c_ps, int64_t c_cs,
                         int B, int N, int S, float radius, int nsample, int32_t* out, void* stream);
+/* The same query on a named kernel (pc3d_ball_query_f32 chooses by problem size; results are identical): kernel 1 = a
+ * wavefront per centre, 2 = a centre per lane with the cloud split over the workgroup's four wavefronts (N <= 65535,
+ * nsample <= 96). For tests and measurements. */
+int pc3d_ball_query_kernel_f32(int kernel, const float* xyz, int64_t x_bs, int64_t x_ps, int64_t x_cs,
+                               const float* centers, int64_t c_bs, int64_t c_ps, int64_t c_cs,
+                               int B, int N, int S, float radius, int nsample, int32_t* out, void* stream);
 
 /* K7  group gather, channels-last (model/pointnet2_utils.py:41-57,121-131): out[b,s,j,:] =
  * [xyz[b,idx[b,s,j]] - centers[b,s] (3, xyz may be NULL), feat[b,idx[b,s,j],:] (D, feat [B,N,D] contiguous or NULL)].

@@ -79,6 +79,28 @@ def test_ball_query_no_hit_and_padding(ops, dev):
     assert out[0, 1].tolist() == [4, 4, 4, 4]       # no hit: N, like the reference's sort leaves it
 
 
+@pytest.mark.parametrize("N,S,r,ns,cf", [(4096, 1000, 0.05, 20, False), (4096, 1024, 0.05, 20, True), (1000, 70, 0.3, 64, False),
+                                         (777, 1, 0.5, 96, True), (2048, 130, 0.4, 100, False), (300, 64, 2.0, 8, False)])
+def test_ball_query_both_kernels_equal_the_direct_form(ops, dev, N, S, r, ns, cf):
+    """The centre-per-lane kernel (nsample <= 96: quarters of the cloud per wavefront, early exit, ragged last tile of
+    centres, rows concatenated from the quarters), the wavefront-per-centre kernel and the library's choice against the oracle's
+    direct-difference form: same indices, order and padding; sparse (r = 0.05: most balls hold one point) and
+    saturated (r = 2: every ball is full after nsample points) cases, both memory layouts."""
+    g = torch.Generator().manual_seed(N + S)
+    xyz = torch.rand(2, N, 3, generator=g) - 0.5
+    ctr = xyz[:, torch.randperm(N, generator=g)[:S]].contiguous()
+    ctr[:, -1] = 7.0                                  # a centre with no point in its ball
+    exact = ort.query_ball_point(r, ns, xyz, ctr, exact=True).numpy()
+    a, c = (xyz.transpose(1, 2).contiguous(), ctr.transpose(1, 2).contiguous()) if cf else (xyz, ctr)
+    for kernel in (None, "wave") + (("lane",) if ns <= 96 else ()):
+        got = ops.ball_query(r, ns, a.to(dev), c.to(dev), cf=cf, kernel=kernel).cpu().numpy()
+        assert np.array_equal(got, exact), kernel
+        assert (got[:, -1] == N).all()
+    if ns > 96:
+        with pytest.raises(Exception, match="centre-per-lane"):
+            ops.ball_query(r, ns, a.to(dev), c.to(dev), cf=cf, kernel="lane")
+
+
 def test_sample_and_group_matches_reference(pu, dev, fx):
     for nm in fx["names"]:
         xyz = torch.from_numpy(fx[f"{nm}_xyz"]).to(dev)
