@@ -23,7 +23,9 @@ def _ref(x, w, b, act, slope):
 
 
 @pytest.mark.parametrize("M,N,K", [(1, 1, 1), (5, 40, 3), (200, 64, 3), (1000, 128, 131), (257, 130, 259), (4096, 64, 64),
-                                   (32768, 128, 64), (3000, 1024, 512), (129, 129, 33)])
+                                   (32768, 128, 64), (3000, 1024, 512), (129, 129, 33),
+                                   # few 128-row tiles, long K (CurveNet's deep levels)
+                                   (8192, 128, 256), (2048, 512, 128), (2048, 128, 512), (2050, 130, 70)])
 @pytest.mark.parametrize("act", [None, "relu", "leaky"])
 def test_gemm_values(dev, M, N, K, act):
     g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
