@@ -78,13 +78,17 @@ __device__ __forceinline__ float4 gm_load4(const float* p, int k, int K, bool ro
 
 // WM x WN waves of 64 x 64 outputs each: <2,2> = 128 x 128 tile (wide layers), <4,1> = 256 x 64 (layers with <= 64
 // outputs: no half-empty MFMA tiles, and the kernel is then bound by reading / writing the [M, 64] activations).
-template <int WM, int WN, int TM, int TN, bool DB, int OCC, int GA = 0>   // GA: generated A operand — 1: GemmArgs::ga_idx, 2: ::pb_g
-__global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_nt_kernel(GemmArgs a) {
-  constexpr int NT = WM * WN * 64;               // threads
+// KS > 1: K split INSIDE the workgroup — KS groups of WM x WN waves work on the same output tile, group g on K steps
+// g, g + KS, ...; a step stages KS slices of 32 k and the groups' accumulators are summed through LDS before the
+// epilogue. For launches with few tiles and a long K (CurveNet's deep levels): more waves per tile, not more tiles.
+template <int WM, int WN, int TM, int TN, bool DB, int OCC, int GA = 0, int KS = 1>   // GA: generated A operand — 1: GemmArgs::ga_idx, 2: ::pb_g
+__global__ __launch_bounds__(WM * WN * KS * 64, OCC) void gemm_nt_kernel(GemmArgs a) {
+  constexpr int NT = WM * WN * KS * 64;          // threads
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  constexpr int RPS = NT / 8;                    // tile rows covered by one pass of the staging threads
-  constexpr int QA = BM / RPS, QB = BN / RPS;    // float4 per thread and step of the X / W tile
-  static_assert(BM % RPS == 0 && BN % RPS == 0, "tile rows must be a multiple of the staging pass");
+  constexpr int RPS = NT / 8;                    // staged rows (tile row x K slice) covered by one pass of the staging threads
+  constexpr int QA = BM * KS / RPS, QB = BN * KS / RPS;    // float4 per thread and step of the X / W tile
+  static_assert((BM * KS) % RPS == 0 && (BN * KS) % RPS == 0, "tile rows must be a multiple of the staging pass");
+  static_assert(KS == 1 || (GA == 0 && !DB), "the K split is written for the plain single-buffered path");
   extern __shared__ __attribute__((aligned(16))) float gm_lds[];   // 2 x (As[BM][GM_LD] + Bs[BN][GM_LD])
   // XCD-aware tile order: consecutive workgroup ids land on different XCDs (round-robin dispatch), so give each XCD a
   // contiguous band of row tiles — its L2 then holds one band of X and all of W instead of a slice of everything.
@@ -101,7 +105,8 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_nt_kernel(GemmArgs a) 
   const int tm = wg / tiles_n, tn = wg - tm * tiles_n;   // column tiles of one row band are neighbours: X stays in L2
   const int m0 = tm * BM, n0 = tn * BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = (wave / WN) * (TM * 32), wn = (wave % WN) * (TN * 32);
+  const int kg = wave / (WM * WN), wv = wave - kg * (WM * WN);   // K group of this wave, its place in the tile
+  const int wm = (wv / WN) * (TM * 32), wn = (wv % WN) * (TN * 32);
   const int r = lane & 31, h = lane >> 5;
 
   gm_f32x16 acc[TM][TN];
@@ -180,6 +185,19 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_nt_kernel(GemmArgs a) 
         xa[q] = v;
         continue;
       }
+      if constexpr (KS > 1) {
+        const int sr = q * RPS + lrow, ks = sr / BM, row = m0 + (sr - ks * BM), k = k0 + ks * GM_BK + lk;
+        float4 v = gm_load4(a.X + (int64_t)row * a.ldx, k, a.K, row < a.M);
+        if (a.gate) {
+          const float4 g = gm_load4(a.gate + (int64_t)row * a.ldg, k, a.K, row < a.M);
+          v.x = g.x > 0.f ? v.x : a.gslope * v.x;
+          v.y = g.y > 0.f ? v.y : a.gslope * v.y;
+          v.z = g.z > 0.f ? v.z : a.gslope * v.z;
+          v.w = g.w > 0.f ? v.w : a.gslope * v.w;
+        }
+        xa[q] = v;
+        continue;
+      }
       float4 v = gm_load4(a.X + (int64_t)gm * a.ldx, k0 + lk, a.K, gm < a.M);
       if (a.gate) {
         const float4 g = gm_load4(a.gate + (int64_t)gm * a.ldg, k0 + lk, a.K, gm < a.M);
@@ -192,6 +210,11 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_nt_kernel(GemmArgs a) 
     }
 #pragma unroll
     for (int q = 0; q < QB; ++q) {
+      if constexpr (KS > 1) {
+        const int sr = q * RPS + lrow, ks = sr / BN, gn = n0 + (sr - ks * BN);
+        wb[q] = gm_load4(a.W + (int64_t)gn * a.K, k0 + ks * GM_BK + lk, a.K, gn < a.N);
+        continue;
+      }
       const int gn = n0 + q * RPS + lrow;
       wb[q] = gm_load4(a.W + (int64_t)gn * a.K, k0 + lk, a.K, gn < a.N);
     }
@@ -203,18 +226,19 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_nt_kernel(GemmArgs a) 
     for (int q = 0; q < QB; ++q) *reinterpret_cast<float4*>(Bs + (q * RPS + lrow) * GM_LD + lk) = wb[q];
   };
 
-  constexpr int BUF = (BM + BN) * GM_LD;
+  constexpr int BUF = (BM + BN) * KS * GM_LD;   // staged rows are (K slice, tile row): slice s of the X tile at s * BM
+  constexpr int KSTEP = GM_BK * KS;
   fetch(0);
-  stash(gm_lds, gm_lds + BM * GM_LD);
+  stash(gm_lds, gm_lds + BM * KS * GM_LD);
   __syncthreads();
   int cur = 0;
-  for (int k0 = 0; k0 < a.K; k0 += GM_BK) {
-    const bool more = k0 + GM_BK < a.K;
-    if (more) fetch(k0 + GM_BK);   // global loads in flight during this step's MFMAs
-    const float* As = gm_lds + cur * BUF;
-    const float* Bs = As + BM * GM_LD;
-    const int kleft = a.K - k0;
-    const int groups = kleft >= GM_BK ? GM_BK / 8 : (kleft + 7) / 8;   // narrow layers (K = 3) run one group, not four
+  for (int k0 = 0; k0 < a.K; k0 += KSTEP) {
+    const bool more = k0 + KSTEP < a.K;
+    if (more) fetch(k0 + KSTEP);   // global loads in flight during this step's MFMAs
+    const float* As = gm_lds + cur * BUF + kg * BM * GM_LD;
+    const float* Bs = gm_lds + cur * BUF + BM * KS * GM_LD + kg * BN * GM_LD;
+    const int kleft = a.K - k0 - kg * GM_BK;
+    const int groups = kleft >= GM_BK ? GM_BK / 8 : (kleft > 0 ? (kleft + 7) / 8 : 0);   // narrow layers (K = 3) run one group, not four
     for (int t = 0; t < groups; ++t) {
       float4 av[TM], bv[TN];
 #pragma unroll
@@ -240,8 +264,34 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void gemm_nt_kernel(GemmArgs a) 
       cur ^= 1;
     } else if (more) {
       __syncthreads();                           // everyone is done reading the tile
-      stash(gm_lds, gm_lds + BM * GM_LD);
+      stash(gm_lds, gm_lds + BM * KS * GM_LD);
       __syncthreads();
+    }
+  }
+
+  if constexpr (KS > 1) {   // sum the K groups' accumulators into group 0 (the operand tiles are dead: reuse their LDS)
+    static_assert((KS - 1) * WM * WN * TM * TN * 16 * 64 <= (BM + BN) * KS * GM_LD, "K-split partial sums must fit the operand tiles");
+    __syncthreads();
+    float* red = gm_lds + ((kg > 0 ? kg - 1 : 0) * WM * WN + wv) * (TM * TN * 16 * 64);
+    if (kg > 0) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) red[((i * TN + j) * 16 + e) * 64 + lane] = acc[i][j][e];
+    }
+    __syncthreads();
+    if (kg > 0) return;
+#pragma unroll
+    for (int g = 1; g < KS; ++g) {
+      const float* rg = gm_lds + ((g - 1) * WM * WN + wv) * (TM * TN * 16 * 64);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][j][e] += rg[((i * TN + j) * 16 + e) * 64 + lane];
     }
   }
 
@@ -366,8 +416,15 @@ static int gemm_nt_launch(const float* X, int64_t ldx, const float* W, const flo
   // the group-max epilogue is written for 128-row tiles of 32-row wave tiles; with K <= 64 (two K steps per tile) four
   // workgroups per CU instead of two hide the tile prologue better: 221 -> 203 us on SSG's SA1 (no change at K = 128)
   if (gm_ns) v = (K <= 64) ? 8 : 5;
+  // Few tiles and a long K (CurveNet's deep levels: M = B x 64 .. 256 rows, K up to 512: 16 - 64 tiles of 128 x 128 on
+  // 256 CUs, 31 - 41 us a launch): 64 x 64 tiles with the K steps split over two groups of waves (variant 11).
+  int ks = 1;
+  if (g_gemm_variant < 0 && !ga_idx && !pb_g && !gm_ns && !ymask && K >= 128 &&
+      (long)cdiv(M, 128) * cdiv(N, v == 2 ? 64 : 128) < 192)
+    v = 11;
   int bm, bn, db;
   switch (v) {
+    case 11: bm = 64, bn = 64, db = 0, ks = 2; break;
     case 1: bm = 128, bn = 128, db = 0; break;
     case 2: bm = 128, bn = 64, db = 0; break;
     case 3: bm = 256, bn = 64, db = 1; break;
@@ -380,7 +437,7 @@ static int gemm_nt_launch(const float* X, int64_t ldx, const float* W, const flo
   const long tiles = (long)cdiv(M, bm) * cdiv(N, bn);
   PC3D_REQUIRE(tiles <= 0x7fffff00L, "pc3d_gemm_nt_f32: too many tiles (%ld)", tiles);
   const int per = (int)((tiles + 7) / 8);
-  const size_t lds = (size_t)(db ? 2 : 1) * (bm + bn) * GM_LD * sizeof(float);
+  const size_t lds = (size_t)(db ? 2 : 1) * (bm + bn) * ks * GM_LD * sizeof(float);
   const dim3 grid(per * 8), block(v == 5 || v == 6 || v == 8 ? 512 : GM_T);
   hipStream_t st = as_stream(stream);
   if (ga_idx) {
@@ -405,6 +462,7 @@ static int gemm_nt_launch(const float* X, int64_t ldx, const float* W, const flo
     case 5: hipLaunchKernelGGL((gemm_nt_kernel<4, 2, 1, 2, false, 2>), grid, block, lds, st, a); break;
     case 6: hipLaunchKernelGGL((gemm_nt_kernel<4, 2, 1, 2, true, 2>), grid, block, lds, st, a); break;
     case 8: hipLaunchKernelGGL((gemm_nt_kernel<4, 2, 1, 2, false, 4>), grid, block, lds, st, a); break;
+    case 11: hipLaunchKernelGGL((gemm_nt_kernel<2, 1, 1, 2, false, 2, 0, 2>), grid, block, lds, st, a); break;
     default: hipLaunchKernelGGL((gemm_nt_kernel<2, 2, 2, 2, true, 2>), grid, block, lds, st, a); break;
   }
   PC3D_LAUNCH_CHECK("pc3d_gemm_nt_f32");
