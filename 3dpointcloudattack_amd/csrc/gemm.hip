@@ -421,10 +421,11 @@ static int gemm_nt_launch(const float* X, int64_t ldx, const float* W, const flo
   int ks = 1;
   if (g_gemm_variant < 0 && !ga_idx && !pb_g && !gm_ns && !ymask && K >= 128 &&
       (long)cdiv(M, 128) * cdiv(N, v == 2 ? 64 : 128) < 192)
-    v = 11;
+    v = ((long)cdiv(M, 64) * cdiv(N, 64) < 192 && K >= 256) ? 12 : 11;   // 12: 32 x 64 tiles, four K groups of one wave
   int bm, bn, db;
   switch (v) {
     case 11: bm = 64, bn = 64, db = 0, ks = 2; break;
+    case 12: bm = 32, bn = 64, db = 0, ks = 4; break;
     case 1: bm = 128, bn = 128, db = 0; break;
     case 2: bm = 128, bn = 64, db = 0; break;
     case 3: bm = 256, bn = 64, db = 1; break;
@@ -463,6 +464,7 @@ static int gemm_nt_launch(const float* X, int64_t ldx, const float* W, const flo
     case 6: hipLaunchKernelGGL((gemm_nt_kernel<4, 2, 1, 2, true, 2>), grid, block, lds, st, a); break;
     case 8: hipLaunchKernelGGL((gemm_nt_kernel<4, 2, 1, 2, false, 4>), grid, block, lds, st, a); break;
     case 11: hipLaunchKernelGGL((gemm_nt_kernel<2, 1, 1, 2, false, 2, 0, 2>), grid, block, lds, st, a); break;
+    case 12: hipLaunchKernelGGL((gemm_nt_kernel<1, 1, 1, 2, false, 2, 0, 4>), grid, block, lds, st, a); break;
     default: hipLaunchKernelGGL((gemm_nt_kernel<2, 2, 2, 2, true, 2>), grid, block, lds, st, a); break;
   }
   PC3D_LAUNCH_CHECK("pc3d_gemm_nt_f32");
