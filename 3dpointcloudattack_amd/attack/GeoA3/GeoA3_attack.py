@@ -16,6 +16,7 @@ import torch.nn as nn
 import torch.optim as optim
 
 from ... import graphed as _graphed
+from ... import streams as _streams
 
 from .knn_utils import knn_gather, knn_points
 from .loss_utils import (_get_kappa_adv, _get_kappa_ori, chamfer_loss, curvature_loss, hausdorff_loss, norm_l2_loss,
@@ -93,7 +94,23 @@ def _forward_step(net, pc_ori, input_curr_iter, normal_ori, ori_kappa, target, s
     """:103-183 — one forward of the victim and all loss terms; returns the reference's 10-tuple."""
     b, _, n = input_curr_iter.size()
     dev = input_curr_iter.device
+    fused_terms = input_curr_iter.is_cuda and cfg.dis_loss_type == 'CD' and cfg.uniform_loss_weight == 0
+    searches = None
+    if (fused_terms and getattr(cfg, "search_stream", True) and getattr(net, "sampling_chain_front", False)
+            and not torch.cuda.is_current_stream_capturing()):
+        # the two nearest-neighbour searches of the distance terms depend on the iterate only: beside a victim whose
+        # forward starts with a farthest-point-sampling chain (one workgroup per cloud: most of the chip idle) they run on
+        # the process-wide TERMS stream, and autograd runs their backward there too. B=32, N=4096 on CurveNet: 5.01 ->
+        # 4.85 ms per iteration; beside DGCNN (no such chain) the same move costs 2 %, hence the victim's flag.
+        main, side = torch.cuda.current_stream(dev), _streams.side_stream(dev, _streams.TERMS)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            adv_t, ori_t = input_curr_iter.permute(0, 2, 1), pc_ori.permute(0, 2, 1)
+            searches = (knn_points(adv_t, ori_t, K=1),
+                        None if cfg.is_cd_single_side else knn_points(ori_t, adv_t, K=1).dists.squeeze(-1))
     output_curr_iter = _logits_of(net(input_curr_iter))
+    if searches is not None:
+        main.wait_stream(side)
 
     if cfg.cls_loss_type == 'Margin':
         target_onehot = torch.zeros(target.size() + (cfg.classes,), device=dev)
@@ -118,13 +135,16 @@ def _forward_step(net, pc_ori, input_curr_iter, normal_ori, ori_kappa, target, s
         assert False, 'Not support such clssification loss'
 
     scale_const = scale_const.float().to(dev)
-    if input_curr_iter.is_cuda and cfg.dis_loss_type == 'CD' and cfg.uniform_loss_weight == 0:
+    if fused_terms:
         # The default configuration's terms (:139-181) assembled by ONE launch each way (pc3d_geoa3_terms_f32) from the
         # search kernels' outputs, instead of ~15 reductions / scalings and their ~20 backward launches.
         from ... import ops
-        adv_t, ori_t = input_curr_iter.permute(0, 2, 1), pc_ori.permute(0, 2, 1)
-        nn_ao = knn_points(adv_t, ori_t, K=1)
-        d_oa = None if cfg.is_cd_single_side else knn_points(ori_t, adv_t, K=1).dists.squeeze(-1)
+        if searches is not None:
+            nn_ao, d_oa = searches
+        else:
+            adv_t, ori_t = input_curr_iter.permute(0, 2, 1), pc_ori.permute(0, 2, 1)
+            nn_ao = knn_points(adv_t, ori_t, K=1)
+            d_oa = None if cfg.is_cd_single_side else knn_points(ori_t, adv_t, K=1).dists.squeeze(-1)
         if cfg.curv_loss_weight != 0:
             # DGCNN and CurveNet build the k = 20 graph of this very cloud in their forward: its first curv_loss_knn + 1
             # columns ARE the search the curvature proxy needs (same kernel, same tie rule)

@@ -20,6 +20,7 @@ class CurveNet(_FrozenFusedMixin, nn.Module):
     # FPS start draw (curvenet_util.hold_rng_position), which a hipGraph replay re-issues through consume_forward_rng.
     deterministic_forward = True
     geometry_stream = True      # FPS / ball queries / kNN graphs on a side stream beside the feature path
+    sampling_chain_front = True   # the forward starts with an FPS chain: attacks overlap their own searches with it
 
     def _blocks(self):
         return (self.cic11, self.cic12, self.cic21, self.cic22, self.cic31, self.cic32, self.cic41, self.cic42)

@@ -10,6 +10,8 @@ from .pointnet2_utils import PointNetSetAbstraction, PointNetSetAbstractionMsg, 
 
 
 class PointNet_Msg(_FrozenFusedMixin, nn.Module):
+    sampling_chain_front = True   # the forward starts with an FPS chain: attacks overlap their own searches with it
+
     def __init__(self, num_class, normal_channel=True):
         super(PointNet_Msg, self).__init__()
         in_channel = 3 if normal_channel else 0

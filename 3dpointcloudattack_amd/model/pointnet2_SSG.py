@@ -10,6 +10,8 @@ from .pointnet2_utils import PointNetSetAbstraction, geometry_chain, geometry_jo
 
 
 class PointNet_Ssg(_FrozenFusedMixin, nn.Module):
+    sampling_chain_front = True   # the forward starts with an FPS chain: attacks overlap their own searches with it
+
     def __init__(self, num_classes=40):
         super(PointNet_Ssg, self).__init__()
         self.sa1 = PointNetSetAbstraction(npoint=512, radius=0.2, nsample=32, in_channel=3, mlp=[64, 64, 128], group_all=False)

@@ -54,6 +54,7 @@ if "geoa3_curvenet" in which:
     for it in (6, 6, 6 + IT):
         cfg = _geo_cfg(iter_max_steps=it, binary_max_steps=1, npoint=N, cls_loss_type='CE', hd_loss_weight=0.1, curv_loss_weight=1.0)
         cfg.graph_victim = GRAPH
+        cfg.search_stream = os.environ.get("PC3D_GEOA3_SEARCH_STREAM", "1") != "0"
         torch.manual_seed(0); np.random.seed(0)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         ga.geoA3_attack(net, None, None, None, None, None, pcs, lab, cfg, 0, 1)
@@ -70,6 +71,7 @@ if "geoa3" in which:
     for it in (10, 10, 10 + IT):
         cfg = _geo_cfg(iter_max_steps=it, binary_max_steps=1, npoint=N, cls_loss_type='CE', hd_loss_weight=0.1, curv_loss_weight=1.0)
         cfg.graph_victim = GRAPH
+        cfg.search_stream = os.environ.get("PC3D_GEOA3_SEARCH_STREAM", "1") != "0"
         torch.manual_seed(0); np.random.seed(0)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         ga.geoA3_attack(net, None, None, None, None, None, pcs, lab, cfg, 0, 1)
