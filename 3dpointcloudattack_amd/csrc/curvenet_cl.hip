@@ -137,26 +137,40 @@ __global__ __launch_bounds__(256) void lpfa_prep_fwd_kernel(const float* __restr
 }
 
 // gx = gA - gBc;  gpts = G1^T gA + G2^T gBc   (one thread per point)
+// LP lanes per point (a power of two <= 32, chosen so that LP float4 cover a row when C <= 128): rows are read and
+// written coalesced, the three sums of a point are reduced across its lanes. (A thread per point read its row with a
+// stride of C floats between lanes and left the deep levels at 8 workgroups: 7 - 20 us a launch, eight launches per
+// CurveNet backward.)
+template <int LP>
 __global__ __launch_bounds__(256) void lpfa_prep_bwd_kernel(const float* __restrict__ gA, const float* __restrict__ gBc,
                                                             const float* __restrict__ G1, const float* __restrict__ G2,
                                                             int64_t M, int C, float* __restrict__ gx,
                                                             float* __restrict__ gpts) {
-  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (p >= M) return;
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t p = gid / LP;
+  const int l = (int)(gid % LP);
+  const bool live = p < M;                 // dead lanes stay for the shuffles below
   float s[3] = {0.f, 0.f, 0.f};
-  for (int c4 = 0; c4 < C / 4; ++c4) {
-    const float4 a = *reinterpret_cast<const float4*>(gA + p * C + 4 * c4);
-    const float4 b = *reinterpret_cast<const float4*>(gBc + p * C + 4 * c4);
-    *reinterpret_cast<float4*>(gx + p * C + 4 * c4) = make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
-    const float ae[4] = {a.x, a.y, a.z, a.w}, be[4] = {b.x, b.y, b.z, b.w};
+  if (live) {
+    for (int c4 = l; c4 < C / 4; c4 += LP) {
+      const float4 a = *reinterpret_cast<const float4*>(gA + p * C + 4 * c4);
+      const float4 b = *reinterpret_cast<const float4*>(gBc + p * C + 4 * c4);
+      *reinterpret_cast<float4*>(gx + p * C + 4 * c4) = make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
+      const float ae[4] = {a.x, a.y, a.z, a.w}, be[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int c = 4 * c4 + e;
+      for (int e = 0; e < 4; ++e) {
+        const int c = 4 * c4 + e;
 #pragma unroll
-      for (int d = 0; d < 3; ++d) s[d] += G1[c * 3 + d] * ae[e] + G2[c * 3 + d] * be[e];
+        for (int d = 0; d < 3; ++d) s[d] += G1[c * 3 + d] * ae[e] + G2[c * 3 + d] * be[e];
+      }
     }
   }
-  gpts[p * 3] = s[0], gpts[p * 3 + 1] = s[1], gpts[p * 3 + 2] = s[2];
+#pragma unroll
+  for (int o = LP / 2; o > 0; o >>= 1) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) s[d] += __shfl_xor(s[d], o, 64);
+  }
+  if (live && l == 0) gpts[p * 3] = s[0], gpts[p * 3 + 1] = s[1], gpts[p * 3 + 2] = s[2];
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -517,8 +531,18 @@ extern "C" int pc3d_lpfa_prep_bwd_f32(const float* gA, const float* gBc, const f
   PC3D_REQUIRE(M >= 0 && C >= 4 && C % 4 == 0, "pc3d_lpfa_prep_bwd_f32: bad sizes (C %% 4 == 0)");
   if (M == 0) return PC3D_OK;
   PC3D_REQUIRE(gA && gBc && G1 && G2 && gx && gpts, "pc3d_lpfa_prep_bwd_f32: null pointer");
-  hipLaunchKernelGGL(lpfa_prep_bwd_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, as_stream(stream), gA, gBc, G1,
-                     G2, M, C, gx, gpts);
+  const int c4 = C / 4, lp = c4 >= 32 ? 32 : c4 >= 16 ? 16 : c4 >= 8 ? 8 : c4 >= 4 ? 4 : c4 >= 2 ? 2 : 1;
+  const int64_t blocks = (M * lp + 255) / 256;
+  PC3D_REQUIRE(blocks <= 0x7fffffffLL, "pc3d_lpfa_prep_bwd_f32: too many elements");
+  const dim3 grid((unsigned)blocks), block(256);
+  switch (lp) {
+    case 32: hipLaunchKernelGGL(lpfa_prep_bwd_kernel<32>, grid, block, 0, as_stream(stream), gA, gBc, G1, G2, M, C, gx, gpts); break;
+    case 16: hipLaunchKernelGGL(lpfa_prep_bwd_kernel<16>, grid, block, 0, as_stream(stream), gA, gBc, G1, G2, M, C, gx, gpts); break;
+    case 8: hipLaunchKernelGGL(lpfa_prep_bwd_kernel<8>, grid, block, 0, as_stream(stream), gA, gBc, G1, G2, M, C, gx, gpts); break;
+    case 4: hipLaunchKernelGGL(lpfa_prep_bwd_kernel<4>, grid, block, 0, as_stream(stream), gA, gBc, G1, G2, M, C, gx, gpts); break;
+    case 2: hipLaunchKernelGGL(lpfa_prep_bwd_kernel<2>, grid, block, 0, as_stream(stream), gA, gBc, G1, G2, M, C, gx, gpts); break;
+    default: hipLaunchKernelGGL(lpfa_prep_bwd_kernel<1>, grid, block, 0, as_stream(stream), gA, gBc, G1, G2, M, C, gx, gpts); break;
+  }
   PC3D_LAUNCH_CHECK("pc3d_lpfa_prep_bwd_f32");
   return PC3D_OK;
 }

@@ -104,7 +104,7 @@ def test_curve_attn(ops, dev, B, N, C, cn, cl):
     assert _rel(xa.grad, xd.grad) < 1e-5 and _rel(Ka.grad, Kd.grad) < 1e-5 and _rel(Va.grad, Vd.grad) < 1e-5
 
 
-@pytest.mark.parametrize("B,N,C", [(2, 300, 16), (3, 1024, 32), (1, 50, 128)])
+@pytest.mark.parametrize("B,N,C", [(2, 300, 16), (3, 1024, 32), (1, 50, 128), (2, 77, 64), (1, 33, 256), (2, 19, 4), (1, 9, 12)])
 def test_lpfa_prep(ops, dev, B, N, C):
     g = torch.Generator().manual_seed(C + N)
     x, p = torch.randn(B, N, C, generator=g).to(dev), torch.randn(B, N, 3, generator=g).to(dev)
