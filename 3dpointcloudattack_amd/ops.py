@@ -1612,8 +1612,8 @@ class _CurveWalkFn(torch.autograd.Function):
         B, N, C = feats.shape
         k, cn = adj.shape[2], nodes.shape[1]
         g = g.contiguous()
-        gF = torch.zeros((B, N, C), dtype=torch.float32, device=g.device)
-        coef = torch.zeros((B, N), dtype=torch.float32, device=g.device)
+        acc = torch.zeros(B * N * (C + 1), dtype=torch.float32, device=g.device)     # one fill for both accumulators
+        gF, coef = acc[:B * N * C].view(B, N, C), acc[B * N * C:].view(B, N)
         ws = torch.empty(int(_lib.load().pc3d_curve_walk_bwd_ws_floats(B, cn, C)), dtype=torch.float32, device=g.device)
         with torch.cuda.device(g.device):
             _lib.call("pc3d_curve_walk_bwd_f32", g.data_ptr(), feats.data_ptr(), adj.data_ptr(), aw.data_ptr(),
