@@ -96,6 +96,11 @@ __global__ __launch_bounds__(1024) void topk_desc_kernel(const float* __restrict
   for (int i = threadIdx.x; i < npow2; i += 1024)
     tk_keys[i] = i < N ? (((unsigned long long)(~ordered_bits(score[(int64_t)b * N + i])) << 32) | (unsigned)i) : ~0ull;
   __syncthreads();
+  // A stage with partner distance j <= 64 keeps every pair of a wavefront's 64 consecutive i inside one aligned block of
+  // 128 keys, and so do the stages after it down to j = 1: those need no workgroup barrier, only the wavefront's own
+  // LDS order. A barrier follows a stage only when the NEXT stage reaches across blocks (j > 64): 6 barriers instead of
+  // 55 for 1024 keys (18.4 -> 16.3 us: the launch is one workgroup per cloud, and what is left is 55 dependent LDS
+  // round trips).
   for (int k = 2; k <= npow2; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
       for (int i = threadIdx.x; i < npow2 / 2; i += 1024) {
@@ -104,9 +109,12 @@ __global__ __launch_bounds__(1024) void topk_desc_kernel(const float* __restrict
         const unsigned long long a = tk_keys[lo], c = tk_keys[hi];
         if ((a > c) == asc) tk_keys[lo] = c, tk_keys[hi] = a;
       }
-      __syncthreads();
+      const int jn = j > 1 ? (j >> 1) : k;      // partner distance of the next stage (k: first stage of size 2k)
+      if (jn > 64) __syncthreads();
+      else wave_lds_sync();
     }
   }
+  __syncthreads();
   for (int i = threadIdx.x; i < K; i += 1024) idx[(int64_t)b * K + i] = (int32_t)(tk_keys[i] & 0xffffffffu);
 }
 
