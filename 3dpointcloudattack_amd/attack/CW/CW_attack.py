@@ -263,11 +263,12 @@ class CW:
                 logits, pred, _, gx_model = self.model.fused_loss_and_grad(adv_data.detach(), st["target"], *fml,
                                                                            scale=st["ratio"] / st["B"])
         else:
-            if (adv_data.is_cuda and getattr(self, "dist_stream", True)
+            if (adv_data.is_cuda and getattr(self, "dist_stream", True) and getattr(self.model, "sampling_chain_front", False)
                     and not torch.cuda.is_current_stream_capturing()):
-                # the distance term depends on the iterate only: it runs on the process-wide TERMS stream beside the
-                # victim's forward (whose sampling chain leaves most of the chip idle), and autograd runs its backward
-                # there too (as in attack/KNN/KNN_attack.py)
+                # the distance term depends on the iterate only: beside a victim whose forward starts with a sampling
+                # chain (most of the chip idle: CurveNet, PointNet++) it runs on the process-wide TERMS stream, and
+                # autograd runs its backward there too (as in attack/KNN/KNN_attack.py). Beside DGCNN the same move cost
+                # GeoA3 2 %, hence the victim's flag.
                 main = torch.cuda.current_stream(adv_data.device)
                 side = _streams.side_stream(adv_data.device, _streams.TERMS)
                 side.wait_stream(main)

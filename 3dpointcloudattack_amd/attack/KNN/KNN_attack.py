@@ -126,8 +126,9 @@ class CWKNN:
         # victim's forward, whose first kernels (farthest-point sampling: one workgroup per cloud) leave most of the
         # chip idle. Autograd runs each node's backward on its forward's stream, so the two backwards overlap as well.
         cur = torch.cuda.current_stream(dev) if adv_data.is_cuda else None
-        side = (_streams.side_stream(dev, _streams.TERMS) if cur is not None and getattr(self, "dist_stream", True)
-                else None)                      # ONE per process (see streams.py)
+        side = (_streams.side_stream(dev, _streams.TERMS)
+                if cur is not None and getattr(self, "dist_stream", True) and getattr(self.model, "sampling_chain_front", False)
+                else None)                      # ONE per process (see streams.py); only beside a sampling-chain victim
         for iteration in range(self.num_iter):
             if side is not None:
                 side.wait_stream(cur)
