@@ -30,7 +30,8 @@ SIGNATURES = {
     "pc3d_nn_bidir_shared_ws_bytes": [_I, _I, _I],
     "pc3d_nn_bidir_shared_f32": _PTS + _PTS + [_I, _I, _I, _P, _P, _P, _P, _P, _L, _P],
     "pc3d_gemm_nt_f32": [_P, _L, _P, _P, _P, _L, _F, _I, _I, _I, _I, _F, _P, _L, _P],
-    "pc3d_gemm_nt_res_f32": [_P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _F, _P, _L, _P],
+    "pc3d_gemm_nt_tiled_f32": [_P, _L, _P, _P, _P, _L, _F, _I, _I, _I, _I, _F, _P, _L, _I, _P],
+    "pc3d_gemm_nt_res_f32": [_P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _F, _P, _L, _I, _P],
     "pc3d_gate_f32": [_P, _P, _L, _F, _P, _P],
     "pc3d_gather_max_rows_f32": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
     "pc3d_gather_max_rows_bwd_f32": [_P, _P, _I, _I, _I, _I, _P, _P],
@@ -79,6 +80,7 @@ SIGNATURES = {
     "pc3d_adam_clip_step_f32": _PTS + _PTS + [_P, _P] + _PTS + _PTS + [_I, _I, _D, _D, _D, _D, _F, _P, _I, _P],
     "pc3d_i32_add": [_P, _I, _P],
     "pc3d_group_linear_max_f32": [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
+    "pc3d_group_linear_max_kernel_f32": [_I, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
     "pc3d_act_pool_f32": [_P, _I, _I, _I, _F, _P, _P, _P],
     "pc3d_act_pool_bwd_f32": [_P, _P, _P, _I, _I, _I, _F, _P, _P],
     "pc3d_curve_walk_fwd_f32": [_P] * 7 + [_I] * 6 + [_P] * 5 + [_P],

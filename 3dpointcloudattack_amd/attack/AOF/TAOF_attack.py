@@ -208,12 +208,12 @@ class CWTAOF:
                     for _ in range(2):
                         iterate()
                 torch.cuda.current_stream(dev).wait_stream(side)
-                with _graphed.capture_guard():
+                with _graphed.capture_guard() as keep:
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g):
                         iterate()
                 run = g.replay
-                st["graph_keep"] = (g, _graphed._cached_tensors(self.model))   # the graph points into the weight caches
+                st["graph_keep"] = (g, _graphed._cached_tensors(self.model), keep)   # the graph points into the weight caches
                 st["o_bestdist"].fill_(1e10), st["o_bestscore"].fill_(-1), st["o_bestattack"].zero_()
                 begin_step(adv0, reuse_basis=True)
             for _ in range(self.num_iter):

@@ -354,7 +354,7 @@ class CW:
         # after _make_runner (bench) or use _begin_binary_step to reset the state (attack()).
         st["adv"].grad = None
         graphs = {}
-        with _graphed.capture_guard():           # no cyclic-GC destruction of older graphs while a stream captures
+        with _graphed.capture_guard() as cap_keep:   # no cyclic-GC destruction of older graphs while a stream captures
             for n in sorted({1, min(4, max(1, unroll)), max(1, unroll)}):
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
@@ -365,7 +365,7 @@ class CW:
         victim = self.model.model if isinstance(self.model, _graphed.GraphedVictim) else self.model
         # the runner keeps the state's tensors alive, not the dict itself (st -> runner -> st would be a cycle that only
         # the cycle collector frees, at an arbitrary later time)
-        keep = [v for v in st.values() if torch.is_tensor(v)]
+        keep = [v for v in st.values() if torch.is_tensor(v)] + cap_keep
         st["graph_run"] = _GraphRunner(keep, graphs, weights=_graphed._cached_tensors(victim))
         return st["graph_run"]
 

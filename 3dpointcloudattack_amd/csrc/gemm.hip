@@ -374,13 +374,10 @@ __global__ __launch_bounds__(WM * WN * KS * 64, OCC) void gemm_nt_kernel(GemmArg
 
 using namespace pc3d;
 
-static int g_gemm_variant = -1;
-extern "C" int pc3d_gemm_nt_tune(int variant) {   // tuning hook (tools/bench_gemm.py), not part of the ABI
-  g_gemm_variant = variant;
-  return 0;
-}
-
-static int gemm_nt_launch(const float* X, int64_t ldx, const float* W, const float* bias, const float* gate, int64_t ldg,
+// variant < 0: the library chooses the tiling from (N, K) — never from M, so the fp32 summation order of an output
+// element does not depend on how many rows (clouds) share the launch; variants 11 / 12 (K split inside the workgroup:
+// a different summation order) are only ever taken on explicit request (pc3d_gemm_nt_tiled_f32).
+static int gemm_nt_launch(int variant, const float* X, int64_t ldx, const float* W, const float* bias, const float* gate, int64_t ldg,
                           float gate_slope, const float* R, int64_t ldr, int M, int N, int K, int act, float slope,
                           float* Y, int64_t ldy, void* stream, int gm_ns = 0, float* gm_out = nullptr,
                           int64_t* gm_arg = nullptr, const int32_t* ga_idx = nullptr, const float* ga_Bc = nullptr,
@@ -411,17 +408,19 @@ static int gemm_nt_launch(const float* X, int64_t ldx, const float* W, const flo
   //   0 / 1: 128x128, 4 waves of 64x64, double / single buffered     2: 128x64, 4 waves of 32x64 (N <= 64)
   //   3: 256x64, 4 waves of 64x64, double buffered                    4: 64x128, 4 waves of 32x64
   //   5 / 6: 128x128, 8 waves of 32x64, single / double buffered       8: as 5 with four workgroups per CU (<= 64 VGPRs)
-  int v = g_gemm_variant;
+  int v = variant;
+  PC3D_REQUIRE(v < 0 || v <= 6 || v == 8 || v == 11 || v == 12, "pc3d_gemm_nt_f32: unknown tile variant %d", v);
+  PC3D_REQUIRE(v < 11 || (!ga_idx && !pb_g && !gm_ns && !ymask), "pc3d_gemm_nt_f32: the K-split variants take plain operands only");
   if (v < 0 || ga_idx || pb_g) v = (N <= 64) ? 2 : 5;
   // the group-max epilogue is written for 128-row tiles of 32-row wave tiles; with K <= 64 (two K steps per tile) four
   // workgroups per CU instead of two hide the tile prologue better: 221 -> 203 us on SSG's SA1 (no change at K = 128)
   if (gm_ns) v = (K <= 64) ? 8 : 5;
   // Few tiles and a long K (CurveNet's deep levels: M = B x 64 .. 256 rows, K up to 512: 16 - 64 tiles of 128 x 128 on
-  // 256 CUs, 31 - 41 us a launch): 64 x 64 tiles with the K steps split over two groups of waves (variant 11).
+  // 256 CUs, 31 - 41 us a launch): 64 x 64 tiles with the K steps split over two groups of waves (variant 11), or
+  // 32 x 64 tiles with four K groups of one wave (variant 12). The CALLER asks for them (the host picks from the rows
+  // per cloud, see ops.gemm_nt): the K split changes the order in which an element's products are summed, and that
+  // order must not depend on the batch size.
   int ks = 1;
-  if (g_gemm_variant < 0 && !ga_idx && !pb_g && !gm_ns && !ymask && K >= 128 &&
-      (long)cdiv(M, 128) * cdiv(N, v == 2 ? 64 : 128) < 192)
-    v = ((long)cdiv(M, 64) * cdiv(N, 64) < 192 && K >= 256) ? 12 : 11;   // 12: 32 x 64 tiles, four K groups of one wave
   int bm, bn, db;
   switch (v) {
     case 11: bm = 64, bn = 64, db = 0, ks = 2; break;
@@ -475,21 +474,28 @@ static int gemm_nt_launch(const float* X, int64_t ldx, const float* W, const flo
 namespace pc3d {
 int gemm_nt_groupmax(const float* X, const float* W, const float* bias, int G, int ns, int K, int N, float* out, int64_t* arg,
                      void* stream) {
-  return gemm_nt_launch(X, K, W, bias, nullptr, 0, 0.f, nullptr, 0, G * ns, N, K, 0, 0.f, nullptr, N, stream, ns, out, arg);
+  return gemm_nt_launch(-1, X, K, W, bias, nullptr, 0, 0.f, nullptr, 0, G * ns, N, K, 0, 0.f, nullptr, N, stream, ns, out, arg);
 }
 }  // namespace pc3d
 
 extern "C" int pc3d_gemm_nt_f32(const float* X, int64_t ldx, const float* W, const float* bias, const float* gate,
                                 int64_t ldg, float gate_slope, int M, int N, int K, int act, float slope, float* Y,
                                 int64_t ldy, void* stream) {
-  return gemm_nt_launch(X, ldx, W, bias, gate, ldg, gate_slope, nullptr, 0, M, N, K, act, slope, Y, ldy, stream);
+  return gemm_nt_launch(-1, X, ldx, W, bias, gate, ldg, gate_slope, nullptr, 0, M, N, K, act, slope, Y, ldy, stream);
+}
+
+extern "C" int pc3d_gemm_nt_tiled_f32(const float* X, int64_t ldx, const float* W, const float* bias, const float* gate,
+                                      int64_t ldg, float gate_slope, int M, int N, int K, int act, float slope, float* Y,
+                                      int64_t ldy, int variant, void* stream) {
+  PC3D_REQUIRE(variant >= 0, "pc3d_gemm_nt_tiled_f32: variant %d (0-6, 8, 11, 12)", variant);
+  return gemm_nt_launch(variant, X, ldx, W, bias, gate, ldg, gate_slope, nullptr, 0, M, N, K, act, slope, Y, ldy, stream);
 }
 
 extern "C" int pc3d_gemm_nt_res_f32(const float* X, int64_t ldx, const float* W, const float* bias, const float* R,
                                     int64_t ldr, int M, int N, int K, int act, float slope, float* Y, int64_t ldy,
-                                    void* stream) {
+                                    int variant, void* stream) {
   PC3D_REQUIRE(R != nullptr, "pc3d_gemm_nt_res_f32: null residual");
-  return gemm_nt_launch(X, ldx, W, bias, nullptr, 0, 0.f, R, ldr, M, N, K, act, slope, Y, ldy, stream);
+  return gemm_nt_launch(variant < 0 ? -1 : variant, X, ldx, W, bias, nullptr, 0, 0.f, R, ldr, M, N, K, act, slope, Y, ldy, stream);
 }
 
 extern "C" int pc3d_gemm_nt_gather_f32(const float* P, int64_t ldp, const float* Bc, const int32_t* idx, int B, int NA, int S,
@@ -500,7 +506,7 @@ extern "C" int pc3d_gemm_nt_gather_f32(const float* P, int64_t ldp, const float*
   if (B == 0) return PC3D_OK;
   PC3D_REQUIRE(P && Bc && idx, "pc3d_gemm_nt_gather_f32: null pointer");
   PC3D_REQUIRE(!mask || K % 4 == 0, "pc3d_gemm_nt_gather_f32: the sign mask needs K %% 4 == 0 (K=%d)", K);
-  return gemm_nt_launch(P, ldp, W, bias, nullptr, 0, 0.f, nullptr, 0, B * S * ns, N, K, act, slope, Y, ldy, stream, 0, nullptr,
+  return gemm_nt_launch(-1, P, ldp, W, bias, nullptr, 0, 0.f, nullptr, 0, B * S * ns, N, K, act, slope, Y, ldy, stream, 0, nullptr,
                         nullptr, idx, Bc, ns, S, NA, slope_in, mask, nullptr, nullptr, 0, 0.f, ymask);
 }
 
@@ -513,6 +519,6 @@ extern "C" int pc3d_gemm_nt_poolbwd_f32(const float* Y, int64_t ldy_in, const fl
   if (B == 0) return PC3D_OK;
   PC3D_REQUIRE(Y && g && arg, "pc3d_gemm_nt_poolbwd_f32: null pointer");
   PC3D_REQUIRE(Npts % 128 == 0, "pc3d_gemm_nt_poolbwd_f32: Npts=%d must be a multiple of the 128-row tile", Npts);
-  return gemm_nt_launch(Y, ldy_in, W, nullptr, nullptr, 0, 0.f, nullptr, 0, B * Npts, N, K, 0, 0.f, dX, ldx_out, stream, 0,
+  return gemm_nt_launch(-1, Y, ldy_in, W, nullptr, nullptr, 0, 0.f, nullptr, 0, B * Npts, N, K, 0, 0.f, dX, ldx_out, stream, 0,
                         nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0.f, nullptr, g, arg, Npts, slope_pool);
 }

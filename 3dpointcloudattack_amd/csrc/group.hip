@@ -1034,14 +1034,9 @@ extern "C" int pc3d_group_act_bwd_rev_f32(const float* gH, const float* H, const
   return PC3D_OK;
 }
 
-static int g_glm_gemm = 1;
-extern "C" int pc3d_glm_tune(int use_gemm) {   // timing experiments (tools/bench_glm.py), not part of the ABI
-  g_glm_gemm = use_gemm;
-  return 0;
-}
-
-extern "C" int pc3d_group_linear_max_f32(const float* x, const float* W, const float* b, int G, int ns, int C2, int C3,
-                                         float* out, int64_t* arg, void* stream) {
+// kernel: 0 = choose, 1 = a workgroup per group, 2 = the tiled GEMM main loop with the group-max epilogue (ns = 32 / 64 / 128)
+static int group_linear_max_launch(int kernel, const float* x, const float* W, const float* b, int G, int ns, int C2, int C3,
+                                   float* out, int64_t* arg, void* stream) {
   PC3D_REQUIRE(G >= 0 && ns >= 1 && ns <= 128 && C2 >= 8 && C2 <= 128 && C2 % 8 == 0 && C3 >= 32 && C3 % 32 == 0 && C3 <= 4096,
                "pc3d_group_linear_max_f32: unsupported sizes ns=%d C2=%d C3=%d (ns <= 128, C2 %% 8 == 0 <= 128, C3 %% 32 == 0)",
                ns, C2, C3);
@@ -1049,8 +1044,9 @@ extern "C" int pc3d_group_linear_max_f32(const float* x, const float* W, const f
   PC3D_REQUIRE(x && W && b && out && arg, "pc3d_group_linear_max_f32: null pointer");
   // groups of 32 / 64 / 128 rows: the tiled GEMM main loop (operands through LDS, 128 rows share a weight tile) with a
   // group-max epilogue — measured against the one-workgroup-per-group kernel below in tools/bench_glm.py
-  if (g_glm_gemm && (ns == 32 || ns == 64 || ns == 128) && (int64_t)G * ns <= 0x7fffffff)
-    return gemm_nt_groupmax(x, W, b, G, ns, C2, C3, out, arg, stream);
+  const bool gemm_ok = (ns == 32 || ns == 64 || ns == 128) && (int64_t)G * ns <= 0x7fffffff;
+  PC3D_REQUIRE(kernel != 2 || gemm_ok, "pc3d_group_linear_max_kernel_f32: the GEMM form needs ns in {32, 64, 128} (ns=%d)", ns);
+  if (kernel != 1 && gemm_ok) return gemm_nt_groupmax(x, W, b, G, ns, C2, C3, out, arg, stream);
   GroupLinMaxArgs a{x, W, b, ns, C2, C3, out, arg};
   const int nw = cdiv(ns, 32);
   const size_t lds = nw > 1 ? (size_t)2 * nw * C3 * sizeof(float) : 0;
@@ -1059,4 +1055,15 @@ extern "C" int pc3d_group_linear_max_f32(const float* x, const float* W, const f
   else hipLaunchKernelGGL(group_linear_max_kernel<16>, dim3(G), dim3(64 * nw), lds, st, a);
   PC3D_LAUNCH_CHECK("pc3d_group_linear_max_f32");
   return PC3D_OK;
+}
+
+extern "C" int pc3d_group_linear_max_f32(const float* x, const float* W, const float* b, int G, int ns, int C2, int C3,
+                                         float* out, int64_t* arg, void* stream) {
+  return group_linear_max_launch(0, x, W, b, G, ns, C2, C3, out, arg, stream);
+}
+
+extern "C" int pc3d_group_linear_max_kernel_f32(int kernel, const float* x, const float* W, const float* b, int G, int ns,
+                                                int C2, int C3, float* out, int64_t* arg, void* stream) {
+  PC3D_REQUIRE(kernel >= 0 && kernel <= 2, "pc3d_group_linear_max_kernel_f32: kernel=%d (0 choose, 1 per group, 2 GEMM)", kernel);
+  return group_linear_max_launch(kernel, x, W, b, G, ns, C2, C3, out, arg, stream);
 }

@@ -25,9 +25,26 @@ import torch.nn as nn
 from . import streams as _streams
 
 
+_KEEP_STACK = []     # one list per capture in progress: tensors handed out by process-wide caches during it
+
+
+def note_captured(*tensors):
+    """Called by the operator layer's process-wide caches (transposed weights, search workspaces) for every tensor they
+    hand out: while a capture_guard() is open the tensors join that capture's keep-alive list, so the graph that bakes
+    their addresses in owns a reference — the cache itself may then evict the entry."""
+    if _KEEP_STACK:
+        _KEEP_STACK[-1].extend(t for t in tensors if t is not None)
+
+
+def capturing():
+    """True while a capture_guard() of this module is open (warm-up passes of a capture included)."""
+    return bool(_KEEP_STACK)
+
+
 @contextlib.contextmanager
 def capture_guard():
-    """Run a hipGraph capture with Python's cyclic garbage collector off (after one explicit collection).
+    """Run a hipGraph capture with Python's cyclic garbage collector off (after one explicit collection); yields the
+    capture's keep-alive list (see note_captured) — whoever owns the graph must hold on to it.
     A victim and its wrapper reference each other, as do an attack's state and its graph runner, so captured graphs
     die in the CYCLE collector, at whatever allocation happens to trigger it — if that is inside another capture, the
     graph's destructor runs HIP calls that are illegal while a stream is capturing and the process aborts (seen once
@@ -35,9 +52,12 @@ def capture_guard():
     was = gc.isenabled()
     gc.collect()
     gc.disable()
+    keep = []
+    _KEEP_STACK.append(keep)
     try:
-        yield
+        yield keep
     finally:
+        _KEEP_STACK.remove(keep)
         if was:
             gc.enable()
 
@@ -181,8 +201,10 @@ class GraphedVictim(nn.Module):
         times, the call they serve counts as ONE forward (its draws are re-issued by consume_forward_rng)."""
         rng = torch.get_rng_state()
         try:
-            with capture_guard():
-                return self._capture_impl(x, with_grad)
+            with capture_guard() as keep:
+                slot = self._capture_impl(x, with_grad)
+                slot.keepalive = slot.keepalive + keep     # W^T / workspace tensors the graphs point at
+                return slot
         finally:
             torch.set_rng_state(rng)
 

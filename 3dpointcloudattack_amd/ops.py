@@ -6,6 +6,7 @@ hand-written gfx950 kernels of libpc3d_hip.so. There is no CPU/eager fallback: t
 import torch
 
 from . import _lib
+from . import graphed as _graphed
 
 
 def _stream():
@@ -66,11 +67,18 @@ def _nn_workspace(dev, nbytes):
     """Scratch for pc3d_nn_bidir_shared_f32: one cached buffer per (device, stream) — work on one stream is ordered, so
     consecutive calls may reuse it; it only ever grows (a captured hipGraph keeps pointing at a buffer that stays
     alive and that later, smaller calls on the same stream still fit into)."""
+    if torch.cuda.is_current_stream_capturing():
+        # every capture runs on torch's one capture stream: a cached buffer would be baked into ALL captured graphs, and
+        # two of them replayed on different streams would race on it. A capture gets its own scratch, owned by the
+        # graph's keep-alive list (graphed.note_captured) and never entered into the cache.
+        ws = torch.empty((max(nbytes, 1 << 20),), dtype=torch.uint8, device=dev)
+        _graphed.note_captured(ws)
+        if not _graphed.capturing():
+            _NN_KEEP.append(ws)          # a capture outside capture_guard(): nobody else would own the buffer
+        return ws
     key = (dev.index if dev.index is not None else torch.cuda.current_device(), _stream())
     ws = _NN_WS.get(key)
     if ws is None or ws.numel() < nbytes:
-        if ws is not None and torch.cuda.is_current_stream_capturing():
-            _NN_KEEP.append(ws)          # an earlier capture on this stream may still point at the old buffer
         ws = torch.empty((max(nbytes, 1 << 20),), dtype=torch.uint8, device=dev)
         _NN_WS[key] = ws
     return ws
@@ -818,6 +826,7 @@ def geoa3_terms(d_ao, d_oa, k_adv, k_ori, idx_ao, cls, scale, w_dis, w_hd, w_cur
 # ------------------------------------------------------------------------------------------------------
 _ACTS = {None: 0, "none": 0, "relu": 1, "leaky": 2}
 GEMM_SMALL_M = 64
+GEMM_HEAD_MAX_M = 4096      # sample rows up to which a head runs on the small-batch kernel (32-row tiles)
 
 
 def F_leaky(y, slope):
@@ -825,6 +834,7 @@ def F_leaky(y, slope):
 
 
 _WT_CACHE = {}      # (data_ptr, version, shape) -> (w, W^T): the backward's operand; weights are frozen
+WT_CACHE_MAX = 512
 
 
 def _w_transposed(w):
@@ -836,16 +846,47 @@ def _w_transposed(w):
     key = (w.data_ptr(), w._version, tuple(w.shape))
     hit = _WT_CACHE.get(key)
     if hit is None:
-        if len(_WT_CACHE) > 512:
-            _WT_CACHE.clear()
+        while len(_WT_CACHE) >= WT_CACHE_MAX:             # oldest entry out, one at a time — never wholesale: a captured
+            _WT_CACHE.pop(next(iter(_WT_CACHE)))          # graph that used it holds its own reference (note_captured)
         hit = (w, w.t().contiguous())
         _WT_CACHE[key] = hit
+    _graphed.note_captured(hit[0], hit[1])
     return hit[1]
 
 
-def gemm_nt(x2d, w, bias=None, act=None, slope=0.0, gate=None, gate_slope=0.0, out=None):
+GEMM_NOMINAL_BATCH = 32      # clouds per launch the K-split rule below is tuned for (one GPU's share of every config)
+
+
+def _unit_rows(shape):
+    """Rows per cloud of a [B, ..., K] operand (None for a plain [M, K] matrix: no K split)."""
+    if len(shape) < 3:
+        return None
+    n = 1
+    for d in shape[1:-1]:
+        n *= int(d)
+    return n
+
+
+def gemm_variant(unit_rows, N, K):
+    """Tile variant of pc3d_gemm_nt_tiled_f32 for a layer with `unit_rows` rows per cloud: -1 (the library's default
+    tiling) or one of the K-split variants 11 / 12 for launches with few tiles and a long K (CurveNet's deep levels).
+    The K split changes the order in which an output element's products are summed, so the choice is made from the
+    PER-CLOUD shape and a nominal batch of GEMM_NOMINAL_BATCH clouds — never from the actual row count: a cloud's
+    arithmetic is the same alone, in a batch of 32 or in a shard of any size."""
+    if unit_rows is None or K < 128:
+        return -1
+    M = GEMM_NOMINAL_BATCH * unit_rows
+    cd = lambda a, b: (a + b - 1) // b
+    if cd(M, 128) * cd(N, 64 if N <= 64 else 128) >= 192:
+        return -1
+    return 12 if (cd(M, 64) * cd(N, 64) < 192 and K >= 256) else 11
+
+
+def gemm_nt(x2d, w, bias=None, act=None, slope=0.0, gate=None, gate_slope=0.0, out=None, unit_rows=None, head=False):
     """Y[M,N] = act(gate(x2d)[M,K] @ w[N,K]^T + bias) on pc3d_gemm_nt_f32 (exact fp32 MFMA). x2d / gate / out may be
-    row-strided views (last dimension contiguous)."""
+    row-strided views (last dimension contiguous). unit_rows: rows per cloud (see gemm_variant). head: the rows are
+    SAMPLES (a classifier head, [B, K]) — those go to the small-batch kernel whatever B is, so that a sample's logits
+    do not depend on the batch size it is evaluated in."""
     _check(x2d, "x")
     _check(w, "w")
     M, K = x2d.shape
@@ -854,7 +895,7 @@ def gemm_nt(x2d, w, bias=None, act=None, slope=0.0, gate=None, gate_slope=0.0, o
         raise ValueError("gemm_nt: w must be a contiguous [N,K] matrix matching x's K")
     if x2d.stride(1) != 1 or (gate is not None and (gate.stride(1) != 1 or gate.shape != x2d.shape)):
         raise ValueError("gemm_nt: x / gate need a contiguous last dimension and equal shapes")
-    if M <= GEMM_SMALL_M and K % 8 == 0 and x2d.stride(0) % 4 == 0 and out is None:
+    if head and K % 8 == 0 and x2d.stride(0) % 4 == 0 and out is None and M <= GEMM_HEAD_MAX_M:
         # a handful of rows (the classifier heads: M = batch): the 128-row tile would leave all but N/128 CUs idle and
         # walk K serially; the small-batch kernel (32 x 16 tiles, K split over the 8 waves of a workgroup) is 10-30x
         # faster there. It has ReLU in its epilogue; the LeakyReLU / the input mask of the backward are elementwise
@@ -864,10 +905,16 @@ def gemm_nt(x2d, w, bias=None, act=None, slope=0.0, gate=None, gate_slope=0.0, o
         return F_leaky(y, slope) if act == "leaky" else y
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=x2d.device)
+    variant = gemm_variant(unit_rows, N, K)
     with torch.cuda.device(x2d.device):
-        _lib.call("pc3d_gemm_nt_f32", x2d.data_ptr(), x2d.stride(0), w.data_ptr(), _ptr(bias), _ptr(gate),
-                  gate.stride(0) if gate is not None else 0, float(gate_slope), M, N, K, _ACTS[act], float(slope),
-                  out.data_ptr(), out.stride(0), _stream())
+        if variant < 0:
+            _lib.call("pc3d_gemm_nt_f32", x2d.data_ptr(), x2d.stride(0), w.data_ptr(), _ptr(bias), _ptr(gate),
+                      gate.stride(0) if gate is not None else 0, float(gate_slope), M, N, K, _ACTS[act], float(slope),
+                      out.data_ptr(), out.stride(0), _stream())
+        else:
+            _lib.call("pc3d_gemm_nt_tiled_f32", x2d.data_ptr(), x2d.stride(0), w.data_ptr(), _ptr(bias), _ptr(gate),
+                      gate.stride(0) if gate is not None else 0, float(gate_slope), M, N, K, _ACTS[act], float(slope),
+                      out.data_ptr(), out.stride(0), variant, _stream())
     return out
 
 
@@ -881,7 +928,7 @@ class _LinearActFn(torch.autograd.Function):
         x2 = x.reshape(-1, shp[-1])
         if x2.stride(1) != 1:
             x2 = x2.contiguous()
-        y = gemm_nt(x2, w, b, act, slope)
+        y = gemm_nt(x2, w, b, act, slope, unit_rows=_unit_rows(shp), head=len(shp) == 2)
         ctx.act, ctx.slope, ctx.shp = act, slope, shp
         ctx.save_for_backward(y if act in ("relu", "leaky") else None, w)
         return y.view(*shp[:-1], w.shape[0])
@@ -893,7 +940,8 @@ class _LinearActFn(torch.autograd.Function):
         if g2.stride(1) != 1:
             g2 = g2.contiguous()
         gx = gemm_nt(g2, _w_transposed(w), None, None, 0.0, gate=y,
-                     gate_slope=ctx.slope if ctx.act == "leaky" else 0.0)
+                     gate_slope=ctx.slope if ctx.act == "leaky" else 0.0, unit_rows=_unit_rows(ctx.shp),
+                     head=len(ctx.shp) == 2)
         return gx.view(ctx.shp), None, None, None, None
 
 
@@ -1099,7 +1147,7 @@ class _LinearActPoolFn(torch.autograd.Function):
     def forward(ctx, x, w, b, slope):
         B, N, K = x.shape
         C = w.shape[0]
-        Y = gemm_nt(x.reshape(B * N, K), w, b)
+        Y = gemm_nt(x.reshape(B * N, K), w, b, unit_rows=N)
         out = torch.empty((B, 2 * C), dtype=torch.float32, device=x.device)
         arg = torch.empty((B, C), dtype=torch.int32, device=x.device)
         with torch.cuda.device(x.device):
@@ -1126,7 +1174,7 @@ def linear_act_maxmean_pool(x, w, b, slope):
     Differentiable in x (see _LinearActPoolFn). C % 4 == 0; a handful of rows, or N not a multiple of 128, goes through
     the two-operator form."""
     _check(x, "x"), _check(w, "w")
-    if x.dim() != 3 or w.shape[0] % 4 or x.shape[0] * x.shape[1] <= GEMM_SMALL_M or x.shape[1] % 128:
+    if x.dim() != 3 or w.shape[0] % 4 or x.shape[1] % 128:
         return act_maxmean_pool(linear_act(x, w, b), slope)      # (the fused backward wants whole 128-row tiles per cloud)
     w = w.detach()
     return _LinearActPoolFn.apply(x.contiguous(), w if w.is_contiguous() else w.contiguous(),
@@ -1387,7 +1435,8 @@ class _LinearResActFn(torch.autograd.Function):
         y = torch.empty((M, N), dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
             _lib.call("pc3d_gemm_nt_res_f32", x2.data_ptr(), x2.stride(0), w.data_ptr(), _ptr(b), r2.data_ptr(),
-                      r2.stride(0), M, N, K, _ACTS[act], float(slope), y.data_ptr(), y.stride(0), _stream())
+                      r2.stride(0), M, N, K, _ACTS[act], float(slope), y.data_ptr(), y.stride(0),
+                      gemm_variant(_unit_rows(shp), N, K), _stream())
         ctx.act, ctx.slope, ctx.shp, ctx.rshp = act, slope, shp, r.shape
         ctx.save_for_backward(y if act in ("relu", "leaky") else None, w)
         return y.view(*shp[:-1], N)
@@ -1400,7 +1449,7 @@ class _LinearResActFn(torch.autograd.Function):
             g2 = gate(g2, y, ctx.slope if ctx.act == "leaky" else 0.0)
         elif not g2.is_contiguous():
             g2 = g2.contiguous()
-        gx = gemm_nt(g2, _w_transposed(w)) if ctx.needs_input_grad[0] else None
+        gx = gemm_nt(g2, _w_transposed(w), unit_rows=_unit_rows(ctx.shp)) if ctx.needs_input_grad[0] else None
         return (gx.view(ctx.shp) if gx is not None else None), None, None, g2.view(ctx.rshp), None, None
 
 

@@ -84,11 +84,22 @@ int pc3d_nn_bidir_shared_f32(const float* a, int64_t a_bs, int64_t a_ps, int64_t
  * ------------------------------------------------------------------------------------------------------- */
 int pc3d_gemm_nt_f32(const float* X, int64_t ldx, const float* W, const float* bias, const float* gate, int64_t ldg,
                      float gate_slope, int M, int N, int K, int act, float slope, float* Y, int64_t ldy, void* stream);
+/* The same product with an EXPLICIT tiling. pc3d_gemm_nt_f32 picks its tile shape from (N, K) alone and sums every
+ * output element's products in ascending k — its result for a row never depends on how many rows share the launch.
+ * variant: 0 / 1 128x128 tiles, 4 waves (double / single buffered); 2 128x64 (N <= 64); 3 256x64; 4 64x128; 5 / 6
+ * 128x128, 8 waves (single / double buffered); 8 as 5 with four workgroups per CU; 11: 64x64 tiles with the K steps
+ * split over two groups of waves, 12: 32x64 tiles with four K groups — for launches with few tiles and a long K
+ * (CurveNet's deep levels); the K split sums an element's products in a different (fixed) order, so a caller chooses
+ * it from per-cloud shapes, not from the batch (ops.gemm_variant). Anything else: PC3D_EINVAL. */
+int pc3d_gemm_nt_tiled_f32(const float* X, int64_t ldx, const float* W, const float* bias, const float* gate,
+                           int64_t ldg, float gate_slope, int M, int N, int K, int act, float slope, float* Y,
+                           int64_t ldy, int variant, void* stream);
 /* The same layer with a residual branch summed in before the activation:  Y = act(X . W^T + bias + R)  — the tail
  * of a CurveNet CIC block, relu(conv2(..) + shortcut) (model/curvenet_util.py:372-376). R: [M,N] row stride ldr.
  * Its backward: G = pc3d_gate_f32(dY, Y) once, then dR = G and dX = pc3d_gemm_nt_f32(G, W^T). */
 int pc3d_gemm_nt_res_f32(const float* X, int64_t ldx, const float* W, const float* bias, const float* R, int64_t ldr,
-                         int M, int N, int K, int act, float slope, float* Y, int64_t ldy, void* stream);
+                         int M, int N, int K, int act, float slope, float* Y, int64_t ldy, int variant, void* stream);
+/* (variant: < 0 = the default tiling, else as pc3d_gemm_nt_tiled_f32) */
 /* out[i] = y[i] > 0 ? g[i] : slope * g[i] over n contiguous floats (16-byte aligned buffers): the derivative of a
  * (Leaky)ReLU taken from its OUTPUT's sign, for layers whose pre-activation had more than one producer. */
 int pc3d_gate_f32(const float* g, const float* y, int64_t n, float slope, float* out, void* stream);
@@ -431,6 +442,10 @@ int pc3d_group_gather_bwd_f32(const float* g_out, const int32_t* idx, const int3
  * C2 % 8 == 0 and <= 128, C3 % 32 == 0. fp32 MFMA. */
 int pc3d_group_linear_max_f32(const float* x, const float* W, const float* b, int G, int ns, int C2, int C3,
                               float* out, int64_t* arg, void* stream);
+/* The same with the kernel named (identical results): 0 = the library chooses, 1 = a workgroup per group, 2 = the
+ * tiled GEMM main loop with a group-max epilogue (ns in {32, 64, 128} only, else PC3D_EINVAL). */
+int pc3d_group_linear_max_kernel_f32(int kernel, const float* x, const float* W, const float* b, int G, int ns, int C2,
+                                     int C3, float* out, int64_t* arg, void* stream);
 int pc3d_group_max_linear_bwd_f32(const float* gout, const float* out, const int64_t* arg, const float* W,
                                   int G, int ns, int C2, int C3, const float* xin, float* gx, void* stream);
 
