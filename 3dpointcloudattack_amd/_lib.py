@@ -34,7 +34,10 @@ SIGNATURES = {
     "pc3d_gemm_nt_res_f32": [_P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _F, _P, _L, _I, _P],
     "pc3d_gate_f32": [_P, _P, _L, _F, _P, _P],
     "pc3d_gather_max_rows_f32": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
-    "pc3d_gather_max_rows_bwd_f32": [_P, _P, _I, _I, _I, _I, _P, _P],
+    "pc3d_gather_max_rows_bwd_f32": [_P, _P, _I, _I, _I, _I, _P, _I, _P],
+    "pc3d_rev_index_i32": [_P, _I, _I, _I, _I, _P, _P, _P, _P],
+    "pc3d_rev_gather_sum_f32": [_P, _L, _P, _L, _F, _P, _P, _I, _I, _I, _I, _P, _L, _P],
+    "pc3d_scatter_rows_det_f32": [_P, _P, _L, _P, _L, _F, _I, _I, _I, _I, _P, _L, _I, _I, _P],
     "pc3d_att_scale_f32": [_P, _P, _L, _I, _P, _P, _P],
     "pc3d_att_scale_bwd_f32": [_P, _P, _P, _P, _L, _I, _P, _P],
     "pc3d_topk_desc_f32": [_P, _I, _I, _I, _P, _P],
@@ -44,10 +47,10 @@ SIGNATURES = {
     "pc3d_lpfa_prep_f32": [_P, _P, _P, _P, _P, _L, _I, _P, _P, _P],
     "pc3d_lpfa_prep_bwd_f32": [_P, _P, _P, _P, _L, _I, _P, _P, _P],
     "pc3d_kappa_f32": _PTS + _PTS + [_P, _I, _I, _I, _P, _P],
-    "pc3d_kappa_bwd_f32": _PTS + _PTS + [_P, _P, _I, _I, _I, _P, _P],
+    "pc3d_kappa_bwd_f32": _PTS + _PTS + [_P, _P, _I, _I, _I, _P, _I, _P],
     "pc3d_kappa_gather_f32": _PTS + _PTS + [_I, _P, _P, _I, _I, _I, _P, _P, _P],
     "pc3d_geoa3_record_f32": [_P, _I, _I, _I, _P, _I, _P, _P, _I, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P],
-    "pc3d_group_act_bwd_mask_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P],
+    "pc3d_group_act_bwd_mask_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _I, _P],
     "pc3d_gemm_nt_gather_f32": [_P, _L, _P, _P, _I, _I, _I, _I, _F, _P, _P, _I, _I, _I, _F, _P, _L, _P, _P, _P],
     "pc3d_group_max_linear_bwd_mask_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
     "pc3d_gemm_nt_poolbwd_f32": [_P, _L, _P, _P, _I, _I, _F, _P, _I, _I, _P, _L, _P],
@@ -57,24 +60,24 @@ SIGNATURES = {
     "pc3d_geoa3_terms_f32": [_P] * 7 + [_I, _I, _I, _F, _F, _F, _P, _P, _P],
     "pc3d_geoa3_terms_bwd_f32": [_P] * 6 + [_I, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P],
     "pc3d_lpfa_fused_f32": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _P],
-    "pc3d_lpfa_fused_bwd_f32": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _P, _P],
+    "pc3d_lpfa_fused_bwd_f32": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P, _P],
     "pc3d_estimate_normal_f32": _PTS + [_P, _I, _I, _I] + _PTS + [_P],
     "pc3d_group_act_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P],
-    "pc3d_group_act_bwd_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P],
+    "pc3d_group_act_bwd_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _I, _P],
     "pc3d_rowreduce_f32": [_P, _I, _I, _I, _I, _P, _P],
     "pc3d_nn_bwd_f32": _PTS + _PTS + [_I, _I, _I]
     + [_P, _P, _L, _L, _F] + [_P, _P, _L, _L, _F]
     + _PTS + _PTS + [_I, _P],
     "pc3d_knn_f32": _PTS + _PTS + [_I, _I, _I, _I, _P, _P, _P],
-    "pc3d_knn_bwd_f32": _PTS + _PTS + [_I, _I, _I, _I, _P, _P] + _PTS + _PTS + [_I, _P],
+    "pc3d_knn_bwd_f32": _PTS + _PTS + [_I, _I, _I, _I, _P, _P] + _PTS + _PTS + [_I, _P, _P],
     "pc3d_fps_f32": _PTS + [_I, _I, _I, _P, _P, _P],
     "pc3d_ball_query_f32": _PTS + _PTS + [_I, _I, _I, _F, _I, _P, _P],
     "pc3d_ball_query_kernel_f32": [_I] + _PTS + _PTS + [_I, _I, _I, _F, _I, _P, _P],
     "pc3d_group_gather_f32": _PTS + [_P, _I, _P] + _PTS + [_I, _I, _I, _I, _P, _P],
-    "pc3d_group_gather_bwd_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
+    "pc3d_group_gather_bwd_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "pc3d_knn_feat_f32": [_P, _I, _I, _I, _I, _P, _P],
     "pc3d_gather_max_f32": [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
-    "pc3d_gather_max_bwd_f32": [_P, _P, _I, _I, _I, _P, _P],
+    "pc3d_gather_max_bwd_f32": [_P, _P, _I, _I, _I, _P, _I, _P],
     "pc3d_graph_laplacian_f32": _PTS + [_P, _I, _I, _I, _P, _P],
     "pc3d_clip_f32": _PTS + _PTS + _PTS + [_I, _I, _I, _F] + _PTS + [_P],
     "pc3d_adam_clip_step_f32": _PTS + _PTS + [_P, _P] + _PTS + _PTS + [_I, _I, _D, _D, _D, _D, _F, _P, _I, _P],
@@ -84,17 +87,18 @@ SIGNATURES = {
     "pc3d_act_pool_f32": [_P, _I, _I, _I, _F, _P, _P, _P],
     "pc3d_act_pool_bwd_f32": [_P, _P, _P, _I, _I, _I, _F, _P, _P],
     "pc3d_curve_walk_fwd_f32": [_P] * 7 + [_I] * 6 + [_P] * 5 + [_P],
-    "pc3d_curve_walk_bwd_f32": [_P] * 7 + [_I] * 6 + [_P] * 8 + [_P],
-    "pc3d_curve_walk_bwd_ws_floats": [_I] * 3,
+    "pc3d_curve_walk_bwd_f32": [_P] * 7 + [_I] * 6 + [_P] * 8 + [_I, _P],
+    "pc3d_curve_walk_bwd_ws_floats": [_I] * 6,
     "pc3d_curve_agg_lds_bytes": [_I] * 5,
     "pc3d_curve_agg_kv_f32": [_P] * 9 + [_I] * 5 + [_P, _P, _P],
     "pc3d_curve_agg_kv_bwd_f32": [_P] * 11 + [_I] * 5 + [_P, _P],
     "pc3d_edge_act_f32": [_P, _P, _P, _I, _I, _I, _I, _F, _P, _P],
-    "pc3d_edge_act_bwd_f32": [_P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P],
+    "pc3d_edge_act_bwd_f32": [_P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _I, _P, _P, _P],
     "pc3d_act_mean_f32": [_P, _I, _I, _I, _I, _F, _P, _P],
     "pc3d_act_mean_bwd_f32": [_P, _P, _I, _I, _I, _I, _F, _P, _P],
     "pc3d_edge_max_f32": [_P, _P, _I, _I, _I, _I, _F, _P, _P, _P],
-    "pc3d_edge_max_bwd_f32": [_P, _L, _P, _P, _I, _I, _I, _F, _P, _P],
+    "pc3d_edge_max_bwd_f32": [_P, _L, _P, _P, _I, _I, _I, _F, _P, _I, _P],
+    "pc3d_edge_max_bwd_slice_f32": [_P, _L, _P, _P, _I, _I, _I, _F, _P, _I, _P],
     "pc3d_group_max_linear_bwd_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
     "pc3d_cls_tail_f32": [_P, _I, _I, _P, _P, _I, _P, _I, _F, _F, _P, _P, _P, _P, _P, _P],
     "pc3d_cw_update_f32": _PTS + _PTS + [_I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P] + _PTS + [_P, _P]

@@ -495,11 +495,13 @@ static int gather_max_launch(const char* name, const float* P, const int32_t* id
 }
 
 static int gather_max_bwd_launch(const char* name, const float* g, const int32_t* arg, int B, int N, int S, int C,
-                                 float* gP, void* stream) {
+                                 float* gP, int deterministic, void* stream) {
   PC3D_REQUIRE(B >= 0 && N >= 1 && S >= 1 && C >= 1, "%s: bad sizes", name);
   PC3D_REQUIRE(B <= 65535, "%s: B=%d exceeds grid.y limit", name, B);
   if (B == 0) return PC3D_OK;
   PC3D_REQUIRE(g && arg && gP, "%s: null pointer", name);
+  // deterministic: one wavefront per (cloud, channel slice) accumulates in LDS in source order (det.hip), no zero fill
+  if (deterministic) return arg_scatter_det(name, g, C, nullptr, arg, B, S, N, C, 0.f, gP, 0, stream);
   hipStream_t st = as_stream(stream);
   hipError_t e = zero_async(gP, (size_t)B * N * C, st);
   if (e != hipSuccess) {
@@ -518,8 +520,8 @@ extern "C" int pc3d_gather_max_f32(const float* P, const int32_t* idx, const flo
 }
 
 extern "C" int pc3d_gather_max_bwd_f32(const float* g, const int32_t* arg, int B, int N, int C, float* gP,
-                                       void* stream) {
-  return gather_max_bwd_launch("pc3d_gather_max_bwd_f32", g, arg, B, N, N, C, gP, stream);
+                                       int deterministic, void* stream) {
+  return gather_max_bwd_launch("pc3d_gather_max_bwd_f32", g, arg, B, N, N, C, gP, deterministic, stream);
 }
 
 extern "C" int pc3d_gather_max_rows_f32(const float* P, const int32_t* idx, int B, int N, int S, int C, int K, float* out,
@@ -528,8 +530,8 @@ extern "C" int pc3d_gather_max_rows_f32(const float* P, const int32_t* idx, int 
 }
 
 extern "C" int pc3d_gather_max_rows_bwd_f32(const float* g, const int32_t* arg, int B, int N, int S, int C, float* gP,
-                                            void* stream) {
-  return gather_max_bwd_launch("pc3d_gather_max_rows_bwd_f32", g, arg, B, N, S, C, gP, stream);
+                                            int deterministic, void* stream) {
+  return gather_max_bwd_launch("pc3d_gather_max_rows_bwd_f32", g, arg, B, N, S, C, gP, deterministic, stream);
 }
 
 extern "C" int pc3d_edge_max_f32(const float* PQ, const int32_t* idx, int B, int N, int C, int K, float slope,
@@ -546,11 +548,14 @@ extern "C" int pc3d_edge_max_f32(const float* PQ, const int32_t* idx, int B, int
 }
 
 extern "C" int pc3d_edge_max_bwd_f32(const float* g, int64_t ldg, const float* out, const int32_t* arg, int B, int N, int C,
-                                     float slope, float* gPQ, void* stream) {
+                                     float slope, float* gPQ, int deterministic, void* stream) {
   PC3D_REQUIRE(B >= 0 && N >= 1 && C >= 1 && ldg >= C, "pc3d_edge_max_bwd_f32: bad sizes (row stride of g smaller than C)");
   PC3D_REQUIRE(B <= 65535, "pc3d_edge_max_bwd_f32: B=%d exceeds grid.y limit", B);
   if (B == 0) return PC3D_OK;
   PC3D_REQUIRE(g && out && arg && gPQ, "pc3d_edge_max_bwd_f32: null pointer");
+  // deterministic: the LDS accumulator tile belongs to ONE wavefront, which walks the points in order (det.hip); the
+  // kernels below share a tile between four wavefronts, whose ds_add_f32 interleave differently from run to run
+  if (deterministic) return arg_scatter_det("pc3d_edge_max_bwd_f32", g, ldg, out, arg, B, N, N, C, slope, gPQ, 1, stream);
   hipStream_t st = as_stream(stream);
   const bool al = ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(arg) |
                     reinterpret_cast<uintptr_t>(gPQ)) & 15) == 0 && ldg % 4 == 0;
@@ -575,6 +580,15 @@ extern "C" int pc3d_edge_max_bwd_f32(const float* g, int64_t ldg, const float* o
                      arg, N, C, slope, gPQ);
   PC3D_LAUNCH_CHECK("pc3d_edge_max_bwd_f32");
   return PC3D_OK;
+}
+
+extern "C" int pc3d_edge_max_bwd_slice_f32(const float* g, int64_t ldg, const float* out, const int32_t* arg, int B, int N, int C,
+                                           float slope, float* gPQ, int slice, void* stream) {
+  PC3D_REQUIRE(B >= 0 && N >= 1 && C >= 1 && ldg >= C, "pc3d_edge_max_bwd_slice_f32: bad sizes (row stride of g smaller than C)");
+  PC3D_REQUIRE(B <= 65535, "pc3d_edge_max_bwd_slice_f32: B=%d exceeds grid.y limit", B);
+  if (B == 0) return PC3D_OK;
+  PC3D_REQUIRE(g && out && arg && gPQ, "pc3d_edge_max_bwd_slice_f32: null pointer");
+  return arg_scatter_det("pc3d_edge_max_bwd_slice_f32", g, ldg, out, arg, B, N, N, C, slope, gPQ, 1, stream, slice);
 }
 
 extern "C" int pc3d_act_pool_f32(const float* Y, int B, int N, int C, float slope, float* out, int32_t* arg,

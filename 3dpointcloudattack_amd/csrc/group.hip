@@ -363,6 +363,7 @@ constexpr int GAB_MAXC = 512;   // channels (<= 8 per lane)
 // output on load (that output was never stored): C/4 bytes per row instead of a second [B,S,K,C] stream. (Recomputing
 // the sign from P[idx] + Bc was measured first: 270 us against 179 us with H at SSG's SA1 — the row gather from the
 // 33 MB P misses the L2 where the H stream did not.)
+template <bool SCATTER>   // false: only gBc (the deterministic path scatters gP in a second, ordered launch: det.hip)
 __global__ __launch_bounds__(256) void group_act_bwd_kernel(const float* __restrict__ gH, const float* __restrict__ H,
                                                             const int* __restrict__ idx, int NA, int S, int K, int C,
                                                             float slope, float* __restrict__ gP,
@@ -391,6 +392,7 @@ __global__ __launch_bounds__(256) void group_act_bwd_kernel(const float* __restr
         const bool pos = H ? h[c] > 0.f : ((mrow[c >> 2] >> (c & 3)) & 1) != 0;
         const float v = pos ? g[c] : g[c] * slope;
         tot[q] += v;
+        if (!SCATTER) continue;
         if (rep) tail[q] += v;
         else if (ok) atomicAdd(dst + c, v);
       }
@@ -408,7 +410,7 @@ __global__ __launch_bounds__(256) void group_act_bwd_kernel(const float* __restr
   for (int c = threadIdx.x; c < C; c += 256) {
     gBc[((int64_t)b * S + s) * C + c] = (s_tot[c] + s_tot[C + c]) + (s_tot[2 * C + c] + s_tot[3 * C + c]);
     const float v = (s_tail[c] + s_tail[C + c]) + (s_tail[2 * C + c] + s_tail[3 * C + c]);
-    if (v != 0.f && i0_ok) atomicAdd(gP + ((int64_t)b * NA + i0) * C + c, v);
+    if (SCATTER && v != 0.f && i0_ok) atomicAdd(gP + ((int64_t)b * NA + i0) * C + c, v);
   }
 }
 
@@ -887,14 +889,47 @@ extern "C" int pc3d_group_gather_f32(const float* xyz, int64_t x_bs, int64_t x_p
   return PC3D_OK;
 }
 
+// deterministic centre term: csum[b,s,c] = - sum_j g[b,s,j,c] over the rows whose index is valid (c < 3), j ascending
+__global__ __launch_bounds__(256) void group_center_sum_kernel(const float* __restrict__ g, const int* __restrict__ idx, int N,
+                                                               int ns, int C, float* __restrict__ csum, int64_t total) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;     // over B * S * 3
+  if (t >= total) return;
+  const int c = (int)(t % 3);
+  const int64_t bs = t / 3;
+  float acc = 0.f;
+  for (int j = 0; j < ns; ++j)
+    if ((unsigned)idx[bs * ns + j] < (unsigned)N) acc += g[(bs * ns + j) * C + c];
+  csum[t] = -acc;
+}
+
 extern "C" int pc3d_group_gather_bwd_f32(const float* g_out, const int32_t* idx, const int32_t* center_idx, int B,
                                          int N, int S, int ns, int D, int has_xyz, float* grad_xyz, float* grad_feat,
-                                         void* stream) {
+                                         float* det_ws, void* stream) {
   PC3D_REQUIRE(B >= 0 && N >= 1 && S >= 1 && ns >= 1 && D >= 0, "pc3d_group_gather_bwd_f32: bad sizes");
   PC3D_REQUIRE(B <= 65535, "pc3d_group_gather_bwd_f32: B=%d exceeds grid.y limit", B);
   if (B == 0) return PC3D_OK;
   PC3D_REQUIRE(g_out && idx, "pc3d_group_gather_bwd_f32: null pointer");
   hipStream_t st = as_stream(stream);
+  if (det_ws) {
+    // deterministic (det_ws: B * S * 3 floats of scratch): every output is OVERWRITTEN by an ordered LDS scatter over
+    // the S * ns rows of a cloud (det.hip); the centre term is summed per group first and scattered on top
+    const char* nm = "pc3d_group_gather_bwd_f32";
+    PC3D_REQUIRE((int64_t)S * ns <= 0x7fffffffLL, "%s: S * ns too large", nm);
+    const int C = (has_xyz ? 3 : 0) + D;
+    if (grad_xyz && has_xyz) {
+      if (int rc = scatter_rows_det(nm, idx, g_out, C, nullptr, 0, 0.f, B, S * ns, N, 3, grad_xyz, 3, 0, 0, stream)) return rc;
+      if (center_idx) {
+        const int64_t total = (int64_t)B * S * 3;
+        hipLaunchKernelGGL(group_center_sum_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, g_out, idx, N, ns, C,
+                           det_ws, total);
+        PC3D_LAUNCH_CHECK(nm);
+        if (int rc = scatter_rows_det(nm, center_idx, det_ws, 3, nullptr, 0, 0.f, B, S, N, 3, grad_xyz, 3, 1, 0, stream)) return rc;
+      }
+    }
+    if (grad_feat && D > 0)
+      return scatter_rows_det(nm, idx, g_out + (has_xyz ? 3 : 0), C, nullptr, 0, 0.f, B, S * ns, N, D, grad_feat, D, 0, 0, stream);
+    return PC3D_OK;
+  }
   hipError_t e = hipSuccess;
   if (grad_xyz) e = zero_async(grad_xyz, (size_t)B * N * 3, st);
   if (e == hipSuccess && grad_feat) e = zero_async(grad_feat, (size_t)B * N * D, st);
@@ -954,34 +989,46 @@ extern "C" int pc3d_group_act_f32(const float* P, const float* Bc, const int32_t
 }
 
 extern "C" int pc3d_group_act_bwd_f32(const float* gH, const float* H, const int32_t* idx, int B, int NA, int S, int K,
-                                      int C, float slope, float* gP, float* gBc, void* stream) {
+                                      int C, float slope, float* gP, float* gBc, int deterministic, void* stream) {
   PC3D_REQUIRE(B >= 0 && NA >= 1 && S >= 1 && K >= 1 && C >= 1 && C <= GAB_MAXC, "pc3d_group_act_bwd_f32: bad sizes B=%d NA=%d S=%d K=%d C=%d (C <= %d)", B, NA, S, K, C, GAB_MAXC);
   PC3D_REQUIRE(B <= 65535, "pc3d_group_act_bwd_f32: B=%d exceeds grid.y limit", B);
   if (B == 0) return PC3D_OK;
   PC3D_REQUIRE(gH && H && idx && gP && gBc, "pc3d_group_act_bwd_f32: null pointer");
   hipStream_t st = as_stream(stream);
+  if (deterministic) {
+    hipLaunchKernelGGL(group_act_bwd_kernel<false>, dim3(S, B), dim3(256), (size_t)8 * C * sizeof(float), st, gH, H, idx, NA, S,
+                       K, C, slope, gP, gBc, (const uint8_t*)nullptr);
+    PC3D_LAUNCH_CHECK("pc3d_group_act_bwd_f32");
+    return scatter_rows_det("pc3d_group_act_bwd_f32", idx, gH, C, H, C, slope, B, S * K, NA, C, gP, C, 0, 0, stream);
+  }
   if (hipError_t e = zero_async(gP, (size_t)B * NA * C, st); e != hipSuccess) {
     set_error("pc3d_group_act_bwd_f32: zero fill failed: %s", hipGetErrorString(e));
     return (int)e;
   }
-  hipLaunchKernelGGL(group_act_bwd_kernel, dim3(S, B), dim3(256), (size_t)8 * C * sizeof(float), st, gH, H, idx, NA, S,
+  hipLaunchKernelGGL(group_act_bwd_kernel<true>, dim3(S, B), dim3(256), (size_t)8 * C * sizeof(float), st, gH, H, idx, NA, S,
                      K, C, slope, gP, gBc, (const uint8_t*)nullptr);
   PC3D_LAUNCH_CHECK("pc3d_group_act_bwd_f32");
   return PC3D_OK;
 }
 
 extern "C" int pc3d_group_act_bwd_mask_f32(const float* gH, const uint8_t* mask, const int32_t* idx, int B, int NA, int S,
-                                           int K, int C, float slope, float* gP, float* gBc, void* stream) {
+                                           int K, int C, float slope, float* gP, float* gBc, int deterministic, void* stream) {
   PC3D_REQUIRE(B >= 0 && NA >= 1 && S >= 1 && K >= 1 && C >= 4 && C % 4 == 0 && C <= GAB_MAXC, "pc3d_group_act_bwd_mask_f32: bad sizes B=%d NA=%d S=%d K=%d C=%d (C %% 4 == 0, C <= %d)", B, NA, S, K, C, GAB_MAXC);
   PC3D_REQUIRE(B <= 65535, "pc3d_group_act_bwd_mask_f32: B=%d exceeds grid.y limit", B);
   if (B == 0) return PC3D_OK;
   PC3D_REQUIRE(gH && mask && idx && gP && gBc, "pc3d_group_act_bwd_mask_f32: null pointer");
   hipStream_t st = as_stream(stream);
+  if (deterministic) {
+    hipLaunchKernelGGL(group_act_bwd_kernel<false>, dim3(S, B), dim3(256), (size_t)8 * C * sizeof(float), st, gH,
+                       (const float*)nullptr, idx, NA, S, K, C, slope, gP, gBc, mask);
+    PC3D_LAUNCH_CHECK("pc3d_group_act_bwd_mask_f32");
+    return scatter_rows_det("pc3d_group_act_bwd_mask_f32", idx, gH, C, nullptr, 0, slope, B, S * K, NA, C, gP, C, 0, 0, stream, mask);
+  }
   if (hipError_t e = zero_async(gP, (size_t)B * NA * C, st); e != hipSuccess) {
     set_error("pc3d_group_act_bwd_mask_f32: zero fill failed: %s", hipGetErrorString(e));
     return (int)e;
   }
-  hipLaunchKernelGGL(group_act_bwd_kernel, dim3(S, B), dim3(256), (size_t)8 * C * sizeof(float), st, gH,
+  hipLaunchKernelGGL(group_act_bwd_kernel<true>, dim3(S, B), dim3(256), (size_t)8 * C * sizeof(float), st, gH,
                      (const float*)nullptr, idx, NA, S, K, C, slope, gP, gBc, mask);
   PC3D_LAUNCH_CHECK("pc3d_group_act_bwd_mask_f32");
   return PC3D_OK;
@@ -1007,7 +1054,9 @@ extern "C" int pc3d_group_reverse_i32(const int32_t* idx, int B, int NA, int S, 
   hipLaunchKernelGGL(group_rev_scan_kernel, dim3(B), dim3(256), 0, st, cnt, NA, off);
   hipLaunchKernelGGL(group_rev_fill_kernel, dim3((unsigned)nb), dim3(256), 0, st, idx, NA, S, K, cnt, off, lst, L, total);
   PC3D_LAUNCH_CHECK("pc3d_group_reverse_i32");
-  return PC3D_OK;
+  // the fill hands out slots through integer atomics: a point's entries arrive in a different order every run. Sorted,
+  // the points pass of the backward sums them in ONE order (deterministic gradients; det.hip)
+  return sort_segments("pc3d_group_reverse_i32", off, lst, B, NA, L, stream);
 }
 
 extern "C" int pc3d_group_act_bwd_rev_f32(const float* gH, const float* H, const uint8_t* mask, const int32_t* idx,

@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void knn_bwd_r_atomic_kernel(KnnBwdArgs a) {
 }
 
 __global__ __launch_bounds__(256) void knn_bwd_r_det_kernel(KnnBwdArgs a) {
-  __shared__ int s_idx[1024];
+  __shared__ __attribute__((aligned(16))) int s_idx[1024];
   __shared__ float s_w[1024];
   const int b = blockIdx.y;
   const int j = blockIdx.x * 256 + threadIdx.x;
@@ -221,11 +221,17 @@ __global__ __launch_bounds__(256) void knn_bwd_r_det_kernel(KnnBwdArgs a) {
     }
     __syncthreads();
     const int lim = (total - t0) < 1024 ? (total - t0) : 1024;
-    for (int t = 0; t < lim; ++t) {
-      if (s_idx[t] == j) {
-        const int i = (t0 + t) / a.K;
+    // eight list entries per trip (two broadcast ds_read_b128; entries past lim hold -1): see nn_bwd_scatter_det_kernel
+    for (int t = 0; t < lim; t += 8) {
+      const int4 ia = *reinterpret_cast<const int4*>(s_idx + t), ib = *reinterpret_cast<const int4*>(s_idx + t + 4);
+      const int ii[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
+      if (!live || (ia.x != j && ia.y != j && ia.z != j && ia.w != j && ib.x != j && ib.y != j && ib.z != j && ib.w != j)) continue;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (ii[e] != j) continue;
+        const int i = (t0 + t + e) / a.K;
         const float* qp = a.q.p + (int64_t)b * a.q.bs + (int64_t)i * a.q.ps;
-        const float w = s_w[t];
+        const float w = s_w[t + e];
         gx += w * (rx - qp[0]);
         gy += w * (ry - qp[a.q.cs]);
         gz += w * (rz - qp[2 * a.q.cs]);
@@ -238,6 +244,24 @@ __global__ __launch_bounds__(256) void knn_bwd_r_det_kernel(KnnBwdArgs a) {
   }
 }
 
+// deterministic form for long lists: every edge's contribution to grad_r as a record val[b, e, 0:3] = 2 w (r_j - q_i);
+// the ordered LDS scatter of det.hip then sums the records of every reference point in edge order
+__global__ __launch_bounds__(256) void knn_bwd_r_edges_kernel(KnnBwdArgs a, float* __restrict__ val) {
+  const int t = blockIdx.x * 256 + threadIdx.x;  // over N*K
+  const int b = blockIdx.y;
+  if (t >= a.N * a.K) return;
+  const int i = t / a.K;
+  const int64_t e = (int64_t)b * a.N * a.K + t;
+  const float w = 2.f * a.w[e];
+  const int j = min(max(a.idx[e], 0), a.M - 1);
+  const float* qp = a.q.p + (int64_t)b * a.q.bs + (int64_t)i * a.q.ps;
+  const float* rp = a.r.p + (int64_t)b * a.r.bs + (int64_t)j * a.r.ps;
+  float* v = val + e * 3;
+  v[0] = w * (rp[0] - qp[0]);
+  v[1] = w * (rp[a.r.cs] - qp[a.q.cs]);
+  v[2] = w * (rp[2 * a.r.cs] - qp[2 * a.q.cs]);
+}
+
 }  // namespace pc3d
 
 using namespace pc3d;
@@ -247,7 +271,7 @@ extern "C" int pc3d_knn_bwd_f32(const float* q, int64_t q_bs, int64_t q_ps, int6
                                 int B, int N, int M, int K, const int32_t* idx, const float* w,
                                 float* grad_q, int64_t gq_bs, int64_t gq_ps, int64_t gq_cs,
                                 float* grad_r, int64_t gr_bs, int64_t gr_ps, int64_t gr_cs,
-                                int deterministic, void* stream) {
+                                int deterministic, float* det_ws, void* stream) {
   PC3D_REQUIRE(B >= 0 && N >= 1 && M >= 1 && K >= 1, "pc3d_knn_bwd_f32: bad sizes B=%d N=%d M=%d K=%d", B, N, M, K);
   PC3D_REQUIRE(B <= 65535, "pc3d_knn_bwd_f32: B=%d exceeds grid.y limit", B);
   if (B == 0) return PC3D_OK;
@@ -259,6 +283,14 @@ extern "C" int pc3d_knn_bwd_f32(const float* q, int64_t q_bs, int64_t q_ps, int6
   hipLaunchKernelGGL(knn_bwd_q_kernel, dim3(cdiv(nmax, 256), B), dim3(256), 0, st, a);
   PC3D_LAUNCH_CHECK("pc3d_knn_bwd_f32/q");
   if (grad_r) {
+    if (deterministic && det_ws && (int64_t)N * K <= 0x7fffffffLL && own_fits(M)) {
+      // records + ordered scatter (det_ws: B * N * K * 3 floats); the scan below costs N * K list entries per
+      // reference point: 575 us at B=64, N=M=2048, K=6 (the kNN attack's regulariser) against ~20 us here
+      hipLaunchKernelGGL(knn_bwd_r_edges_kernel, dim3(cdiv(N * K, 256), B), dim3(256), 0, st, a, det_ws);
+      PC3D_LAUNCH_CHECK("pc3d_knn_bwd_f32/edges");
+      return scatter_rows_det("pc3d_knn_bwd_f32", idx, det_ws, 3, nullptr, 0, 0.f, B, N * K, M, 3, grad_r, gr_ps, 0, 1, stream,
+                              nullptr, gr_bs, gr_cs);
+    }
     if (deterministic)
       hipLaunchKernelGGL(knn_bwd_r_det_kernel, dim3(cdiv(M, 256), B), dim3(256), 0, st, a);
     else

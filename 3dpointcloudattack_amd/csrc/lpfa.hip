@@ -36,6 +36,7 @@ __global__ __launch_bounds__(256) void edge_act_fwd_kernel(const float4* __restr
 
 // one thread per (point, channel): gBc = sum_j g_pre, gA[idx] += g_pre. Consecutive lanes own consecutive channels, so
 // every atomic instruction of a wave lands on whole contiguous rows (64 / C of them) instead of strided quarters.
+template <bool SCATTER>   // false: only gBc (the deterministic path scatters gA in a second, ordered launch: det.hip)
 __global__ __launch_bounds__(256) void edge_act_bwd_kernel(const float* __restrict__ gE, const float* __restrict__ E,
                                                            const int* __restrict__ idx, int N, int K, int C,
                                                            float slope, float* __restrict__ gA,
@@ -59,14 +60,14 @@ __global__ __launch_bounds__(256) void edge_act_bwd_kernel(const float* __restri
     for (int u = 0; u < 4; ++u) {
       const float v = o[u] > 0.f ? g[u] : g[u] * slope;
       acc += v;
-      atomicAdd(ga + (int64_t)min(max(r[u], 0), N - 1) * C, v);
+      if (SCATTER) atomicAdd(ga + (int64_t)min(max(r[u], 0), N - 1) * C, v);
     }
   }
   for (; j < K; ++j) {
     const float g = ge[(int64_t)j * C];
     const float v = ev[(int64_t)j * C] > 0.f ? g : g * slope;
     acc += v;
-    atomicAdd(ga + (int64_t)min(max(id[j], 0), N - 1) * C, v);
+    if (SCATTER) atomicAdd(ga + (int64_t)min(max(id[j], 0), N - 1) * C, v);
   }
   gBc[t] = acc;
 }
@@ -134,6 +135,8 @@ struct LpfaFusedArgs {
   const float* gout;   // [B,N,C]
   float* gA;           // [B,N,C] zero-filled by the entry point
   float* gBc;          // [B,N,C]
+  float* dpre;         // [B,N,K,C] or null: deterministic mode — the per-edge gradients are stored here and summed into gA
+                       // by the ordered LDS scatter of det.hip instead of being scattered with float atomics
 };
 
 template <int C>
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(256) void lpfa_fused_fwd_kernel(LpfaFusedArgs a) {
   if (i < a.N) a.out[((int64_t)b * a.N + i) * C + c] = acc * (1.f / (float)a.K);
 }
 
-template <int C>
+template <int C, bool DET>
 __global__ __launch_bounds__(256) void lpfa_fused_bwd_kernel(LpfaFusedArgs a) {
   constexpr int P = 256 / C;
   extern __shared__ __attribute__((aligned(16))) float lf_lds[];
@@ -235,7 +238,10 @@ __global__ __launch_bounds__(256) void lpfa_fused_bwd_kernel(LpfaFusedArgs a) {
       const float e = E[(int64_t)(p * a.K + j) * C + c];
       const float dpre = e > 0.f ? dE : a.s1 * dE;
       sum += dpre;
-      if (i < a.N) atomicAdd(ga + (int64_t)nbr[p * a.K + j] * C, dpre);
+      if (i < a.N) {
+        if (DET) a.dpre[(((int64_t)b * a.N + i) * a.K + j) * C + c] = dpre;
+        else atomicAdd(ga + (int64_t)nbr[p * a.K + j] * C, dpre);
+      }
     }
     if (i < a.N) a.gBc[((int64_t)b * a.N + i) * C + c] = sum;
   }
@@ -264,13 +270,23 @@ extern "C" int pc3d_edge_act_f32(const float* A, const float* Bc, const int32_t*
 }
 
 extern "C" int pc3d_edge_act_bwd_f32(const float* gE, const float* E, const int32_t* idx, int B, int N, int K, int C,
-                                     float slope, float* gA, float* gBc, void* stream) {
+                                     float slope, float* gA, float* gBc, int deterministic, const int32_t* rev_off,
+                                     const int32_t* rev_lst, void* stream) {
   LPFA_SIZES("pc3d_edge_act_bwd_f32");
   PC3D_REQUIRE(gE && E && idx && gA && gBc, "pc3d_edge_act_bwd_f32: null pointer");
   const int64_t total = (int64_t)B * N * C;
   unsigned blocks;
   if (int rc = lpfa_grid(total, &blocks, "pc3d_edge_act_bwd_f32")) return rc;
-  hipLaunchKernelGGL(edge_act_bwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), gE, E, idx, N, K, C, slope,
+  if (deterministic) {   // gBc as before; gA (overwritten: no zero fill needed) by the ordered LDS scatter over the N*K edges
+    PC3D_REQUIRE((int64_t)N * K <= 0x7fffffffLL, "pc3d_edge_act_bwd_f32: N * K too large");
+    hipLaunchKernelGGL(edge_act_bwd_kernel<false>, dim3(blocks), dim3(256), 0, as_stream(stream), gE, E, idx, N, K, C, slope,
+                       gA, gBc, total);
+    PC3D_LAUNCH_CHECK("pc3d_edge_act_bwd_f32");
+    if (rev_off && rev_lst)   // sorted reverse index of idx (pc3d_rev_index_i32, clamp = 1): every gA row gathers its edges
+      return rev_gather_sum("pc3d_edge_act_bwd_f32", gE, C, E, C, slope, rev_off, rev_lst, B, N * K, N, C, gA, C, stream);
+    return scatter_rows_det("pc3d_edge_act_bwd_f32", idx, gE, C, E, C, slope, B, N * K, N, C, gA, C, 0, 1, stream);
+  }
+  hipLaunchKernelGGL(edge_act_bwd_kernel<true>, dim3(blocks), dim3(256), 0, as_stream(stream), gE, E, idx, N, K, C, slope,
                      gA, gBc, total);
   PC3D_LAUNCH_CHECK("pc3d_edge_act_bwd_f32");
   return PC3D_OK;
@@ -311,6 +327,13 @@ static bool lpfa_fused_ok(int B, int N, int K, int C) {
     case 64: hipLaunchKernelGGL((KERNEL<64>), __VA_ARGS__); break;            \
     default: hipLaunchKernelGGL((KERNEL<128>), __VA_ARGS__); break;           \
   }
+#define PC3D_LF_DISPATCH2(KERNEL, DET, ...)                                   \
+  switch (C) {                                                                \
+    case 16: hipLaunchKernelGGL((KERNEL<16, DET>), __VA_ARGS__); break;       \
+    case 32: hipLaunchKernelGGL((KERNEL<32, DET>), __VA_ARGS__); break;       \
+    case 64: hipLaunchKernelGGL((KERNEL<64, DET>), __VA_ARGS__); break;       \
+    default: hipLaunchKernelGGL((KERNEL<128, DET>), __VA_ARGS__); break;      \
+  }
 
 extern "C" int pc3d_lpfa_fused_f32(const float* A, const float* Bc, const int32_t* idx, const float* W, const float* bias,
                                    int B, int N, int K, int C, float slope1, float slope2, float* out, void* stream) {
@@ -318,7 +341,7 @@ extern "C" int pc3d_lpfa_fused_f32(const float* A, const float* Bc, const int32_
                B, N, K, C);
   if (B == 0) return PC3D_OK;
   PC3D_REQUIRE(A && Bc && idx && W && out, "pc3d_lpfa_fused_f32: null pointer");
-  LpfaFusedArgs a{A, Bc, idx, W, nullptr, bias, N, K, slope1, slope2, out, nullptr, nullptr, nullptr};
+  LpfaFusedArgs a{A, Bc, idx, W, nullptr, bias, N, K, slope1, slope2, out, nullptr, nullptr, nullptr, nullptr};
   const int P = 256 / C;
   const size_t lds = (size_t)P * K * C * sizeof(float) + (size_t)P * K * sizeof(int);
   PC3D_LF_DISPATCH(lpfa_fused_fwd_kernel, dim3(cdiv(N, P), B), dim3(256), lds, as_stream(stream), a);
@@ -328,20 +351,29 @@ extern "C" int pc3d_lpfa_fused_f32(const float* A, const float* Bc, const int32_
 
 extern "C" int pc3d_lpfa_fused_bwd_f32(const float* gout, const float* A, const float* Bc, const int32_t* idx,
                                        const float* W, const float* Wt, const float* bias, int B, int N, int K, int C,
-                                       float slope1, float slope2, float* gA, float* gBc, void* stream) {
+                                       float slope1, float slope2, float* gA, float* gBc, float* edge_scratch,
+                                       const int32_t* rev_off, const int32_t* rev_lst, void* stream) {
   PC3D_REQUIRE(lpfa_fused_ok(B, N, K, C),
                "pc3d_lpfa_fused_bwd_f32: bad sizes B=%d N=%d K=%d C=%d (C in {16,32,64,128}, K <= 30)", B, N, K, C);
   if (B == 0) return PC3D_OK;
   PC3D_REQUIRE(gout && A && Bc && idx && W && Wt && gA && gBc, "pc3d_lpfa_fused_bwd_f32: null pointer");
   hipStream_t st = as_stream(stream);
+  LpfaFusedArgs a{A, Bc, idx, W, Wt, bias, N, K, slope1, slope2, nullptr, gout, gA, gBc, edge_scratch};
+  const int P = 256 / C;
+  const size_t lds = (size_t)2 * P * K * C * sizeof(float) + (size_t)P * K * sizeof(int);
+  if (edge_scratch) {    // deterministic: per-edge gradients to the scratch, then the ordered LDS scatter (gA overwritten)
+    PC3D_REQUIRE((int64_t)N * K <= 0x7fffffffLL, "pc3d_lpfa_fused_bwd_f32: N * K too large");
+    PC3D_LF_DISPATCH2(lpfa_fused_bwd_kernel, true, dim3(cdiv(N, P), B), dim3(256), lds, st, a);
+    PC3D_LAUNCH_CHECK("pc3d_lpfa_fused_bwd_f32");
+    if (rev_off && rev_lst)   // sorted reverse index of idx (pc3d_rev_index_i32, clamp = 1): every gA row gathers its edges
+      return rev_gather_sum("pc3d_lpfa_fused_bwd_f32", edge_scratch, C, nullptr, 0, 0.f, rev_off, rev_lst, B, N * K, N, C, gA, C, stream);
+    return scatter_rows_det("pc3d_lpfa_fused_bwd_f32", idx, edge_scratch, C, nullptr, 0, 0.f, B, N * K, N, C, gA, C, 0, 1, stream);
+  }
   if (hipError_t e = zero_async(gA, (size_t)B * N * C, st); e != hipSuccess) {
     set_error("pc3d_lpfa_fused_bwd_f32: zero fill failed: %s", hipGetErrorString(e));
     return (int)e;
   }
-  LpfaFusedArgs a{A, Bc, idx, W, Wt, bias, N, K, slope1, slope2, nullptr, gout, gA, gBc};
-  const int P = 256 / C;
-  const size_t lds = (size_t)2 * P * K * C * sizeof(float) + (size_t)P * K * sizeof(int);
-  PC3D_LF_DISPATCH(lpfa_fused_bwd_kernel, dim3(cdiv(N, P), B), dim3(256), lds, st, a);
+  PC3D_LF_DISPATCH2(lpfa_fused_bwd_kernel, false, dim3(cdiv(N, P), B), dim3(256), lds, st, a);
   PC3D_LAUNCH_CHECK("pc3d_lpfa_fused_bwd_f32");
   return PC3D_OK;
 }

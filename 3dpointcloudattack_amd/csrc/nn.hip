@@ -737,7 +737,7 @@ __global__ __launch_bounds__(256) void nn_bwd_scatter_atomic_kernel(BwdArgs args
 // scattered term, deterministic flavour: one workgroup per (b, 256 destinations); the index list of the
 // opposite side is streamed through LDS and every destination accumulates its matches in ascending order.
 __global__ __launch_bounds__(256) void nn_bwd_scatter_det_kernel(BwdArgs args) {
-  __shared__ int s_idx[1024];
+  __shared__ __attribute__((aligned(16))) int s_idx[1024];
   __shared__ float s_w[1024];
   const BwdSide& S = args.s[blockIdx.z];
   const int b = blockIdx.y;
@@ -762,10 +762,17 @@ __global__ __launch_bounds__(256) void nn_bwd_scatter_det_kernel(BwdArgs args) {
     }
     __syncthreads();
     const int lim = (S.n_self - i0) < 1024 ? (S.n_self - i0) : 1024;
-    for (int t = 0; t < lim; ++t) {
-      if (s_idx[t] == j) {
-        const float w = s_w[t];
-        const float* p = S.self.p + (int64_t)b * S.self.bs + (int64_t)(i0 + t) * S.self.ps;
+    // eight list entries per trip (two broadcast ds_read_b128): a matching entry is rare — one in n_other — so the
+    // loop is bound by how fast the list streams past, and one entry per trip paid a full LDS latency each
+    for (int t0 = 0; t0 < lim; t0 += 8) {          // (entries past lim hold -1: never equal to a live j)
+      const int4 ia = *reinterpret_cast<const int4*>(s_idx + t0), ib = *reinterpret_cast<const int4*>(s_idx + t0 + 4);
+      const int ii[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
+      if (!live || (ia.x != j && ia.y != j && ia.z != j && ia.w != j && ib.x != j && ib.y != j && ib.z != j && ib.w != j)) continue;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {                 // ascending list order: one fixed summation order
+        if (ii[e] != j) continue;
+        const float w = s_w[t0 + e];
+        const float* p = S.self.p + (int64_t)b * S.self.bs + (int64_t)(i0 + t0 + e) * S.self.ps;
         gx += w * (ox - p[0]);
         gy += w * (oy - p[S.self.cs]);
         gz += w * (oz - p[2 * S.self.cs]);

@@ -210,6 +210,61 @@ __global__ __launch_bounds__(1024) void kappa_bwd_slab_kernel(KappaArgs a) {
   for (int i = threadIdx.x; i < a.N; i += 1024) gb[3 * i] = acc[i];
 }
 
+// The slab form made DETERMINISTIC: every wavefront of the workgroup accumulates into its OWN slab (ds_add_f32 of one
+// wave execute in issue order, same-address lanes of one instruction in a fixed lane order), wave w walks the contiguous
+// range of points [w N / W, (w+1) N / W), and the W slabs are combined in ascending w. LDS: (3 + W) N floats.
+template <int W>
+__global__ __launch_bounds__(64 * W) void kappa_bwd_det_kernel(KappaArgs a) {
+  extern __shared__ float kd_lds[];
+  float* xs = kd_lds;                 // [3][N]
+  float* slabs = kd_lds + 3 * a.N;    // [W][N]
+  const int d = blockIdx.x, b = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const float* xb = a.x.p + (int64_t)b * a.x.bs;
+  for (int t = threadIdx.x; t < 3 * a.N; t += 64 * W) {
+    const int c = t / a.N, i = t - c * a.N;
+    xs[t] = xb[(int64_t)i * a.x.ps + (int64_t)c * a.x.cs];
+  }
+  for (int t = threadIdx.x; t < W * a.N; t += 64 * W) slabs[t] = 0.f;
+  __syncthreads();
+  float* acc = slabs + wave * a.N;
+  const int per = (a.N + W - 1) / W, lo = wave * per, hi = min(lo + per, a.N);
+  const float inv_k = 1.f / (float)(a.K1 - 1);
+  for (int i = lo + lane; i < hi; i += 64) {
+    const float* ni = a.nrm.p + (int64_t)b * a.nrm.bs + (int64_t)i * a.nrm.ps;
+    const float nx = ni[0], ny = ni[a.nrm.cs], nz = ni[2 * a.nrm.cs];
+    const float nd = d == 0 ? nx : (d == 1 ? ny : nz);
+    const float px = xs[i], py = xs[a.N + i], pz = xs[2 * a.N + i];
+    const int32_t* nb = a.idx + ((int64_t)b * a.N + i) * a.K1;
+    const float g = a.gout[(int64_t)b * a.N + i] * inv_k;
+    float own = 0.f;
+    for (int k = 1; k < a.K1; ++k) {
+      const int j = min(max(nb[k], 0), a.N - 1);
+      const float dx = xs[j] - px, dy = xs[a.N + j] - py, dz = xs[2 * a.N + j] - pz;
+      const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
+      const bool clamped = !(nrm > 1e-12f);
+      const float len = clamped ? 1e-12f : nrm;
+      const float vx = dx / len, vy = dy / len, vz = dz / len;
+      const float dot = vx * nx + vy * ny + vz * nz;
+      const float sg = dot > 0.f ? g : (dot < 0.f ? -g : 0.f);
+      const float c = clamped ? 0.f : dot;
+      const float vd = d == 0 ? vx : (d == 1 ? vy : vz);
+      const float gk = sg * (nd - vd * c) / len;
+      own += gk;
+      atomicAdd(acc + j, gk);          // wave-private slab
+    }
+    atomicAdd(acc + i, -own);
+  }
+  __syncthreads();
+  float* gb = a.gx + (int64_t)b * a.N * 3 + d;
+  for (int i = threadIdx.x; i < a.N; i += 64 * W) {
+    float s = slabs[i];
+#pragma unroll
+    for (int w = 1; w < W; ++w) s += slabs[w * a.N + i];
+    gb[3 * i] = s;
+  }
+}
+
 }  // namespace pc3d
 
 using namespace pc3d;
@@ -255,13 +310,34 @@ extern "C" int pc3d_kappa_gather_f32(const float* x, int64_t x_bs, int64_t x_ps,
 
 extern "C" int pc3d_kappa_bwd_f32(const float* x, int64_t x_bs, int64_t x_ps, int64_t x_cs, const float* nrm,
                                   int64_t n_bs, int64_t n_ps, int64_t n_cs, const int32_t* idx, const float* gout, int B,
-                                  int N, int K1, float* gx, void* stream) {
+                                  int N, int K1, float* gx, int deterministic, void* stream) {
   PC3D_REQUIRE(B >= 0 && N >= 1 && K1 >= 2, "pc3d_kappa_bwd_f32: bad sizes B=%d N=%d K1=%d", B, N, K1);
   PC3D_REQUIRE(B <= 65535, "pc3d_kappa_bwd_f32: B=%d exceeds grid.y limit", B);
   if (B == 0) return PC3D_OK;
   PC3D_REQUIRE(x && nrm && idx && gout && gx, "pc3d_kappa_bwd_f32: null pointer");
   hipStream_t st = as_stream(stream);
   KappaArgs a{{x, x_bs, x_ps, x_cs}, {nrm, n_bs, n_ps, n_cs}, idx, N, K1, nullptr, gout, gx};
+  if (deterministic) {
+    // per-wave slabs: 4 waves while (3 + 4) N floats fit the default 64 KB window, else 2, else 1 with the window raised
+    const int W = (size_t)7 * N * sizeof(float) <= 64 * 1024 ? 4 : ((size_t)5 * N * sizeof(float) <= 160 * 1024 ? 2 : 1);
+    const size_t lds = (size_t)(3 + W) * N * sizeof(float);
+    PC3D_REQUIRE(lds <= 160 * 1024, "pc3d_kappa_bwd_f32: N=%d does not fit a CU's LDS (deterministic mode)", N);
+    if (W == 4) {
+      hipLaunchKernelGGL(kappa_bwd_det_kernel<4>, dim3(3, B), dim3(256), lds, st, a);
+    } else {
+      auto* kern = W == 2 ? kappa_bwd_det_kernel<2> : kappa_bwd_det_kernel<1>;
+      if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+          set_error("pc3d_kappa_bwd_f32: LDS opt-in failed: %s", hipGetErrorString(e));
+          return (int)e;
+        }
+      }
+      hipLaunchKernelGGL(kern, dim3(3, B), dim3(64 * W), lds, st, a);
+    }
+    PC3D_LAUNCH_CHECK("pc3d_kappa_bwd_f32");
+    return PC3D_OK;
+  }
   if (N <= kKappaSlabMaxN) {
     hipLaunchKernelGGL(kappa_bwd_slab_kernel, dim3(3, B), dim3(1024), (size_t)N * 4 * sizeof(float), st, a);
     PC3D_LAUNCH_CHECK("pc3d_kappa_bwd_f32");

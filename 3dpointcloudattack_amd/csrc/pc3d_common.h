@@ -13,6 +13,22 @@ void set_error(const char* fmt, ...);
 int gemm_nt_groupmax(const float* X, const float* W, const float* bias, int G, int ns, int K, int N, float* out, int64_t* arg,
                      void* stream);
 
+// det.hip: deterministic scatter-adds (one wavefront owns an LDS accumulator tile and walks the records in order)
+//   out[b, tgt[b,r], c] (+)= sum_r mask(val[b,r,c])      — tgt [B,R], val [B,R,ldv], act [B,R,lda] or null
+int scatter_rows_det(const char* nm, const int32_t* tgt, const float* val, int64_t ldv, const float* act, int64_t lda, float slope,
+                     int B, int R, int N, int C, float* out, int64_t ldo, int accumulate, int clamp, void* stream,
+                     const uint8_t* mbits = nullptr,   // mbits [B,R,C/4]: the activation's sign as bits instead of `act`
+                     int64_t out_bs = 0, int64_t out_cs = 1);   // batch / channel strides of out (0: N * ldo)
+//   dst[b, arg[b,i,c], c] += w[b,i,c]  (mode 0: w = g; mode 1: w = g * leaky'(outv), dst = [dP | dQ] with dQ = w)
+int arg_scatter_det(const char* nm, const float* g, int64_t ldg, const float* outv, const int32_t* arg, int B, int S, int N, int C,
+                    float slope, float* dst, int mode, void* stream, int slice = 0);
+// ascending in-place sort of every segment of a CSR list (off [B,NA+1], lst [B,L]): arrival order -> a fixed order
+int sort_segments(const char* nm, const int32_t* off, int32_t* lst, int B, int NA, int64_t L, void* stream);
+// out[b,t,:] = sum over the sorted reverse-index segment of t (off [B,NA+1], lst [B,E]) of mask(val[b,e,:])
+int rev_gather_sum(const char* nm, const float* val, int64_t ldv, const float* act, int64_t lda, float slope, const int32_t* off,
+                   const int32_t* lst, int B, int E, int NA, int C, float* out, int64_t ldo, void* stream);
+bool own_fits(int N);   // N destination rows fit the LDS tile of the owner-wave kernels
+
 // Element strides of a [B, n_points, 3] fp32 point set in caller memory.
 struct PtsView {
   const float* p;

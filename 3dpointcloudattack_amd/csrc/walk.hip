@@ -41,6 +41,15 @@ struct WalkArgs {
   float* gfeats;         // [B,N,C] (accumulated)
   float* coef;           // [B,N]   (accumulated)
   float* ws;             // pc3d_curve_walk_bwd_ws_floats(B, cn, C) floats of scratch
+  // deterministic mode (rec_rt != null): instead of float atomics the steps RECORD their contributions —
+  //   rows : rec_rt [B, cn (L+1)] target row, rec_rv [B, cn (L+1), C] value   (record (c, s) at c L + s; the start
+  //          row of curve c at cn L + c)
+  //   coefs: rec_ct [B, cn L k] target row, rec_cv [B, cn L k] scalar
+  // — and the entry point sums them in record order with the ordered LDS scatter of det.hip.
+  int* rec_rt;
+  float* rec_rv;
+  int* rec_ct;
+  float* rec_cv;
 };
 
 __device__ __forceinline__ float readlane_f32(float v, int l) {
@@ -263,9 +272,19 @@ __global__ __launch_bounds__(kWalkWaves * 64) void curve_walk_bwd_step_kernel(Wa
   for (int ch = 0; ch < C; ++ch) gy += Gc[ch] * nb[ch];
   const float t = group_sum<G>(act ? y * gy : 0.f);
   const float gsc = act ? y * (gy - t) * d : 0.f;  // softmax backward, then through the (constant) factor d
-  if (valid && act) atomicAdd(coef + idx, gsc);
   const int prow = __shfl(idx, sub * G + jstar, 64);
-  if (valid && gl < C) atomicAdd(gF + (long)prow * C + gl, gc_l);
+  const long rrec = (long)b * cn * (a.L + 1) + (long)cc * a.L + s;      // this (curve, step)'s row record
+  if (a.rec_rt) {
+    if (valid && act) {
+      const long cr = (((long)b * cn + cc) * a.L + s) * a.k + gl;
+      a.rec_ct[cr] = idx, a.rec_cv[cr] = gsc;
+    }
+    if (valid && gl == 0) a.rec_rt[rrec] = prow;
+    if (valid && gl < C) a.rec_rv[rrec * C + gl] = gc_l;
+  } else {
+    if (valid && act) atomicAdd(coef + idx, gsc);
+    if (valid && gl < C) atomicAdd(gF + (long)prow * C + gl, gc_l);
+  }
   const float S = group_sum<G>(gsc);
   float gp = 0.f;
   if (gl < C) gp = gp_l + S * a.aw[C + gl];  // total gradient with respect to pre_s
@@ -277,8 +296,12 @@ __global__ __launch_bounds__(kWalkWaves * 64) void curve_walk_bwd_step_kernel(Wa
     walk_momentum(a, b, cc, s, &m0, &m1);
     if (valid && gl == 0) gMw[2 * cc] = g0, gMw[2 * cc + 1] = g1;
     if (valid && gl < C) Gcg[gl] = gp * m0, Gpg[gl] = gp * m1;  // direct terms of d pre_s / d cur_{s-1}, d pre_{s-1}
+  } else if (a.rec_rt) {                      // pre_0 is the start row
+    const long srec = (long)b * cn * (a.L + 1) + (long)cn * a.L + cc;
+    if (valid && gl == 0) a.rec_rt[srec] = node;
+    if (valid && gl < C) a.rec_rv[srec * C + gl] = gp;
   } else if (valid && gl < C) {
-    atomicAdd(gF + (long)node * C + gl, gp);  // pre_0 is the start row
+    atomicAdd(gF + (long)node * C + gl, gp);
   }
 }
 
@@ -327,7 +350,7 @@ extern "C" int pc3d_curve_walk_fwd_f32(const float* feats, const int32_t* adj, c
                                        int32_t* nodes, int32_t* pick, float* pre, float* mom, void* stream) {
   PC3D_REQUIRE(start != nullptr, "pc3d_curve_walk_fwd_f32: null start");
   pc3d::WalkArgs a{feats, adj, start, agent_w, agent_b, mom_w, mom_b, B, N, k, cn, L, curves, nodes, pick, pre, mom,
-                   nullptr, nullptr, nullptr, nullptr};
+                   nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   return pc3d::walk_dispatch(false, a, C, stream);
 }
 
@@ -336,15 +359,34 @@ extern "C" int pc3d_curve_walk_bwd_f32(const float* gcurves, const float* feats,
                                        const float* mom_b, int B, int N, int C, int k, int cn, int L,
                                        const float* curves, const int32_t* nodes, const int32_t* pick,
                                        const float* pre, const float* mom, float* gfeats, float* coef, float* ws,
-                                       void* stream) {
+                                       int deterministic, void* stream) {
   PC3D_REQUIRE(gcurves && gfeats && coef && ws, "pc3d_curve_walk_bwd_f32: null gradient / workspace pointer");
   pc3d::WalkArgs a{feats, adj, nullptr, agent_w, agent_b, mom_w, mom_b, B, N, k, cn, L,
                    const_cast<float*>(curves), const_cast<int32_t*>(nodes), const_cast<int32_t*>(pick),
-                   const_cast<float*>(pre), const_cast<float*>(mom), gcurves, gfeats, coef, ws};
-  return pc3d::walk_dispatch(true, a, C, stream);
+                   const_cast<float*>(pre), const_cast<float*>(mom), gcurves, gfeats, coef, ws,
+                   nullptr, nullptr, nullptr, nullptr};
+  if (!deterministic) return pc3d::walk_dispatch(true, a, C, stream);
+  // deterministic: the record arrays live behind the running-gradient scratch (pc3d_curve_walk_bwd_ws_floats with
+  // deterministic = 1 sizes them); gfeats and coef are OVERWRITTEN (no zero fill needed)
+  PC3D_REQUIRE(B > 0 && cn > 0 && L > 0 && k >= 1 && C >= 1, "pc3d_curve_walk_bwd_f32: empty problem");
+  const int64_t nrow = (int64_t)cn * (L + 1), ncoef = (int64_t)cn * L * k;
+  PC3D_REQUIRE(nrow <= 0x7fffffffLL && ncoef <= 0x7fffffffLL, "pc3d_curve_walk_bwd_f32: too many curve records");
+  float* p = ws + 2 * (int64_t)B * cn * C + 4 * (int64_t)B * cn;
+  a.rec_rv = p, p += (int64_t)B * nrow * C;
+  a.rec_cv = p, p += (int64_t)B * ncoef;
+  a.rec_rt = reinterpret_cast<int*>(p), p += (int64_t)B * nrow;
+  a.rec_ct = reinterpret_cast<int*>(p);
+  if (int rc = pc3d::walk_dispatch(true, a, C, stream)) return rc;
+  if (int rc = pc3d::scatter_rows_det("pc3d_curve_walk_bwd_f32", a.rec_rt, a.rec_rv, C, nullptr, 0, 0.f, B, (int)nrow, N, C, gfeats,
+                                      C, 0, 1, stream))
+    return rc;
+  return pc3d::scatter_rows_det("pc3d_curve_walk_bwd_f32", a.rec_ct, a.rec_cv, 1, nullptr, 0, 0.f, B, (int)ncoef, N, 1, coef, 1, 0,
+                                1, stream);
 }
 
-extern "C" int64_t pc3d_curve_walk_bwd_ws_floats(int B, int cn, int C) {
-  if (B < 0 || cn < 0 || C < 0) return -1;
-  return 2 * (int64_t)B * cn * C + 4 * (int64_t)B * cn;
+extern "C" int64_t pc3d_curve_walk_bwd_ws_floats(int B, int cn, int C, int L, int k, int deterministic) {
+  if (B < 0 || cn < 0 || C < 0 || L < 0 || k < 0) return -1;
+  int64_t n = 2 * (int64_t)B * cn * C + 4 * (int64_t)B * cn;
+  if (deterministic) n += (int64_t)B * cn * (L + 1) * (C + 1) + 2 * (int64_t)B * cn * L * k;
+  return n;
 }

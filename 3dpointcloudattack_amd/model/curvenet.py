@@ -56,7 +56,7 @@ class CurveNet(_FrozenFusedMixin, nn.Module):
         self.dp1 = nn.Dropout(p=0.5)
         self._folded_cache = None
 
-    def _geometry(self, pos):
+    def _geometry(self, pos, with_grad=False):
         """Everything in a forward that depends on the COORDINATES only — the FPS chain, the ball queries of the
         down-sampling blocks and the kNN graph of every resolution (curvenet_util.py:69-113, :10-17) — for detached
         pos [B,N,3], on the current stream: one (pool, graph, event) entry per block. FPS is a chain of npoint dependent
@@ -76,6 +76,10 @@ class CurveNet(_FrozenFusedMixin, nn.Module):
             if key not in graphs:
                 idx = ops.knn_raw(pts, pts, blk.k + 1)[1]
                 graphs[key] = (idx, idx[:, :, 1:].contiguous(), idx[:, :, :blk.k].contiguous())
+                if with_grad:
+                    # the LPFA blocks of this resolution gather through the first k columns; their deterministic backward
+                    # gathers back through the sorted reverse index, built here once per graph, off the feature path
+                    ops.attach_rev_index(graphs[key][2], pts.shape[1])
             ev = torch.cuda.Event()
             ev.record()
             levels.append((pool, graphs[key], ev))
@@ -87,14 +91,15 @@ class CurveNet(_FrozenFusedMixin, nn.Module):
         pos = xyz.float().transpose(1, 2).contiguous()
         blocks = self._blocks()
         cur = torch.cuda.current_stream()
+        with_grad = torch.is_grad_enabled() and xyz.requires_grad
         with torch.no_grad():
             if self.geometry_stream:
                 side = _streams.side_stream(pos.device, _streams.GEOMETRY)      # ONE per process (see streams.py)
                 side.wait_stream(cur)
                 with torch.cuda.stream(side):
-                    levels = self._geometry(pos.detach())
+                    levels = self._geometry(pos.detach(), with_grad)
             else:
-                levels = self._geometry(pos.detach())
+                levels = self._geometry(pos.detach(), with_grad)
         feats = self.lpfa(None, pos, None, cl=True)
         _graphed.note_input_knn(self, xyz, self.lpfa.__dict__.get("_last_idx"))   # the input cloud's graph: attacks may reuse it
         for blk, geo in zip(blocks, levels):

@@ -372,6 +372,8 @@ class CIC(nn.Module):
         pd = pts.detach()
         idx = ops.knn_raw(pd, pd, self.k + 1)[1]
         g = (idx, idx[:, :, 1:].contiguous(), idx[:, :, :self.k].contiguous())
+        if torch.is_grad_enabled() and pts.requires_grad:
+            ops.attach_rev_index(g[2], pts.shape[1])     # shared by the LPFA blocks of this resolution (deterministic backward)
         if cache is not None:
             cache[(id(pts), self.k)] = (pts, g)
         return g

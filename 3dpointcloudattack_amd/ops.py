@@ -3,10 +3,40 @@
 PyTorch is plumbing here (device memory, streams, autograd graph); all arithmetic of these ops runs in the
 hand-written gfx950 kernels of libpc3d_hip.so. There is no CPU/eager fallback: tensors must live on the GPU.
 """
+import contextlib
+import os
+
 import torch
 
 from . import _lib
 from . import graphed as _graphed
+
+# Deterministic gradients (default): every backward that scatters through an index (kNN graphs, ball-query groups,
+# arg-max routes) sums in a fixed order — one wavefront owns the LDS accumulator (csrc/det.hip) or gathers through a
+# sorted reverse index — instead of float atomics whose order changes from run to run. Same seed => the same
+# adversarial cloud, bit for bit: run == run, hipGraph replay == eager, a cloud in a batch == the cloud alone.
+# PC3D_DETERMINISTIC=0 (or ops.set_deterministic(False)) selects the float-atomic kernels of rounds 1-2.
+DETERMINISTIC = os.environ.get("PC3D_DETERMINISTIC", "1") != "0"
+
+
+def set_deterministic(on):
+    """Process-wide switch between the ordered and the float-atomic backward kernels; returns the previous value."""
+    global DETERMINISTIC
+    was, DETERMINISTIC = DETERMINISTIC, bool(on)
+    return was
+
+
+@contextlib.contextmanager
+def deterministic(on=True):
+    was = set_deterministic(on)
+    try:
+        yield
+    finally:
+        set_deterministic(was)
+
+
+def _det(flag=None):
+    return 1 if (DETERMINISTIC if flag is None else flag) else 0
 
 
 def _stream():
@@ -158,7 +188,7 @@ def _nn_bwd(a, a_cf, b, b_cf, iA, wA, sA, iB, wB, sB, need_a, need_b, determinis
     with torch.cuda.device(a.device):
         _lib.call("pc3d_nn_bwd_f32", ap, abs_, aps, acs, bp, bbs, bps, bcs, B, N, M,
                   _ptr(iA), *wview(wA), float(sA), _ptr(iB), *wview(wB), float(sB),
-                  *gview(ga, a_cf), *gview(gb, b_cf), 1 if deterministic else 0, _stream())
+                  *gview(ga, a_cf), *gview(gb, b_cf), _det(deterministic), _stream())
     return ga, gb
 
 
@@ -189,7 +219,7 @@ class _NNBidirFn(torch.autograd.Function):
         return ga, gb, None, None, None
 
 
-def nn_bidir(a, b, a_cf=False, b_cf=False, deterministic=False):
+def nn_bidir(a, b, a_cf=False, b_cf=False, deterministic=None):
     """Differentiable bidirectional NN: returns (dA [B,N], dB [B,M], iA, iB)."""
     return _NNBidirFn.apply(a, b, a_cf, b_cf, deterministic)
 
@@ -237,7 +267,7 @@ class _SetDistFn(torch.autograd.Function):
         return ga, gb, None, None, None, None
 
 
-def set_distance(a, b, reduce="mean", a_cf=False, b_cf=False, deterministic=False):
+def set_distance(a, b, reduce="mean", a_cf=False, b_cf=False, deterministic=None):
     """(loss_a2b [B], loss_b2a [B]) — squared Chamfer (reduce='mean') or Hausdorff (reduce='max') terms."""
     return _SetDistFn.apply(a, b, a_cf, b_cf, reduce, deterministic)
 
@@ -462,13 +492,14 @@ class _KnnFn(torch.autograd.Function):
         _, _, _, _, _, M = _pts(r, r_cf, "r")
         gq = torch.empty(q.shape, dtype=torch.float32, device=q.device) if need_q else None
         gr = torch.empty(r.shape, dtype=torch.float32, device=r.device) if need_r else None
+        ws = torch.empty((B, N * K, 3), dtype=torch.float32, device=q.device) if (_det(det) and need_r) else None
         with torch.cuda.device(q.device):
             _lib.call("pc3d_knn_bwd_f32", *_pv(q, q_cf, "q"), *_pv(r, r_cf, "r"), B, N, M, K, idx.data_ptr(),
-                      gd.data_ptr(), *_pv(gq, q_cf, "gq"), *_pv(gr, r_cf, "gr"), 1 if det else 0, _stream())
+                      gd.data_ptr(), *_pv(gq, q_cf, "gq"), *_pv(gr, r_cf, "gr"), _det(det), _ptr(ws), _stream())
         return gq, gr, None, None, None, None
 
 
-def knn(q, r, K, q_cf=False, r_cf=False, deterministic=False):
+def knn(q, r, K, q_cf=False, r_cf=False, deterministic=None):
     """Differentiable K-NN: (dists [B,N,K], idx [B,N,K] int32). For self-kNN pass the same tensor twice
     (autograd sums the two gradient roles)."""
     return _KnnFn.apply(q, r, K, q_cf, r_cf, deterministic)
@@ -647,7 +678,7 @@ class _KappaFn(torch.autograd.Function):
         gx = torch.empty((B, N, 3), dtype=torch.float32, device=pts.device)
         with torch.cuda.device(pts.device):
             _lib.call("pc3d_kappa_bwd_f32", p, bs, ps, cs, n, nbs, nps, ncs, idx.data_ptr(), g.data_ptr(), B, N,
-                      idx.shape[2], gx.data_ptr(), _stream())
+                      idx.shape[2], gx.data_ptr(), _det(), _stream())
         return (gx.transpose(1, 2) if ctx.cf else gx), None, None, None
 
 
@@ -684,7 +715,7 @@ class _KappaGatherFn(torch.autograd.Function):
         gx = torch.empty((B, N, 3), dtype=torch.float32, device=pts.device)
         with torch.cuda.device(pts.device):
             _lib.call("pc3d_kappa_bwd_f32", p, bs, ps, cs, n, nbs, nps, ncs, idx.data_ptr(), g.data_ptr(), B, N,
-                      idx.shape[2], gx.data_ptr(), _stream())
+                      idx.shape[2], gx.data_ptr(), _det(), _stream())
         return gx.transpose(1, 2), None, None, None
 
 
@@ -1015,11 +1046,12 @@ class _GroupGatherFn(torch.autograd.Function):
         if need_c and center_idx is None:
             # centres are an independent tensor: their gradient is minus the group sums
             gc = -g[..., :3].sum(dim=2)
+        det_ws = torch.empty((B, S, 3), dtype=torch.float32, device=g.device) if _det() else None
         with torch.cuda.device(g.device):
             _lib.call("pc3d_group_gather_bwd_f32", g.data_ptr(), idx.data_ptr(),
                       _ptr(center_idx) if (has_c and center_idx is not None) else 0, B, N, S, ns, D,
                       1 if has_x else 0, _ptr(gx) if need_x or (need_c and center_idx is not None) else 0, _ptr(gf),
-                      _stream())
+                      _ptr(det_ws), _stream())
         return (gx if need_x else None), gf, None, gc, None
 
 
@@ -1055,7 +1087,7 @@ class _GroupActFn(torch.autograd.Function):
         gBc = torch.empty((B, S, C), dtype=torch.float32, device=H.device)
         with torch.cuda.device(H.device):
             _lib.call("pc3d_group_act_bwd_f32", gH.data_ptr(), H.data_ptr(), idx.data_ptr(), B, NA, S, K, C, slope,
-                      gP.data_ptr(), gBc.data_ptr(), _stream())
+                      gP.data_ptr(), gBc.data_ptr(), _det(), _stream())
         return gP, gBc, None, None
 
 
@@ -1104,7 +1136,7 @@ class _GatherMaxFn(torch.autograd.Function):
         B, N, C = g.shape
         gP = torch.empty_like(g)
         with torch.cuda.device(g.device):
-            _lib.call("pc3d_gather_max_bwd_f32", g.data_ptr(), arg.data_ptr(), B, N, C, gP.data_ptr(), _stream())
+            _lib.call("pc3d_gather_max_bwd_f32", g.data_ptr(), arg.data_ptr(), B, N, C, gP.data_ptr(), _det(), _stream())
         return gP, None
 
 
@@ -1213,7 +1245,7 @@ class _EdgeMaxFn(torch.autograd.Function):
         gPQ = torch.empty((B, N, 2 * C), dtype=torch.float32, device=g.device)
         with torch.cuda.device(g.device):
             _lib.call("pc3d_edge_max_bwd_f32", g.data_ptr(), g.stride(1), out.data_ptr(), arg.data_ptr(), B, N, C,
-                      ctx.slope, gPQ.data_ptr(), _stream())
+                      ctx.slope, gPQ.data_ptr(), _det(), _stream())
         return gPQ, None, None
 
 
@@ -1229,30 +1261,67 @@ def edge_max(PQ, idx, slope=0.2):
 # ------------------------------------------------------------------------------------------------------
 # K17: CurveNet local point-feature aggregation (edge activation, activation + neighbour mean)
 # ------------------------------------------------------------------------------------------------------
+def rev_index(idx, NA, clamp=True):
+    """Sorted reverse index of a gather through idx [B, ...] int32 (flattened per cloud to E entries, values in [0, NA)):
+    (off [B,NA+1], lst [B,E]) with lst[b, off[b,t]:off[b,t+1]] = the entries that read row t, ascending. The
+    deterministic backward of the gather sums through it (pc3d_rev_gather_sum_f32)."""
+    if idx.dtype != torch.int32 or not idx.is_cuda:
+        raise ValueError("rev_index: idx must be an int32 GPU tensor")
+    idx = idx.contiguous()
+    B = idx.shape[0]
+    E = idx[0].numel()
+    dev = idx.device
+    cnt = torch.empty((B, NA), dtype=torch.int32, device=dev)
+    off = torch.empty((B, NA + 1), dtype=torch.int32, device=dev)
+    lst = torch.empty((B, E), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.call("pc3d_rev_index_i32", idx.data_ptr(), B, E, int(NA), 1 if clamp else 0, cnt.data_ptr(), off.data_ptr(),
+                  lst.data_ptr(), _stream())
+    return off, lst
+
+
+def attach_rev_index(idx, NA):
+    """Build the sorted reverse index of a neighbour graph once, where the graph is built (a victim's geometry stream),
+    and hang it on the tensor: every operator that later gathers through this idx object (lpfa_fused, edge_act) finds
+    it there instead of building its own. No-op outside deterministic mode."""
+    if DETERMINISTIC and getattr(idx, "_pc3d_rev", None) is None:
+        idx._pc3d_rev = rev_index(idx, NA)
+    return idx
+
+
+def _rev_of(idx, NA, needs_grad):
+    """The reverse index an operator's deterministic backward will gather through, or None."""
+    if not (DETERMINISTIC and needs_grad and torch.is_grad_enabled()):
+        return None
+    rev = getattr(idx, "_pc3d_rev", None)
+    return rev if rev is not None else rev_index(idx, NA)
+
+
 class _EdgeActFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, A, Bc, idx, slope):
+    def forward(ctx, A, Bc, idx, slope, rev_off, rev_lst):
         B, N, C = A.shape
         K = idx.shape[2]
         E = torch.empty((B, N, K, C), dtype=torch.float32, device=A.device)
         with torch.cuda.device(A.device):
             _lib.call("pc3d_edge_act_f32", A.data_ptr(), Bc.data_ptr(), idx.data_ptr(), B, N, K, C, float(slope),
                       E.data_ptr(), _stream())
-        ctx.save_for_backward(E, idx)
+        ctx.save_for_backward(E, idx, rev_off, rev_lst)
         ctx.slope = float(slope)
         return E
 
     @staticmethod
     def backward(ctx, gE):
-        E, idx = ctx.saved_tensors
+        E, idx, rev_off, rev_lst = ctx.saved_tensors
         B, N, K, C = E.shape
         gE = gE.contiguous()
-        gA = torch.zeros((B, N, C), dtype=torch.float32, device=E.device)
+        det = 1 if (_det() or rev_off is not None) else 0
+        gA = (torch.empty if det else torch.zeros)((B, N, C), dtype=torch.float32, device=E.device)
         gBc = torch.empty((B, N, C), dtype=torch.float32, device=E.device)
         with torch.cuda.device(E.device):
             _lib.call("pc3d_edge_act_bwd_f32", gE.data_ptr(), E.data_ptr(), idx.data_ptr(), B, N, K, C, ctx.slope,
-                      gA.data_ptr(), gBc.data_ptr(), _stream())
-        return gA, gBc, None, None
+                      gA.data_ptr(), gBc.data_ptr(), det, _ptr(rev_off), _ptr(rev_lst), _stream())
+        return gA, gBc, None, None, None, None
 
 
 def edge_act(A, Bc, idx, slope=0.2):
@@ -1261,7 +1330,8 @@ def edge_act(A, Bc, idx, slope=0.2):
     _check(A, "A"), _check(Bc, "Bc")
     if A.shape != Bc.shape or A.shape[2] % 4 or idx.dtype != torch.int32 or idx.shape[:2] != A.shape[:2]:
         raise ValueError("edge_act: A, Bc [B,N,C] with C % 4 == 0 and idx [B,N,K] int32 expected")
-    return _EdgeActFn.apply(A.contiguous(), Bc.contiguous(), idx.contiguous(), slope)
+    rev = _rev_of(idx, A.shape[1], A.requires_grad)
+    return _EdgeActFn.apply(A.contiguous(), Bc.contiguous(), idx.contiguous(), slope, *(rev or (None, None)))
 
 
 class _ActMeanFn(torch.autograd.Function):
@@ -1300,27 +1370,30 @@ LPFA_FUSED_MAX_K = 30
 
 class _LpfaFusedFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, A, Bc, idx, W, b, s1, s2):
+    def forward(ctx, A, Bc, idx, W, b, s1, s2, rev_off, rev_lst):
         B, N, C = A.shape
         out = torch.empty_like(A)
         with torch.cuda.device(A.device):
             _lib.call("pc3d_lpfa_fused_f32", A.data_ptr(), Bc.data_ptr(), idx.data_ptr(), W.data_ptr(), _ptr(b), B, N,
                       idx.shape[2], C, float(s1), float(s2), out.data_ptr(), _stream())
-        ctx.save_for_backward(A, Bc, idx, W, b)
+        ctx.save_for_backward(A, Bc, idx, W, b, rev_off, rev_lst)
         ctx.slopes = (float(s1), float(s2))
         return out
 
     @staticmethod
     def backward(ctx, g):
-        A, Bc, idx, W, b = ctx.saved_tensors
+        A, Bc, idx, W, b, rev_off, rev_lst = ctx.saved_tensors
         B, N, C = A.shape
         g = g.contiguous()
         gA, gBc = torch.empty_like(A), torch.empty_like(A)
+        # deterministic: the per-edge gradients [B,N,K,C] go through memory and are summed in edge order (csrc/det.hip)
+        det = _det() or rev_off is not None
+        scratch = torch.empty((B, N, idx.shape[2], C), dtype=torch.float32, device=A.device) if det else None
         with torch.cuda.device(A.device):
             _lib.call("pc3d_lpfa_fused_bwd_f32", g.data_ptr(), A.data_ptr(), Bc.data_ptr(), idx.data_ptr(), W.data_ptr(),
                       _w_transposed(W).data_ptr(), _ptr(b), B, N, idx.shape[2], C, ctx.slopes[0], ctx.slopes[1],
-                      gA.data_ptr(), gBc.data_ptr(), _stream())
-        return gA, gBc, None, None, None, None, None
+                      gA.data_ptr(), gBc.data_ptr(), _ptr(scratch), _ptr(rev_off), _ptr(rev_lst), _stream())
+        return gA, gBc, None, None, None, None, None, None, None
 
 
 def lpfa_fused_supported(C, Cout, K):
@@ -1337,8 +1410,10 @@ def lpfa_fused(A, Bc, idx, W, b, slope1=0.2, slope2=0.2):
             or W.shape != (C, C):
         raise ValueError("lpfa_fused: A, Bc [B,N,C] (C in 16/32/64/128), idx int32 [B,N,K<=30], W [C,C] expected")
     W = W.detach().contiguous().float()
+    rev = _rev_of(idx, N, A.requires_grad or Bc.requires_grad)
     return _LpfaFusedFn.apply(A.contiguous(), Bc.contiguous(), idx.contiguous(), W,
-                              b.detach().contiguous().float() if b is not None else None, slope1, slope2)
+                              b.detach().contiguous().float() if b is not None else None, slope1, slope2,
+                              *(rev or (None, None)))
 
 
 def h2d(t, device, dtype=None):
@@ -1483,7 +1558,8 @@ class _GatherMaxRowsFn(torch.autograd.Function):
         B, S, C = g.shape
         gP = torch.empty((B, ctx.N, C), dtype=torch.float32, device=g.device)
         with torch.cuda.device(g.device):
-            _lib.call("pc3d_gather_max_rows_bwd_f32", g.data_ptr(), arg.data_ptr(), B, ctx.N, S, C, gP.data_ptr(), _stream())
+            _lib.call("pc3d_gather_max_rows_bwd_f32", g.data_ptr(), arg.data_ptr(), B, ctx.N, S, C, gP.data_ptr(), _det(),
+                      _stream())
         return gP, None
 
 
@@ -1661,14 +1737,17 @@ class _CurveWalkFn(torch.autograd.Function):
         B, N, C = feats.shape
         k, cn = adj.shape[2], nodes.shape[1]
         g = g.contiguous()
-        acc = torch.zeros(B * N * (C + 1), dtype=torch.float32, device=g.device)     # one fill for both accumulators
+        det = _det()
+        # (deterministic: both accumulators are overwritten by the ordered scatter; else one fill for both)
+        acc = (torch.empty if det else torch.zeros)(B * N * (C + 1), dtype=torch.float32, device=g.device)
         gF, coef = acc[:B * N * C].view(B, N, C), acc[B * N * C:].view(B, N)
-        ws = torch.empty(int(_lib.load().pc3d_curve_walk_bwd_ws_floats(B, cn, C)), dtype=torch.float32, device=g.device)
+        ws = torch.empty(int(_lib.load().pc3d_curve_walk_bwd_ws_floats(B, cn, C, ctx.L, k, det)), dtype=torch.float32,
+                         device=g.device)
         with torch.cuda.device(g.device):
             _lib.call("pc3d_curve_walk_bwd_f32", g.data_ptr(), feats.data_ptr(), adj.data_ptr(), aw.data_ptr(),
                       ab.data_ptr(), mw.data_ptr(), mb.data_ptr(), B, N, C, k, cn, ctx.L, curves.data_ptr(),
                       nodes.data_ptr(), pick.data_ptr(), pre.data_ptr(), mom.data_ptr(), gF.data_ptr(),
-                      coef.data_ptr(), ws.data_ptr(), _stream())
+                      coef.data_ptr(), ws.data_ptr(), det, _stream())
         gF.addcmul_(coef.unsqueeze(-1), aw[:C])      # the rank-1 score term: every candidate row gets coef * w_nbr
         return gF, None, None, None, None, None, None, None
 
@@ -1874,7 +1953,7 @@ class _GroupedMLPMaxFn(torch.autograd.Function):
         gBc = torch.empty((B, S, C1), dtype=torch.float32, device=g.device)
         with torch.cuda.device(g.device):
             _lib.call("pc3d_group_act_bwd_mask_f32", gh1.data_ptr(), mask.data_ptr(), idx.data_ptr(), B, NA, S, ns, C1,
-                      0.0, gP.data_ptr(), gBc.data_ptr(), _stream())
+                      0.0, gP.data_ptr(), gBc.data_ptr(), _det(), _stream())
         return gP, gBc, None, None, None, None, None, None, None
 
 

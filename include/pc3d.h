@@ -125,7 +125,10 @@ int pc3d_kappa_gather_f32(const float* x, int64_t x_bs, int64_t x_ps, int64_t x_
                           float* out, float* nout, void* stream);
 int pc3d_kappa_bwd_f32(const float* x, int64_t x_bs, int64_t x_ps, int64_t x_cs, const float* nrm, int64_t n_bs,
                        int64_t n_ps, int64_t n_cs, const int32_t* idx, const float* gout, int B, int N, int K1, float* gx,
-                       void* stream);
+                       int deterministic, void* stream);
+/* (deterministic = 1: every wavefront accumulates into its own LDS slab and the slabs are combined in a fixed order —
+ * bit-identical gradients run to run and for a cloud alone or inside a batch; 0: slabs shared by the wavefronts / global
+ * float atomics, order-dependent in the last bits. (3 + 4) N floats of LDS, N <= 8192.) */
 
 /* GeoA3's per-sample loss assembly as one launch each way (attack/GeoA3/GeoA3_attack.py:139-181 on top of
  * loss_utils.py:36-58,92-105): from the adv->ori nearest-neighbour squared distances d_ao [B,N] (and indices idx_ao
@@ -164,7 +167,8 @@ int pc3d_geoa3_record_f32(const float* logits, int ld, int B, int ncls, const in
 int pc3d_group_act_f32(const float* P, const float* Bc, const int32_t* idx, int B, int NA, int S, int K, int C,
                        float slope, float* H, void* stream);
 int pc3d_group_act_bwd_f32(const float* gH, const float* H, const int32_t* idx, int B, int NA, int S, int K, int C,
-                           float slope, float* gP, float* gBc, void* stream);
+                           float slope, float* gP, float* gBc, int deterministic, void* stream);
+/* (deterministic = 1: gP through the ordered LDS scatter described at pc3d_scatter_rows_det_f32 instead of float atomics) */
 /* Layers 1 + 2 of a set-abstraction MLP in one launch, without the [B,S,ns,C1] layer-1 output:
  *   Y[(b,s,j), :] = act(W act_in(P[b, idx[b,s,j], :] + Bc[b,s,:]) + bias)
  * = pc3d_group_act_f32 followed by pc3d_gemm_nt_f32, with the rows of the GEMM's X operand generated on load (P [B*NA, K]
@@ -182,7 +186,7 @@ int pc3d_gemm_nt_gather_f32(const float* P, int64_t ldp, const float* Bc, const 
 int pc3d_group_max_linear_bwd_mask_f32(const float* gout, const float* out, const int64_t* arg, const float* W, int G, int ns,
                                        int C2, int C3, const uint32_t* xmask, float* gx, void* stream);
 int pc3d_group_act_bwd_mask_f32(const float* gH, const uint8_t* mask, const int32_t* idx, int B, int NA, int S, int K, int C,
-                                float slope, float* gP, float* gBc, void* stream);
+                                float slope, float* gP, float* gBc, int deterministic, void* stream);
 
 /* The same backward WITHOUT float atomics, as a gather over a reverse index of the grouping.
  * pc3d_group_reverse_i32: per cloud, the list of grouped rows that reference each point (a counting sort on the device:
@@ -190,7 +194,8 @@ int pc3d_group_act_bwd_mask_f32(const float* gH, const uint8_t* mask, const int3
  *   (list of point p = lst[b][off[b,p] .. off[b,p+1])); lst [B, L] int32 with L = pc3d_group_reverse_list_len(S, K) =
  *   S*K + S. Entry codes: s*K + j = row (s,j) of the cloud; S*K + s = "the sum of the rows of group s that repeat its
  *   first index" (the ball query's padding), listed under that first index. Entries outside [0,NA) are in no list.
- *   It depends on idx only: build it once per forward, beside the MLPs.
+ *   Every list is sorted ascending after the fill (the atomics hand out slots in arrival order), so the gather below
+ *   sums in ONE order: deterministic gradients. It depends on idx only: build it once per forward, beside the MLPs.
  * pc3d_group_act_bwd_rev_f32: gBc and the per-group padded-tail sums in one pass over the groups (tail [B,S,C] scratch),
  *   then gP[b,p,:] = sum over the list of p — every row of gP written once, no zero fill. The sign of the activation
  *   comes from H [B,S,K,C] or, when H is NULL, from the bit mask of pc3d_gemm_nt_gather_f32. C % 4 == 0, C <= 512. */
@@ -358,15 +363,17 @@ int pc3d_knn_f32(const float* q, int64_t q_bs, int64_t q_ps, int64_t q_cs,
                  const float* r, int64_t r_bs, int64_t r_ps, int64_t r_cs,
                  int B, int N, int M, int K, float* dists, int32_t* idx, void* stream);
 
-/* Backward of the K distances with upstream w [B,N,K]: grad_q dense, grad_r scattered (float atomics, or an
- * ordered scan when deterministic != 0). Both are OVERWRITTEN; either may be NULL. When q and r are the same
- * cloud (self-kNN) the caller adds the two results. */
+/* Backward of the K distances with upstream w [B,N,K]: grad_q dense, grad_r scattered (float atomics; when
+ * deterministic != 0 in a fixed order: with det_ws = B*N*K*3 floats of scratch the edges' contributions are recorded
+ * and summed by the ordered LDS scatter of pc3d_scatter_rows_det_f32, with det_ws NULL every reference point scans
+ * the whole index list). Both are OVERWRITTEN; either may be NULL. When q and r are the same cloud (self-kNN) the
+ * caller adds the two results. */
 int pc3d_knn_bwd_f32(const float* q, int64_t q_bs, int64_t q_ps, int64_t q_cs,
                      const float* r, int64_t r_bs, int64_t r_ps, int64_t r_cs,
                      int B, int N, int M, int K, const int32_t* idx, const float* w,
                      float* grad_q, int64_t gq_bs, int64_t gq_ps, int64_t gq_cs,
                      float* grad_r, int64_t gr_bs, int64_t gr_ps, int64_t gr_cs,
-                     int deterministic, void* stream);
+                     int deterministic, float* det_ws, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * K11  per-iteration bookkeeping of the CW-family loops on the device (attack/CW/CW_attack.py:129-153): per-sample
@@ -427,9 +434,10 @@ int pc3d_group_gather_f32(const float* xyz, int64_t x_bs, int64_t x_ps, int64_t 
 
 /* Backward of K7: grad_xyz [B,N,3] / grad_feat [B,N,D] (contiguous, OVERWRITTEN, either may be NULL) receive the
  * scatter-add of g_out [B,S,ns,(3)+D]; center_idx [B,S] (index of each centre in xyz, or NULL) receives minus the
- * sum over its group. Float atomics (order-dependent in the last bits). */
+ * sum over its group. det_ws NULL: float atomics (order-dependent in the last bits); det_ws = B*S*3 floats of scratch:
+ * the ordered LDS scatter of pc3d_scatter_rows_det_f32 (deterministic). */
 int pc3d_group_gather_bwd_f32(const float* g_out, const int32_t* idx, const int32_t* center_idx, int B, int N, int S,
-                              int ns, int D, int has_xyz, float* grad_xyz, float* grad_feat, void* stream);
+                              int ns, int D, int has_xyz, float* grad_xyz, float* grad_feat, float* det_ws, void* stream);
 
 /* Backward to x of out[g,c] = max_r relu(x[g,r,:] . W[c,:] + b[c]) — the last 1x1 conv + ReLU + max over the group of
  * a set-abstraction layer (model/pointnet2_utils.py:190-197, :243-257). gout/out [G,C3], arg [G,C3] int64 = winning row
@@ -458,19 +466,45 @@ int pc3d_group_max_linear_bwd_f32(const float* gout, const float* out, const int
  * [B,N,N] and calls topk).
  * pc3d_gather_max_f32: out[b,i,c] = max (sign[c] < 0: min; sign NULL: max) over j in idx[b,i,:] of P[b,j,c], with
  * the winning j in arg (may be NULL) — the neighbour reduction of an EdgeConv expressed as W[xj-xi; xi] = P_j + Q_i.
- * pc3d_gather_max_bwd_f32: gP[b,arg,c] += g (gP overwritten; float atomics).
+ * pc3d_gather_max_bwd_f32: gP[b,arg,c] += g (gP overwritten; deterministic = 0: global float atomics, 1: one wavefront
+ * per (cloud, channel slice) accumulates in LDS in source order — see pc3d_scatter_rows_det_f32).
  * ------------------------------------------------------------------------------------------------------- */
 int pc3d_knn_feat_f32(const float* x, int B, int N, int C, int K, int32_t* idx, void* stream);
 int pc3d_gather_max_f32(const float* P, const int32_t* idx, const float* sign, int B, int N, int C, int K,
                         float* out, int32_t* arg, void* stream);
-int pc3d_gather_max_bwd_f32(const float* g, const int32_t* arg, int B, int N, int C, float* gP, void* stream);
+int pc3d_gather_max_bwd_f32(const float* g, const int32_t* arg, int B, int N, int C, float* gP, int deterministic,
+                            void* stream);
 /* The same reduction for S query rows over N source points (idx, out, arg, g: [B,S,..]; P, gP: [B,N,C]; indices are
  * clamped to [0,N-1]): CurveNet's MaskedMaxPool, max over the ball-query neighbours of every FPS centroid
  * (model/curvenet_util.py:469-484). */
 int pc3d_gather_max_rows_f32(const float* P, const int32_t* idx, int B, int N, int S, int C, int K, float* out,
                              int32_t* arg, void* stream);
 int pc3d_gather_max_rows_bwd_f32(const float* g, const int32_t* arg, int B, int N, int S, int C, float* gP,
-                                 void* stream);
+                                 int deterministic, void* stream);
+
+/* -------------------------------------------------------------------------------------------------------
+ * Deterministic scatter-add (new; the reference's autograd of index_points / get_graph_feature / knn_gather —
+ * model/pointnet2_utils.py:41-57, model/dgcnn.py:203-227, attack/GeoA3/knn_utils.py:58-86 — is deterministic on its CPU
+ * path, a scatter with global float atomics is not):
+ *   out[b, tgt[b,r], c] = sum over the records r = 0 .. R-1, in that order, of m(val[b,r,c])
+ * with m = identity, or the derivative of a LeakyReLU taken from the sign of act[b,r,c]. ONE wavefront owns the LDS tile
+ * of all N destination rows x a slice of channels and walks the records in order (ds_add_f32 of one wave execute in
+ * issue order), so the result is a pure function of the inputs: the same run to run, under hipGraph replay, and for a
+ * cloud alone or inside a batch. tgt [B,R] int32 (outside [0,N): skipped, or clamped when clamp = 1); val [B,R,ldv],
+ * act [B,R,lda] or NULL; out [B,N,ldo] overwritten (accumulate = 1: added to). N <= 40960 (a CU's LDS).
+ * The deterministic modes of the backward entry points above run on this kernel.
+ * ------------------------------------------------------------------------------------------------------- */
+/* Sorted reverse index of a gather (CSR): for idx [B,E] int32 with values in [0,NA) (clamp = 1: clamped into it; 0:
+ * others are in no list), lst[b, off[b,t] .. off[b,t+1]) = the entries e with idx[b,e] == t in ASCENDING e. cnt [B,NA]
+ * int32 scratch, off [B,NA+1], lst [B,E]. pc3d_rev_gather_sum_f32: out[b,t,:] = sum over that segment, front to back, of
+ * m(val[b,e,:]) (m as for pc3d_scatter_rows_det_f32) — the same sums as the scatter below, every destination row in
+ * parallel; what the deterministic backward of the wide many-edge gathers (LPFA) runs on. */
+int pc3d_rev_index_i32(const int32_t* idx, int B, int E, int NA, int clamp, int32_t* cnt, int32_t* off, int32_t* lst,
+                       void* stream);
+int pc3d_rev_gather_sum_f32(const float* val, int64_t ldv, const float* act, int64_t lda, float slope, const int32_t* off,
+                            const int32_t* lst, int B, int E, int NA, int C, float* out, int64_t ldo, void* stream);
+int pc3d_scatter_rows_det_f32(const int32_t* tgt, const float* val, int64_t ldv, const float* act, int64_t lda, float slope,
+                              int B, int R, int N, int C, float* out, int64_t ldo, int accumulate, int clamp, void* stream);
 /* One EdgeConv layer's epilogue (model/dgcnn.py:299-313): PQ [B,N,2C] = [P | Q] from ONE GEMM against [U;V];
  * out[b,i,c] = leaky_slope(max_j P[b,idx[b,i,j],c] + Q[b,i,c]), arg = the winning j. C % 4 == 0.
  * Backward: gPQ [B,N,2C] overwritten: dQ = g * leaky'(out), dP scattered to arg (float atomics). */
@@ -485,7 +519,11 @@ int pc3d_act_pool_bwd_f32(const float* Y, const float* gout, const int32_t* arg,
 /* g [B,N,C] with row stride ldg >= C floats: the slice of a wider gradient (the backward of DGCNN's torch.cat over the four
  * EdgeConv outputs hands over [B,N,512] column slices) is read in place. */
 int pc3d_edge_max_bwd_f32(const float* g, int64_t ldg, const float* out, const int32_t* arg, int B, int N, int C,
-                          float slope, float* gPQ, void* stream);
+                          float slope, float* gPQ, int deterministic, void* stream);
+/* The deterministic form with the channel-slice width of its owner-wave kernel named (1, 2, 4, 8, 16; 0 = the library
+ * chooses; identical results for every width — a wavefront per (cloud, slice) sums the points in order). */
+int pc3d_edge_max_bwd_slice_f32(const float* g, int64_t ldg, const float* out, const int32_t* arg, int B, int N, int C,
+                                float slope, float* gPQ, int slice, void* stream);
 
 /* K16  guided curve walk of CurveNet (model/walk.py:74-153 `Walk.forward`), one launch per step and direction: one or
  * two curves per wavefront, lane j scores neighbour j. feats [B,N,C] (C in {8,16,32,64}), adj [B,N,k] (k <= 64, self
@@ -497,7 +535,10 @@ int pc3d_edge_max_bwd_f32(const float* g, int64_t ldg, const float* out, const i
  * for the backward, nodes / pick [B,cn,L], pre [B,cn,L,C], mom [B,cn,L,2].
  * Backward: gfeats [B,N,C] and coef [B,N] are ACCUMULATED into (zero them first); the full gradient is
  * gfeats + coef (x) agent_w[0:C] (the rank-1 score term is left to the caller as one dense pass). Float atomics.
- * ws: pc3d_curve_walk_bwd_ws_floats(B, cn, C) floats of scratch (the gradients that travel from step to step). */
+ * deterministic = 1: the steps record their contributions in ws and the entry point sums them in record order with
+ * the ordered LDS scatter (pc3d_scatter_rows_det_f32); gfeats and coef are then OVERWRITTEN.
+ * ws: pc3d_curve_walk_bwd_ws_floats(B, cn, C, L, k, deterministic) floats of scratch (the gradients that travel from
+ * step to step; in deterministic mode also the records). */
 int pc3d_curve_walk_fwd_f32(const float* feats, const int32_t* adj, const int32_t* start, const float* agent_w,
                             const float* agent_b, const float* mom_w, const float* mom_b, int B, int N, int C, int k,
                             int cn, int L, float* curves, int32_t* nodes, int32_t* pick, float* pre, float* mom,
@@ -505,8 +546,9 @@ int pc3d_curve_walk_fwd_f32(const float* feats, const int32_t* adj, const int32_
 int pc3d_curve_walk_bwd_f32(const float* gcurves, const float* feats, const int32_t* adj, const float* agent_w,
                             const float* agent_b, const float* mom_w, const float* mom_b, int B, int N, int C, int k,
                             int cn, int L, const float* curves, const int32_t* nodes, const int32_t* pick,
-                            const float* pre, const float* mom, float* gfeats, float* coef, float* ws, void* stream);
-int64_t pc3d_curve_walk_bwd_ws_floats(int B, int cn, int C);
+                            const float* pre, const float* mom, float* gfeats, float* coef, float* ws, int deterministic,
+                            void* stream);
+int64_t pc3d_curve_walk_bwd_ws_floats(int B, int cn, int C, int L, int k, int deterministic);
 
 /* K17  the two bandwidth-bound halves of CurveNet's local point-feature aggregation (model/curvenet_util.py:199-236,
  * `LPFA.group_feature` / `LPFA.forward`) around its 1x1-conv GEMM; channels-last, C % 4 == 0:
@@ -517,7 +559,11 @@ int64_t pc3d_curve_walk_bwd_ws_floats(int B, int cn, int C);
 int pc3d_edge_act_f32(const float* A, const float* Bc, const int32_t* idx, int B, int N, int K, int C, float slope,
                       float* E, void* stream);
 int pc3d_edge_act_bwd_f32(const float* gE, const float* E, const int32_t* idx, int B, int N, int K, int C, float slope,
-                          float* gA, float* gBc, void* stream);
+                          float* gA, float* gBc, int deterministic, const int32_t* rev_off, const int32_t* rev_lst,
+                          void* stream);
+/* (deterministic = 0: gA must be zero-filled by the caller, float atomics; 1: gA overwritten — by a gather through the
+ * sorted reverse index of idx when rev_off / rev_lst (pc3d_rev_index_i32 with E = N*K, NA = N, clamp = 1) are given,
+ * else by the ordered LDS scatter) */
 int pc3d_act_mean_f32(const float* Z, int B, int N, int K, int C, float slope, float* out, void* stream);
 int pc3d_act_mean_bwd_f32(const float* Z, const float* gout, int B, int N, int K, int C, float slope, float* gZ,
                           void* stream);
@@ -525,12 +571,16 @@ int pc3d_act_mean_bwd_f32(const float* Z, const float* gout, int B, int N, int K
  * CIC block of the classifier uses) in one launch each way, without any [B,N,K,C] tensor:
  *   out[b,i,:] = mean_j LeakyReLU_s2( W . LeakyReLU_s1(A[b,idx[b,i,j],:] + Bc[b,i,:]) + bias )
  * A, Bc, out, gout, gA, gBc [B,N,C]; idx [B,N,K] int32 (clamped); W [C,C] (out, in), Wt its transpose; C in
- * {16,32,64,128}, K <= 30. Backward: gA, gBc overwritten (gA through float atomics). */
+ * {16,32,64,128}, K <= 30. Backward: gA, gBc overwritten — gA through float atomics when edge_scratch is NULL, else
+ * deterministically: the per-edge gradients go to edge_scratch [B,N,K,C] and every gA row sums its edges in ascending edge
+ * order — a gather through the sorted reverse index of idx (rev_off / rev_lst from pc3d_rev_index_i32, E = N*K, NA = N,
+ * clamp = 1) when given, else the ordered LDS scatter. */
 int pc3d_lpfa_fused_f32(const float* A, const float* Bc, const int32_t* idx, const float* W, const float* bias, int B,
                         int N, int K, int C, float slope1, float slope2, float* out, void* stream);
 int pc3d_lpfa_fused_bwd_f32(const float* gout, const float* A, const float* Bc, const int32_t* idx, const float* W,
                             const float* Wt, const float* bias, int B, int N, int K, int C, float slope1, float slope2,
-                            float* gA, float* gBc, void* stream);
+                            float* gA, float* gBc, float* edge_scratch, const int32_t* rev_off, const int32_t* rev_lst,
+                            void* stream);
 
 /* K18  per-cloud half of CurveNet's curve aggregation (model/curvenet_util.py:379-437 `CurveAggregation.forward`):
  * curves [B,cn,cl,C] (channels-last) -> attention keys Kp [B,C,R] and values Vp [B,R,C], R = cn + cl, such that the
