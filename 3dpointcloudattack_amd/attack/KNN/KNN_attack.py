@@ -35,7 +35,12 @@ class CWKNN:
 
     def __init__(self, model, pt_model, ptm_model, pts_model, dgcnn_model, cur_model, adv_func, dist_func, clip_func,
                  attack_lr=1e-3, num_iter=2500, attack_method='untarget', device=None, verbose=False, fused=True,
-                 graph=True):
+                 graph=True, sample_seeds=None, global_batch=None):
+        """Extra keywords (defaults = the reference's behaviour). For sharded runs: `sample_seeds` (one int
+        per sample) draws every sample's start noise AND a PointNet++ victim's FPS start indices from that sample's own
+        generator instead of the shared global stream, and `global_batch` is the size of the unsharded batch whose loss
+        mean the shard is a part of — with both, a sample's trajectory does not depend on the batch or rank it runs in
+        (bit for bit: the backward kernels sum in a fixed order, ops.DETERMINISTIC)."""
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
 
         def prep(m):
@@ -68,6 +73,8 @@ class CWKNN:
         self.cur_fail = 0
         self.verbose = verbose
         self.fused = fused
+        self.sample_seeds = sample_seeds
+        self.global_batch = global_batch
 
     def _success(self, pred, target):
         return (pred != target) if self.attack_method == 'untarget' else (pred == target)
@@ -90,8 +97,20 @@ class CWKNN:
             target (torch.LongTensor): target output, [B]
         Returns (adv [B,K,3] float32 numpy, success_num) like the reference (:244-246).
         """
+        if self.sample_seeds is None:
+            return self._attack(data, target, None)
+        from ...model import pointnet2_utils as _pn2
+        assert len(self.sample_seeds) == data.shape[0], "sample_seeds needs one seed per sample"
+        prev = _pn2.set_fps_start_source(_pn2.SeededFpsStarts([int(s) + 7919 for s in self.sample_seeds]))
+        try:
+            return self._attack(data, target, [torch.Generator().manual_seed(int(s)) for s in self.sample_seeds])
+        finally:
+            _pn2.set_fps_start_source(prev)
+
+    def _attack(self, data, target, gens):
         dev = self.device
         B, K = data.shape[:2]
+        ratio = (float(B) / float(self.global_batch)) if self.global_batch else 1.0
         data = data.float().to(dev).detach()
         data = data.transpose(1, 2).contiguous()
         ori_data = data.clone().detach()
@@ -113,7 +132,8 @@ class CWKNN:
         target = target.long().to(dev).detach().view(-1)
 
         # init variables with small perturbation (CPU generator like the reference, :84-85)
-        adv_data = ori_data.clone().detach() + torch.randn((B, 3, K)).to(dev) * 1e-7
+        noise = torch.randn((B, 3, K)) if gens is None else torch.stack([torch.randn((3, K), generator=g) for g in gens])
+        adv_data = ori_data.clone().detach() + noise.to(dev) * 1e-7
         adv_data.requires_grad_()
         fc = self._fused_clip()
         if fc is None:
@@ -142,6 +162,8 @@ class CWKNN:
             else:
                 dist_loss = self.dist_func(adv_data.transpose(1, 2).contiguous(), ori_t).mean() * K
             loss = adv_loss + dist_loss
+            if ratio != 1.0:
+                loss = loss * ratio            # batch means (:117-123) of a shard of a larger batch
             if fc is None:
                 opt.zero_grad()
                 loss.backward()

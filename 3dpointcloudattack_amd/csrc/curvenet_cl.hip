@@ -586,8 +586,11 @@ extern "C" int pc3d_curve_attn_f32(const float* x, const float* Kp, const float*
 // slices of a cloud for the per-cloud half of the backward: ~128 points each, at least one LDS tile, enough of them
 // that B * nsplit covers the chip
 static int curve_attn_per_split(int B, int N) {
+  // The split sets the ORDER in which a cloud's per-point terms are summed, so it is chosen from N and a nominal batch of
+  // 32 clouds — never from the actual B: a cloud's gradient is the same alone and inside any batch or shard.
+  (void)B;
   int per_split = 128;
-  while (per_split > CA_PT && (int64_t)B * cdiv(N, per_split) < 512) per_split /= 2;
+  while (per_split > CA_PT && (int64_t)32 * cdiv(N, per_split) < 512) per_split /= 2;
   return per_split;
 }
 

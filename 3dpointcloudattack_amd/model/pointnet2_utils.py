@@ -98,7 +98,37 @@ def index_points(points, idx):
     return ops.group_gather(None, points, _i32(idx).contiguous())
 
 
+_FPS_START_SOURCE = None      # None: the global CPU generator, like the reference; else callable(B, N, device) -> int32 [B]
+
+
+def set_fps_start_source(src):
+    """Where farthest-point sampling takes its start indices from: None = one torch.randint(0, N, (B,)) on the global CPU
+    generator per sampling layer and forward (model/pointnet2_utils.py:72, SURVEY A-4), or a callable (B, N, device) ->
+    int32 [B] device tensor (SeededFpsStarts: a stream per SAMPLE, what a sharded run needs). Returns the previous one."""
+    global _FPS_START_SOURCE
+    prev, _FPS_START_SOURCE = _FPS_START_SOURCE, src
+    return prev
+
+
+class SeededFpsStarts:
+    """FPS start indices drawn per SAMPLE: sample i takes its r-th start from its own generator (seed seeds[i]), whatever
+    batch or shard it is evaluated in — the reference's single shared stream (:72) makes a sample's starts depend on its
+    position in the batch and on every other forward of the process ("FPS start indices must be drawn
+    per-sample from a seed, not from a shared stream")."""
+
+    def __init__(self, seeds):
+        self.gens = [torch.Generator().manual_seed(int(s)) for s in seeds]
+
+    def __call__(self, B, N, device):
+        if B != len(self.gens):
+            raise ValueError(f"SeededFpsStarts: batch of {B} clouds, {len(self.gens)} seeds")
+        vals = torch.tensor([int(torch.randint(0, N, (1,), generator=g)) for g in self.gens], dtype=torch.int32)
+        return ops.h2d(vals, device, torch.int32)
+
+
 def _fps_start(B, N, device):
+    if _FPS_START_SOURCE is not None:
+        return _FPS_START_SOURCE(B, N, device)
     # the reference draws the first index from the GLOBAL CPU generator every forward (:72, SURVEY A-4); same call,
     # same stream position -> same start indices under the same seed
     return ops.h2d(torch.randint(0, N, (B,), dtype=torch.long), device, torch.int32)     # no queue stall (ops.h2d)

@@ -1,7 +1,5 @@
 """Shared test helpers (not product code)."""
-import functools
 import importlib
-import sys
 
 import numpy as np
 import torch
@@ -34,25 +32,3 @@ def oracle_pointnet(seed, k=40):
     m.load_state_dict(sd)
     m.eval()
     return m, ort.state_sha256(sd)
-
-
-def chaotic(attempts=2):
-    """For tests that compare two RUNS of an attack loop on DGCNN / CurveNet / PointNet++ victims: the backward's float
-    atomics add 1e-7 order noise, a near-tie in a kNN graph / arg-max of a later iterate can flip on it, and Adam amplifies
-    the re-wiring (12 runs of one fixture case follow two different branches). Their tolerances
-    are tiers measured on the branches seen so far; one more branch shows up about once in fifteen suite runs. Such a
-    failure has to REPRODUCE to count: the test body is run again, and the retry is reported on stderr. Kernel-level
-    parity tests (bit-exact or float64-referenced) never use this."""
-    def deco(fn):
-        @functools.wraps(fn)
-        def run(*a, **k):
-            for n in range(attempts):
-                try:
-                    return fn(*a, **k)
-                except AssertionError as e:
-                    if n + 1 == attempts:
-                        raise
-                    print(f"[chaotic] {fn.__name__}: attempt {n + 1} failed ({str(e).splitlines()[0][:200] if str(e) else 'assert'}); "
-                          f"running it again", file=sys.stderr)
-        return run
-    return deco
