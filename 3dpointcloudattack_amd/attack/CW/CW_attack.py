@@ -399,8 +399,10 @@ class CW:
         st = self._begin(data, target)
         target = st["target"]
         run = None
+        self.weight_history = []          # [binary_step][B]: the distance weight every binary step ran with (reference :93-200)
         for binary_step in range(self.binary_step):
             self._begin_binary_step(st)
+            self.weight_history.append(st["current_weight"].copy())
             if run is None and self._capturable() and self.num_iter >= 8:
                 # capture once (its warm-up passes advance the state), then restart this binary step cleanly with
                 # the SAME start point so results do not depend on whether a graph is used

@@ -61,6 +61,50 @@ def ev_ms(fn, iters, stream):
     return e0.elapsed_time(e1) / iters
 
 
+def geo_cfg(**over):
+    """GeoA3's default flags (attack/GeoA3/Eval_GeoA3.py:109-204: CE classification loss, CD + 0.1 HD + curvature
+    consistency with 16 neighbours, Adam lr 1e-2) as the namespace geoA3_attack reads (GeoA3_attack.py:186-190)."""
+    import types
+    base = dict(attack_method='untarget', curv_loss_weight=1.0, curv_loss_knn=16, initial_const=10, iter_max_steps=12,
+                binary_max_steps=1, is_partial_var=False, optim='adam', lr=0.01, npoint=1024, is_subsample_opt=False,
+                eval_num=1, is_pre_jitter_input=False, cls_loss_type='CE', classes=NCLS, confidence=0, dis_loss_type='CD',
+                is_cd_single_side=False, dis_loss_weight=1.0, hd_loss_weight=0.1, uniform_loss_weight=0.0,
+                is_use_lr_scheduler=False, is_debug=False, is_pro_grad=False, cc_linf=0.0, binary_step=1, num_iter=12,
+                is_real_offset=False, knn_range=3, calculate_project_jitter_noise_iter=50, jitter_k=16,
+                jitter_sigma=0.01, jitter_clip=0.05)
+    base.update(over)
+    return types.SimpleNamespace(**base)
+
+
+def slope_ms(run_attack, base, inc):
+    """ms per iteration of a whole attack call as the MEDIAN of three slopes: wall time of runs with base, base + inc,
+    base + 2 inc, base + 3 inc iterations (after one untimed run of `base` that pays the captures); everything a call
+    does besides its loop (upload, clean forward, final checks, D2H) cancels in the differences, and a one-off stall
+    moves only one of the three."""
+    run_attack(base)
+    ts = []
+    for it in (base, base + inc, base + 2 * inc, base + 3 * inc):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_attack(it)
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    slopes = [(ts[i + 1] - ts[i]) / inc * 1e3 for i in range(3)]
+    return sorted(slopes)[1], slopes
+
+
+def pmc_provenance(path):
+    """Commit that last touched the committed PMC file (the counters are collected under the rocprofv3 wrapper, not in
+    this process): printed next to `traffic` so that a figure older than the kernels it describes is visible."""
+    import subprocess
+    try:
+        out = subprocess.run(["git", "-C", ROOT, "log", "-1", "--format=%h %cs", "--", path], capture_output=True, text=True,
+                             timeout=10).stdout.strip()
+        return out or None
+    except Exception:
+        return None
+
+
 def chamfer_cpu_baseline():
     """SURVEY §8(d) "CPU baseline beside it", metric 2: the reference's two CPU Chamfer paths per cloud pair, via the
     oracle's restatements — float64 direct-difference matrix + two min-reductions (utils/dis_utils_numpy.py:13-26) and
@@ -219,10 +263,15 @@ def main():
         # Three timings per size: `values` = what Chamfer / Hausdorff VALUES need (utils/dis_utils_*.py, the metric's
         # kernel: scan + fold launches, no arg-min), `with_idx` = values + both arg-min index arrays (what the
         # backward of the distance functors needs), `two_scan` = the round-1 kernel (one scan per direction).
-        pmc_all = {}
-        pmc2 = os.path.join(ROOT, "profiles", "r02_pmc_hbm_counters.json")
-        if os.path.exists(pmc2):
-            pmc_all = json.load(open(pmc2))
+        pmc_all, pmc_file = {}, None
+        for cand in ("r03_pmc_hbm_counters.json", "r02_pmc_hbm_counters.json"):
+            if os.path.exists(os.path.join(ROOT, "profiles", cand)):
+                pmc_file = os.path.join("profiles", cand)
+                pmc_all = json.load(open(os.path.join(ROOT, pmc_file)))
+                break
+        pmc_src = {"file": pmc_file, "commit": pmc_provenance(pmc_file) if pmc_file else None,
+                   "note": "HBM counters come from separate rocprofv3 --pmc passes of this command (tools/prof_pmc.sh), "
+                           "not from this run"}
 
         def counter_bytes(keys):
             """HBM bytes per call (sum over the launches of one call) from the committed PMC passes of THIS bench
@@ -287,6 +336,7 @@ def main():
                             "pc3d::nn_shared_finalize_kernel|grid=262144|run=0"))
         chamfer["hbm_counter_bytes"] = cb                      # FETCH+WRITE of the values path's launches, per call
         chamfer["hbm_counter_GBps"] = (cb / (chamfer["launch_us"] * 1e-6) / 1e9) if cb else None
+        chamfer["hbm_counter_source"] = pmc_src
         chamfer["other_sizes"] = {f"N{n}": {k: v for k, v in chamfer_point(n).items()
                                             if k in ("launch_us", "with_idx_us", "two_scan_us", "hbm_alg_GBps", "valu_frac", "timing",
                                                      "valu_frac_with_idx", "valu_frac_two_scan")}
@@ -302,20 +352,18 @@ def main():
         k_ms = ev_ms(lambda: ops.pointmlp3_max_fwd_raw(x, tower, False, fold=False), 50, stream)
         ach = flops / (k_ms * 1e-3) / 1e12
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r02_pmc_hbm_counters.json")
-        if os.path.exists(pmc):
+        if pmc_all:
             # HBM bytes per launch from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE
             # runs of this same command at this round's kernels, KiB units). gfx950 correction (MI355X_MICROARCH.md
             # §HBM): FETCH_SIZE counts 64 B per 128-B request for 16-B-per-lane reads -> doubled; WRITE_SIZE is exact.
             # (PMC collection needs the rocprofv3 wrapper, so it cannot run inside this process; the file is regenerated
             # by tools/prof_pmc.sh whenever a kernel on this line changes.)
-            pj = json.load(open(pmc))
-            c = pj.get("pc3d::pointmlp3_max_fwd_kernel|grid=131072|run=0")
+            c = pmc_all.get("pc3d::pointmlp3_max_fwd_kernel|grid=131072|run=0")
             if c and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
                 traffic = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
         roofline = {"kernel": "pointmlp3_max_fwd_kernel", "bound": "mfma", "achieved": ach,
                     "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS,
-                    "traffic": traffic, "launch_us": k_ms * 1e3, "launches_per_step": 2}
+                    "traffic": traffic, "traffic_source": pmc_src, "launch_us": k_ms * 1e3, "launches_per_step": 2}
 
     it = 0
     for _ in range(args.warmup):
@@ -386,6 +434,118 @@ def main():
         if dist_on:
             sharding.broadcast_frozen_weights([cnet], src=0)
         sweep[f"cfg5_share_cw_curvenet_chamfer_B{B}_N4096"] = time_cw(cnet, cnet, 4096, "chamfer", 4, 12, 555)
+
+        # ---- BASELINE configs[2], configs[3] and the GeoA3 half of configs[4] as WHOLE attack calls (median of three
+        # slopes, see slope_ms), each with the roofline of the kernel that dominates its loop — measured stand-alone with
+        # HIP events at the layer's shape; every rank runs them, the slowest rank is reported
+        def kernel_roof(name, fn, flops=None, lane_ops=None, note=None, it=20):
+            for _ in range(3):
+                fn()
+            us = ev_ms(fn, it, stream) * 1e3
+            r = {"kernel": name, "launch_us": us}
+            if flops is not None:
+                r.update(bound="mfma", alg_flops=flops, achieved=flops / us / 1e6, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
+                         frac=flops / us / 1e6 / MFMA_F32_PEAK_TFLOPS)
+            if lane_ops is not None:
+                r.update(bound="valu", alg_lane_ops=lane_ops, achieved=lane_ops / us / 1e6, peak=VALU_LANE_OPS_PEAK / 1e12,
+                         unit="T lane-op/s", frac=lane_ops / (us * 1e-6) / VALU_LANE_OPS_PEAK)
+            if note:
+                r["note"] = note
+            return r
+
+        def whole(tag, run_attack, base, inc, roof):
+            med, slopes = slope_ms(run_attack, base, inc)
+            ms, per = across_ranks(med)
+            sweep[tag] = {"ms_per_iter": ms, "iters_per_s": world * 1e3 / ms, "per_rank_ms": per, "slopes_ms_rank0": slopes,
+                          "timing": f"whole attack() calls, wall clock, median of three {inc}-iteration slopes", "roofline": roof}
+
+        import types
+        ga = M("3dpointcloudattack_amd.attack.GeoA3.GeoA3_attack")
+        DGCNN = M("3dpointcloudattack_amd.model.dgcnn").DGCNN
+        dg = DGCNN(types.SimpleNamespace(k=20, emb_dims=1024, dropout=0.5), output_channels=NCLS)
+        if rank == 0:
+            dg.load_state_dict(seeded_state(dg, 5))
+        dg = dg.to(dev).eval()
+        if dist_on:
+            sharding.broadcast_frozen_weights([dg], src=0)
+
+        def clouds(n, npts, seed):
+            rs = np.random.default_rng(seed + 1000 * rank)
+            d = torch.from_numpy(np.stack([unit_cloud(rs, npts) for _ in range(n)]))
+            return d
+
+        def labels_of(net, d):
+            with torch.no_grad():
+                return net(d.transpose(1, 2).contiguous().to(dev))[0].argmax(1).cpu()
+
+        def geo_runner(net, d, lab, npts):
+            def run_attack(iters):
+                torch.manual_seed(3 + rank)
+                np.random.seed(3 + rank)
+                ga.geoA3_attack(net, None, None, None, None, None, d, lab, geo_cfg(iter_max_steps=iters, npoint=npts), 0, 1)
+            return run_attack
+
+        d3 = clouds(B, 1024, 777)
+        xg = torch.randn(B * 1024, 512, device=dev)
+        wg = torch.randn(1024, 512, device=dev) / 512 ** 0.5
+        whole(f"cfg3_geoa3_dgcnn_B{B}_N1024", geo_runner(dg, d3, labels_of(dg, d3), 1024), 8, 40,
+              kernel_roof("gemm_nt_kernel (conv5 forward, [32768,1024,512])", lambda: ops.gemm_nt(xg, wg, None, "leaky", 0.2),
+                          flops=2.0 * B * 1024 * 1024 * 512))
+        del xg, wg
+
+        knn_mod = M("3dpointcloudattack_amd.attack.KNN.KNN_attack")
+        SSG = M("3dpointcloudattack_amd.model.pointnet2_SSG").PointNet_Ssg
+        ssg = SSG(NCLS)
+        if rank == 0:
+            ssg.load_state_dict(seeded_state(ssg, 3))
+        ssg = ssg.to(dev).eval()
+        if dist_on:
+            sharding.broadcast_frozen_weights([ssg], src=0)
+        B4 = 64
+        d4 = clouds(B4, 2048, 888)
+        torch.manual_seed(11 + rank)
+        l4 = labels_of(ssg, d4)
+
+        def knn_run(iters):
+            atk = knn_mod.CWKNN(ssg, None, None, None, None, None, adv_utils.UntargetedLogitsAdvLoss(kappa=15.),
+                                dist_utils.ChamferDist(method='adv2ori'), clip_utils.ProjectInnerClipLinf(budget=BUDGET),
+                                attack_lr=LR, num_iter=iters, device=dev)
+            torch.manual_seed(5 + rank)
+            np.random.seed(5 + rank)
+            atk.attack(d4, l4)
+        x4 = torch.relu(torch.randn(B4 * 128 * 64, 128, device=dev))
+        w4 = torch.randn(128, 128, device=dev) / 128 ** 0.5
+        b4 = torch.randn(128, device=dev)
+        whole(f"cfg4_knn_ssg_B{B4}_N2048", knn_run, 8, 40,
+              kernel_roof("gemm_nt_kernel (SA2 layer 2, [524288,128,128])", lambda: ops.gemm_nt(x4, w4, b4, "relu"),
+                          flops=2.0 * B4 * 128 * 64 * 128 * 128,
+                          note="K = 128: also HBM-bound on reading + writing [M,128] fp32 rows (537 MB)"))
+        del x4, w4, b4
+
+        d5 = clouds(B, 4096, 999)
+        p5 = d5.to(dev)
+        whole(f"cfg5_share_geoa3_curvenet_B{B}_N4096", geo_runner(cnet, d5, labels_of(cnet, d5), 4096), 4, 12,
+              kernel_roof("fps_kernel<16> (4096 -> 1024, the front of every CurveNet forward)", lambda: ops.fps(p5, 1024, None),
+                          lane_ops=12.0 * B * 4096 * 1024, it=5,
+                          note="a chain of 1024 dependent arg-max steps on one workgroup per cloud (32 of 256 CUs): "
+                               "latency-bound, the VALU fraction only says how far from compute-bound it is"))
+
+        # ---- one WHOLE CW.attack at the headline shape, 2 binary steps x 500 iterations: wall time of the call —
+        # upload, clean forward, graph capture, the two binary-search boundaries, final checks and the D2H of the result
+        atk_full = CW(model, trans_model, adv_func=adv_utils.UntargetedLogitsAdvLoss(kappa=KAPPA),
+                      clip_func=clip_utils.ClipPointsLinf(budget=BUDGET), dist_func=dist_utils.ChamferDist(),
+                      attack_lr=LR, binary_step=2, num_iter=500, device=dev)
+        torch.manual_seed(1000 + rank)
+        np.random.seed(1000 + rank)
+        torch.cuda.synchronize()
+        tw = time.perf_counter()
+        bd_full, _, sn_full = atk_full.attack(data, labels)
+        torch.cuda.synchronize()
+        wall, per = across_ranks(time.perf_counter() - tw)
+        sweep[f"whole_cw_attack_pointnet_chamfer_B{B}_N{NPTS}_2x500"] = {
+            "wall_s": wall, "iters_per_s_incl_boundaries": world * 1000.0 / wall, "per_rank_s": per,
+            "success_rank0": int(sn_full), "includes": "upload, clean forward, hipGraph capture, 2 binary-search boundaries, "
+                                                        "final attack / shuffle / transfer checks, D2H of the result"}
 
     # ---- the one collective at the end of a job: gather every rank's results (unequal shards are padded inside)
     gather = None

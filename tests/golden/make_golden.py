@@ -271,6 +271,124 @@ def gen_cw():
     print("cw.npz:", len(fx), "arrays")
 
 
+def gen_cw_full():
+    """The FULL binary-search schedule at the headline size: the REAL reference's CW.attack on PointNet,
+    B=1, N=1024, L2Dist (reproducible arithmetic), 10 binary steps x 100 iterations (attack/CW/CW_attack.py:93-200 with the
+    Eval_CW.py:79-90 wiring), two untargeted seeds and one targeted. Stored: o_bestdist, o_bestattack, success, the fail
+    counters, and the weight each binary step ran with (captured through the dist_func hook, which receives
+    torch.from_numpy(current_weight) every iteration)."""
+    install_cpu_shim()
+    import contextlib
+    import io
+    from model.pointnet import PointNetCls
+    from attack.CW.CW_attack import CW
+    from attack.CW.CW_utils.adv_utils import UntargetedLogitsAdvLoss, LogitsAdvLoss
+    from attack.CW.CW_utils.dist_utils import L2Dist
+    from attack.CW.CW_utils.clip_utils import ClipPointsLinf
+
+    class WeightRecorder(torch.nn.Module):
+        def __init__(self, inner):
+            super().__init__()
+            self.inner, self.weights = inner, []
+
+        def forward(self, adv, ori, weights=None, batch_avg=True):
+            self.weights.append(np.asarray(weights.detach().numpy(), dtype=np.float64).copy())
+            return self.inner(adv, ori, weights, batch_avg)
+
+    model, sha = _seeded_pointnet(PointNetCls, 40, 0)
+    trans_model, _ = _seeded_pointnet(PointNetCls, 40, 1)
+    fx = {"sha256": np.array(sha)}
+    STEPS, ITERS, N = 10, 100, 1024
+    cases = {"untarget_a": dict(method="untarget", kappa=2., cloud=4101, seed=1000),
+             "untarget_b": dict(method="untarget", kappa=8., cloud=4102, seed=1001),
+             "target_a": dict(method="target", kappa=0., cloud=4103, seed=1002)}
+    fx["names"] = np.array(sorted(cases))
+    for nm in sorted(cases):
+        c = cases[nm]
+        pc = unit_cloud(np.random.default_rng(c["cloud"]), N)[None]
+        x = torch.from_numpy(pc).transpose(1, 2).contiguous()
+        with torch.no_grad():
+            logp = model(x)[0]
+        clean = int(torch.argmax(logp, dim=1))
+        tgt = clean if c["method"] == "untarget" else int(torch.topk(logp, 2)[1][0, 1])
+        adv_func = UntargetedLogitsAdvLoss(kappa=c["kappa"]) if c["method"] == "untarget" else LogitsAdvLoss(kappa=c["kappa"])
+        rec = WeightRecorder(L2Dist())
+        atk = CW(model, trans_model, adv_func=adv_func, clip_func=ClipPointsLinf(budget=0.18), dist_func=rec,
+                 attack_lr=1e-2, init_weight=10., max_weight=80., binary_step=STEPS, num_iter=ITERS,
+                 attack_method=c["method"])
+        torch.manual_seed(c["seed"])
+        np.random.seed(c["seed"])
+        with contextlib.redirect_stdout(io.StringIO()):
+            bd, ba, sn = atk.attack(torch.from_numpy(pc), torch.tensor([tgt]))
+        W = np.stack(rec.weights)                                  # [STEPS * ITERS, B]
+        assert W.shape[0] == STEPS * ITERS
+        with torch.no_grad():
+            adv_lab = int(torch.argmax(model(torch.from_numpy(ba).float().transpose(1, 2).contiguous())[0], dim=1))
+        fx[f"{nm}_pc"], fx[f"{nm}_target"], fx[f"{nm}_clean"] = pc, np.array([tgt]), np.array([clean])
+        fx[f"{nm}_cfg"] = np.array([STEPS, ITERS, c["kappa"], c["seed"]])
+        fx[f"{nm}_bestdist"], fx[f"{nm}_bestattack"], fx[f"{nm}_success"] = bd, ba.astype(np.float32), np.array(sn)
+        fx[f"{nm}_weights"] = W[::ITERS].copy()                    # the weight of every binary step [STEPS, B]
+        fx[f"{nm}_fails"] = np.array([atk.attack_fail, atk.shuffle_fail, atk.trans_fail])
+        fx[f"{nm}_adv_label"] = np.array([adv_lab])
+        print(nm, "bestdist", bd, "success", sn, "weights", W[::ITERS, 0], "fails", fx[f"{nm}_fails"], "adv label", adv_lab,
+              "clean", clean, flush=True)
+    np.savez_compressed(os.path.join(OUT, "cw_full.npz"), **fx)
+    print("cw_full.npz:", len(fx), "arrays")
+
+
+def gen_knn_full():
+    """The REAL reference's CWKNN.attack on its PointNet++ SSG at N=1024 (B=1), ChamferDist + ProjectInnerClipLinf(0.18),
+    lr 1e-2 (attack/KNN/Eval_KNN.py:139,243-244), 100 iterations. The victim draws an FPS start index from torch's global
+    CPU generator in every set-abstraction layer of every forward (model/pointnet2_utils.py:72): the seed below fixes that
+    stream, and the mirror consumes it in the same order."""
+    install_cpu_shim()
+    import contextlib
+    import io
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from oracle.ref_torch import seeded_state_dict, state_sha256
+    from model.pointnet import PointNetCls
+    from model.pointnet2_SSG import PointNet_Ssg
+    from attack.KNN.KNN_attack import CWKNN
+    from attack.CW.CW_utils.adv_utils import UntargetedLogitsAdvLoss
+    from attack.CW.CW_utils.dist_utils import ChamferDist
+    from attack.CW.CW_utils.clip_utils import ProjectInnerClipLinf
+
+    ssg = PointNet_Ssg(num_classes=40)
+    sd = seeded_state_dict(ssg, 3)
+    ssg.load_state_dict(sd)
+    ssg.eval()
+    pn = PointNetCls(k=40, feature_transform=False)
+    pn.load_state_dict(seeded_state_dict(pn, 0))
+    pn.eval()
+    fx = {"sha256": np.array(state_sha256(sd))}
+    # (On this seeded random-init victim the logit margin is a few hundredths and the Chamfer term, multiplied by K as in
+    # the reference, dominates: the decisive outcome of a run is "not adversarial". The two cases below were picked among
+    # several because their final margin stays > 0.025 under eight different FPS start draws — a success flag that does
+    # not hinge on rounding. What they pin: the RNG stream order, the clean prediction, the fail counters, the cloud.)
+    N, ITERS = 1024, 100
+    cases = {"a": dict(cloud=5102, seed=2001, kappa=0.), "b": dict(cloud=5104, seed=2003, kappa=0.)}
+    fx["names"] = np.array(sorted(cases))
+    for nm in sorted(cases):
+        c = cases[nm]
+        pc = unit_cloud(np.random.default_rng(c["cloud"]), N)[None]
+        torch.manual_seed(50)
+        with torch.no_grad():
+            clean = int(torch.argmax(ssg(torch.from_numpy(pc).transpose(1, 2).contiguous())[0], dim=1))
+        atk = CWKNN(ssg, pn, pn, pn, pn, pn, adv_func=UntargetedLogitsAdvLoss(kappa=c["kappa"]), dist_func=ChamferDist(),
+                    clip_func=ProjectInnerClipLinf(budget=0.18), attack_lr=1e-2, num_iter=ITERS, attack_method='untarget')
+        torch.manual_seed(c["seed"])
+        np.random.seed(c["seed"])
+        with contextlib.redirect_stdout(io.StringIO()):
+            adv, sn = atk.attack(torch.from_numpy(pc), torch.tensor([clean]))
+        fx[f"{nm}_pc"], fx[f"{nm}_target"] = pc, np.array([clean])
+        fx[f"{nm}_cfg"] = np.array([ITERS, 1e-2, c["kappa"], c["seed"]])
+        fx[f"{nm}_adv"], fx[f"{nm}_success"] = adv.astype(np.float32), np.array(sn)
+        fx[f"{nm}_fails"] = np.array([atk.attack_fail, atk.pt_fail])
+        print(nm, "success", sn, "fails", fx[f"{nm}_fails"], "moved", float(np.abs(adv - pc).max()), flush=True)
+    np.savez_compressed(os.path.join(OUT, "knn_full.npz"), **fx)
+    print("knn_full.npz:", len(fx), "arrays")
+
+
 def gen_pointnet2():
     """PointNet++ ops (FPS / ball query / grouping) and the SSG / MSG classifiers of the reference on seeded inputs.
     The reference draws the FPS start index from the global CPU generator (pointnet2_utils.py:72): every call below is
@@ -960,7 +1078,8 @@ def gen_curvenet_trace():
     print("curvenet_trace.npz:", {k: v.shape for k, v in fx.items() if hasattr(v, "shape")})
 
 
-SECTIONS = {"metrics_n4096": gen_metrics_n4096, "curvenet_trace": gen_curvenet_trace, "f4": gen_f4, "geoa3_dgcnn": gen_geoa3_dgcnn, "cw_curvenet": gen_cw_curvenet, "curvenet_blocks": gen_curvenet_blocks, "formats": gen_formats, "cw_additional": gen_cw_additional, "curvenet": gen_curvenet, "aof": gen_aof, "geoa3": gen_geoa3, "dgcnn": gen_dgcnn, "metrics": gen_metrics, "pointnet": gen_pointnet, "cw": gen_cw, "pointnet2": gen_pointnet2, "knn": gen_knn}
+SECTIONS = {"metrics_n4096": gen_metrics_n4096, "curvenet_trace": gen_curvenet_trace, "f4": gen_f4, "geoa3_dgcnn": gen_geoa3_dgcnn, "cw_curvenet": gen_cw_curvenet, "curvenet_blocks": gen_curvenet_blocks, "formats": gen_formats, "cw_additional": gen_cw_additional, "curvenet": gen_curvenet, "aof": gen_aof, "geoa3": gen_geoa3, "dgcnn": gen_dgcnn, "metrics": gen_metrics, "pointnet": gen_pointnet, "cw": gen_cw, "pointnet2": gen_pointnet2, "knn": gen_knn, "cw_full": gen_cw_full,
+            "knn_full": gen_knn_full}
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(SECTIONS)
