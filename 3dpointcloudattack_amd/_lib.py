@@ -112,7 +112,7 @@ SIGNATURES = {
     "pc3d_linear_pre_f32": [_P, _I, _I, _I, _P, _P, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P],
     "pc3d_pointmlp3_max_bwd_f32": _PTS + [_I, _I] + [_P] * 7 + [_I, _I, _I] + [_P, _P, _P, _P] + _PTS + [_P, _I, _P],
     "pc3d_pointmlp3_bwd_tile_points": [],
-    "pc3d_linear_f32": [_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _P, _I, _P],
+    "pc3d_linear_f32": [_P, _I, _I, _I, _I, _P, _P, _I, _I, _F, _P, _I, _F, _P, _I, _P],
     "pc3d_cls_loss_f32": [_P, _I, _I, _I, _P, _I, _F, _F, _P, _P, _P, _P, _P],
 }
 

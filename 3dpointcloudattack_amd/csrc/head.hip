@@ -22,12 +22,13 @@ struct LinArgs {
   int P;
   const float* W;     // [O, K] row-major
   const float* bias;  // [O] or null
-  const float* gate;  // [B, O] or null: Y = gate > 0 ? Y : 0  (ReLU mask of a saved forward activation)
+  const float* gate;  // [B, O] or null: Y = gate > 0 ? Y : gslope * Y  (the (Leaky)ReLU mask of a saved forward activation)
   int ldg;
   float* Y;           // [B, O]
   int ldy;
   int B, K, O;
-  int relu;
+  int relu;           // 1: Y = Y > 0 ? Y : slope * Y  (slope 0 = ReLU)
+  float slope, gslope;
 };
 
 __global__ __launch_bounds__(LN_T) void linear_kernel(LinArgs a) {
@@ -123,8 +124,8 @@ __global__ __launch_bounds__(LN_T) void linear_kernel(LinArgs a) {
     const int b = b0 + row, o = o0 + col;
     if (b < a.B && o < a.O) {
       if (a.bias) s += a.bias[o];
-      if (a.relu) s = fmaxf(s, 0.f);
-      if (a.gate && !(a.gate[(int64_t)b * a.ldg + o] > 0.f)) s = 0.f;
+      if (a.relu) s = s > 0.f ? s : s * a.slope;
+      if (a.gate && !(a.gate[(int64_t)b * a.ldg + o] > 0.f)) s *= a.gslope;
       a.Y[(int64_t)b * a.ldy + o] = s;
     }
   }
@@ -189,8 +190,8 @@ __global__ __launch_bounds__(LN_T) void linear16_kernel(LinArgs a) {
     const int b = b0 + row, o = o0 + col;
     if (b < a.B && o < a.O) {
       if (a.bias) s += a.bias[o];
-      if (a.relu) s = fmaxf(s, 0.f);
-      if (a.gate && !(a.gate[(int64_t)b * a.ldg + o] > 0.f)) s = 0.f;
+      if (a.relu) s = s > 0.f ? s : s * a.slope;
+      if (a.gate && !(a.gate[(int64_t)b * a.ldg + o] > 0.f)) s *= a.gslope;
       a.Y[(int64_t)b * a.ldy + o] = s;
     }
   }
@@ -510,14 +511,15 @@ extern "C" int pc3d_cls_tail_f32(const float* c2, int B, int K2, const float* W3
 }
 
 extern "C" int pc3d_linear_f32(const float* X, int ldx, int P, int B, int K, const float* W, const float* bias,
-                               int O, int relu, const float* gate, int ldg, float* Y, int ldy, void* stream) {
+                               int O, int relu, float slope, const float* gate, int ldg, float gate_slope, float* Y, int ldy,
+                               void* stream) {
   PC3D_REQUIRE(B >= 0 && K >= 1 && O >= 1 && P >= 1, "pc3d_linear_f32: bad sizes B=%d K=%d O=%d P=%d", B, K, O, P);
   PC3D_REQUIRE(ldx >= P * K && ldy >= O, "pc3d_linear_f32: leading dimensions too small (ldx=%d ldy=%d)", ldx, ldy);
   PC3D_REQUIRE((K % 8 != 0) || (ldx % 4 == 0), "pc3d_linear_f32: ldx=%d must be a multiple of 4 for 16-byte loads", ldx);
   if (B == 0) return PC3D_OK;
   PC3D_REQUIRE(X && W && Y, "pc3d_linear_f32: null pointer");
   PC3D_REQUIRE(gate == nullptr || ldg >= O, "pc3d_linear_f32: ldg=%d too small", ldg);
-  LinArgs a{X, ldx, P, W, bias, gate, ldg, Y, ldy, B, K, O, relu};
+  LinArgs a{X, ldx, P, W, bias, gate, ldg, Y, ldy, B, K, O, relu, slope, gate_slope};
   if ((K & 15) == 0 && P == 1 && K / 16 <= 8 * LN_W && O >= 64)
     hipLaunchKernelGGL(linear16_kernel, dim3(cdiv(O, 16), cdiv(B, 32)), dim3(LN_T), 0, as_stream(stream), a);
   else

@@ -109,6 +109,7 @@ class CurveNet(_FrozenFusedMixin, nn.Module):
         # conv0's ReLU is applied inside the pooling launch: [max_i relu(y) | mean_i relu(y)] (:66-68)
         _, _, w0, b0 = folded_pw(self.conv0, None)
         x = ops.linear_act_maxmean_pool(feats, w0, b0, 0.0)
-        x = pw_cl(self.conv1, x, bn=self.bn1, act=("relu", 0.0))
-        x = pw_cl(self.conv2, self.dp1(x))
+        _, _, w1, b1 = folded_pw(self.conv1, self.bn1)
+        _, _, w2, b2 = folded_pw(self.conv2, None)
+        x = ops.head_mlp(x, [(w1, b1, "relu", 0.0), (w2, b2, None, 0.0)])      # (dropout is the identity in eval mode)
         return x, x, x

@@ -106,8 +106,6 @@ class DGCNN(_FrozenFusedMixin, nn.Module):
         g = torch.cat(feats, dim=2)                         # [B,N,512]
         g = ops.linear_act_maxmean_pool(g, *c5, 0.2)            # conv5, leaky + adaptive max / avg pool over N (backward:
                                                                 # one GEMM, the pooled gradient generated on load)
-        g = ops.linear_act(g, *head[0], "leaky", 0.2)
-        g = ops.linear_act(g, *head[1], "leaky", 0.2)
-        g = ops.linear_act(g, *head[2])
+        g = ops.head_mlp(g, [(*head[0], "leaky", 0.2), (*head[1], "leaky", 0.2), (*head[2], None, 0.0)])
         g = F.log_softmax(g, -1)
         return g, g, g

@@ -40,8 +40,6 @@ class PointNet_Ssg(_FrozenFusedMixin, nn.Module):
         geometry_join(self, xyz)
         l3_xyz, l3_points = self.sa3(l2_xyz, l2_points)
         x = l3_points.reshape(B, 1024)
-        x = ops.linear_act(x, *head[0], "relu")      # dropout is identity in eval
-        x = ops.linear_act(x, *head[1], "relu")
-        x = ops.linear_act(x, *head[2])
+        x = ops.head_mlp(x, [(*head[0], "relu", 0.0), (*head[1], "relu", 0.0), (*head[2], None, 0.0)])   # dropout: identity in eval
         x = F.log_softmax(x, -1)
         return x, x, x

@@ -508,8 +508,9 @@ def knn(q, r, K, q_cf=False, r_cf=False, deterministic=None):
 # ------------------------------------------------------------------------------------------------------
 # classifier heads
 # ------------------------------------------------------------------------------------------------------
-def linear(X, W, bias=None, relu=False, gate=None, parts=1, out=None):
-    """Y = epi(X @ W.T + bias). X [B,K] (or [B,parts,K] summed over parts), W [O,K] contiguous fp32."""
+def linear(X, W, bias=None, relu=False, gate=None, parts=1, out=None, slope=0.0, gate_slope=0.0):
+    """Y = epi(X @ W.T + bias). X [B,K] (or [B,parts,K] summed over parts), W [O,K] contiguous fp32. relu: (Leaky)ReLU
+    with `slope` in the epilogue; gate [B,O]: Y = gate > 0 ? Y : gate_slope * Y afterwards (a saved activation's mask)."""
     _check(X, "X")
     _check(W, "W")
     if parts == 1:
@@ -528,7 +529,8 @@ def linear(X, W, bias=None, relu=False, gate=None, parts=1, out=None):
     Y = out if out is not None else torch.empty((B, O), dtype=torch.float32, device=X.device)
     with torch.cuda.device(X.device):
         _lib.call("pc3d_linear_f32", X.data_ptr(), ldx, parts, B, K, W.data_ptr(), _ptr(bias), O, 1 if relu else 0,
-                  _ptr(gate), gate.stride(0) if gate is not None else 0, Y.data_ptr(), Y.stride(0), _stream())
+                  float(slope), _ptr(gate), gate.stride(0) if gate is not None else 0, float(gate_slope), Y.data_ptr(),
+                  Y.stride(0), _stream())
     return Y
 
 
@@ -932,8 +934,7 @@ def gemm_nt(x2d, w, bias=None, act=None, slope=0.0, gate=None, gate_slope=0.0, o
         # faster there. It has ReLU in its epilogue; the LeakyReLU / the input mask of the backward are elementwise
         # passes over [M, N] / [M, K] with M <= 64 rows.
         xs = x2d if gate is None else torch.where(gate > 0, x2d, gate_slope * x2d)
-        y = linear(xs, w, bias, relu=(act == "relu"))
-        return F_leaky(y, slope) if act == "leaky" else y
+        return linear(xs, w, bias, relu=act in ("relu", "leaky"), slope=slope if act == "leaky" else 0.0)
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=x2d.device)
     variant = gemm_variant(unit_rows, N, K)
@@ -974,6 +975,56 @@ class _LinearActFn(torch.autograd.Function):
                      gate_slope=ctx.slope if ctx.act == "leaky" else 0.0, unit_rows=_unit_rows(ctx.shp),
                      head=len(ctx.shp) == 2)
         return gx.view(ctx.shp), None, None, None, None
+
+
+class _HeadMLPFn(torch.autograd.Function):
+    """A classifier head — Linear + (Leaky)ReLU layers over the SAMPLES of a batch, [B,K0] -> [B,Kn] — as one launch per
+    layer each way: the activation sits in the forward launch's epilogue and the backward chains
+    dX_{l-1} = act'_{l-1}(dX_l . W_l) with the previous layer's saved output as the launch's gate (pc3d_linear_f32), instead
+    of an activation pass forward and a compare / scale / select triple backward per layer."""
+
+    @staticmethod
+    def forward(ctx, x, acts, *wb):
+        n = len(wb) // 2
+        ys, h = [], x
+        for l in range(n):
+            name, slope = acts[l]
+            h = linear(h, wb[2 * l], wb[2 * l + 1], relu=name is not None, slope=slope)
+            ys.append(h)
+        ctx.acts, ctx.n = acts, n
+        ctx.save_for_backward(*[ys[l] if acts[l][0] is not None else None for l in range(n - 1)], *[wb[2 * l] for l in range(n)])
+        ctx.last = ys[-1] if acts[-1][0] is not None else None
+        return ys[-1]
+
+    @staticmethod
+    def backward(ctx, g):
+        n, acts = ctx.n, ctx.acts
+        saved = ctx.saved_tensors
+        ys, ws = saved[:n - 1], saved[n - 1:]
+        g = g.contiguous()
+        if ctx.last is not None:                    # an activation on the LAST layer: mask the incoming gradient once
+            g = gate(g, ctx.last, acts[-1][1])
+        for l in range(n - 1, -1, -1):
+            prev = ys[l - 1] if l > 0 else None
+            g = linear(g, _w_transposed(ws[l]), None, gate=prev, gate_slope=acts[l - 1][1] if prev is not None else 0.0)
+        return (g, None) + (None,) * (2 * n)
+
+
+def head_mlp(x, layers):
+    """x [B,K0] through layers = [(W [O,K], b or None, act in {None,"relu","leaky"}, slope), ...] of a frozen classifier
+    head; differentiable in x. One pc3d_linear_f32 launch per layer forward and backward."""
+    _check(x, "x")
+    if x.dim() != 2:
+        raise ValueError("head_mlp: x must be [B,K] (rows are samples)")
+    acts, wb = [], []
+    for (w, b, act, slope) in layers:
+        w = w.detach()
+        wb += [w if w.is_contiguous() else w.contiguous(), b.detach() if b is not None else None]
+        acts.append((act, float(slope) if act == "leaky" else 0.0))
+        if w.shape[1] % 8 or act not in (None, "relu", "leaky"):
+            raise ValueError("head_mlp: K % 8 == 0 and act in {None, relu, leaky} expected")
+    x = x if x.stride(1) == 1 and x.stride(0) % 4 == 0 else x.contiguous()
+    return _HeadMLPFn.apply(x, tuple(acts), *wb)
 
 
 def linear_act(x, w, b=None, act=None, slope=0.0):

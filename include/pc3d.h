@@ -292,12 +292,14 @@ int pc3d_pointmlp3_max_bwd_f32(const float* x, int64_t x_bs, int64_t x_ps, int64
 /* ---------------------------------------------------------------------------------------------------------
  * Classifier heads. Y[b,o] = epi(sum_k X[b,k] W[o,k] + bias[o]) for small row counts (the B samples of a batch),
  * fp32 MFMA. X may be given as P partial slabs per row ([B,P,K], summed on load; P=1 = plain matrix; ldx = row
- * stride in floats). epi: optional ReLU, then optional gate (Y = gate[b,o] > 0 ? Y : 0 — the ReLU mask of a saved
- * forward activation, which makes the same kernel the backward of Linear+ReLU when W is passed transposed).
- * Replaces F.linear / BatchNorm1d(eval, folded) / ReLU of model/pointnet.py:38-47,144-147 and their autograd.
+ * stride in floats). epi: optional (Leaky)ReLU (relu = 1: Y = Y > 0 ? Y : slope * Y; slope 0 = ReLU), then optional
+ * gate (Y = gate[b,o] > 0 ? Y : gate_slope * Y — the activation mask of a saved forward output, which makes the same
+ * kernel the backward of Linear + (Leaky)ReLU when W is passed transposed: dX_prev = gate_prev(dY . W)).
+ * Replaces F.linear / BatchNorm1d(eval, folded) / ReLU of model/pointnet.py:38-47,144-147 (LeakyReLU(0.2): the DGCNN
+ * head, model/dgcnn.py:322-326) and their autograd.
  * ------------------------------------------------------------------------------------------------------- */
 int pc3d_linear_f32(const float* X, int ldx, int P, int B, int K, const float* W, const float* bias, int O,
-                    int relu, const float* gate, int ldg, float* Y, int ldy, void* stream);
+                    int relu, float slope, const float* gate, int ldg, float gate_slope, float* Y, int ldy, void* stream);
 /* The same layer with its X operand produced on the fly by a tiny pre-layer (the backward of STN3d's fc3, 9 -> 256,
  * folded into the launch of fc2's backward, model/pointnet.py:44-45 and their autograd):
  *   X[b,k] = gate_pre[b,k] > 0 ? sum_{j<J} (sum_p parts[b,p,j]) Wp[j,k] : 0 ;   Y[b,o] = gate(sum_k X[b,k] W[o,k])

@@ -128,3 +128,43 @@ def test_wt_cache_eviction_keeps_captured_graphs_valid(ops, dev):
     assert torch.equal(out1, out2) and torch.equal(g1, g2)
     np.testing.assert_allclose(out2.cpu().numpy(), ref_out.cpu().numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(g2.cpu().numpy(), ref_g.cpu().numpy(), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("B", [1, 32, 100])
+@pytest.mark.parametrize("acts", [("relu", "relu", None), ("leaky", "leaky", None), ("leaky", None, "relu")])
+def test_head_mlp_vs_torch_float64(ops, dev, B, acts):
+    """The classifier heads as one pc3d_linear_f32 launch per layer each way (activation in the epilogue, the backward's
+    mask as the launch's gate): values and input gradient against torch in double; a sample's row does not depend on B."""
+    rng = np.random.default_rng(B)
+    dims = [256, 128, 64, 40]
+    x = torch.from_numpy(rng.standard_normal((B, dims[0])).astype(np.float32)).to(dev)
+    layers, ref_layers = [], []
+    for l, act in enumerate(acts):
+        w = torch.from_numpy((rng.standard_normal((dims[l + 1], dims[l])) / dims[l] ** 0.5).astype(np.float32)).to(dev)
+        b = torch.from_numpy(rng.standard_normal(dims[l + 1]).astype(np.float32)).to(dev) if l != 1 else None
+        layers.append((w, b, act, 0.2 if act == "leaky" else 0.0))
+    gw = torch.from_numpy(rng.standard_normal((B, dims[-1])).astype(np.float32)).to(dev)
+
+    def ref(xd):
+        h = xd
+        for (w, b, act, slope) in layers:
+            h = h @ w.double().t() + (b.double() if b is not None else 0.0)
+            if act == "relu":
+                h = torch.relu(h)
+            elif act == "leaky":
+                h = torch.nn.functional.leaky_relu(h, slope)
+        return h
+
+    xg = x.clone().requires_grad_()
+    y = ops.head_mlp(xg, layers)
+    (y * gw).sum().backward()
+    xd = x.double().requires_grad_()
+    yr = ref(xd)
+    (yr * gw.double()).sum().backward()
+    np.testing.assert_allclose(y.detach().cpu().numpy(), yr.detach().cpu().numpy(), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xd.grad.cpu().numpy(), rtol=2e-4, atol=2e-5)
+    if B > 1:
+        x1 = x[:1].clone().requires_grad_()
+        y1 = ops.head_mlp(x1, layers)
+        (y1 * gw[:1]).sum().backward()
+        assert torch.equal(y1[0], y[0].detach()) and torch.equal(x1.grad[0], xg.grad[0])
