@@ -70,6 +70,8 @@ SIGNATURES = {
     + _PTS + _PTS + [_I, _P],
     "pc3d_knn_f32": _PTS + _PTS + [_I, _I, _I, _I, _P, _P, _P],
     "pc3d_knn_bwd_f32": _PTS + _PTS + [_I, _I, _I, _I, _P, _P] + _PTS + _PTS + [_I, _P, _P],
+    "pc3d_knn_self_bwd_f32": _PTS + [_I, _I, _I, _P, _P, _P] + _PTS + [_I, _P, _P],
+    "pc3d_knn_outlier_loss_f32": [_P, _I, _I, _I, _F, _P, _P, _P],
     "pc3d_fps_f32": _PTS + [_I, _I, _I, _P, _P, _P],
     "pc3d_ball_query_f32": _PTS + _PTS + [_I, _I, _I, _F, _I, _P, _P],
     "pc3d_ball_query_kernel_f32": [_I] + _PTS + _PTS + [_I, _I, _I, _F, _I, _P, _P],

@@ -58,13 +58,13 @@ class _SetDist(nn.Module):
     def forward(self, adv_pc, ori_pc, weights=None, batch_avg=True):
         B = adv_pc.shape[0]
         weights = _weights(weights, B, adv_pc.device)
-        loss1, loss2 = ops.set_distance(adv_pc.float(), ori_pc.float(), self._reduce,
-                                        a_cf=_is_cf(adv_pc), b_cf=_is_cf(ori_pc))  # adv2ori, ori2adv
-        if self.method == 'adv2ori':
-            loss = loss1
+        a, o, a_cf, o_cf = adv_pc.float(), ori_pc.float(), _is_cf(adv_pc), _is_cf(ori_pc)
+        if self.method == 'adv2ori':          # one search: the other direction is never looked at (:62-63)
+            loss = ops.set_distance_one(a, o, self._reduce, a_cf=a_cf, b_cf=o_cf)
         elif self.method == 'ori2adv':
-            loss = loss2
+            loss = ops.set_distance_one(o, a, self._reduce, a_cf=o_cf, b_cf=a_cf)
         else:
+            loss1, loss2 = ops.set_distance(a, o, self._reduce, a_cf=a_cf, b_cf=o_cf)  # adv2ori, ori2adv
             loss = (loss1 + loss2) / 2.
         loss = loss * weights
         if batch_avg:
@@ -94,15 +94,8 @@ class KNNDist(nn.Module):
         B = pc.shape[0]
         cf = _is_cf(pc)
         pc = pc.float()
-        d, _ = ops.knn(pc, pc, self.k + 1, q_cf=cf, r_cf=cf)    # [B,K,k+1], first is the point itself
-        value = d[..., 1:]
-        value = torch.mean(value, dim=-1)  # d_p, [B,K]
-        with torch.no_grad():
-            mean = torch.mean(value, dim=-1)
-            std = torch.std(value, dim=-1)
-            threshold = mean + self.alpha * std
-            weight_mask = (value > threshold[:, None]).float().detach()
-        loss = torch.mean(value * weight_mask, dim=1)  # [B]
+        # search + one loss launch (mean neighbour distance, mean + alpha * std threshold, masked mean: :133-151)
+        loss = ops.knn_outlier_loss(pc, self.k, self.alpha, cf)  # [B]
         weights = _weights(weights, B, pc.device)
         loss = loss * weights
         if batch_avg:

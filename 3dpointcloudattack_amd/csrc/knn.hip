@@ -155,6 +155,8 @@ struct KnnBwdArgs {
   const int32_t* idx;  // [B,N,K]
   const float* w;      // [B,N,K]
   PtsViewMut gq, gr;
+  const float* wscale = nullptr;   // [B] or null: every w[b,...] is multiplied by wscale[b] (an upstream per-sample gradient)
+  int self_sum = 0;                // 1: q and r are the SAME cloud and gr == gq: the scattered term is added to the dense one
 };
 
 __global__ __launch_bounds__(256) void knn_bwd_q_kernel(KnnBwdArgs a) {
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(256) void knn_bwd_q_kernel(KnnBwdArgs a) {
   const int b = blockIdx.y;
   const int nmax = a.N > a.M ? a.N : a.M;
   if (i >= nmax) return;
-  if (a.gr.p && i < a.M) {  // zero-fill grad_r (the scatter pass accumulates into it)
+  if (a.gr.p && i < a.M && !a.self_sum) {  // zero-fill grad_r (the scatter pass accumulates into it)
     float* g = a.gr.p + (int64_t)b * a.gr.bs + (int64_t)i * a.gr.ps;
     g[0] = 0.f, g[a.gr.cs] = 0.f, g[2 * a.gr.cs] = 0.f;
   }
@@ -171,8 +173,9 @@ __global__ __launch_bounds__(256) void knn_bwd_q_kernel(KnnBwdArgs a) {
   const float qx = qp[0], qy = qp[a.q.cs], qz = qp[2 * a.q.cs];
   float gx = 0.f, gy = 0.f, gz = 0.f;
   const int64_t base = ((int64_t)b * a.N + i) * a.K;
+  const float ws = a.wscale ? 2.f * a.wscale[b] : 2.f;
   for (int k = 0; k < a.K; ++k) {
-    const float w = 2.f * a.w[base + k];
+    const float w = ws * a.w[base + k];
     const float* rp = a.r.p + (int64_t)b * a.r.bs + (int64_t)a.idx[base + k] * a.r.ps;
     gx += w * (qx - rp[0]);
     gy += w * (qy - rp[a.r.cs]);
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(256) void knn_bwd_r_atomic_kernel(KnnBwdArgs a) {
   if (t >= a.N * a.K) return;
   const int i = t / a.K;
   const int64_t e = (int64_t)b * a.N * a.K + t;
-  const float w = 2.f * a.w[e];
+  const float w = (a.wscale ? 2.f * a.wscale[b] : 2.f) * a.w[e];
   if (w == 0.f) return;
   const int j = a.idx[e];
   const float* qp = a.q.p + (int64_t)b * a.q.bs + (int64_t)i * a.q.ps;
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(256) void knn_bwd_r_det_kernel(KnnBwdArgs a) {
     for (int t = threadIdx.x; t < 1024; t += 256) {
       const int e = t0 + t;
       s_idx[t] = (e < total) ? a.idx[(int64_t)b * total + e] : -1;
-      s_w[t] = (e < total) ? 2.f * a.w[(int64_t)b * total + e] : 0.f;
+      s_w[t] = (e < total) ? (a.wscale ? 2.f * a.wscale[b] : 2.f) * a.w[(int64_t)b * total + e] : 0.f;
     }
     __syncthreads();
     const int lim = (total - t0) < 1024 ? (total - t0) : 1024;
@@ -240,7 +243,8 @@ __global__ __launch_bounds__(256) void knn_bwd_r_det_kernel(KnnBwdArgs a) {
   }
   if (live) {
     float* g = a.gr.p + (int64_t)b * a.gr.bs + (int64_t)j * a.gr.ps;
-    g[0] = gx, g[a.gr.cs] = gy, g[2 * a.gr.cs] = gz;
+    if (a.self_sum) g[0] += gx, g[a.gr.cs] += gy, g[2 * a.gr.cs] += gz;
+    else g[0] = gx, g[a.gr.cs] = gy, g[2 * a.gr.cs] = gz;
   }
 }
 
@@ -252,7 +256,7 @@ __global__ __launch_bounds__(256) void knn_bwd_r_edges_kernel(KnnBwdArgs a, floa
   if (t >= a.N * a.K) return;
   const int i = t / a.K;
   const int64_t e = (int64_t)b * a.N * a.K + t;
-  const float w = 2.f * a.w[e];
+  const float w = (a.wscale ? 2.f * a.wscale[b] : 2.f) * a.w[e];
   const int j = min(max(a.idx[e], 0), a.M - 1);
   const float* qp = a.q.p + (int64_t)b * a.q.bs + (int64_t)i * a.q.ps;
   const float* rp = a.r.p + (int64_t)b * a.r.bs + (int64_t)j * a.r.ps;
@@ -262,9 +266,109 @@ __global__ __launch_bounds__(256) void knn_bwd_r_edges_kernel(KnnBwdArgs a, floa
   v[2] = w * (rp[2 * a.r.cs] - qp[2 * a.q.cs]);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The kNN-distance outlier penalty of the kNN attack (attack/CW/CW_utils/dist_utils.py:112-160 KNNDist.forward) from the
+// K1 = k + 1 sorted self-kNN distances d [B,N,K1] (entry 0 = the point itself):
+//   value_i = mean_{j=1..k} d[i,j];  thr = mean_i value + alpha * std_i value (unbiased, as torch.std);
+//   loss[b] = mean_i value_i [value_i > thr]            (the mask is a constant of the graph: torch.no_grad, :146-151)
+// and the weights the backward hands to the kNN backward: w[b,i,j] = [value_i > thr] / (N k) for j >= 1, 0 for j = 0.
+// One workgroup per sample, fixed-order reductions (deterministic); replaces ~15 ATen launches forward and as many backward.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum256(float v, float* part) {   // all 256 threads call it; result in every thread
+  v = wave_sum(v);
+  __syncthreads();                       // part may still be read from the previous call
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+__global__ __launch_bounds__(256) void knn_outlier_loss_kernel(const float* __restrict__ d, int N, int K1, float alpha,
+                                                               float* __restrict__ loss, float* __restrict__ w) {
+  __shared__ float part[4];
+  const int b = blockIdx.x, k = K1 - 1;
+  const float* db = d + (int64_t)b * N * K1;
+  const float inv_k = 1.f / (float)k;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < N; i += 256) {
+    float v = 0.f;
+    for (int j = 1; j < K1; ++j) v += db[(int64_t)i * K1 + j];
+    s += v * inv_k;
+  }
+  const float mean = block_sum256(s, part) / (float)N;
+  float q = 0.f;
+  for (int i = threadIdx.x; i < N; i += 256) {
+    float v = 0.f;
+    for (int j = 1; j < K1; ++j) v += db[(int64_t)i * K1 + j];
+    const float dv = v * inv_k - mean;
+    q += dv * dv;
+  }
+  const float var = block_sum256(q, part) / (float)(N > 1 ? N - 1 : 1);
+  const float thr = mean + alpha * sqrtf(var);
+  const float wv = 1.f / ((float)N * (float)k);
+  float l = 0.f;
+  float* wb = w + (int64_t)b * N * K1;
+  for (int i = threadIdx.x; i < N; i += 256) {
+    float v = 0.f;
+    for (int j = 1; j < K1; ++j) v += db[(int64_t)i * K1 + j];
+    v *= inv_k;
+    const bool out = v > thr;
+    if (out) l += v;
+    wb[(int64_t)i * K1] = 0.f;
+    for (int j = 1; j < K1; ++j) wb[(int64_t)i * K1 + j] = out ? wv : 0.f;
+  }
+  l = block_sum256(l, part);
+  if (threadIdx.x == 0) loss[b] = l / (float)N;
+}
+
+static int knn_bwd_launch(const char* nm, KnnBwdArgs a, int B, float* grad_r, int64_t gr_bs, int64_t gr_ps, int64_t gr_cs,
+                          int deterministic, float* det_ws, void* stream) {
+  const int N = a.N, M = a.M, K = a.K;
+  hipStream_t st = as_stream(stream);
+  const int nmax = N > M ? N : M;
+  hipLaunchKernelGGL(knn_bwd_q_kernel, dim3(cdiv(nmax, 256), B), dim3(256), 0, st, a);
+  PC3D_LAUNCH_CHECK(nm);
+  if (grad_r) {
+    if (deterministic && det_ws && (int64_t)N * K <= 0x7fffffffLL && own_fits(M)) {
+      // records + ordered scatter (det_ws: B * N * K * 3 floats); the scan below costs N * K list entries per
+      // reference point: 575 us at B=64, N=M=2048, K=6 (the kNN attack's regulariser) against ~20 us here
+      hipLaunchKernelGGL(knn_bwd_r_edges_kernel, dim3(cdiv(N * K, 256), B), dim3(256), 0, st, a, det_ws);
+      PC3D_LAUNCH_CHECK(nm);
+      return scatter_rows_det(nm, a.idx, det_ws, 3, nullptr, 0, 0.f, B, N * K, M, 3, grad_r, gr_ps, a.self_sum, 1, stream, nullptr,
+                              gr_bs, gr_cs);
+    }
+    if (deterministic)
+      hipLaunchKernelGGL(knn_bwd_r_det_kernel, dim3(cdiv(M, 256), B), dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL(knn_bwd_r_atomic_kernel, dim3(cdiv(N * K, 256), B), dim3(256), 0, st, a);
+    PC3D_LAUNCH_CHECK(nm);
+  }
+  return PC3D_OK;
+}
+
 }  // namespace pc3d
 
 using namespace pc3d;
+
+extern "C" int pc3d_knn_outlier_loss_f32(const float* d, int B, int N, int K1, float alpha, float* loss, float* w, void* stream) {
+  PC3D_REQUIRE(B >= 0 && N >= 1 && K1 >= 2, "pc3d_knn_outlier_loss_f32: bad sizes B=%d N=%d K1=%d (self + >= 1 neighbour)", B, N, K1);
+  if (B == 0) return PC3D_OK;
+  PC3D_REQUIRE(d && loss && w, "pc3d_knn_outlier_loss_f32: null pointer");
+  hipLaunchKernelGGL(knn_outlier_loss_kernel, dim3(B), dim3(256), 0, as_stream(stream), d, N, K1, alpha, loss, w);
+  PC3D_LAUNCH_CHECK("pc3d_knn_outlier_loss_f32");
+  return PC3D_OK;
+}
+
+extern "C" int pc3d_knn_self_bwd_f32(const float* x, int64_t x_bs, int64_t x_ps, int64_t x_cs, int B, int N, int K,
+                                     const int32_t* idx, const float* w, const float* w_scale, float* grad, int64_t g_bs,
+                                     int64_t g_ps, int64_t g_cs, int deterministic, float* det_ws, void* stream) {
+  PC3D_REQUIRE(B >= 0 && N >= 1 && K >= 1, "pc3d_knn_self_bwd_f32: bad sizes B=%d N=%d K=%d", B, N, K);
+  PC3D_REQUIRE(B <= 65535, "pc3d_knn_self_bwd_f32: B=%d exceeds grid.y limit", B);
+  if (B == 0) return PC3D_OK;
+  PC3D_REQUIRE(x && idx && w && grad, "pc3d_knn_self_bwd_f32: null pointer");
+  KnnBwdArgs a{{x, x_bs, x_ps, x_cs}, {x, x_bs, x_ps, x_cs}, N, N, K, idx, w,
+               {grad, g_bs, g_ps, g_cs}, {grad, g_bs, g_ps, g_cs}, w_scale, 1};
+  return knn_bwd_launch("pc3d_knn_self_bwd_f32", a, B, grad, g_bs, g_ps, g_cs, deterministic, det_ws, stream);
+}
 
 extern "C" int pc3d_knn_bwd_f32(const float* q, int64_t q_bs, int64_t q_ps, int64_t q_cs,
                                 const float* r, int64_t r_bs, int64_t r_ps, int64_t r_cs,
@@ -278,26 +382,7 @@ extern "C" int pc3d_knn_bwd_f32(const float* q, int64_t q_bs, int64_t q_ps, int6
   PC3D_REQUIRE(q && r && idx && w, "pc3d_knn_bwd_f32: null input pointer");
   KnnBwdArgs a{{q, q_bs, q_ps, q_cs}, {r, r_bs, r_ps, r_cs}, N, M, K, idx, w,
                {grad_q, gq_bs, gq_ps, gq_cs}, {grad_r, gr_bs, gr_ps, gr_cs}};
-  hipStream_t st = as_stream(stream);
-  const int nmax = N > M ? N : M;
-  hipLaunchKernelGGL(knn_bwd_q_kernel, dim3(cdiv(nmax, 256), B), dim3(256), 0, st, a);
-  PC3D_LAUNCH_CHECK("pc3d_knn_bwd_f32/q");
-  if (grad_r) {
-    if (deterministic && det_ws && (int64_t)N * K <= 0x7fffffffLL && own_fits(M)) {
-      // records + ordered scatter (det_ws: B * N * K * 3 floats); the scan below costs N * K list entries per
-      // reference point: 575 us at B=64, N=M=2048, K=6 (the kNN attack's regulariser) against ~20 us here
-      hipLaunchKernelGGL(knn_bwd_r_edges_kernel, dim3(cdiv(N * K, 256), B), dim3(256), 0, st, a, det_ws);
-      PC3D_LAUNCH_CHECK("pc3d_knn_bwd_f32/edges");
-      return scatter_rows_det("pc3d_knn_bwd_f32", idx, det_ws, 3, nullptr, 0, 0.f, B, N * K, M, 3, grad_r, gr_ps, 0, 1, stream,
-                              nullptr, gr_bs, gr_cs);
-    }
-    if (deterministic)
-      hipLaunchKernelGGL(knn_bwd_r_det_kernel, dim3(cdiv(M, 256), B), dim3(256), 0, st, a);
-    else
-      hipLaunchKernelGGL(knn_bwd_r_atomic_kernel, dim3(cdiv(N * K, 256), B), dim3(256), 0, st, a);
-    PC3D_LAUNCH_CHECK("pc3d_knn_bwd_f32/r");
-  }
-  return PC3D_OK;
+  return knn_bwd_launch("pc3d_knn_bwd_f32", a, B, grad_r, gr_bs, gr_ps, gr_cs, deterministic, det_ws, stream);
 }
 
 extern "C" int pc3d_knn_f32(const float* q, int64_t q_bs, int64_t q_ps, int64_t q_cs,

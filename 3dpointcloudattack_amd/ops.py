@@ -267,6 +267,42 @@ class _SetDistFn(torch.autograd.Function):
         return ga, gb, None, None, None, None
 
 
+class _SetDistOneFn(torch.autograd.Function):
+    """ONE direction of _SetDistFn: loss [B] = reduce_i min_j |a_i - b_j|^2 (a -> b). The distance functors of the attacks
+    default to method='adv2ori' (attack/CW/CW_utils/dist_utils.py:40,62-63): the other direction's search, its reduction
+    and — in the backward — its scatter are not needed at all."""
+
+    @staticmethod
+    def forward(ctx, a, b, a_cf, b_cf, reduce, deterministic):
+        dA, iA = nn_raw(a, b, a_cf, b_cf)
+        l1 = rowreduce(dA, reduce)
+        if reduce == "max":
+            ctx.hot = dA == l1[:, None]
+        ctx.save_for_backward(a, b, iA)
+        ctx.cfg = (a_cf, b_cf, reduce, deterministic, dA.shape[1])
+        return l1
+
+    @staticmethod
+    def backward(ctx, g1):
+        a, b, iA = ctx.saved_tensors
+        a_cf, b_cf, reduce, det, N = ctx.cfg
+        need_a, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if not (need_a or need_b):
+            return None, None, None, None, None, None
+        if reduce == "mean":
+            wA, sA = g1.contiguous().view(-1, 1).expand(-1, N), 1.0 / N
+        else:
+            h = ctx.hot
+            wA, sA = ((h.int().cumsum(1) == 1) & h).float() * g1.view(-1, 1), 1.0
+        ga, gb = _nn_bwd(a, a_cf, b, b_cf, iA, wA, sA, None, None, 1.0, need_a, need_b, det)
+        return ga, gb, None, None, None, None
+
+
+def set_distance_one(a, b, reduce="mean", a_cf=False, b_cf=False, deterministic=None):
+    """loss_a2b [B] only: squared Chamfer (reduce='mean') / Hausdorff ('max') term from a to b, one search."""
+    return _SetDistOneFn.apply(a, b, a_cf, b_cf, reduce, deterministic)
+
+
 def set_distance(a, b, reduce="mean", a_cf=False, b_cf=False, deterministic=None):
     """(loss_a2b [B], loss_b2a [B]) — squared Chamfer (reduce='mean') or Hausdorff (reduce='max') terms."""
     return _SetDistFn.apply(a, b, a_cf, b_cf, reduce, deterministic)
@@ -503,6 +539,43 @@ def knn(q, r, K, q_cf=False, r_cf=False, deterministic=None):
     """Differentiable K-NN: (dists [B,N,K], idx [B,N,K] int32). For self-kNN pass the same tensor twice
     (autograd sums the two gradient roles)."""
     return _KnnFn.apply(q, r, K, q_cf, r_cf, deterministic)
+
+
+class _KnnOutlierFn(torch.autograd.Function):
+    """KNNDist (attack/CW/CW_utils/dist_utils.py:112-160) per sample: self-kNN search, the outlier-masked mean of the mean
+    neighbour distances, and its gradient to the points — search + loss launch forward, q / edges / scatter backward,
+    instead of ~15 ATen launches each way around the search."""
+
+    @staticmethod
+    def forward(ctx, pc, k, alpha, cf):
+        d, idx = knn_raw(pc, pc, k + 1, cf, cf)
+        B, N, K1 = d.shape
+        loss = torch.empty((B,), dtype=torch.float32, device=pc.device)
+        w = torch.empty_like(d)
+        with torch.cuda.device(pc.device):
+            _lib.call("pc3d_knn_outlier_loss_f32", d.data_ptr(), B, N, K1, float(alpha), loss.data_ptr(), w.data_ptr(), _stream())
+        ctx.save_for_backward(pc, idx, w)
+        ctx.cf = cf
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        pc, idx, w = ctx.saved_tensors
+        B, N, K1 = w.shape
+        g = g.contiguous()
+        grad = torch.empty(pc.shape, dtype=torch.float32, device=pc.device)
+        det = _det()
+        ws = torch.empty((B, N * K1, 3), dtype=torch.float32, device=pc.device) if det else None
+        with torch.cuda.device(pc.device):
+            _lib.call("pc3d_knn_self_bwd_f32", *_pv(pc, ctx.cf, "pc"), B, N, K1, idx.data_ptr(), w.data_ptr(), g.data_ptr(),
+                      *_pv(grad, ctx.cf, "grad"), det, _ptr(ws), _stream())
+        return grad, None, None, None
+
+
+def knn_outlier_loss(pc, k=5, alpha=1.05, cf=False):
+    """Per-sample kNN-distance outlier penalty [B] of pc ([B,N,3], or [B,3,N] with cf); differentiable in pc."""
+    _check(pc, "pc")
+    return _KnnOutlierFn.apply(pc, int(k), float(alpha), bool(cf))
 
 
 # ------------------------------------------------------------------------------------------------------

@@ -376,6 +376,18 @@ int pc3d_knn_bwd_f32(const float* q, int64_t q_bs, int64_t q_ps, int64_t q_cs,
                      float* grad_q, int64_t gq_bs, int64_t gq_ps, int64_t gq_cs,
                      float* grad_r, int64_t gr_bs, int64_t gr_ps, int64_t gr_cs,
                      int deterministic, float* det_ws, void* stream);
+/* Self-kNN form of that backward (q and r are the SAME cloud x, the kNN attack's regulariser): grad [B,N,3 strides] =
+ * the dense term + the scattered term in one buffer; w_scale [B] (may be NULL) multiplies every w[b,...] — an upstream
+ * per-sample gradient folded into the launch. deterministic / det_ws as above. */
+int pc3d_knn_self_bwd_f32(const float* x, int64_t x_bs, int64_t x_ps, int64_t x_cs, int B, int N, int K,
+                          const int32_t* idx, const float* w, const float* w_scale, float* grad, int64_t g_bs, int64_t g_ps,
+                          int64_t g_cs, int deterministic, float* det_ws, void* stream);
+/* The kNN-distance outlier penalty of the kNN attack (attack/CW/CW_utils/dist_utils.py:112-160 KNNDist.forward) from the
+ * K1 = k + 1 sorted self-kNN distances d [B,N,K1] (entry 0 = the point itself): value_i = mean_{j>=1} d[i,j]; thr =
+ * mean_i value + alpha * std_i value (unbiased); loss[b] = mean_i value_i [value_i > thr]; and the weights its backward
+ * hands to pc3d_knn_self_bwd_f32: w[b,i,j] = [value_i > thr] / (N k) for j >= 1, 0 for j = 0 (the mask is a constant of
+ * the graph, :146-151). One workgroup per sample, fixed-order reductions. */
+int pc3d_knn_outlier_loss_f32(const float* d, int B, int N, int K1, float alpha, float* loss, float* w, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * K11  per-iteration bookkeeping of the CW-family loops on the device (attack/CW/CW_attack.py:129-153): per-sample
