@@ -51,6 +51,7 @@ SIGNATURES = {
     "pc3d_kappa_gather_f32": _PTS + _PTS + [_I, _P, _P, _I, _I, _I, _P, _P, _P],
     "pc3d_geoa3_record_f32": [_P, _I, _I, _I, _P, _I, _P, _P, _I, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P],
     "pc3d_group_act_bwd_mask_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _I, _P],
+    "pc3d_sa_chain_f32": [_P, _L, _P, _P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P],
     "pc3d_gemm_nt_gather_f32": [_P, _L, _P, _P, _I, _I, _I, _I, _F, _P, _P, _I, _I, _I, _F, _P, _L, _P, _P, _P],
     "pc3d_group_max_linear_bwd_mask_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
     "pc3d_gemm_nt_poolbwd_f32": [_P, _L, _P, _P, _I, _I, _F, _P, _I, _I, _P, _L, _P],

@@ -1,0 +1,530 @@
+// A set-abstraction MLP after its (per-point) first layer as ONE launch: gather -> layer 1 (generated) -> layer 2 ->
+// layer 3 -> max over the group, without the [B*S*ns, C2] layer-2 output ever leaving the chip.
+//
+//   out[g, c] = relu( max_{j < ns} ( W3 . relu( W2 . relu(P[b, idx[g, j], :] + Bc[g, :]) + b2 ) )[c] + b3[c] )
+//
+// = model/pointnet2_utils.py:173-199 (PointNetSetAbstraction.forward: index_points + centring + three Conv2d 1x1 + BN +
+// ReLU + max over nsample) with the first layer in its per-point form (group.hip). Until round 3 this was two launches —
+// pc3d_gemm_nt_gather_f32 (layers 1 + 2) and the group-max GEMM (layer 3 + max) — with the [1 048 576, 64] layer-2 output
+// of SSG's SA1 (268 MB at B=64, N=2048; 268 MB again at SA2) written by the first and read back by the second: both
+// launches sat on that traffic (3.4 TB/s; 0.40 / 0.56 of the fp32-MFMA peak end to end).
+//
+// Workgroup = 128 rows (128 / ns groups), 8 waves in 4 x 2. One LDS buffer AH [128][max(C1, C2) + 4] holds first the
+// generated layer-1 rows (the A operand of layer 2), then — once every wave has finished reading it — the layer-2
+// output (the A operand of layer 3); the weights stream through a double-buffered [128][32 + 4] slice per K step, as in
+// gemm_nt_kernel (same operand k-order, same fp32 MFMA sequence: results are bit-identical to the two-launch form).
+// The signs the backward needs leave as bits: one byte per 4 generated layer-1 elements, one word per 32 layer-2 outputs.
+#include "pc3d_common.h"
+
+namespace pc3d {
+
+using sc_f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int SC_T = 512, SC_BM = 128, SC_BK = 32, SC_LD = SC_BK + 4;
+
+struct SaChainArgs {
+  const float* P;       // [B*NA, C1], row stride ldp
+  const float* Bc;      // [B*S, C1]
+  const int32_t* idx;   // [B*S*ns]
+  const float* W2;      // [C2, C1]
+  const float* b2;      // [C2]
+  const float* W3;      // [C3, C2]
+  const float* b3;      // [C3]
+  int64_t ldp;
+  int M, NA, S, ns, C1, C2, C3;
+  int ns_shift, c4_shift;   // log2(ns), log2(C1 / 4): both powers of two (the entry point checks) — the row / group / channel
+                            // of a generated element come from shifts; an integer division costs ~25 VALU instructions, and
+                            // fp32 VALU work does NOT overlap fp32 MFMA work of other waves on the same SIMD (they share the
+                            // multipliers): with three divisions per gathered float4 the non-MFMA skeleton of a tile took
+                            // as long as its MFMAs (measured: 375 us full, 190 us with the MFMAs removed)
+  uint8_t* mask1;       // [M, C1/4]
+  uint32_t* mask2;      // [M, C2/32]
+  float* out;           // [M/ns, C3]
+  int64_t* arg;         // [M/ns, C3]
+};
+
+// one K step of a 32 x (32 TN) wave tile: A from the resident buffer (row stride lda, k offset k0), B from the staged slice
+// (the operand fragments of group t + 1 are requested before the MFMAs of group t are issued: with two waves per SIMD
+// nothing else hides the ds_read latency of a "read, wait, 4 MFMAs" loop)
+template <int TN, bool FIRST = false>
+__device__ __forceinline__ void sc_step(sc_f32x16 (&acc)[TN], const float* __restrict__ Arow, const float* __restrict__ Bs, int wn,
+                                        int r, int h, int ldb = SC_LD) {
+  const float* Ap = Arow + 4 * h;
+  const float* Bp = Bs + (wn + r) * ldb + 4 * h;
+  float4 av[2], bv[2][TN];
+  av[0] = *reinterpret_cast<const float4*>(Ap);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) bv[0][j] = *reinterpret_cast<const float4*>(Bp + j * 32 * ldb);
+#pragma unroll
+  for (int t = 0; t < SC_BK / 8; ++t) {
+    const int c = t & 1, n = c ^ 1;
+    if (t + 1 < SC_BK / 8) {
+      av[n] = *reinterpret_cast<const float4*>(Ap + 8 * (t + 1));
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bv[n][j] = *reinterpret_cast<const float4*>(Bp + j * 32 * ldb + 8 * (t + 1));
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].x, bv[c][j].x, acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].y, bv[c][j].y, acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].z, bv[c][j].z, acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].w, bv[c][j].w, acc[j], 0, 0, 0);
+    }
+  }
+}
+
+// TN2: 32-column MFMA tiles per wave in layer 2 (its output has <= 64 TN2 columns)
+template <int TN2>
+__global__ __launch_bounds__(SC_T, 2) void sa_chain_kernel(SaChainArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sc_lds[];
+  const int LDH = (a.C1 > a.C2 ? a.C1 : a.C2) + 4;
+  float* AH = sc_lds;                                   // [128][LDH]
+  float* Ws = sc_lds + SC_BM * LDH;                      // [2][128][SC_LD]
+  float* pv = Ws + 2 * 128 * SC_LD;                      // [4][128] partial maxima of a column tile (ns > 32)
+  int* pi = reinterpret_cast<int*>(pv + 4 * 128);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wm = (wave >> 1) * 32;                       // this wave's 32 rows
+  const int m0 = blockIdx.x * SC_BM;
+  const int lrow = tid >> 3, lk = (tid & 7) * 4;         // weight staging: 8 threads cover a row's 32 k
+
+  // ---- gather + layer 1: AH[row][:] = relu(P[src(row)] + Bc[group(row)]), one sign bit per element to mask1
+  {
+    const int c4n = a.C1 >> 2;                           // float4 per row
+    const int b_first = (m0 >> a.ns_shift) / a.S;        // uniform: one division per workgroup
+    for (int f0 = tid; f0 < SC_BM * c4n; f0 += 4 * SC_T) {
+      float4 v[4], c[4];
+      int rowv[4], c4v[4];
+      bool live[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int f = f0 + u * SC_T;
+        live[u] = f < SC_BM * c4n;
+        const int row = live[u] ? f >> a.c4_shift : 0, c4 = live[u] ? f & (c4n - 1) : 0;
+        rowv[u] = row, c4v[u] = c4;
+        v[u] = make_float4(0.f, 0.f, 0.f, 0.f), c[u] = v[u];
+        const int gm = m0 + row;
+        if (live[u] && gm < a.M) {
+          const int g = gm >> a.ns_shift, p = a.idx[gm];
+          // the cloud of group g: the tile's first group's cloud (one division per workgroup), + 1 per cloud boundary crossed
+          int bb = b_first;
+          for (int gs = (bb + 1) * a.S; g >= gs; gs += a.S) ++bb;          // (a tile of 128 rows spans <= 4 groups)
+          c[u] = *reinterpret_cast<const float4*>(a.Bc + (int64_t)g * a.C1 + 4 * c4);
+          if ((unsigned)p < (unsigned)a.NA)
+            v[u] = *reinterpret_cast<const float4*>(a.P + ((int64_t)bb * a.NA + p) * a.ldp + 4 * c4);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (!live[u]) continue;
+        float4 x = make_float4(v[u].x + c[u].x, v[u].y + c[u].y, v[u].z + c[u].z, v[u].w + c[u].w);
+        const int gm = m0 + rowv[u];
+        if (gm < a.M)
+          a.mask1[(int64_t)gm * c4n + c4v[u]] =
+              (uint8_t)((x.x > 0.f ? 1 : 0) | (x.y > 0.f ? 2 : 0) | (x.z > 0.f ? 4 : 0) | (x.w > 0.f ? 8 : 0));
+        x.x = x.x > 0.f ? x.x : 0.f, x.y = x.y > 0.f ? x.y : 0.f, x.z = x.z > 0.f ? x.z : 0.f, x.w = x.w > 0.f ? x.w : 0.f;
+        *reinterpret_cast<float4*>(AH + rowv[u] * LDH + 4 * c4v[u]) = x;
+      }
+    }
+  }
+
+  // weight slice of K step k0 of W [ncols, K] into registers (rows past ncols read as zero)
+  float4 wb[2];
+  auto fetch_w = [&](const float* W, int ncols, int K, int n0, int k0) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int gn = n0 + q * 64 + lrow;
+      wb[q] = (gn < ncols) ? *reinterpret_cast<const float4*>(W + (int64_t)gn * K + k0 + lk) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto stash_w = [&](float* dst) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) *reinterpret_cast<float4*>(dst + (q * 64 + lrow) * SC_LD + lk) = wb[q];
+  };
+
+  // ---- layer 2: H = relu(A . W2^T + b2), 128 x (64 TN2) per workgroup, wave (wm, wn2)
+  const int wn2 = (wave & 1) * (32 * TN2);
+  sc_f32x16 acc2[TN2];
+#pragma unroll
+  for (int j = 0; j < TN2; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc2[j][e] = 0.f;
+  fetch_w(a.W2, a.C2, a.C1, 0, 0);
+  stash_w(Ws);
+  __syncthreads();                                       // AH (generated rows) and the first slice are in place
+  int cur = 0;
+  for (int k0 = 0; k0 < a.C1; k0 += SC_BK) {
+    const bool more = k0 + SC_BK < a.C1;
+    if (more) fetch_w(a.W2, a.C2, a.C1, 0, k0 + SC_BK);
+    sc_step<TN2>(acc2, AH + (wm + r) * LDH + k0, Ws + cur * 128 * SC_LD, wn2, r, h);
+    if (more) stash_w(Ws + (cur ^ 1) * 128 * SC_LD);
+    __syncthreads();                                     // (after the last step: every wave has finished reading AH)
+    cur ^= 1;
+  }
+  // first slice of layer 3's weights on its way while the epilogue below runs
+  fetch_w(a.W3, a.C3, a.C2, 0, 0);
+  // epilogue of layer 2 into AH: D[row][col]: lane holds column r of each 32-column tile, rows (e & 3) + 8 (e >> 2) + 4 h
+#pragma unroll
+  for (int j = 0; j < TN2; ++j) {
+    const int col = wn2 + j * 32 + r;
+    const bool col_ok = col < a.C2;
+    const float bj = col_ok ? a.b2[col] : 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = wm + (e & 3) + 8 * (e >> 2) + 4 * h;
+      const float v = acc2[j][e] + bj;
+      const unsigned long long bal = __builtin_amdgcn_ballot_w64(v > 0.f && col_ok);
+      const int gm = m0 + row;
+      if (r == 0 && gm < a.M && wn2 + j * 32 < a.C2)      // (C2 % 32 == 0: a 32-column tile is all in or all out)
+        a.mask2[(int64_t)gm * (a.C2 >> 5) + ((wn2 + j * 32) >> 5)] = (uint32_t)(h ? (bal >> 32) : bal);
+      if (col_ok) AH[row * LDH + col] = v > 0.f ? v : 0.f;
+    }
+  }
+  stash_w(Ws + cur * 128 * SC_LD);
+  __syncthreads();                                       // AH now holds the layer-2 output; W3's first slice is staged
+
+  // ---- layer 3 + group max, one 128-column tile of C3 at a time; wave (wm, wn3 = 64 (wave & 1))
+  const int wn3 = (wave & 1) * 64;
+  const int tpg = a.ns >> 5;                             // 32-row MFMA tiles per group
+  for (int n0 = 0; n0 < a.C3; n0 += 128) {
+    sc_f32x16 acc3[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc3[j][e] = 0.f;
+    for (int k0 = 0; k0 < a.C2; k0 += SC_BK) {
+      const bool more_k = k0 + SC_BK < a.C2, more_n = n0 + 128 < a.C3;
+      if (more_k) fetch_w(a.W3, a.C3, a.C2, n0, k0 + SC_BK);
+      else if (more_n) fetch_w(a.W3, a.C3, a.C2, n0 + 128, 0);
+      sc_step<2>(acc3, AH + (wm + r) * LDH + k0, Ws + cur * 128 * SC_LD, wn3, r, h);
+      if (more_k || more_n) stash_w(Ws + (cur ^ 1) * 128 * SC_LD);
+      __syncthreads();
+      cur ^= 1;
+    }
+    // group-max epilogue (bias + ReLU after the max: both monotone). Per 32-row tile and column: in-lane over the 16
+    // accumulator rows (ascending in e: strict > keeps the lowest row), across the lane halves (compare (value, row)).
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float best = -__builtin_inff();
+      int bi = wm;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int rl = wm + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (m0 + rl < a.M && acc3[j][e] > best) best = acc3[j][e], bi = rl;
+      }
+      const float ov = __shfl_xor(best, 32, 64);
+      const int oi = __shfl_xor(bi, 32, 64);
+      if (ov > best || (ov == best && oi < bi)) best = ov, bi = oi;
+      const int col = n0 + wn3 + j * 32 + r;
+      if (tpg == 1) {                                    // ns == 32: the tile IS the group
+        const int64_t grp = (int64_t)((m0 + wm) >> a.ns_shift);
+        if (h == 0 && m0 + wm < a.M && col < a.C3) {
+          a.out[grp * a.C3 + col] = fmaxf(best + a.b3[col], 0.f);
+          a.arg[grp * a.C3 + col] = bi - wm;
+        }
+      } else if (h == 0) {
+        pv[(wm >> 5) * 128 + wn3 + j * 32 + r] = best;
+        pi[(wm >> 5) * 128 + wn3 + j * 32 + r] = bi;
+      }
+    }
+    if (tpg > 1) {
+      __syncthreads();
+      for (int t = tid; t < (SC_BM >> a.ns_shift) * 128; t += SC_T) {
+        const int g = t >> 7, cl = t & 127;
+        float best = pv[g * tpg * 128 + cl];
+        int bi = pi[g * tpg * 128 + cl];
+        for (int w = 1; w < tpg; ++w) {                  // ascending tile = ascending rows: strict >
+          const float v = pv[(g * tpg + w) * 128 + cl];
+          if (v > best) best = v, bi = pi[(g * tpg + w) * 128 + cl];
+        }
+        const int64_t grp = (int64_t)(m0 >> a.ns_shift) + g;
+        const int col = n0 + cl;
+        if ((int64_t)m0 + ((int64_t)g << a.ns_shift) < a.M && col < a.C3) {
+          a.out[grp * a.C3 + col] = fmaxf(best + a.b3[col], 0.f);
+          a.arg[grp * a.C3 + col] = bi - (g << a.ns_shift);
+        }
+      }
+      __syncthreads();                                   // pv / pi are rewritten by the next column tile
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// The same chain for SMALL weights (SSG's first level: 64 -> 64 -> 128, 48 KB): W2 and W3 stay in LDS for the lifetime
+// of a PERSISTENT workgroup that loops over 64-row tiles. In the streaming kernel above a K step of this level is 16-32
+// MFMAs per wave (~0.5-1 us) — shorter than the L2 latency of the next weight slice it prefetches, and six barriers per
+// tile: 340 us for 25.8 GFLOP. Here a tile costs four barriers and no weight traffic, the next tile's rows are gathered
+// into registers while the current tile's layer 3 runs, and two 4-wave workgroups per CU are in different phases.
+// Same operand order and MFMA sequence: bit-identical results. ns in {32, 64}; C3 <= 128 per resident column tile.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int SR_T = 256, SR_BM = 64;
+
+// A 32 x (32 TN) wave tile over K = 32 KS from two LDS-resident operands, fully unrolled, with the operand fragments of
+// group g + 1 (8 k each) requested BEFORE the MFMAs of group g are issued: with two waves per SIMD nothing else hides the
+// ds_read latency of a "read, wait, 4 MFMAs" loop. The chain's first MFMA takes a literal zero accumulator.
+template <int TN, int KS, int LDA, int LDB>
+__device__ __forceinline__ void sc_mm(sc_f32x16 (&acc)[TN], const float* __restrict__ Ap, const float* __restrict__ Bp) {
+  // Ap = A + row * LDA + 4 h;  Bp = B + (wn + r) * LDB + 4 h   (this lane's operand rows, its half of every 8-k group)
+  constexpr int NG = 4 * KS;
+  float4 av[2], bv[2][TN];
+  av[0] = *reinterpret_cast<const float4*>(Ap);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) bv[0][j] = *reinterpret_cast<const float4*>(Bp + j * 32 * LDB);
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const int c = g & 1, n = c ^ 1;
+    if (g + 1 < NG) {
+      av[n] = *reinterpret_cast<const float4*>(Ap + 8 * (g + 1));
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bv[n][j] = *reinterpret_cast<const float4*>(Bp + j * 32 * LDB + 8 * (g + 1));
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      if (g == 0) {
+        const sc_f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].x, bv[c][j].x, zero, 0, 0, 0);
+      } else {
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].x, bv[c][j].x, acc[j], 0, 0, 0);
+      }
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].y, bv[c][j].y, acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].z, bv[c][j].z, acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].w, bv[c][j].w, acc[j], 0, 0, 0);
+    }
+  }
+}
+
+// C1, C2 in {32, 64}: every LDS stride and trip count is a compile-time constant (operand addresses become immediate
+// offsets: the address arithmetic of the generic form was a sixth of a tile's VALU instructions)
+template <int C1, int C2>
+__global__ __launch_bounds__(SR_T, 2) void sa_chain_res_kernel(SaChainArgs a, int tiles) {
+  extern __shared__ __attribute__((aligned(16))) float sc_lds[];
+  constexpr int LDH = (C1 > C2 ? C1 : C2) + 4, LD2 = C1 + 4, LD3 = C2 + 4;
+  constexpr int c4n = C1 / 4, G4 = C1 / 16;              // float4 per generated row / per thread (64 rows x c4n = 256 x G4)
+  float* W2s = sc_lds;                                   // [64][LD2] (rows past C2 are zero)
+  float* W3s = W2s + 64 * LD2;                            // [round128(C3)][LD3] (rows past C3 are zero)
+  const int C3p = (a.C3 + 127) & ~127;
+  float* AH = W3s + C3p * LD3;                            // [64][LDH]
+  float* pv = AH + SR_BM * LDH;                           // [2][128]
+  int* pi = reinterpret_cast<int*>(pv + 2 * 128);
+  float* b2s = reinterpret_cast<float*>(pi + 2 * 128);     // [64] + [C3p]: the biases, read by every tile's epilogues
+  float* b3s = b2s + 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wm = (wave >> 1) * 32;
+
+  for (int f = tid; f < 64 * c4n; f += SR_T) {            // weights + biases: once per workgroup
+    const int row = f / c4n, c4 = f % c4n;
+    *reinterpret_cast<float4*>(W2s + row * LD2 + 4 * c4) =
+        row < C2 ? *reinterpret_cast<const float4*>(a.W2 + (int64_t)row * C1 + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int f = tid; f < C3p * (C2 / 4); f += SR_T) {
+    const int row = f / (C2 / 4), c4 = f % (C2 / 4);
+    *reinterpret_cast<float4*>(W3s + row * LD3 + 4 * c4) =
+        row < a.C3 ? *reinterpret_cast<const float4*>(a.W3 + (int64_t)row * C2 + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int c = tid; c < 64; c += SR_T) b2s[c] = c < C2 ? a.b2[c] : 0.f;
+  for (int c = tid; c < C3p; c += SR_T) b3s[c] = c < a.C3 ? a.b3[c] : 0.f;
+
+  // generated rows of a tile, G4 float4 per thread: element f = u * 256 + tid -> (row = f / c4n, c4 = f % c4n).
+  // Two-stage prefetch: the INDICES of tile i+2 and the ROWS of tile i+1 are in flight while tile i computes — a row's
+  // address depends on its index, and a load -> address -> load chain inside one stage would stall the wave for a memory
+  // latency per tile right before its MFMAs (measured with the loads removed: 53 us of the 375 us first version).
+  float4 gv[G4], gc[G4];
+  int nidx[G4];
+  auto load_idx = [&](int m0) {
+#pragma unroll
+    for (int u = 0; u < G4; ++u) {
+      const int gm = m0 + (u * SR_T + tid) / c4n;
+      nidx[u] = gm < a.M ? a.idx[gm] : -1;
+    }
+  };
+  auto load_rows = [&](int m0) {
+    const int g_first = m0 >> a.ns_shift, b_first = g_first / a.S;       // uniform: one division per tile
+#pragma unroll
+    for (int u = 0; u < G4; ++u) {
+      const int f = u * SR_T + tid, row = f / c4n, c4 = f % c4n;
+      const int gm = m0 + row;
+      gv[u] = make_float4(0.f, 0.f, 0.f, 0.f), gc[u] = gv[u];
+      if (gm < a.M) {
+        const int g = gm >> a.ns_shift, p = nidx[u];
+        const int bb = b_first + (g >= (b_first + 1) * a.S ? 1 : 0);       // a 64-row tile spans <= 2 groups
+        gc[u] = *reinterpret_cast<const float4*>(a.Bc + (int64_t)g * C1 + 4 * c4);
+        if ((unsigned)p < (unsigned)a.NA)
+          gv[u] = *reinterpret_cast<const float4*>(a.P + ((int64_t)bb * a.NA + p) * a.ldp + 4 * c4);
+      }
+    }
+  };
+  int tile = blockIdx.x;
+  if (tile < tiles) {
+    load_idx(tile * SR_BM);
+    load_rows(tile * SR_BM);
+    if (tile + (int)gridDim.x < tiles) load_idx((tile + gridDim.x) * SR_BM);
+  }
+  const int wn2 = (wave & 1) * 32, wn3 = (wave & 1) * 64;
+  const int tpg = a.ns >> 5;
+  const float* Ap = AH + (wm + r) * LDH + 4 * h;           // this lane's A-operand row (both layers)
+  for (; tile < tiles; tile += gridDim.x) {
+    const int m0 = tile * SR_BM;
+    __syncthreads();                                      // the previous tile's layer 3 has finished reading AH (first trip: weights are in)
+#pragma unroll
+    for (int u = 0; u < G4; ++u) {
+      const int f = u * SR_T + tid, row = f / c4n, c4 = f % c4n;
+      float4 x = make_float4(gv[u].x + gc[u].x, gv[u].y + gc[u].y, gv[u].z + gc[u].z, gv[u].w + gc[u].w);
+      const int gm = m0 + row;
+      if (gm < a.M)
+        a.mask1[(int64_t)gm * c4n + c4] = (uint8_t)((x.x > 0.f ? 1 : 0) | (x.y > 0.f ? 2 : 0) | (x.z > 0.f ? 4 : 0) | (x.w > 0.f ? 8 : 0));
+      x.x = x.x > 0.f ? x.x : 0.f, x.y = x.y > 0.f ? x.y : 0.f, x.z = x.z > 0.f ? x.z : 0.f, x.w = x.w > 0.f ? x.w : 0.f;
+      *reinterpret_cast<float4*>(AH + row * LDH + 4 * c4) = x;
+    }
+    __syncthreads();
+    if (tile + (int)gridDim.x < tiles) {                   // in flight under this tile's MFMAs
+      load_rows((tile + gridDim.x) * SR_BM);              // (their indices arrived during the previous tile)
+      if (tile + 2 * (int)gridDim.x < tiles) load_idx((tile + 2 * gridDim.x) * SR_BM);
+    }
+    // ---- layer 2: wave tile 32 x 32 (columns wn2 ..)
+    sc_f32x16 acc2[1];
+    sc_mm<1, C1 / 32, LDH, LD2>(acc2, Ap, W2s + (wn2 + r) * LD2 + 4 * h);
+    __syncthreads();                                      // every wave has finished reading the generated rows
+    {
+      const int col = wn2 + r;
+      const float bj = b2s[col];
+      float* hp = AH + (wm + 4 * h) * LDH + col;           // rows (e & 3) + 8 (e >> 2) of this lane's column
+      if (col < C2) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float v = acc2[0][e] + bj;
+          hp[((e & 3) + 8 * (e >> 2)) * LDH] = v > 0.f ? v : 0.f;
+        }
+      }
+    }
+    __syncthreads();
+    // the layer-2 signs, one word per row and 32 columns: relu(v) > 0 iff v > 0, so they are read back from the tile just
+    // written (a packed pass: 8 ds_read_b128 + 32 compares per word) instead of a ballot, an address and a two-lane store
+    // per accumulator register in the epilogue above
+    for (int t = tid; t < SR_BM * (C2 / 32); t += SR_T) {
+      const int row = t & (SR_BM - 1), w = t >> 6;        // consecutive lanes: consecutive rows (conflict-free reads)
+      const float* hp = AH + row * LDH + 32 * w;
+      uint32_t bits = 0;
+#pragma unroll
+      for (int c = 0; c < 32; c += 4) {
+        const float4 x = *reinterpret_cast<const float4*>(hp + c);
+        bits |= (x.x > 0.f ? 1u : 0u) << c | (x.y > 0.f ? 2u : 0u) << c | (x.z > 0.f ? 4u : 0u) << c | (x.w > 0.f ? 8u : 0u) << c;
+      }
+      if (m0 + row < a.M) a.mask2[(int64_t)(m0 + row) * (C2 / 32) + w] = bits;
+    }
+    // ---- layer 3 + group max: wave tile 32 x 64 of every 128-column tile
+    const bool full = m0 + SR_BM <= a.M;                   // (uniform) every row of the tile exists: no row guards below
+    for (int n0 = 0; n0 < a.C3; n0 += 128) {
+      sc_f32x16 acc3[2];
+      sc_mm<2, C2 / 32, LDH, LD3>(acc3, Ap, W3s + (n0 + wn3 + r) * LD3 + 4 * h);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        float best = -__builtin_inff();
+        int bi = wm;
+        if (full) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            if (acc3[j][e] > best) best = acc3[j][e], bi = wm + (e & 3) + 8 * (e >> 2) + 4 * h;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int rl = wm + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (m0 + rl < a.M && acc3[j][e] > best) best = acc3[j][e], bi = rl;
+          }
+        }
+        const float ov = __shfl_xor(best, 32, 64);
+        const int oi = __shfl_xor(bi, 32, 64);
+        if (ov > best || (ov == best && oi < bi)) best = ov, bi = oi;
+        const int col = n0 + wn3 + j * 32 + r;
+        if (tpg == 1) {
+          const int64_t grp = (int64_t)((m0 + wm) >> a.ns_shift);
+          if (h == 0 && m0 + wm < a.M && col < a.C3) {
+            a.out[grp * a.C3 + col] = fmaxf(best + b3s[col], 0.f);
+            a.arg[grp * a.C3 + col] = bi - wm;
+          }
+        } else if (h == 0) {
+          pv[(wm >> 5) * 128 + wn3 + j * 32 + r] = best;
+          pi[(wm >> 5) * 128 + wn3 + j * 32 + r] = bi;
+        }
+      }
+      if (tpg > 1) {                                      // ns == 64: the two 32-row tiles of this workgroup are ONE group
+        __syncthreads();
+        for (int cl = tid; cl < 128; cl += SR_T) {
+          float best = pv[cl];
+          int bi = pi[cl];
+          const float v = pv[128 + cl];
+          if (v > best) best = v, bi = pi[128 + cl];       // ascending tile = ascending rows: strict >
+          const int64_t grp = (int64_t)(m0 >> a.ns_shift);
+          const int col = n0 + cl;
+          if (m0 < a.M && col < a.C3) {
+            a.out[grp * a.C3 + col] = fmaxf(best + b3s[col], 0.f);
+            a.arg[grp * a.C3 + col] = bi;
+          }
+        }
+        __syncthreads();
+      }
+    }
+  }
+}
+
+}  // namespace pc3d
+
+using namespace pc3d;
+
+extern "C" int pc3d_sa_chain_f32(const float* P, int64_t ldp, const float* Bc, const int32_t* idx, int B, int NA, int S, int ns,
+                                 const float* W2, const float* b2, int C1, int C2, const float* W3, const float* b3, int C3,
+                                 uint8_t* mask1, uint32_t* mask2, float* out, int64_t* arg, void* stream) {
+  const char* nm = "pc3d_sa_chain_f32";
+  PC3D_REQUIRE(B >= 0 && NA >= 1 && S >= 1 && (ns == 32 || ns == 64 || ns == 128), "%s: bad sizes B=%d NA=%d S=%d ns=%d (ns in {32,64,128})",
+               nm, B, NA, S, ns);
+  PC3D_REQUIRE((C1 == 32 || C1 == 64 || C1 == 128) && C2 >= 32 && C2 <= 128 && C2 % 32 == 0 && C3 >= 32 && C3 % 32 == 0,
+               "%s: widths C1=%d C2=%d C3=%d (C1 in {32,64,128}, C2 a multiple of 32 up to 128, C3 a multiple of 32)", nm, C1, C2, C3);
+  PC3D_REQUIRE((int64_t)B * S * ns <= 0x7fffffffLL && (int64_t)B * NA <= 0x7fffffffLL && ldp >= C1 && ldp % 4 == 0,
+               "%s: problem too large or row stride of P not a multiple of 4", nm);
+  if (B == 0) return PC3D_OK;
+  PC3D_REQUIRE(P && Bc && idx && W2 && b2 && W3 && b3 && mask1 && mask2 && out && arg, "%s: null pointer", nm);
+  PC3D_REQUIRE(((reinterpret_cast<uintptr_t>(P) | reinterpret_cast<uintptr_t>(Bc) | reinterpret_cast<uintptr_t>(W2) |
+                 reinterpret_cast<uintptr_t>(W3)) & 15) == 0, "%s: operands must be 16-byte aligned", nm);
+  SaChainArgs a{P, Bc, idx, W2, b2, W3, b3, ldp, B * S * ns, NA, S, ns, C1, C2, C3, ns == 32 ? 5 : (ns == 64 ? 6 : 7),
+                C1 == 32 ? 3 : (C1 == 64 ? 4 : 5), mask1, mask2, out, arg};
+  const int ldh = (C1 > C2 ? C1 : C2) + 4;
+  hipStream_t st = as_stream(stream);
+  if ((C1 == 32 || C1 == 64) && (C2 == 32 || C2 == 64) && ns <= 64) {
+    // small weights: the persistent resident-weight kernel, when its LDS (weights padded to 64 / 128 rows, a 64-row
+    // tile) leaves room for two workgroups per CU
+    const int c3p = (C3 + 127) & ~127;
+    const size_t lds_r = ((size_t)64 * (C1 + 4) + (size_t)c3p * (C2 + 4) + (size_t)SR_BM * ldh + 2 * 2 * 128 + 64 + c3p) * sizeof(float);
+    if (lds_r <= 80 * 1024) {
+      const int tiles = cdiv(a.M, SR_BM);
+      const int grid_r = tiles < 512 ? tiles : 512;
+      auto launch = [&](auto kern) -> int {
+        if (lds_r > 64 * 1024)
+          if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r);
+              e != hipSuccess) { set_error("%s: LDS opt-in failed: %s", nm, hipGetErrorString(e)); return (int)e; }
+        hipLaunchKernelGGL(kern, dim3(grid_r), dim3(SR_T), lds_r, st, a, tiles);
+        return PC3D_OK;
+      };
+      int rc = C1 == 32 ? (C2 == 32 ? launch(sa_chain_res_kernel<32, 32>) : launch(sa_chain_res_kernel<32, 64>))
+                        : (C2 == 32 ? launch(sa_chain_res_kernel<64, 32>) : launch(sa_chain_res_kernel<64, 64>));
+      if (rc) return rc;
+      PC3D_LAUNCH_CHECK(nm);
+      return PC3D_OK;
+    }
+  }
+  const size_t lds = ((size_t)SC_BM * ldh + 2 * 128 * SC_LD + 2 * 4 * 128) * sizeof(float);
+  const dim3 grid(cdiv(a.M, SC_BM)), block(SC_T);
+  if (C2 <= 64) {
+    if (lds > 64 * 1024)
+      if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sa_chain_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+          e != hipSuccess) { set_error("%s: LDS opt-in failed: %s", nm, hipGetErrorString(e)); return (int)e; }
+    hipLaunchKernelGGL(sa_chain_kernel<1>, grid, block, lds, st, a);
+  } else {
+    if (lds > 64 * 1024)
+      if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sa_chain_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+          e != hipSuccess) { set_error("%s: LDS opt-in failed: %s", nm, hipGetErrorString(e)); return (int)e; }
+    hipLaunchKernelGGL(sa_chain_kernel<2>, grid, block, lds, st, a);
+  }
+  PC3D_LAUNCH_CHECK(nm);
+  return PC3D_OK;
+}

@@ -2027,6 +2027,14 @@ def group_act_bwd_rev(gH, H, mask, idx, rev, NA, slope=0.0):
 # pc3d_group_max_linear_bwd_mask_f32 loads a wave's mask words in one go; with a word load per row and thread it was
 # 30 us per level slower).
 LAYER2_SIGN_BITS = True
+# Layers 1-2-3 + group max as ONE launch (pc3d_sa_chain_f32): the layer-2 output never leaves the chip. False = the
+# two-launch form of round 2 (bit-identical results; kept for A/B timing and as the fallback for other shapes).
+SA_CHAIN = True
+
+
+def sa_chain_supported(C1, C2, C3, ns):
+    return (SA_CHAIN and ns in (32, 64, 128) and C1 in (32, 64, 128) and C2 % 32 == 0 and 32 <= C2 <= 128
+            and C3 % 32 == 0 and LAYER2_SIGN_BITS)
 
 
 class _GroupedMLPMaxFn(torch.autograd.Function):
@@ -2041,8 +2049,20 @@ class _GroupedMLPMaxFn(torch.autograd.Function):
         B, NA, C1 = P.shape
         S, ns = idx.shape[1], idx.shape[2]
         C2 = w2.shape[0]
-        H2 = torch.empty((B * S * ns, C2), dtype=torch.float32, device=P.device)
         mask = torch.empty((B * S * ns, C1 // 4), dtype=torch.uint8, device=P.device)
+        if sa_chain_supported(C1, C2, w3.shape[0], ns) and P.stride(1) % 4 == 0:
+            C3 = w3.shape[0]
+            m2 = torch.empty((B * S * ns, C2 // 32), dtype=torch.int32, device=P.device)
+            out = torch.empty((B * S, C3), dtype=torch.float32, device=P.device)
+            arg = torch.empty((B * S, C3), dtype=torch.int64, device=P.device)
+            with torch.cuda.device(P.device):
+                _lib.call("pc3d_sa_chain_f32", P.data_ptr(), P.stride(1), Bc.data_ptr(), idx.data_ptr(), B, NA, S, ns,
+                          w2.data_ptr(), b2.data_ptr(), C1, C2, w3.data_ptr(), b3.data_ptr(), C3, mask.data_ptr(),
+                          m2.data_ptr(), out.data_ptr(), arg.data_ptr(), _stream())
+            ctx.save_for_backward(out, arg, None, m2, mask, idx, w2, w3, rev_off, rev_lst)
+            ctx.dims = (B, NA, C1)
+            return out.view(B, S, -1)
+        H2 = torch.empty((B * S * ns, C2), dtype=torch.float32, device=P.device)
         # layer 2's own sign bits (C2 % 32 == 0): H2 is then not kept for the backward at all
         m2 = torch.empty((B * S * ns, C2 // 32), dtype=torch.int32, device=P.device) if (C2 % 32 == 0 and LAYER2_SIGN_BITS) else None
         with torch.cuda.device(P.device):

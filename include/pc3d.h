@@ -188,6 +188,19 @@ int pc3d_group_max_linear_bwd_mask_f32(const float* gout, const float* out, cons
 int pc3d_group_act_bwd_mask_f32(const float* gH, const uint8_t* mask, const int32_t* idx, int B, int NA, int S, int K, int C,
                                 float slope, float* gP, float* gBc, int deterministic, void* stream);
 
+/* The WHOLE set-abstraction MLP after its per-point first layer + the max over the group in ONE launch
+ * (model/pointnet2_utils.py:173-199): out[g,c] = relu(max_j (W3 relu(W2 relu(P[b, idx[g,j], :] + Bc[g,:]) + b2))[c] + b3[c]),
+ * arg[g,c] = the winning member j (lowest on ties) — pc3d_gemm_nt_gather_f32 followed by the group-max form of the last
+ * layer, without the [B*S*ns, C2] layer-2 output in memory (268 MB per level at SSG's sizes). Results are bit-identical
+ * to that two-launch form (same operand order, same fp32 MFMA sequence). P [B*NA, C1] row stride ldp, Bc [B*S, C1],
+ * idx [B,S,ns] int32 (outside [0,NA): zero row of P), W2 [C2,C1], W3 [C3,C2]; ns in {32, 64, 128}; C1 in {32, 64, 128},
+ * C2 a multiple of 32 up to 128, C3 a multiple of 32. mask1 [B*S*ns, C1/4] bytes and mask2 [B*S*ns, C2/32] words receive the sign bits
+ * of the generated layer-1 rows / of the layer-2 pre-activations (as pc3d_gemm_nt_gather_f32 writes them): all the
+ * backward (pc3d_group_max_linear_bwd_mask_f32, pc3d_gemm_nt_f32 on W2^T, pc3d_group_act_bwd_*) needs. */
+int pc3d_sa_chain_f32(const float* P, int64_t ldp, const float* Bc, const int32_t* idx, int B, int NA, int S, int ns,
+                      const float* W2, const float* b2, int C1, int C2, const float* W3, const float* b3, int C3,
+                      uint8_t* mask1, uint32_t* mask2, float* out, int64_t* arg, void* stream);
+
 /* The same backward WITHOUT float atomics, as a gather over a reverse index of the grouping.
  * pc3d_group_reverse_i32: per cloud, the list of grouped rows that reference each point (a counting sort on the device:
  *   two passes of integer atomics + a scan). idx [B,S,K] int32 as above; cnt [B,NA] int32 scratch; off [B,NA+1] int32

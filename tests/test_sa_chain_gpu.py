@@ -1,0 +1,78 @@
+"""GPU: the one-launch set-abstraction MLP (pc3d_sa_chain_f32: gather -> layer 1 -> layer 2 -> layer 3 -> group max,
+model/pointnet2_utils.py:173-199) against the two-launch form it replaces (pc3d_gemm_nt_gather_f32 + the group-max GEMM),
+which is pinned to the reference's SSG / MSG logits and input gradients elsewhere (tests/test_pointnet2_gpu.py): outputs,
+arg-max members and the gradients to P / Bc are BIT-identical, at SSG's two levels, MSG-like shapes, a ragged last tile
+and indices outside the cloud; plus a float64 evaluation of the same chain."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import unit_cloud
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(ops, dev, B, N, S, ns, C1, C2, C3, seed, bad_idx=False):
+    rng = np.random.default_rng(seed)
+    xyz = torch.from_numpy(np.stack([unit_cloud(rng, N) for _ in range(B)])).to(dev)
+    cidx = torch.from_numpy(np.stack([rng.choice(N, S, replace=False) for _ in range(B)]).astype(np.int64)).to(dev)
+    centers = torch.gather(xyz, 1, cidx[..., None].expand(-1, -1, 3)).contiguous()
+    idx = ops.ball_query(0.3, ns, xyz, centers)
+    if bad_idx:
+        idx = idx.clone()
+        idx[0, 0, 1] = N            # the ball query's "no point" marker: a zero row of P
+        idx[-1, -1, -1] = -3
+    P = torch.from_numpy(rng.standard_normal((B, N, C1)).astype(np.float32)).to(dev)
+    Bc = torch.from_numpy(rng.standard_normal((B, S, C1)).astype(np.float32)).to(dev)
+    mk = lambda o, i: (torch.from_numpy((rng.standard_normal((o, i)) / i ** 0.5).astype(np.float32)).to(dev),
+                       torch.from_numpy(rng.standard_normal(o).astype(np.float32)).to(dev))
+    layers = [mk(C2, C1), mk(C3, C2)]
+    w = torch.from_numpy(rng.standard_normal((B, S, C3)).astype(np.float32)).to(dev)
+    return P, Bc, idx.contiguous(), layers, w
+
+
+def _run(ops, P, Bc, idx, layers, w, chain):
+    ops.SA_CHAIN = chain
+    try:
+        p, bc = P.clone().requires_grad_(), Bc.clone().requires_grad_()
+        rev = ops.group_reverse(idx, P.shape[1])
+        out = ops.grouped_mlp_max(p, bc, idx, layers, rev=rev)
+        (out * w).sum().backward()
+        return out.detach(), p.grad, bc.grad
+    finally:
+        ops.SA_CHAIN = True
+
+
+@pytest.mark.parametrize("B,N,S,ns,C1,C2,C3", [(8, 2048, 512, 32, 64, 64, 128),     # SSG SA1 (B reduced)
+                                                (8, 512, 128, 64, 128, 128, 256),    # SSG SA2
+                                                (3, 512, 128, 128, 64, 96, 128),     # MSG widest scale
+                                                (2, 512, 100, 32, 32, 32, 64),       # narrow widths, C3 < a column tile
+                                                (1, 300, 7, 64, 64, 128, 320),       # ragged last row tile, three column tiles
+                                                (2, 256, 9, 32, 128, 64, 96)])
+def test_sa_chain_equals_two_launch_form_bitwise(ops, dev, B, N, S, ns, C1, C2, C3):
+    P, Bc, idx, layers, w = _case(ops, dev, B, N, S, ns, C1, C2, C3, seed=C3 + ns, bad_idx=True)
+    if not ops.grouped_mlp_max_supported(C1, ns, layers):
+        pytest.skip("shape not on the fused path")
+    assert ops.sa_chain_supported(C1, C2, C3, ns)
+    o1, gp1, gb1 = _run(ops, P, Bc, idx, layers, w, chain=True)
+    o0, gp0, gb0 = _run(ops, P, Bc, idx, layers, w, chain=False)
+    assert torch.equal(o1, o0), float((o1 - o0).abs().max())
+    assert torch.equal(gp1, gp0) and torch.equal(gb1, gb0)
+
+
+def test_sa_chain_vs_float64(ops, dev):
+    B, N, S, ns, C1, C2, C3 = 2, 256, 16, 32, 64, 64, 128
+    P, Bc, idx, layers, w = _case(ops, dev, B, N, S, ns, C1, C2, C3, seed=3)
+    out, gp, gb = _run(ops, P, Bc, idx, layers, w, chain=True)
+    p, bc = P.double().requires_grad_(), Bc.double().requires_grad_()
+    rows = torch.gather(p, 1, idx.long().reshape(B, S * ns, 1).expand(-1, -1, C1)).view(B, S, ns, C1)
+    h = torch.relu(rows + bc[:, :, None, :])
+    h = torch.relu(h @ layers[0][0].double().t() + layers[0][1].double())
+    h = torch.relu(h @ layers[1][0].double().t() + layers[1][1].double())
+    ref = h.max(dim=2)[0]
+    (ref * w.double()).sum().backward()
+    np.testing.assert_allclose(out.cpu().numpy(), ref.detach().cpu().numpy(), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(gp.cpu().numpy(), p.grad.cpu().numpy(), rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(gb.cpu().numpy(), bc.grad.cpu().numpy(), rtol=2e-4, atol=2e-5)
