@@ -239,6 +239,36 @@ __global__ __launch_bounds__(WM * WN * KS * 64, OCC) void gemm_nt_kernel(GemmArg
     const float* Bs = gm_lds + cur * BUF + BM * KS * GM_LD + kg * BN * GM_LD;
     const int kleft = a.K - k0 - kg * GM_BK;
     const int groups = kleft >= GM_BK ? GM_BK / 8 : (kleft > 0 ? (kleft + 7) / 8 : 0);   // narrow layers (K = 3) run one group, not four
+    if (groups == GM_BK / 8) {
+      // a full K step, unrolled, with the operand fragments of group t + 1 requested before the MFMAs of group t are
+      // issued (the rolled loop below waits for each group's ds_read_b128 right before its MFMAs)
+      const float* Ap = As + (wm + r) * GM_LD + 4 * h;
+      const float* Bp = Bs + (wn + r) * GM_LD + 4 * h;
+      float4 av[2][TM], bv[2][TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) av[0][i] = *reinterpret_cast<const float4*>(Ap + i * 32 * GM_LD);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bv[0][j] = *reinterpret_cast<const float4*>(Bp + j * 32 * GM_LD);
+#pragma unroll
+      for (int t = 0; t < GM_BK / 8; ++t) {
+        const int c = t & 1, n = c ^ 1;
+        if (t + 1 < GM_BK / 8) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) av[n][i] = *reinterpret_cast<const float4*>(Ap + i * 32 * GM_LD + 8 * (t + 1));
+#pragma unroll
+          for (int j = 0; j < TN; ++j) bv[n][j] = *reinterpret_cast<const float4*>(Bp + j * 32 * GM_LD + 8 * (t + 1));
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c][i].x, bv[c][j].x, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c][i].y, bv[c][j].y, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c][i].z, bv[c][j].z, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c][i].w, bv[c][j].w, acc[i][j], 0, 0, 0);
+          }
+      }
+    } else
     for (int t = 0; t < groups; ++t) {
       float4 av[TM], bv[TN];
 #pragma unroll
@@ -408,6 +438,10 @@ static int gemm_nt_launch(int variant, const float* X, int64_t ldx, const float*
   //   0 / 1: 128x128, 4 waves of 64x64, double / single buffered     2: 128x64, 4 waves of 32x64 (N <= 64)
   //   3: 256x64, 4 waves of 64x64, double buffered                    4: 64x128, 4 waves of 32x64
   //   5 / 6: 128x128, 8 waves of 32x64, single / double buffered       8: as 5 with four workgroups per CU (<= 64 VGPRs)
+  // Round 3, measured and not kept: 256x128 workgroup tiles with eight waves of 64x64 (a third less L2 -> LDS traffic per
+  // flop, half the ds_read_b128 per MFMA) — conv5 335-338 us against 320 for variant 5, every narrower layer 10-60 %
+  // slower; operand fragments of group t + 1 requested before the MFMAs of group t (kept: same 320 us — with four waves
+  // per SIMD the ds_read latency was already hidden).
   int v = variant;
   PC3D_REQUIRE(v < 0 || v <= 6 || v == 8 || v == 11 || v == 12, "pc3d_gemm_nt_f32: unknown tile variant %d", v);
   PC3D_REQUIRE(v < 11 || (!ga_idx && !pb_g && !gm_ns && !ymask), "pc3d_gemm_nt_f32: the K-split variants take plain operands only");
