@@ -93,16 +93,12 @@ def slope_ms(run_attack, base, inc):
     return sorted(slopes)[1], slopes
 
 
-def pmc_provenance(path):
-    """Commit that last touched the committed PMC file (the counters are collected under the rocprofv3 wrapper, not in
-    this process): printed next to `traffic` so that a figure older than the kernels it describes is visible."""
-    import subprocess
-    try:
-        out = subprocess.run(["git", "-C", ROOT, "log", "-1", "--format=%h %cs", "--", path], capture_output=True, text=True,
-                             timeout=10).stdout.strip()
-        return out or None
-    except Exception:
-        return None
+def pmc_provenance(counters):
+    """Where and when the committed PMC file was collected (its "_meta" entry: the commit of the kernels it describes and
+    the date, written when the file is copied from gpurun_out/ into profiles/): printed next to `traffic` so that a figure
+    older than the kernels it describes is visible. The counters are collected under the rocprofv3 wrapper, not here."""
+    meta = counters.get("_meta") if isinstance(counters, dict) else None
+    return meta if isinstance(meta, dict) else None
 
 
 def chamfer_cpu_baseline():
@@ -269,7 +265,7 @@ def main():
                 pmc_file = os.path.join("profiles", cand)
                 pmc_all = json.load(open(os.path.join(ROOT, pmc_file)))
                 break
-        pmc_src = {"file": pmc_file, "commit": pmc_provenance(pmc_file) if pmc_file else None,
+        pmc_src = {"file": pmc_file, "collected_at": pmc_provenance(pmc_all),
                    "note": "HBM counters come from separate rocprofv3 --pmc passes of this command (tools/prof_pmc.sh), "
                            "not from this run"}
 
