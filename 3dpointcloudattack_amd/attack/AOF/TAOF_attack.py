@@ -43,8 +43,9 @@ class CWTAOF:
     """Class for CW attack."""
 
     def __init__(self, model, adv_func, dist_func, attack_lr=1e-2, binary_step=2, num_iter=200, GAMMA=0.5,
-                 low_pass=100, clip_func=None, device=None, verbose=False, fused=True, graph=True):
+                 low_pass=100, clip_func=None, device=None, verbose=False, fused=True, graph=True, deterministic=None):
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.deterministic = deterministic     # None: ops.DETERMINISTIC; True / False: that mode during attack()
         self.model = model.to(self.device)
         self.model.eval()
         self.adv_func = adv_func
@@ -72,6 +73,12 @@ class CWTAOF:
         return None
 
     def attack(self, data, target, y_truth=None):
+        if self.deterministic is None:
+            return self._attack(data, target, y_truth)
+        with ops.deterministic(self.deterministic):
+            return self._attack(data, target, y_truth)
+
+    def _attack(self, data, target, y_truth=None):
         """data [B,num_points,3], target [B], y_truth [B] (true labels: success additionally requires the
         low-frequency cloud to be misclassified, :201)."""
         dev = self.device

@@ -68,7 +68,8 @@ class CW:
 
     def __init__(self, model, trans_model, adv_func, clip_func, dist_func, attack_lr=1e-2,
                  init_weight=10., max_weight=80., binary_step=10, num_iter=500, attack_method="untarget",
-                 device=None, verbose=False, fused=True, graph=True, sample_seeds=None, global_batch=None):
+                 device=None, verbose=False, fused=True, graph=True, sample_seeds=None, global_batch=None,
+                 deterministic=None):
         """Arguments as attack/CW/CW_attack.py:26-38. Extra keyword-only style options (defaults keep the
         reference behaviour): device (default: current CUDA device), verbose (reference prints), fused (use the
         fused Adam+clip launch when clip_func is recognised). For sharded runs: `sample_seeds` (one int
@@ -101,6 +102,9 @@ class CW:
         self.graph = graph
         self.sample_seeds = sample_seeds
         self.global_batch = global_batch
+        # None: the process-wide setting (ops.DETERMINISTIC, default on: ordered backward sums, bit-reproducible runs);
+        # True / False: that mode for the duration of attack()
+        self.deterministic = deterministic
 
     # -- helpers ---------------------------------------------------------------------------------------
     def _success(self, pred, label):
@@ -389,6 +393,12 @@ class CW:
             current_weight[e] = (lower_bound[e] + upper_bound[e]) / 2.
 
     def attack(self, data, target):
+        if self.deterministic is None:
+            return self._attack(data, target)
+        with ops.deterministic(self.deterministic):
+            return self._attack(data, target)
+
+    def _attack(self, data, target):
         """Attack on given data to target.
         Args:
             data (torch.FloatTensor): victim data, [B, num_points, 3]

@@ -16,6 +16,7 @@ import torch.nn as nn
 import torch.optim as optim
 
 from ... import graphed as _graphed
+from ... import ops
 from ... import streams as _streams
 
 from .knn_utils import knn_gather, knn_points
@@ -215,6 +216,17 @@ def _forward_step(net, pc_ori, input_curr_iter, normal_ori, ori_kappa, target, s
 
 def geoA3_attack(net, pt_model, ptm_model, pts_model, dgcnn_model, cur_model, pc, label, cfg, i, loader_len,
                  saved_dir=None):
+    """cfg.deterministic (optional; None = the process-wide ops.DETERMINISTIC, default on): ordered backward sums, i.e.
+    bit-reproducible runs, for the duration of the call."""
+    det = getattr(cfg, "deterministic", None)
+    if det is None:
+        return _geoA3_attack(net, pt_model, ptm_model, pts_model, dgcnn_model, cur_model, pc, label, cfg, i, loader_len, saved_dir)
+    with ops.deterministic(det):
+        return _geoA3_attack(net, pt_model, ptm_model, pts_model, dgcnn_model, cur_model, pc, label, cfg, i, loader_len, saved_dir)
+
+
+def _geoA3_attack(net, pt_model, ptm_model, pts_model, dgcnn_model, cur_model, pc, label, cfg, i, loader_len,
+                  saved_dir=None):
     """:185-473. pc [B,N,3], label [B]. Returns (best_attack [B,3,N] tensor, target [B], success mask np.bool [B],
     best_attack_step list[B], all_loss_list [iter_max_steps][B])."""
     dev = next(net.parameters()).device if any(True for _ in net.parameters()) else torch.device("cuda")

@@ -35,7 +35,7 @@ class CWKNN:
 
     def __init__(self, model, pt_model, ptm_model, pts_model, dgcnn_model, cur_model, adv_func, dist_func, clip_func,
                  attack_lr=1e-3, num_iter=2500, attack_method='untarget', device=None, verbose=False, fused=True,
-                 graph=True, sample_seeds=None, global_batch=None):
+                 graph=True, sample_seeds=None, global_batch=None, deterministic=None):
         """Extra keywords (defaults = the reference's behaviour). For sharded runs: `sample_seeds` (one int
         per sample) draws every sample's start noise AND a PointNet++ victim's FPS start indices from that sample's own
         generator instead of the shared global stream, and `global_batch` is the size of the unsharded batch whose loss
@@ -75,6 +75,7 @@ class CWKNN:
         self.fused = fused
         self.sample_seeds = sample_seeds
         self.global_batch = global_batch
+        self.deterministic = deterministic     # None: ops.DETERMINISTIC; True / False: that mode during attack()
 
     def _success(self, pred, target):
         return (pred != target) if self.attack_method == 'untarget' else (pred == target)
@@ -97,6 +98,9 @@ class CWKNN:
             target (torch.LongTensor): target output, [B]
         Returns (adv [B,K,3] float32 numpy, success_num) like the reference (:244-246).
         """
+        if self.deterministic is not None and self.deterministic != ops.DETERMINISTIC:
+            with ops.deterministic(self.deterministic):
+                return self.attack(data, target)
         if self.sample_seeds is None:
             return self._attack(data, target, None)
         from ...model import pointnet2_utils as _pn2

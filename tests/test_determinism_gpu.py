@@ -242,3 +242,40 @@ def test_set_distance_and_knn_backward(ops, dev, B, N, M):
     K = 6
     w = torch.from_numpy(rng.standard_normal((B, N, K)).astype(np.float32)).to(dev)
     _check(ops, lambda s: (lambda x: (ops.knn(x, x, K)[0] * w[s]).sum(), [a[s]]), B, rtol=1e-4, atol=1e-5)
+
+
+def test_attack_level_deterministic_keyword(ops, dev):
+    """`deterministic=` on the attack constructors / cfg: the mode holds for the duration of attack() and the process-wide
+    switch is restored afterwards; False really selects the float-atomic kernels (the two modes agree to rounding)."""
+    M = importlib.import_module
+    knn = M("3dpointcloudattack_amd.attack.KNN.KNN_attack")
+    adv = M("3dpointcloudattack_amd.attack.CW.CW_utils.adv_utils")
+    dist = M("3dpointcloudattack_amd.attack.CW.CW_utils.dist_utils")
+    clip = M("3dpointcloudattack_amd.attack.CW.CW_utils.clip_utils")
+    from oracle import ref_torch as ort
+    ssg = M("3dpointcloudattack_amd.model.pointnet2_SSG").PointNet_Ssg(40)
+    ssg.load_state_dict(ort.seeded_state_dict(ssg, 3))
+    ssg = ssg.eval().to(dev)
+    rng = np.random.default_rng(9)
+    pcs = _clouds(rng, 2, 512)
+    labels = torch.zeros(2, dtype=torch.long)
+    seen = []
+    orig = ops._det
+
+    def spy(flag=None):
+        seen.append(ops.DETERMINISTIC)
+        return orig(flag)
+    outs = {}
+    for mode in (True, False):
+        atk = knn.CWKNN(ssg, None, None, None, None, None, adv_func=adv.UntargetedLogitsAdvLoss(5.), dist_func=dist.ChamferkNNDist(),
+                        clip_func=clip.ProjectInnerClipLinf(budget=0.18), attack_lr=1e-2, num_iter=3, deterministic=mode)
+        seen.clear()
+        ops._det = spy
+        try:
+            torch.manual_seed(4)
+            outs[mode] = atk.attack(pcs, labels)[0]
+        finally:
+            ops._det = orig
+        assert seen and all(v == mode for v in seen), (mode, set(seen))
+        assert ops.DETERMINISTIC                       # restored
+    np.testing.assert_allclose(outs[True], outs[False], rtol=0, atol=2e-3)
