@@ -515,10 +515,13 @@ class _KnnFn(torch.autograd.Function):
         ctx.save_for_backward(q, r, i)
         ctx.cfg = (K, q_cf, r_cf, deterministic)
         ctx.mark_non_differentiable(i)
+        ctx.set_materialize_grads(False)      # no zero tensor for the index output's "gradient" (a fill launch per call)
         return d, i
 
     @staticmethod
     def backward(ctx, gd, _gi):
+        if gd is None:
+            return None, None, None, None, None, None
         q, r, idx = ctx.saved_tensors
         K, q_cf, r_cf, det = ctx.cfg
         need_q, need_r = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
@@ -779,10 +782,13 @@ class _KappaGatherFn(torch.autograd.Function):
                       idx.shape[2], out.data_ptr(), nout.data_ptr(), _stream())
         ctx.save_for_backward(pts, nout, idx)
         ctx.mark_non_differentiable(nout)
+        ctx.set_materialize_grads(False)
         return out, nout
 
     @staticmethod
     def backward(ctx, g, _g_nout):
+        if g is None:
+            return None, None, None, None
         pts, nout, idx = ctx.saved_tensors
         p, bs, ps, cs, B, N = _pts(pts, True, "pts")
         n, nbs, nps, ncs, _, _ = _pts(nout, True, "normal")
