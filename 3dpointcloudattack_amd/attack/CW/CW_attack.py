@@ -145,6 +145,26 @@ class CW:
             return "cross_entropy", 0.0
         return None
 
+    def _own_adv_kind(self):
+        """(kind, kappa) of this package's own adversarial functors (their gradients are built into pc3d_cls_loss_f32)."""
+        af = self.adv_func
+        if type(af) is _adv_utils.UntargetedLogitsAdvLoss:
+            return "untargeted_logits", float(af.kappa)
+        if type(af) is _adv_utils.LogitsAdvLoss:
+            return "logits", float(af.kappa)
+        if type(af) is _adv_utils.CrossEntropyAdvLoss:
+            return "cross_entropy", 0.0
+        return None
+
+    def _direct_terms(self, st):
+        """The autograd pass without the loss: own functors on both sides, a fused clip and a victim that goes through
+        autograd. The iteration then differentiates the functors' per-sample terms (d loss / d term built in) and the logits
+        (gradient from the loss kernel) directly — no mean / weight / sum / accumulate launches, see attack/KNN."""
+        own_dist = (_dist_utils.ChamferDist, _dist_utils.HausdorffDist, _dist_utils.ChamferkNNDist)
+        return (self.fused and getattr(self, "direct_terms", True) and st["budget"] is not None and st["adv"].is_cuda
+                and type(self.dist_func) in own_dist and self._own_adv_kind() is not None
+                and st["adv"].shape[1] == 3 and st["input_val"] is not None)
+
     def _fused_dist_kind(self):
         """1 / 2 when the distance functor's gradient is built into pc3d_cw_step_f32 (L2Dist, ChamferDist adv2ori),
         else 0 (its gradient then comes from autograd through the functor)."""
@@ -209,6 +229,9 @@ class CW:
             st["bestdist"] = torch.full((B,), 1e10, dtype=torch.float32, device=dev)
             st["bestscore"] = torch.full((B,), -1, dtype=torch.long, device=dev)
             st["weights"] = torch.from_numpy(st["current_weight"] * st["ratio"]).float().to(dev)
+            # d loss / d (distance term of sample b) for `dist_func(adv, ori, weights).mean()`: weights[b] / B, what autograd
+            # derives in two launches per iteration (the direct-terms pass below reads it from here)
+            st["gdist"] = st["weights"] * float(np.float32(1.0) / np.float32(B))
             if st["budget"] is not None:
                 st["exp_avg"] = torch.zeros_like(adv_data)
                 st["exp_avg_sq"] = torch.zeros_like(adv_data)
@@ -218,6 +241,7 @@ class CW:
                 st["bestdist"].fill_(1e10)
                 st["bestscore"].fill_(-1)
                 st["weights"].copy_(torch.from_numpy(st["current_weight"] * st["ratio"]).float())
+                torch.mul(st["weights"], float(np.float32(1.0) / np.float32(B)), out=st["gdist"])
                 if st["budget"] is not None:
                     st["exp_avg"].zero_()
                     st["exp_avg_sq"].zero_()
@@ -261,6 +285,40 @@ class CW:
                     _, nn_idx = ops.nn_raw(cur, ori_data, True, True)
                 ops.cw_step(cur, gx_model, st["exp_avg"], st["exp_avg_sq"], st["step"], self.attack_lr, ori_data,
                             st["budget"], dist_kind=dk, w=st["weights"], l2norm=st["dist_val"], nn_idx=nn_idx)
+            return
+        if fml is None and self._direct_terms(st):
+            B = st["B"]
+            alias = st.get("adv_alias")
+            if alias is None or alias.data_ptr() != adv_data.data_ptr():
+                alias = st["adv_alias"] = adv_data.detach().requires_grad_()      # same storage, its own .grad
+            capturing = torch.cuda.is_current_stream_capturing()
+            if (getattr(self, "dist_stream", True) and getattr(self.model, "sampling_chain_front", False) and not capturing):
+                main = torch.cuda.current_stream(adv_data.device)
+                side = _streams.side_stream(adv_data.device, _streams.TERMS)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    terms = self.dist_func.per_sample_terms(alias, ori_data, st["gdist"], mean=False)
+            logits = _logits_of(self.model(adv_data))
+            kind, kappa = self._own_adv_kind()
+            lg = logits if (logits.dtype == torch.float32 and logits.stride(1) == 1) else logits.float().contiguous()
+            # the loss kernel in raw mode (+4: the functor's value on the logits as given): prediction into st["pred"],
+            # gradient already scaled by ratio / B (the batch mean)
+            _, pred, _, g_logits = ops.cls_loss(lg.detach(), st["target"], ops.LOSS_KINDS[kind] + 4, kappa,
+                                                float(np.float32(st["ratio"]) / np.float32(B)), pred_out=st["pred"])
+            with torch.no_grad():
+                ops.cw_bookkeep(adv_data.detach(), ori_data, pred, label, self.attack_method == 'untarget', st["bestdist"],
+                                st["bestscore"], st["o_bestdist"], st["o_bestscore"], st["o_bestattack"],
+                                input_val=st["input_val"], dist_val=st["dist_val"], step=st["step"])
+            if side is not None:
+                main.wait_stream(side)
+            else:
+                terms = self.dist_func.per_sample_terms(alias, ori_data, st["gdist"], mean=False)
+            adv_data.grad = None
+            alias.grad = None
+            ones = ops.const_vec(adv_data.device, B, 1.0)
+            torch.autograd.backward([lg] + terms, [g_logits] + [ones] * len(terms))
+            ops.adam_clip_step(adv_data.data, adv_data.grad, st["exp_avg"], st["exp_avg_sq"], st["step"],
+                               self.attack_lr, ori=ori_data, budget=st["budget"], g2=alias.grad)
             return
         if fml is not None:
             with torch.no_grad():  # victim forward + adversarial loss + backward-to-input without autograd

@@ -17,6 +17,20 @@ def _kernel_loss(logits, targets, kind, kappa=0.):
     return ops.adv_loss_raw(logits, targets.reshape(-1).long(), kind, kappa).mean()
 
 
+def _kernel_term(logits, targets, kind, kappa, up):
+    """Per-sample loss [B] whose gradient is fixed by the caller: the functor's value enters the attack's loss as
+    `up * mean_b(term_b)`, so d loss / d term_b = up / B is multiplied into the gradient by the forward launch and the
+    backward passes it on untouched (no mean / scale launches either way). None when the kernel does not take the inputs."""
+    if not (torch.is_tensor(logits) and logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 2
+            and logits.stride(1) == 1 and 2 <= logits.shape[1] <= 64 and torch.is_tensor(targets) and targets.is_cuda
+            and targets.numel() == logits.shape[0]):
+        return None
+    import numpy as np
+    from .... import ops
+    return ops.adv_loss_raw(logits, targets.reshape(-1).long(), kind, kappa,
+                            gscale=np.float32(up) / np.float32(logits.shape[0]))
+
+
 def _real_other(logits, targets):
     B, K = logits.shape
     if len(targets.shape) == 1:
@@ -35,6 +49,10 @@ class LogitsAdvLoss(nn.Module):
         super(LogitsAdvLoss, self).__init__()
         self.kappa = kappa
 
+    def per_sample(self, logits, targets, up=1.0):
+        """[B] terms with d loss / d term = up / B built in (see _kernel_term), or None."""
+        return _kernel_term(logits, targets, "logits", self.kappa, up)
+
     def forward(self, logits, targets):
         fast = _kernel_loss(logits, targets, "logits", self.kappa)
         if fast is not None:
@@ -49,6 +67,10 @@ class CrossEntropyAdvLoss(nn.Module):
     def __init__(self):
         super(CrossEntropyAdvLoss, self).__init__()
 
+    def per_sample(self, logits, targets, up=1.0):
+        """[B] terms with d loss / d term = up / B built in (see _kernel_term), or None."""
+        return _kernel_term(logits, targets, "cross_entropy", 0., up)
+
     def forward(self, logits, targets):
         fast = _kernel_loss(logits, targets, "cross_entropy")
         if fast is not None:
@@ -62,6 +84,10 @@ class UntargetedLogitsAdvLoss(nn.Module):
     def __init__(self, kappa=0.):
         super(UntargetedLogitsAdvLoss, self).__init__()
         self.kappa = kappa
+
+    def per_sample(self, logits, targets, up=1.0):
+        """[B] terms with d loss / d term = up / B built in (see _kernel_term), or None."""
+        return _kernel_term(logits, targets, "untargeted_logits", self.kappa, up)
 
     def forward(self, logits, targets):
         fast = _kernel_loss(logits, targets, "untargeted_logits", self.kappa)

@@ -71,6 +71,22 @@ class _SetDist(nn.Module):
             return loss.mean()
         return loss
 
+    def per_sample_terms(self, adv_pc, ori_pc, up=1.0, mean=True):
+        """The functor's per-sample values as a list of [B] autograd tensors whose backward uses a gradient FIXED here —
+        d loss / d term_b for a loss that contains `up * forward(adv_pc, ori_pc)` (batch mean; `up` a float, or a [B]
+        tensor of per-sample weights standing for forward's `weights`) — and ignores the incoming one. mean=False: `up`
+        already is d loss / d term_b (the caller divided by the batch size). An attack loop calls
+        torch.autograd.backward on the terms directly: none of the weight / mean / scale launches around the functor,
+        forward or backward (ops.scaled_gvec keeps autograd's arithmetic order)."""
+        B = adv_pc.shape[0]
+        a, o, a_cf, o_cf = adv_pc.float(), ori_pc.float(), _is_cf(adv_pc), _is_cf(ori_pc)
+        if self.method == 'adv2ori':
+            return [ops.set_distance_one(a, o, self._reduce, a_cf=a_cf, b_cf=o_cf, gvec=ops.scaled_gvec(up, 1.0, B, a.device, mean))]
+        if self.method == 'ori2adv':
+            return [ops.set_distance_one(o, a, self._reduce, a_cf=o_cf, b_cf=a_cf, gvec=ops.scaled_gvec(up, 1.0, B, a.device, mean))]
+        l1, l2 = ops.set_distance(a, o, self._reduce, a_cf=a_cf, b_cf=o_cf, gvec=ops.scaled_gvec(up, 0.5, B, a.device, mean))
+        return [l1, l2]
+
 
 class ChamferDist(_SetDist):
     """dist_utils.py:38-72 — mean squared NN distance, method in {adv2ori, ori2adv, both}."""
@@ -102,6 +118,11 @@ class KNNDist(nn.Module):
             return loss.mean()
         return loss
 
+    def per_sample_terms(self, pc, up=1.0, mean=True):
+        """As _SetDist.per_sample_terms, for a loss that contains `up * forward(pc)`."""
+        B = pc.shape[0]
+        return [ops.knn_outlier_loss(pc.float(), self.k, self.alpha, _is_cf(pc), gvec=ops.scaled_gvec(up, 1.0, B, pc.device, mean))]
+
 
 class ClipPointsLinf(nn.Module):
     """dist_utils.py:162-186 — duplicate of clip_utils.ClipPointsLinf kept for import compatibility."""
@@ -129,6 +150,15 @@ class ChamferkNNDist(nn.Module):
         chamfer_loss = self.chamfer_dist(adv_pc, ori_pc, weights=weights, batch_avg=batch_avg)
         knn_loss = self.knn_dist(adv_pc, weights=weights, batch_avg=batch_avg)
         return chamfer_loss * self.w1 + knn_loss * self.w2
+
+    def per_sample_terms(self, adv_pc, ori_pc, up=1.0, mean=True):
+        """As _SetDist.per_sample_terms: the Chamfer terms, then the kNN term, the functor's two weights in their gradients."""
+        if torch.is_tensor(up):
+            up1, up2 = up * self.w1, up * self.w2
+        else:
+            import numpy as np
+            up1, up2 = np.float32(up) * np.float32(self.w1), np.float32(up) * np.float32(self.w2)
+        return self.chamfer_dist.per_sample_terms(adv_pc, ori_pc, up1, mean) + self.knn_dist.per_sample_terms(adv_pc, up2, mean)
 
 
 class FarthestDist(nn.Module):

@@ -91,11 +91,18 @@ def _draw_offset(b, c, n, dev, cfg, gens):
     return o
 
 
-def _forward_step(net, pc_ori, input_curr_iter, normal_ori, ori_kappa, target, scale_const, cfg, targeted):
-    """:103-183 — one forward of the victim and all loss terms; returns the reference's 10-tuple."""
+def _forward_step(net, pc_ori, input_curr_iter, normal_ori, ori_kappa, target, scale_const, cfg, targeted, direct=False):
+    """:103-183 — one forward of the victim and all loss terms; returns the reference's 10-tuple. direct (the fused-terms
+    configuration with the cross-entropy loss only): the scalar `loss` is not formed — it would only be differentiated —
+    and the tuple's `loss` slot is None, its last slot {"roots", "grads"} for torch.autograd.backward: the terms tensor
+    with d loss / d loss_n = 1 / B (or 1 / global_batch) as a cached constant, the same constant inside the
+    cross-entropy launch's gradient. Saves the mean / unbind-backward / scale launches (~12 per iteration)."""
     b, _, n = input_curr_iter.size()
     dev = input_curr_iter.device
     fused_terms = input_curr_iter.is_cuda and cfg.dis_loss_type == 'CD' and cfg.uniform_loss_weight == 0
+    gb = getattr(cfg, "global_batch", None)
+    gval = np.float32(1.0) / np.float32(gb if gb else b)            # d loss / d loss_n[b]
+    direct = direct and fused_terms and cfg.cls_loss_type == 'CE'
     searches = None
     if (fused_terms and getattr(cfg, "search_stream", True) and getattr(net, "sampling_chain_front", False)
             and not torch.cuda.is_current_stream_capturing()):
@@ -126,8 +133,10 @@ def _forward_step(net, pc_ori, input_curr_iter, normal_ori, ori_kappa, target, s
         if output_curr_iter.is_cuda and output_curr_iter.dtype == torch.float32 and output_curr_iter.dim() == 2 \
                 and output_curr_iter.stride(1) == 1:
             from ... import ops     # log-softmax + NLL (+ sign) and their backward: one launch each way instead of 3 + 3
-            cls_loss = ops.cross_entropy(output_curr_iter, target.long(), 1.0 if targeted else -1.0)
+            cls_loss = ops.cross_entropy(output_curr_iter, target.long(), 1.0 if targeted else -1.0,
+                                         gscale=gval if direct else None)
         else:
+            direct = False
             ce = nn.CrossEntropyLoss(reduction='none')(output_curr_iter, target.long())
             cls_loss = ce if targeted else -ce
     elif cfg.cls_loss_type == 'None':
@@ -154,15 +163,19 @@ def _forward_step(net, pc_ori, input_curr_iter, normal_ori, ori_kappa, target, s
                                                          knn_idx=hint)
         else:
             adv_kappa, normal_curr_iter = None, torch.zeros(b, 3, n, device=dev)
+        gfix = ops.geoa3_loss_grad(dev, b, gval) if direct else None
         terms = ops.geoa3_terms(nn_ao.dists.squeeze(-1), d_oa, adv_kappa, ori_kappa, nn_ao.idx.squeeze(-1),
                                 cls_loss.float().contiguous(), scale_const, cfg.dis_loss_weight, cfg.hd_loss_weight,
-                                cfg.curv_loss_weight)
-        dis_loss, hd_loss, curv_loss, constrain_loss, loss_n = terms.unbind(0)
+                                cfg.curv_loss_weight, gfix=gfix)
+        rows = terms.detach() if direct else terms
+        dis_loss, hd_loss, curv_loss, constrain_loss, loss_n = rows.unbind(0)
         if cfg.hd_loss_weight == 0:
             hd_loss = 0
         if cfg.curv_loss_weight == 0:
             curv_loss = 0
-        gb = getattr(cfg, "global_batch", None)
+        if direct:
+            return (output_curr_iter, normal_curr_iter, None, loss_n, cls_loss, dis_loss, hd_loss, curv_loss, constrain_loss,
+                    {"roots": [terms], "grads": [gfix]})
         loss = loss_n.sum() / float(gb) if gb else loss_n.mean()
         return (output_curr_iter, normal_curr_iter, loss, loss_n, cls_loss, dis_loss, hd_loss, curv_loss, constrain_loss,
                 '')
@@ -358,7 +371,8 @@ def _geoA3_attack(net, pt_model, ptm_model, pts_model, dgcnn_model, cur_model, p
 
             prev_constrain = constrain_loss
             logits_curr, normal_curr_iter, loss, loss_n, cls_loss, dis_loss, hd_loss, nor_loss, constrain_loss, info = \
-                _forward_step(net, pc_ori, input_curr_iter, normal_ori, kappa_ori, target, scale_dev, cfg, targeted)
+                _forward_step(net, pc_ori, input_curr_iter, normal_ori, kappa_ori, target, scale_dev, cfg, targeted,
+                              direct=getattr(cfg, "direct_terms", True))
             if share_forward:
                 with torch.no_grad():   # input_all still holds this iteration's iterate: the optimiser steps below
                     lg, it_ = logits_curr.detach(), input_all.detach()
@@ -378,7 +392,10 @@ def _geoA3_attack(net, pt_model, ptm_model, pts_model, dgcnn_model, cur_model, p
             optimizer.zero_grad()
             if cfg.is_pre_jitter_input:
                 input_curr_iter.retain_grad()
-            loss.backward()
+            if isinstance(info, dict):
+                torch.autograd.backward(info["roots"], info["grads"])
+            else:
+                loss.backward()
             if cfg.is_pre_jitter_input:
                 input_all.grad = input_curr_iter.grad
             optimizer.step()

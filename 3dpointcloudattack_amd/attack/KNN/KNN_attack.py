@@ -130,7 +130,8 @@ class CWKNN:
         # clean forward (:76-78). Kept even when nothing is printed: a PointNet++ victim draws its FPS start indices
         # from the global RNG on every forward, so skipping it would shift the stream the reference sees.
         with torch.no_grad():
-            clean_pred = torch.argmax(_logits_of(self.model(ori_data)), dim=1)
+            clean_logits = _logits_of(self.model(ori_data))
+            clean_pred = torch.argmax(clean_logits, dim=1)
         if self.verbose:
             print("ori label:", clean_pred.tolist())
         target = target.long().to(dev).detach().view(-1)
@@ -145,6 +146,20 @@ class CWKNN:
         else:
             exp_avg, exp_avg_sq = torch.zeros_like(adv_data), torch.zeros_like(adv_data)
         ori_t = ori_data.transpose(1, 2).contiguous()
+        # Own functors on both sides: the loss is never assembled. Each functor hands back its per-sample terms with
+        # d loss / d term built in (per_sample / per_sample_terms: the batch means, `* K`, the functor's own weights and the
+        # shard ratio are constants), the backward starts from the terms, and the distance branch differentiates an ALIAS
+        # of the iterate so that its gradient arrives in a buffer of its own, summed inside the Adam launch — none of the
+        # ~25 mean / scale / add / accumulate launches of `loss = adv.mean() + dist.mean() * K; loss.backward()`.
+        own_dist = (_dist_utils.ChamferDist, _dist_utils.HausdorffDist, _dist_utils.ChamferkNNDist)
+        direct = (fc is not None and adv_data.is_cuda and type(self.dist_func) in own_dist
+                  and hasattr(self.adv_func, "per_sample") and getattr(self, "direct_terms", True)
+                  and clean_logits.dim() == 2 and 2 <= clean_logits.shape[1] <= 64 and clean_logits.dtype == torch.float32)
+        if direct:
+            adv_alias = adv_data.detach().requires_grad_()           # same storage: follows the in-place updates
+            up_adv = np.float32(ratio)
+            up_dist = np.float32(ratio) * np.float32(K) if ratio != 1.0 else np.float32(K)
+            ones = ops.const_vec(dev, B, 1.0)
 
         # The distance term does not depend on the victim: its searches (kNN + Chamfer) run on a side stream beside the
         # victim's forward, whose first kernels (farthest-point sampling: one workgroup per cloud) leave most of the
@@ -154,6 +169,25 @@ class CWKNN:
                 if cur is not None and getattr(self, "dist_stream", True) and getattr(self.model, "sampling_chain_front", False)
                 else None)                      # ONE per process (see streams.py); only beside a sampling-chain victim
         for iteration in range(self.num_iter):
+            if direct:
+                if side is not None:
+                    side.wait_stream(cur)
+                    with torch.cuda.stream(side):
+                        terms = self.dist_func.per_sample_terms(adv_alias, ori_data, up_dist)   # channel-first, zero-copy
+                logits = _logits_of(self.model(adv_data))
+                a_term = self.adv_func.per_sample(logits.contiguous(), target, up_adv)
+                if a_term is None:
+                    raise RuntimeError("CWKNN: the victim's logits changed shape / dtype between forwards")
+                if side is not None:
+                    cur.wait_stream(side)
+                else:
+                    terms = self.dist_func.per_sample_terms(adv_alias, ori_data, up_dist)
+                adv_data.grad = None
+                adv_alias.grad = None
+                torch.autograd.backward([a_term] + terms, [ones] * (1 + len(terms)))
+                ops.adam_clip_step(adv_data.data, adv_data.grad, exp_avg, exp_avg_sq, iteration + 1, self.attack_lr,
+                                   ori=ori_data, normal=normal if fc[1] else None, budget=fc[0], g2=adv_alias.grad)
+                continue
             if side is not None:
                 side.wait_stream(cur)
                 with torch.cuda.stream(side):

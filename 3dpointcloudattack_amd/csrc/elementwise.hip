@@ -101,6 +101,7 @@ __global__ __launch_bounds__(256) void clip_l2_kernel(ClipArgs a) {
 struct AdamArgs {
   PtsViewMut p;        // parameters (adv points), updated in place
   PtsView g;           // gradient
+  PtsView g2;          // second gradient summed with g on load (the two branches of an attack's loss), p null -> none
   PtsViewMut m, v;     // exp_avg, exp_avg_sq
   PtsView ori, normal; // clip against ori (ori.p null -> no clip/projection); normal optional
   int K;
@@ -120,12 +121,14 @@ __global__ __launch_bounds__(256) void adam_clip_kernel(AdamArgs a) {
   const float bc2s = (float)sqrt(1.0 - pow(a.b2, (double)t));
   float* pp = a.p.p + (int64_t)b * a.p.bs + (int64_t)k * a.p.ps;
   const float* gp = a.g.p + (int64_t)b * a.g.bs + (int64_t)k * a.g.ps;
+  const float* gq = a.g2.p ? a.g2.p + (int64_t)b * a.g2.bs + (int64_t)k * a.g2.ps : nullptr;
   float* mp = a.m.p + (int64_t)b * a.m.bs + (int64_t)k * a.m.ps;
   float* vp = a.v.p + (int64_t)b * a.v.bs + (int64_t)k * a.v.ps;
   float np_[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    const float g = gp[c * a.g.cs];
+    float g = gp[c * a.g.cs];
+    if (gq) g += gq[c * a.g2.cs];
     float m = mp[c * a.m.cs], v = vp[c * a.v.cs];
     m = m + (g - m) * omb1;
     v = v * fb2 + omb2 * g * g;
@@ -208,6 +211,7 @@ extern "C" int pc3d_clip_f32(const float* pc, int64_t pc_bs, int64_t pc_ps, int6
 
 extern "C" int pc3d_adam_clip_step_f32(float* p, int64_t p_bs, int64_t p_ps, int64_t p_cs,
                                        const float* g, int64_t g_bs, int64_t g_ps, int64_t g_cs,
+                                       const float* g2, int64_t g2_bs, int64_t g2_ps, int64_t g2_cs,
                                        float* m, float* v, /* same strides as p */
                                        const float* ori, int64_t o_bs, int64_t o_ps, int64_t o_cs,
                                        const float* normal, int64_t n_bs, int64_t n_ps, int64_t n_cs,
@@ -217,7 +221,7 @@ extern "C" int pc3d_adam_clip_step_f32(float* p, int64_t p_bs, int64_t p_ps, int
   PC3D_REQUIRE(step_dev != nullptr || step_host >= 1, "pc3d_adam_clip_step_f32: step_host must be >= 1 without a device counter");
   if (B == 0) return PC3D_OK;
   PC3D_REQUIRE(p && g && m && v, "pc3d_adam_clip_step_f32: null pointer");
-  AdamArgs a{{p, p_bs, p_ps, p_cs}, {g, g_bs, g_ps, g_cs}, {m, p_bs, p_ps, p_cs}, {v, p_bs, p_ps, p_cs},
+  AdamArgs a{{p, p_bs, p_ps, p_cs}, {g, g_bs, g_ps, g_cs}, {g2, g2_bs, g2_ps, g2_cs}, {m, p_bs, p_ps, p_cs}, {v, p_bs, p_ps, p_cs},
              {ori, o_bs, o_ps, o_cs}, {normal, n_bs, n_ps, n_cs}, K, lr, beta1, beta2, (float)eps, budget,
              step_dev, step_host};
   hipLaunchKernelGGL(adam_clip_kernel, dim3(cdiv(K, 256), B), dim3(256), 0, as_stream(stream), a);

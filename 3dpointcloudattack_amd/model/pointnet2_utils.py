@@ -37,8 +37,25 @@ def _split_first(layers):
 
 
 FUSE_LAYERS_1_2 = True    # layer 1 generated inside layer 2's GEMM (ops.grouped_mlp_max); False: group_act + mlp_relu_max
+SA_FRONT = True           # a single-scale layer's centres / per-point / per-centre first layer as one node (ops.sa_front)
+SPLIT_GROUP_ALL = True    # the group-all layer without the [xyz ; points] concatenation
 REVERSE_INDEX = True      # the geometry chain also builds the reverse index of every grouping (ops.group_reverse): layer 1's
                           # backward gathers through it; False: scatter with float atomics
+
+
+def _front_supported(first, layers, ns):
+    """Shapes the per-point / per-centre form of the first layer takes (ops.group_act / ops.grouped_mlp_max behind it)."""
+    C1 = first[0].shape[0]
+    return C1 % 4 == 0 and C1 <= ops.GROUP_ACT_MAX_C and len(layers) >= 2 and ns <= ops.GROUP_MAX_NS
+
+
+def _grouped_tail(P, Bc, idx, layers, rev=None):
+    """relu(P[idx] + Bc) -> the remaining layers -> max over the group: [B,S,C_last]."""
+    C1 = P.shape[2]
+    if FUSE_LAYERS_1_2 and ops.grouped_mlp_max_supported(C1, idx.shape[2], layers[1:]):
+        return ops.grouped_mlp_max(P, Bc, idx, layers[1:], rev=rev)   # layer 1 generated inside layer 2's GEMM
+    h1 = ops.group_act(P, Bc, idx, 0.0)                               # [B,S,ns,C1] = relu(layer 1)
+    return ops.mlp_relu_max(h1, layers[1:])
 
 
 def _grouped_mlp_max(xyz_t, pts, idx, fps_idx, layers, first, rev=None):
@@ -46,23 +63,21 @@ def _grouped_mlp_max(xyz_t, pts, idx, fps_idx, layers, first, rev=None):
     W1 [x_j - c_s ; f_j] + b1 = P[idx[s,j]] + Bc[s], P = Wx x + Wf f per POINT (B*N rows instead of B*S*ns: 16x fewer
     at SSG's second layer), Bc = b1 - (Wx x)[centroid]; pc3d_group_act_f32 gathers P and applies the ReLU, i.e. it
     emits the layer-1 OUTPUT where the reference (and round 1) gathered the layer-1 INPUT and ran a [B*S*ns, 3+D]
-    GEMM on it (model/pointnet2_utils.py:118-135,190-197)."""
+    GEMM on it (model/pointnet2_utils.py:118-135,190-197). (The multi-scale layers' form: the single-scale layer takes
+    P, Bc and the centres from ops.sa_front in one autograd node.)"""
     wx, wf, b1 = first
     C1 = wx.shape[0]
     B, N, _ = xyz_t.shape
     S = fps_idx.shape[1]
-    if C1 % 4 or C1 > ops.GROUP_ACT_MAX_C or len(layers) < 2 or idx.shape[2] > ops.GROUP_MAX_NS:
+    if not _front_supported(first, layers, idx.shape[2]):
         # widths the gather-with-activation kernel does not take: the plain form (gather the grouped input, then the MLP)
         new_xyz = ops.group_gather(xyz_t, None, fps_idx.view(B, S, 1)).view(B, S, 3)
         g = ops.group_gather(xyz_t, pts, idx, centers=new_xyz.detach(), center_idx=fps_idx)
         return _mlp_max(g, layers)
-    px = ops.linear_act(xyz_t.contiguous(), wx)                       # [B,N,C1] = Wx x
-    P = px if pts is None else px + ops.linear_act(pts, wf)
+    px = ops.affine3(xyz_t, wx)                                       # [B,N,C1] = Wx x, xyz read through its strides
+    P = px if pts is None else ops.linear_res_act(pts, wf, None, px)
     Bc = b1 - ops.group_gather(None, px, fps_idx.view(B, S, 1)).view(B, S, C1)
-    if FUSE_LAYERS_1_2 and ops.grouped_mlp_max_supported(C1, idx.shape[2], layers[1:]):
-        return ops.grouped_mlp_max(P, Bc, idx, layers[1:], rev=rev)   # layer 1 generated inside layer 2's GEMM
-    h1 = ops.group_act(P, Bc, idx, 0.0)                               # [B,S,ns,C1] = relu(layer 1)
-    return ops.mlp_relu_max(h1, layers[1:])
+    return _grouped_tail(P, Bc, idx, layers, rev)
 
 
 def _linear_relu(x, w, b):
@@ -237,20 +252,37 @@ class PointNetSetAbstraction(_FrozenFusedMixin, nn.Module):
         pts = _cl(points)
         layers, first = self.folded()
         if self.group_all:
-            new_xyz, new_points = sample_and_group_all(xyz_t, pts)
-            new_points = _mlp_max(new_points, layers)   # [B,1,D'] channels-last 1x1 convs, no permutes
+            wx, wf, b1 = first
+            if pts is not None and xyz_t.is_cuda and wx.shape[0] % 4 == 0 and len(layers) >= 2 and SPLIT_GROUP_ALL:
+                # [xyz ; points] is never concatenated (:138-155): layer 1 = relu(Wf f + (Wx x + b1)), the coordinate
+                # columns as the GEMM's residual operand
+                B, N, _ = xyz_t.shape
+                new_xyz = torch.zeros(B, 1, 3, device=xyz_t.device)
+                h1 = ops.linear_res_act(pts, wf, None, ops.affine3(xyz_t, wx, b1), "relu")
+                new_points = _mlp_max(h1.view(B, 1, N, -1), layers[1:])
+            else:
+                new_xyz, new_points = sample_and_group_all(xyz_t, pts)
+                new_points = _mlp_max(new_points, layers)   # [B,1,D'] channels-last 1x1 convs, no permutes
         else:
             B, N, _ = xyz_t.shape
             rev = None
             if geo is not None:
                 fps_idx, _, idx, ev, rev = geo
                 torch.cuda.current_stream(xyz_t.device).wait_event(ev)
-                new_xyz = ops.group_gather(xyz_t, None, fps_idx.view(B, self.npoint, 1)).view(B, self.npoint, 3)
             else:
                 fps_idx = ops.fps(xyz_t, self.npoint, _fps_start(B, N, xyz_t.device))                   # [B,S] i32
+                idx = None
+            if SA_FRONT and xyz_t.is_cuda and _front_supported(first, layers, self.nsample):
+                # centres, per-point and per-centre forms of layer 1 in ONE autograd node (ops.sa_front)
+                new_xyz, P, Bc = ops.sa_front(xyz_t, pts, fps_idx, *first)
+                if idx is None:
+                    idx = ops.ball_query(self.radius, self.nsample, xyz_t, new_xyz.detach())
+                new_points = _grouped_tail(P, Bc, idx, layers, rev)
+            else:
                 new_xyz = ops.group_gather(xyz_t, None, fps_idx.view(B, self.npoint, 1)).view(B, self.npoint, 3)
-                idx = ops.ball_query(self.radius, self.nsample, xyz_t, new_xyz)                          # [B,S,ns] i32
-            new_points = _grouped_mlp_max(xyz_t, pts, idx, fps_idx, layers, first, rev=rev)
+                if idx is None:
+                    idx = ops.ball_query(self.radius, self.nsample, xyz_t, new_xyz)                      # [B,S,ns] i32
+                new_points = _grouped_mlp_max(xyz_t, pts, idx, fps_idx, layers, first, rev=rev)
         return new_xyz.permute(0, 2, 1), new_points.permute(0, 2, 1)
 
 

@@ -6,6 +6,7 @@ hand-written gfx950 kernels of libpc3d_hip.so. There is no CPU/eager fallback: t
 import contextlib
 import os
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -192,6 +193,37 @@ def _nn_bwd(a, a_cf, b, b_cf, iA, wA, sA, iB, wB, sB, need_a, need_b, determinis
     return ga, gb
 
 
+_CONST_VECS = {}
+
+
+def const_vec(device, n, value):
+    """A cached [n] fp32 tensor filled with `value` (never written again): the fixed upstream gradient of a per-sample
+    loss term. Created once per (device, n, value) — no fill launch inside an attack loop."""
+    device = torch.device(device)
+    key = (device.type, device.index, int(n), float(np.float32(value)))
+    t = _CONST_VECS.get(key)
+    if t is None:
+        if len(_CONST_VECS) >= 256:
+            _CONST_VECS.pop(next(iter(_CONST_VECS)))
+        t = torch.full((int(n),), float(np.float32(value)), dtype=torch.float32, device=device)
+        _CONST_VECS[key] = t
+    _graphed.note_captured(t)
+    return t
+
+
+def scaled_gvec(up, factor, n, device, mean=True):
+    """Upstream gradient of a per-sample term that enters a loss as mean_b(term_b) * factor * up: `up` a Python / numpy
+    float (the same for every sample: a cached constant vector, no launch) or a [n] tensor (per-sample weights). The
+    arithmetic follows autograd's order for `(term.mean() * factor) * up`: ((up * factor) / n)."""
+    if torch.is_tensor(up):
+        g = up * float(factor) if factor != 1.0 else up           # (factor 1, mean False: `up` itself, no launch)
+        return g / float(n) if mean else g
+    v = np.float32(up) * np.float32(factor) if factor != 1.0 else np.float32(up)
+    if mean:
+        v = v / np.float32(n)
+    return const_vec(device, n, v)
+
+
 # ------------------------------------------------------------------------------------------------------
 # differentiable ops
 # ------------------------------------------------------------------------------------------------------
@@ -229,25 +261,28 @@ class _SetDistFn(torch.autograd.Function):
     squared NN distances — distance.py:40-50 (ChamferDistance) / :58-70 (HausdorffDistance)."""
 
     @staticmethod
-    def forward(ctx, a, b, a_cf, b_cf, reduce, deterministic):
+    def forward(ctx, a, b, a_cf, b_cf, reduce, deterministic, gvec=None):
         dA, iA, dB, iB = nn_bidir_raw(a, b, a_cf, b_cf)
         l1 = rowreduce(dA, reduce)
         l2 = rowreduce(dB, reduce)
         if reduce == "max":
             # gradient flows to the arg-max point only (torch.max backward); keep one-hot weights
             ctx.hot = (dA == l1[:, None]), (dB == l2[:, None])
-        ctx.save_for_backward(a, b, iA, iB)
+        ctx.save_for_backward(a, b, iA, iB, gvec)
         ctx.cfg = (a_cf, b_cf, reduce, deterministic, dA.shape[1], dB.shape[1])
         ctx.set_materialize_grads(False)
         return l1, l2
 
     @staticmethod
     def backward(ctx, g1, g2):
-        a, b, iA, iB = ctx.saved_tensors
+        a, b, iA, iB, gvec = ctx.saved_tensors
         a_cf, b_cf, reduce, det, N, M = ctx.cfg
         need_a, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         if (g1 is None and g2 is None) or not (need_a or need_b):
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
+        if gvec is not None:               # the caller fixed d loss / d term per sample: the incoming values are not read
+            g1 = gvec if g1 is not None else None
+            g2 = gvec if g2 is not None else None
         if reduce == "mean":
             wA = None if g1 is None else g1.contiguous().view(-1, 1).expand(-1, N)  # stride (1,0): no copy
             wB = None if g2 is None else g2.contiguous().view(-1, 1).expand(-1, M)
@@ -264,7 +299,7 @@ class _SetDistFn(torch.autograd.Function):
             sA = sB = 1.0
         ga, gb = _nn_bwd(a, a_cf, b, b_cf, iA if wA is not None else None, wA, sA,
                          iB if wB is not None else None, wB, sB, need_a, need_b, det)
-        return ga, gb, None, None, None, None
+        return ga, gb, None, None, None, None, None
 
 
 class _SetDistOneFn(torch.autograd.Function):
@@ -273,39 +308,43 @@ class _SetDistOneFn(torch.autograd.Function):
     and — in the backward — its scatter are not needed at all."""
 
     @staticmethod
-    def forward(ctx, a, b, a_cf, b_cf, reduce, deterministic):
+    def forward(ctx, a, b, a_cf, b_cf, reduce, deterministic, gvec=None):
         dA, iA = nn_raw(a, b, a_cf, b_cf)
         l1 = rowreduce(dA, reduce)
         if reduce == "max":
             ctx.hot = dA == l1[:, None]
-        ctx.save_for_backward(a, b, iA)
+        ctx.save_for_backward(a, b, iA, gvec)
         ctx.cfg = (a_cf, b_cf, reduce, deterministic, dA.shape[1])
         return l1
 
     @staticmethod
     def backward(ctx, g1):
-        a, b, iA = ctx.saved_tensors
+        a, b, iA, gvec = ctx.saved_tensors
         a_cf, b_cf, reduce, det, N = ctx.cfg
         need_a, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         if not (need_a or need_b):
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
+        if gvec is not None:
+            g1 = gvec
         if reduce == "mean":
             wA, sA = g1.contiguous().view(-1, 1).expand(-1, N), 1.0 / N
         else:
             h = ctx.hot
             wA, sA = ((h.int().cumsum(1) == 1) & h).float() * g1.view(-1, 1), 1.0
         ga, gb = _nn_bwd(a, a_cf, b, b_cf, iA, wA, sA, None, None, 1.0, need_a, need_b, det)
-        return ga, gb, None, None, None, None
+        return ga, gb, None, None, None, None, None
 
 
-def set_distance_one(a, b, reduce="mean", a_cf=False, b_cf=False, deterministic=None):
-    """loss_a2b [B] only: squared Chamfer (reduce='mean') / Hausdorff ('max') term from a to b, one search."""
-    return _SetDistOneFn.apply(a, b, a_cf, b_cf, reduce, deterministic)
+def set_distance_one(a, b, reduce="mean", a_cf=False, b_cf=False, deterministic=None, gvec=None):
+    """loss_a2b [B] only: squared Chamfer (reduce='mean') / Hausdorff ('max') term from a to b, one search. gvec [B]:
+    the backward uses it as d loss / d term and ignores the incoming gradient (see scaled_gvec)."""
+    return _SetDistOneFn.apply(a, b, a_cf, b_cf, reduce, deterministic, gvec)
 
 
-def set_distance(a, b, reduce="mean", a_cf=False, b_cf=False, deterministic=None):
-    """(loss_a2b [B], loss_b2a [B]) — squared Chamfer (reduce='mean') or Hausdorff (reduce='max') terms."""
-    return _SetDistFn.apply(a, b, a_cf, b_cf, reduce, deterministic)
+def set_distance(a, b, reduce="mean", a_cf=False, b_cf=False, deterministic=None, gvec=None):
+    """(loss_a2b [B], loss_b2a [B]) — squared Chamfer (reduce='mean') or Hausdorff (reduce='max') terms. gvec: as in
+    set_distance_one, for BOTH outputs."""
+    return _SetDistFn.apply(a, b, a_cf, b_cf, reduce, deterministic, gvec)
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -451,9 +490,9 @@ def clip(pc, ori, normal=None, budget=0.0, mode="point", cf=True, out=None):
 
 
 def adam_clip_step(p, g, m, v, step, lr, betas=(0.9, 0.999), eps=1e-8, ori=None, normal=None, budget=0.0,
-                   cf=True):
+                   cf=True, g2=None):
     """In-place Adam step on p (+ fused per-point clip/projection against ori). `step` is an int (host) or a
-    1-element int32 GPU tensor holding t."""
+    1-element int32 GPU tensor holding t. g2: a second gradient tensor, summed with g inside the launch."""
     _, _, _, _, B, K = _pts(p, cf, "p")
     if m.stride() != p.stride() or v.stride() != p.stride():
         raise ValueError("adam state must share the parameter's strides")
@@ -462,7 +501,7 @@ def adam_clip_step(p, g, m, v, step, lr, betas=(0.9, 0.999), eps=1e-8, ori=None,
     else:
         step_dev, step_host = 0, int(step)
     with torch.cuda.device(p.device):
-        _lib.call("pc3d_adam_clip_step_f32", *_pv(p, cf, "p"), *_pv(g, cf, "g"), m.data_ptr(), v.data_ptr(),
+        _lib.call("pc3d_adam_clip_step_f32", *_pv(p, cf, "p"), *_pv(g, cf, "g"), *_pv(g2, cf, "g2"), m.data_ptr(), v.data_ptr(),
                   *_pv(ori, cf, "ori"), *_pv(normal, cf, "normal"), B, K, float(lr), float(betas[0]),
                   float(betas[1]), float(eps), float(budget), step_dev, step_host, _stream())
     return p
@@ -550,35 +589,36 @@ class _KnnOutlierFn(torch.autograd.Function):
     instead of ~15 ATen launches each way around the search."""
 
     @staticmethod
-    def forward(ctx, pc, k, alpha, cf):
+    def forward(ctx, pc, k, alpha, cf, gvec=None):
         d, idx = knn_raw(pc, pc, k + 1, cf, cf)
         B, N, K1 = d.shape
         loss = torch.empty((B,), dtype=torch.float32, device=pc.device)
         w = torch.empty_like(d)
         with torch.cuda.device(pc.device):
             _lib.call("pc3d_knn_outlier_loss_f32", d.data_ptr(), B, N, K1, float(alpha), loss.data_ptr(), w.data_ptr(), _stream())
-        ctx.save_for_backward(pc, idx, w)
+        ctx.save_for_backward(pc, idx, w, gvec)
         ctx.cf = cf
         return loss
 
     @staticmethod
     def backward(ctx, g):
-        pc, idx, w = ctx.saved_tensors
+        pc, idx, w, gvec = ctx.saved_tensors
         B, N, K1 = w.shape
-        g = g.contiguous()
+        g = gvec if gvec is not None else g.contiguous()
         grad = torch.empty(pc.shape, dtype=torch.float32, device=pc.device)
         det = _det()
         ws = torch.empty((B, N * K1, 3), dtype=torch.float32, device=pc.device) if det else None
         with torch.cuda.device(pc.device):
             _lib.call("pc3d_knn_self_bwd_f32", *_pv(pc, ctx.cf, "pc"), B, N, K1, idx.data_ptr(), w.data_ptr(), g.data_ptr(),
                       *_pv(grad, ctx.cf, "grad"), det, _ptr(ws), _stream())
-        return grad, None, None, None
+        return grad, None, None, None, None
 
 
-def knn_outlier_loss(pc, k=5, alpha=1.05, cf=False):
-    """Per-sample kNN-distance outlier penalty [B] of pc ([B,N,3], or [B,3,N] with cf); differentiable in pc."""
+def knn_outlier_loss(pc, k=5, alpha=1.05, cf=False, gvec=None):
+    """Per-sample kNN-distance outlier penalty [B] of pc ([B,N,3], or [B,3,N] with cf); differentiable in pc. gvec [B]:
+    fixed d loss / d term (the backward then ignores the incoming gradient, see scaled_gvec)."""
     _check(pc, "pc")
-    return _KnnOutlierFn.apply(pc, int(k), float(alpha), bool(cf))
+    return _KnnOutlierFn.apply(pc, int(k), float(alpha), bool(cf), gvec)
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -630,13 +670,16 @@ def linear_pre(parts, J, Wp, gate_pre, W, gate=None):
 LOSS_KINDS = {"untargeted_logits": 0, "logits": 1, "cross_entropy": 2}
 
 
-def cls_loss(logits, target, kind, kappa=0.0, scale=1.0, want_grad=True):
-    """(logp [B,k], pred [B] int64, loss [B], g_logits [B,k] or None) — log_softmax + adversarial loss, one launch."""
+def cls_loss(logits, target, kind, kappa=0.0, scale=1.0, want_grad=True, pred_out=None):
+    """(logp [B,k], pred [B] int64, loss [B], g_logits [B,k] or None) — log_softmax + adversarial loss, one launch.
+    pred_out: a persistent int64 [B] tensor to receive the prediction."""
     _check(logits, "logits")
     B, ncls = logits.shape
     dev = logits.device
     logp = torch.empty((B, ncls), dtype=torch.float32, device=dev)
-    pred = torch.empty((B,), dtype=torch.int64, device=dev)
+    if pred_out is not None and (pred_out.dtype != torch.int64 or pred_out.shape != (B,) or not pred_out.is_contiguous()):
+        raise TypeError("cls_loss: pred_out must be a contiguous int64 [B] tensor")
+    pred = pred_out if pred_out is not None else torch.empty((B,), dtype=torch.int64, device=dev)
     loss = torch.empty((B,), dtype=torch.float32, device=dev)
     g = torch.empty((B, ncls), dtype=torch.float32, device=dev) if want_grad else None
     if target.dtype != torch.int64 or not target.is_cuda:
@@ -814,44 +857,50 @@ def kappa_gather(pts, normal_src, nidx, idx):
 
 class _CrossEntropyFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, target, sign):
-        _, _, loss, g = cls_loss(logits, target, 2, 0.0, sign, want_grad=True)
+    def forward(ctx, logits, target, sign, gscale):
+        _, _, loss, g = cls_loss(logits, target, 2, 0.0, sign if gscale is None else sign * gscale, want_grad=True)
         ctx.save_for_backward(g)
+        ctx.fixed = gscale is not None
         return loss * sign if sign != 1.0 else loss
 
     @staticmethod
     def backward(ctx, gout):
         (g,) = ctx.saved_tensors
-        return g * gout[:, None], None, None
+        return (g if ctx.fixed else g * gout[:, None]), None, None, None
 
 
 class _AdvLossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, target, kind, kappa):
-        _, _, loss, g = cls_loss(logits, target, kind, kappa, 1.0, want_grad=True)
+    def forward(ctx, logits, target, kind, kappa, gscale):
+        _, _, loss, g = cls_loss(logits, target, kind, kappa, 1.0 if gscale is None else gscale, want_grad=True)
         ctx.save_for_backward(g)
+        ctx.fixed = gscale is not None
         return loss
 
     @staticmethod
     def backward(ctx, gout):
         (g,) = ctx.saved_tensors
-        return g * gout[:, None], None, None, None
+        return (g if ctx.fixed else g * gout[:, None]), None, None, None, None
 
 
-def adv_loss_raw(logits, target, kind, kappa=0.0):
+def adv_loss_raw(logits, target, kind, kappa=0.0, gscale=None):
     """Per-sample adversarial loss [B] of attack/CW/CW_utils/adv_utils.py on `logits` AS GIVEN (no log-softmax): kind
     "untargeted_logits" / "logits" = clamp(+-(real - other) + kappa, 0), "cross_entropy" = -logits[target]; one launch
-    each way (LOSS_KINDS)."""
+    each way (LOSS_KINDS). gscale (float): d loss / d term, the same for every sample, multiplied into the gradient by
+    the forward launch — the backward then returns it as is and does not read the incoming gradient."""
     if logits.dim() != 2 or logits.stride(1) != 1:
         raise ValueError("adv_loss_raw: logits must be [B,k] with unit column stride")
-    return _AdvLossFn.apply(logits, target, LOSS_KINDS[kind] + 4, float(kappa))
+    return _AdvLossFn.apply(logits, target, LOSS_KINDS[kind] + 4, float(kappa),
+                            None if gscale is None else float(np.float32(gscale)))
 
 
-def cross_entropy(logits, target, sign=1.0):
-    """sign * CrossEntropyLoss(reduction='none')(logits, target) -> [B], one launch each way (pc3d_cls_loss_f32, kind 2)."""
+def cross_entropy(logits, target, sign=1.0, gscale=None):
+    """sign * CrossEntropyLoss(reduction='none')(logits, target) -> [B], one launch each way (pc3d_cls_loss_f32, kind 2).
+    gscale (float): d loss / d term, the same for every sample, multiplied into the gradient by the forward launch; the
+    backward then does not read the incoming gradient."""
     if logits.dim() != 2 or logits.stride(1) != 1:
         raise ValueError("cross_entropy: logits must be [B,k] with unit column stride")
-    return _CrossEntropyFn.apply(logits, target, float(sign))
+    return _CrossEntropyFn.apply(logits, target, float(sign), None if gscale is None else float(np.float32(gscale)))
 
 
 def geoa3_record(logits, target, targeted, metric, iterate, search_step, step, best_loss, best_attack, best_bs, best_step,
@@ -879,7 +928,7 @@ def geoa3_record(logits, target, targeted, metric, iterate, search_step, step, b
 
 class _GeoTermsFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, d_ao, d_oa, k_adv, k_ori, idx_ao, cls, scale, w):
+    def forward(ctx, d_ao, d_oa, k_adv, k_ori, idx_ao, cls, scale, w, gfix=None):
         B, N = d_ao.shape
         M = d_oa.shape[1] if d_oa is not None else (k_ori.shape[1] if k_ori is not None else N)
         dev = d_ao.device
@@ -889,16 +938,16 @@ class _GeoTermsFn(torch.autograd.Function):
             _lib.call("pc3d_geoa3_terms_f32", d_ao.data_ptr(), _ptr(d_oa), _ptr(k_adv), _ptr(k_ori), _ptr(idx_ao),
                       cls.data_ptr(), scale.data_ptr(), B, N, M, w[0], w[1], w[2], out.data_ptr(), hd_arg.data_ptr(),
                       _stream())
-        ctx.save_for_backward(k_adv, k_ori, idx_ao, scale, hd_arg)
+        ctx.save_for_backward(k_adv, k_ori, idx_ao, scale, hd_arg, gfix)
         ctx.dims, ctx.w, ctx.has_oa = (B, N, M), w, d_oa is not None
         return out
 
     @staticmethod
     def backward(ctx, g):
-        k_adv, k_ori, idx_ao, scale, hd_arg = ctx.saved_tensors
+        k_adv, k_ori, idx_ao, scale, hd_arg, gfix = ctx.saved_tensors
         B, N, M = ctx.dims
         dev = g.device
-        g = g.contiguous()
+        g = gfix if gfix is not None else g.contiguous()
         g_ao = torch.empty((B, N), dtype=torch.float32, device=dev)
         g_oa = torch.empty((B, M), dtype=torch.float32, device=dev) if ctx.has_oa else None
         g_k = torch.empty((B, N), dtype=torch.float32, device=dev) if k_adv is not None else None
@@ -907,12 +956,31 @@ class _GeoTermsFn(torch.autograd.Function):
             _lib.call("pc3d_geoa3_terms_bwd_f32", g.data_ptr(), _ptr(k_adv), _ptr(k_ori), _ptr(idx_ao), scale.data_ptr(),
                       hd_arg.data_ptr(), B, N, M, ctx.w[0], ctx.w[1], ctx.w[2], g_ao.data_ptr(), _ptr(g_oa), _ptr(g_k),
                       g_cls.data_ptr(), _stream())
-        return g_ao, g_oa, g_k, None, None, g_cls, None, None
+        return g_ao, g_oa, g_k, None, None, g_cls, None, None, None
 
 
-def geoa3_terms(d_ao, d_oa, k_adv, k_ori, idx_ao, cls, scale, w_dis, w_hd, w_curv):
+_GEO_GFIX = {}
+
+
+def geoa3_loss_grad(device, B, value):
+    """The [5,B] upstream gradient of geoa3_terms' output when only its last row enters the loss, as value * sum_b loss_n[b]
+    (value = 1/B for the batch mean): cached, never written again."""
+    key = (torch.device(device).index, int(B), float(np.float32(value)))
+    t = _GEO_GFIX.get(key)
+    if t is None:
+        if len(_GEO_GFIX) >= 64:
+            _GEO_GFIX.pop(next(iter(_GEO_GFIX)))
+        t = torch.zeros((5, int(B)), dtype=torch.float32, device=device)
+        t[4].fill_(float(np.float32(value)))
+        _GEO_GFIX[key] = t
+    _graphed.note_captured(t)
+    return t
+
+
+def geoa3_terms(d_ao, d_oa, k_adv, k_ori, idx_ao, cls, scale, w_dis, w_hd, w_curv, gfix=None):
     """GeoA3's loss assembly in one launch (pc3d_geoa3_terms_f32): returns [5,B] = (dis, hd, curv, constrain, loss_n)
-    rows; differentiable in d_ao, d_oa, k_adv and cls. d_oa None = pseudo-Chamfer, k_adv None = no curvature term."""
+    rows; differentiable in d_ao, d_oa, k_adv and cls. d_oa None = pseudo-Chamfer, k_adv None = no curvature term.
+    gfix [5,B] (geoa3_loss_grad): the backward uses it as the output's gradient and does not read the incoming one."""
     for nm, t in (("d_ao", d_ao), ("d_oa", d_oa), ("k_adv", k_adv), ("k_ori", k_ori), ("cls", cls), ("scale", scale)):
         if t is not None:
             _check(t, nm)
@@ -930,7 +998,7 @@ def geoa3_terms(d_ao, d_oa, k_adv, k_ori, idx_ao, cls, scale, w_dis, w_hd, w_cur
             raise NotImplementedError("geoa3_terms: k_ori is a constant of the attack")
     else:
         k_ori = idx_ao = None
-    return _GeoTermsFn.apply(d_ao, d_oa, k_adv, k_ori, idx_ao, cls, scale, (float(w_dis), float(w_hd), float(w_curv)))
+    return _GeoTermsFn.apply(d_ao, d_oa, k_adv, k_ori, idx_ao, cls, scale, (float(w_dis), float(w_hd), float(w_curv)), gfix)
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -1950,8 +2018,12 @@ def _group_linear_max_fwd(x, w, b):
             _lib.call("pc3d_group_linear_max_f32", x.data_ptr(), w.data_ptr(), b.data_ptr(), G, ns, C2, C3,
                       out.data_ptr(), arg.data_ptr(), _stream())
         return out, arg
-    y = gemm_nt(x.reshape(G * ns, C2), w, b, "relu").view(G, ns, -1)
-    return y.max(dim=1)
+    y = gemm_nt(x.reshape(G * ns, C2), w, b, "relu")
+    out = torch.empty((G, C3), dtype=torch.float32, device=x.device)
+    arg = torch.empty((G, C3), dtype=torch.int64, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.call("pc3d_rows_max_f32", y.data_ptr(), G, ns, C3, out.data_ptr(), arg.data_ptr(), _stream())
+    return out, arg
 
 
 class _MLPReLUMaxFn(torch.autograd.Function):
@@ -2026,6 +2098,143 @@ def group_act_bwd_rev(gH, H, mask, idx, rev, NA, slope=0.0):
         _lib.call("pc3d_group_act_bwd_rev_f32", gH.data_ptr(), _ptr(H), _ptr(mask), idx.data_ptr(), off.data_ptr(),
                   lst.data_ptr(), B, NA, S, K, C, float(slope), gP.data_ptr(), gBc.data_ptr(), tail.data_ptr(), _stream())
     return gP, gBc
+
+
+# ------------------------------------------------------------------------------------------------------
+# The front of a set-abstraction layer: per-point / per-centre forms of the first 1x1 convolution
+# ------------------------------------------------------------------------------------------------------
+def _xyz_view(t, name):
+    """(ptr, bs, ps, cs, B, N) of a [B,N,3] fp32 view with any strides (a permuted channels-first tensor is read in place)."""
+    if not (torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 and t.dim() == 3 and t.shape[2] == 3):
+        raise TypeError(f"{name}: expected a float32 [B,N,3] GPU tensor, got {tuple(t.shape)} {t.dtype}")
+    return t.data_ptr(), t.stride(0), t.stride(1), t.stride(2), t.shape[0], t.shape[1]
+
+
+def _affine3_raw(x, w, bias, sign):
+    p, bs, ps, cs, B, N = _xyz_view(x, "affine3")
+    C = w.shape[0]
+    out = torch.empty((B, N, C), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.call("pc3d_affine3_f32", p, bs, ps, cs, B, N, w.data_ptr(), _ptr(bias), float(sign), C, out.data_ptr(), C, _stream())
+    return out
+
+
+def _affine3_bwd_raw(g, w, sign, add, out):
+    """out [B,N,3] view (+)= sign * g [B,N,C] @ w [C,3] (+ add [B,N,3] view)."""
+    B, N, C = g.shape
+    g = g if g.is_contiguous() else g.contiguous()
+    ap = (0, 0, 0, 0) if add is None else _xyz_view(add, "affine3_bwd add")[:4]
+    op = _xyz_view(out, "affine3_bwd out")[:4]
+    with torch.cuda.device(g.device):
+        _lib.call("pc3d_affine3_bwd_f32", g.data_ptr(), C, B, N, C, w.data_ptr(), float(sign), *ap, *op, _stream())
+    return out
+
+
+def _cf_grad(B, N, device):
+    """A [B,N,3] gradient laid out as a contiguous [B,3,N] tensor: what the permute of a channels-first input hands back
+    to its producer without a copy."""
+    return torch.empty((B, 3, N), dtype=torch.float32, device=device).permute(0, 2, 1)
+
+
+class _Affine3Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, sign):
+        ctx.save_for_backward(w)
+        ctx.sign = sign
+        return _affine3_raw(x, w, bias, sign)
+
+    @staticmethod
+    def backward(ctx, g):
+        (w,) = ctx.saved_tensors
+        B, N, _ = g.shape
+        return _affine3_bwd_raw(g, w, ctx.sign, None, _cf_grad(B, N, g.device)), None, None, None
+
+
+def affine3(x, w, bias=None, sign=1.0):
+    """bias + sign * (x @ w.T) for a [B,N,3] view x (any strides) and a frozen w [C,3] (C % 4 == 0): [B,N,C]. The coordinate
+    columns of a 1x1 convolution (pc3d_affine3_f32); differentiable in x."""
+    _check(w, "w")
+    if w.dim() != 2 or w.shape[1] != 3 or w.shape[0] % 4 or not w.is_contiguous():
+        raise ValueError("affine3: w must be a contiguous [C,3] matrix with C % 4 == 0")
+    return _Affine3Fn.apply(x, w.detach(), None if bias is None else bias.detach().contiguous(), float(sign))
+
+
+class _SAFrontFn(torch.autograd.Function):
+    """(new_xyz [B,S,3], P [B,N,C1], Bc [B,S,C1]) of a set-abstraction layer from xyz [B,N,3] (any strides), pts [B,N,D] or
+    None, the centre indices fps_idx [B,S] and the split first layer (Wx [C1,3], Wf [C1,D], b1):
+        new_xyz = xyz[fps_idx],  P = Wx x + Wf f,  Bc = b1 - Wx new_xyz
+    (model/pointnet2_utils.py:113,118-135,190-197). Forward 3-4 launches; backward: the two three-column products, the
+    centres' gradient (their own + Bc's) scattered into xyz's in ONE ordered launch, one GEMM for the features — no
+    gather of P's rows, no negation, no autograd accumulation launches. The gradient of xyz is laid out channels-first."""
+
+    @staticmethod
+    def forward(ctx, xyz, pts, fps_idx, wx, wf, b1):
+        p, bs, ps, cs, B, N = _xyz_view(xyz, "sa_front xyz")
+        S = fps_idx.shape[1]
+        C1 = wx.shape[0]
+        dev = xyz.device
+        new_xyz = torch.empty((B, S, 1, 3), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call("pc3d_group_gather_f32", p, bs, ps, cs, 0, 0, fps_idx.data_ptr(), 0, 0, 0, 0, B, N, S, 1,
+                      new_xyz.data_ptr(), _stream())
+        new_xyz = new_xyz.view(B, S, 3)
+        px = _affine3_raw(xyz, wx, None, 1.0)
+        if pts is None:
+            P = px
+        else:
+            D = pts.shape[2]
+            x2 = pts.reshape(B * N, D)
+            P = torch.empty((B, N, C1), dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                _lib.call("pc3d_gemm_nt_res_f32", x2.data_ptr(), x2.stride(0), wf.data_ptr(), 0, px.data_ptr(), C1,
+                          B * N, C1, D, 0, 0.0, P.data_ptr(), C1, gemm_variant(N, C1, D), _stream())
+        Bc = _affine3_raw(new_xyz, wx, b1, -1.0)
+        ctx.save_for_backward(fps_idx, wx, wf)
+        ctx.dims = (B, N, S, C1, pts is not None)
+        ctx.set_materialize_grads(False)
+        return new_xyz, P, Bc
+
+    @staticmethod
+    def backward(ctx, g_new, gP, gBc):
+        fps_idx, wx, wf = ctx.saved_tensors
+        B, N, S, C1, has_pts = ctx.dims
+        dev = fps_idx.device
+        gxyz = None
+        if ctx.needs_input_grad[0] and (g_new is not None or gP is not None or gBc is not None):
+            gxyz = _cf_grad(B, N, dev)
+            if gP is not None:
+                _affine3_bwd_raw(gP, wx, 1.0, None, gxyz)
+            else:
+                gxyz.zero_()
+            gc = None
+            if gBc is not None:
+                gc = _affine3_bwd_raw(gBc, wx, -1.0, g_new, torch.empty((B, S, 3), dtype=torch.float32, device=dev))
+            elif g_new is not None:
+                gc = g_new.contiguous()
+            if gc is not None:
+                with torch.cuda.device(dev):
+                    _lib.call("pc3d_scatter_points_det_f32", fps_idx.data_ptr(), gc.data_ptr(), B, S, N, gxyz.data_ptr(),
+                              gxyz.stride(0), gxyz.stride(1), gxyz.stride(2), _stream())
+        gpts = None
+        if has_pts and ctx.needs_input_grad[1] and gP is not None:
+            gP2 = gP.reshape(B * N, C1)
+            gpts = gemm_nt(gP2 if gP2.stride(1) == 1 else gP2.contiguous(), _w_transposed(wf), unit_rows=N).view(B, N, -1)
+        return gxyz, gpts, None, None, None, None
+
+
+def sa_front(xyz, pts, fps_idx, wx, wf, b1):
+    """(new_xyz [B,S,3], P [B,N,C1], Bc [B,S,C1]) — see _SAFrontFn. xyz [B,N,3] view with any strides, pts [B,N,D]
+    contiguous or None, fps_idx int32 [B,S]; wx [C1,3] (C1 % 4 == 0), wf [C1,D], b1 [C1] frozen."""
+    if fps_idx.dtype != torch.int32 or fps_idx.dim() != 2 or not fps_idx.is_contiguous():
+        raise ValueError("sa_front: fps_idx must be a contiguous int32 [B,S] tensor")
+    if wx.dim() != 2 or wx.shape[1] != 3 or wx.shape[0] % 4 or not wx.is_contiguous():
+        raise ValueError("sa_front: wx must be a contiguous [C1,3] matrix with C1 % 4 == 0")
+    if pts is not None:
+        _check(pts, "pts")
+        pts = pts if pts.is_contiguous() else pts.contiguous()
+        if wf is None or wf.shape != (wx.shape[0], pts.shape[2]) or not wf.is_contiguous():
+            raise ValueError("sa_front: wf must be a contiguous [C1,D] matrix")
+    return _SAFrontFn.apply(xyz, pts, fps_idx, wx.detach(), None if pts is None else wf.detach(), b1.detach().contiguous())
 
 
 # Keep layer 2's sign bits (pc3d_gemm_nt_gather_f32's ymask) instead of its output for the backward: 0.5 GB less per

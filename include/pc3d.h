@@ -201,6 +201,30 @@ int pc3d_sa_chain_f32(const float* P, int64_t ldp, const float* Bc, const int32_
                       const float* W2, const float* b2, int C1, int C2, const float* W3, const float* b3, int C3,
                       uint8_t* mask1, uint32_t* mask2, float* out, int64_t* arg, void* stream);
 
+/* The coordinate part of a set-abstraction layer's first 1x1 convolution (model/pointnet2_utils.py:118-135,190-197: the
+ * Conv2d over [xyz_j - centre_s ; feat_j] is linear, so it splits into a per-POINT part P = Wx x + Wf f and a per-CENTRE
+ * part Bc = b1 - Wx c; the Wf part is a GEMM with the coordinate part as its residual operand). Three-column products:
+ *   pc3d_affine3_f32      out[b,n,c] = bias[c] + sign * (W[c,0] x + W[c,1] y + W[c,2] z);  x a [B,N,3] view with element
+ *                         strides (x_bs, x_ps, x_cs) — a channels-first [B,3,N] tensor is read in place; W [C,3], bias [C]
+ *                         or NULL, C % 4 == 0, out [B*N, C] with row stride ldo.
+ *   pc3d_affine3_bwd_f32  out[b,n,:] = add[b,n,:] + sign * sum_c g[b,n,c] W[c,:];  g [B*N, C] row stride ldg, add (may be
+ *                         NULL) and out [B,N,3] views with their own strides (the gradient of a channels-first tensor is
+ *                         written in that layout). Fixed summation order.
+ *   pc3d_scatter_points_det_f32  out[b, idx[b,s], :] += val[b,s,:] in ascending s: the gradient of the centres
+ *                         new_xyz = xyz[fps_idx] (:113, index_points) folded into the gradient of xyz; idx [B,S] int32,
+ *                         val [B,S,3] contiguous, out as above. One wavefront owns a cloud's column: no float atomics on
+ *                         memory, repeated centres are summed in order. */
+int pc3d_affine3_f32(const float* x, int64_t x_bs, int64_t x_ps, int64_t x_cs, int B, int N, const float* W,
+                     const float* bias, float sign, int C, float* out, int64_t ldo, void* stream);
+int pc3d_affine3_bwd_f32(const float* g, int64_t ldg, int B, int N, int C, const float* W, float sign,
+                         const float* add, int64_t a_bs, int64_t a_ps, int64_t a_cs,
+                         float* out, int64_t o_bs, int64_t o_ps, int64_t o_cs, void* stream);
+int pc3d_scatter_points_det_f32(const int32_t* idx, const float* val, int B, int S, int N, float* out, int64_t o_bs,
+                                int64_t o_ps, int64_t o_cs, void* stream);
+/* out[g,c] = max_r Y[g,r,c], arg[g,c] = the first row holding it (a NaN wins, as torch.max): the group max of a
+ * set-abstraction layer whose last layer is too wide for the fused form (model/pointnet2_utils.py:198). Y [G,ns,C]. */
+int pc3d_rows_max_f32(const float* Y, int64_t G, int ns, int C, float* out, int64_t* arg, void* stream);
+
 /* The same backward WITHOUT float atomics, as a gather over a reverse index of the grouping.
  * pc3d_group_reverse_i32: per cloud, the list of grouped rows that reference each point (a counting sort on the device:
  *   two passes of integer atomics + a scan). idx [B,S,K] int32 as above; cnt [B,NA] int32 scratch; off [B,NA+1] int32
@@ -347,9 +371,12 @@ int pc3d_clip_f32(const float* pc, int64_t pc_bs, int64_t pc_ps, int64_t pc_cs,
  * with the mode-0 clip/projection against `ori` (ori NULL = plain Adam). Replaces opt.step() + clip_func of
  * attack/CW/CW_attack.py:169-174 and attack/KNN/KNN_attack.py:129-136.
  * m, v (exp_avg, exp_avg_sq) share p's strides and are updated in place. The step number t (>= 1) comes from the
- * device word *step_dev when non-NULL (hipGraph replay), else from step_host. */
+ * device word *step_dev when non-NULL (hipGraph replay), else from step_host. g2 (may be NULL): a second gradient,
+ * summed with g on load — the victim's and the distance term's branches of loss.backward() (attack/KNN/KNN_attack.py:
+ * 125-129), which autograd would add in a launch of its own. */
 int pc3d_adam_clip_step_f32(float* p, int64_t p_bs, int64_t p_ps, int64_t p_cs,
                             const float* g, int64_t g_bs, int64_t g_ps, int64_t g_cs,
+                            const float* g2, int64_t g2_bs, int64_t g2_ps, int64_t g2_cs,
                             float* m, float* v,
                             const float* ori, int64_t o_bs, int64_t o_ps, int64_t o_cs,
                             const float* normal, int64_t n_bs, int64_t n_ps, int64_t n_cs,
