@@ -34,6 +34,9 @@ __global__ __launch_bounds__(FPS_T) void fps_kernel(FpsArgs a) {
   __shared__ float red_v[2][FPS_T / 64];
   __shared__ int red_i[2][FPS_T / 64];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // A chain of dependent steps on one wavefront per SIMD, usually beside a chip-filling kernel of another stream (the
+  // previous layer's MLP, the attack's searches): its instructions go first in the SIMD's issue arbitration.
+  __builtin_amdgcn_s_setprio(3);
   const float* xb = a.x.p + (int64_t)b * a.x.bs;
   float px[PER], py[PER], pz[PER], dist[PER];
 #pragma unroll
@@ -1080,6 +1083,31 @@ extern "C" int pc3d_group_act_bwd_rev_f32(const float* gH, const float* H, const
   else { PC3D_GAB_LAUNCH(8); }
 #undef PC3D_GAB_LAUNCH
   PC3D_LAUNCH_CHECK("pc3d_group_act_bwd_rev_f32");
+  return PC3D_OK;
+}
+
+// the points pass alone, for a caller that already has the groups pass's outputs (pc3d_sa_chain_bwd_f32 writes them)
+extern "C" int pc3d_group_act_bwd_points_f32(const float* gH, const uint8_t* mask, const float* tail, const int32_t* off,
+                                             const int32_t* lst, int B, int NA, int S, int K, int C, float slope, float* gP,
+                                             void* stream) {
+  const char* nm = "pc3d_group_act_bwd_points_f32";
+  PC3D_REQUIRE(B >= 0 && NA >= 1 && S >= 1 && K >= 1 && C >= 4 && C % 4 == 0 && C <= GAB_MAXC,
+               "%s: bad sizes B=%d NA=%d S=%d K=%d C=%d (C %% 4 == 0, C <= %d)", nm, B, NA, S, K, C, GAB_MAXC);
+  PC3D_REQUIRE(B <= 65535, "%s: B=%d exceeds grid.y limit", nm, B);
+  if (B == 0) return PC3D_OK;
+  PC3D_REQUIRE(gH && mask && tail && off && lst && gP, "%s: null pointer", nm);
+  hipStream_t st = as_stream(stream);
+  const int64_t L = (int64_t)S * K + S;
+  const dim3 gp(cdiv(NA, 4), B), blk(256);
+  const float* H = nullptr;
+#define PC3D_GAP_LAUNCH(Q) \
+  hipLaunchKernelGGL(group_act_bwd_points_kernel<Q>, gp, blk, 0, st, gH, H, mask, tail, off, lst, L, NA, S, K, C, slope, gP)
+  if (C <= 64) { PC3D_GAP_LAUNCH(1); }
+  else if (C <= 128) { PC3D_GAP_LAUNCH(2); }
+  else if (C <= 256) { PC3D_GAP_LAUNCH(4); }
+  else { PC3D_GAP_LAUNCH(8); }
+#undef PC3D_GAP_LAUNCH
+  PC3D_LAUNCH_CHECK(nm);
   return PC3D_OK;
 }
 

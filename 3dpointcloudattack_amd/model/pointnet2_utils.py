@@ -182,6 +182,21 @@ def sample_and_group(npoint, radius, nsample, xyz, points, returnfps=False):
     return new_xyz, new_points
 
 
+_ZEROS = {}
+
+
+def _zeros_cached(B, S, C, device):
+    """The all-zero centre of a group-all layer (:143): one tensor per (shape, device) instead of a fill per forward.
+    Read-only by convention (the classifiers never look at it)."""
+    key = (B, S, C, device.type, device.index)
+    z = _ZEROS.get(key)
+    if z is None:
+        if len(_ZEROS) > 16:
+            _ZEROS.clear()
+        z = _ZEROS[key] = torch.zeros(B, S, C, device=device)
+    return z
+
+
 def sample_and_group_all(xyz, points):
     """:138-155 — new_xyz zeros [B,1,3], new_points [B,1,N,3+D]."""
     B, N, C = xyz.shape
@@ -231,18 +246,33 @@ class PointNetSetAbstraction(_FrozenFusedMixin, nn.Module):
         layers = [_fold_bn2d(c, b) for c, b in zip(self.mlp_convs, self.mlp_bns)]
         return layers, _split_first(layers)
 
-    def geometry(self, xyz_t):
-        """What this layer derives from the COORDINATES alone, for detached xyz_t [B,N,3] on the current stream: (centre
-        indices [B,S] i32, detached centres [B,S,3], group indices [B,S,ns] i32, event). A classifier runs the whole
-        chain of its layers on a side stream (geometry_chain) beside the MLPs of the previous layer."""
+    def geometry(self, xyz_t, with_rev=True):
+        """What this layer derives from the COORDINATES alone, for detached xyz_t [B,N,3] on the current stream: [centre
+        indices [B,S] i32, detached centres [B,S,3], group indices [B,S,ns] i32, event, reverse index, its event]. A
+        classifier runs the whole chain of its layers on a side stream (geometry_chain) beside the MLPs of the previous
+        layer; with_rev=False leaves the last two entries None for geometry_rev to fill in later."""
         B, N, _ = xyz_t.shape
         fps_idx = ops.fps(xyz_t, self.npoint, _fps_start(B, N, xyz_t.device))                       # [B,S] i32
         centres = ops.group_gather(xyz_t, None, fps_idx.view(B, self.npoint, 1)).view(B, self.npoint, 3)
         idx = ops.ball_query(self.radius, self.nsample, xyz_t, centres)                              # [B,S,ns] i32
-        rev = ops.group_reverse(idx, N) if REVERSE_INDEX else None      # for the backward of layer 1 (no float atomics)
         ev = torch.cuda.Event()
-        ev.record()
-        return fps_idx, centres, idx, ev, rev
+        ev.record()                      # what the layer's FORWARD waits for
+        g = [fps_idx, centres, idx, ev, None, None, N]
+        if with_rev:
+            self.geometry_rev(g)
+        return g
+
+    @staticmethod
+    def geometry_rev(g):
+        """The reverse index of the grouping (for the backward of layer 1: no float atomics) + its event, on the current
+        stream. Five launches (~85 us at SSG's first level) the layer's forward does not wait for: the consumer's stream
+        waits for them AFTER it has queued the layer's MLP, and geometry_chain queues them after the sampling of every
+        layer so that the next layer's centres are not held up either."""
+        if REVERSE_INDEX:
+            off, lst = ops.group_reverse(g[2], g[6])
+            g[5] = torch.cuda.Event()
+            g[5].record()
+            g[4] = (off, lst, g[5])      # the backward that reads the index waits for the event (ops._GroupedMLPMaxFn)
 
     def forward(self, xyz, points, geo=None):
         """xyz [B,3,N], points [B,D,N] or None -> new_xyz [B,3,S], new_points [B,D',S]. geo: this layer's entry of
@@ -257,7 +287,7 @@ class PointNetSetAbstraction(_FrozenFusedMixin, nn.Module):
                 # [xyz ; points] is never concatenated (:138-155): layer 1 = relu(Wf f + (Wx x + b1)), the coordinate
                 # columns as the GEMM's residual operand
                 B, N, _ = xyz_t.shape
-                new_xyz = torch.zeros(B, 1, 3, device=xyz_t.device)
+                new_xyz = _zeros_cached(B, 1, 3, xyz_t.device)
                 h1 = ops.linear_res_act(pts, wf, None, ops.affine3(xyz_t, wx, b1), "relu")
                 new_points = _mlp_max(h1.view(B, 1, N, -1), layers[1:])
             else:
@@ -266,8 +296,9 @@ class PointNetSetAbstraction(_FrozenFusedMixin, nn.Module):
         else:
             B, N, _ = xyz_t.shape
             rev = None
+            ev_rev = None
             if geo is not None:
-                fps_idx, _, idx, ev, rev = geo
+                fps_idx, _, idx, ev, rev, ev_rev = geo[:6]
                 torch.cuda.current_stream(xyz_t.device).wait_event(ev)
             else:
                 fps_idx = ops.fps(xyz_t, self.npoint, _fps_start(B, N, xyz_t.device))                   # [B,S] i32
@@ -321,18 +352,28 @@ class PointNetSetAbstractionMsg(_FrozenFusedMixin, nn.Module):
             out.append((layers, _split_first(layers)))
         return out
 
-    def geometry(self, xyz_t):
-        """(centre indices, detached centres, [group indices per scale], event) for detached xyz_t [B,N,3]; see
-        PointNetSetAbstraction.geometry."""
+    def geometry(self, xyz_t, with_rev=True):
+        """[centre indices, detached centres, [group indices per scale], event, [reverse indices], their event] for
+        detached xyz_t [B,N,3]; see PointNetSetAbstraction.geometry."""
         B, N, _ = xyz_t.shape
         S = self.npoint
         fps_idx = ops.fps(xyz_t, S, _fps_start(B, N, xyz_t.device))
         centres = ops.group_gather(xyz_t, None, fps_idx.view(B, S, 1)).view(B, S, 3)
         idxs = [ops.ball_query(radius, self.nsample_list[i], xyz_t, centres) for i, radius in enumerate(self.radius_list)]
-        revs = [ops.group_reverse(ix, N) if REVERSE_INDEX else None for ix in idxs]
         ev = torch.cuda.Event()
         ev.record()
-        return fps_idx, centres, idxs, ev, revs
+        g = [fps_idx, centres, idxs, ev, None, None, N]
+        if with_rev:
+            self.geometry_rev(g)
+        return g
+
+    @staticmethod
+    def geometry_rev(g):
+        if REVERSE_INDEX:
+            revs = [ops.group_reverse(ix, g[6]) for ix in g[2]]
+            g[5] = torch.cuda.Event()
+            g[5].record()
+            g[4] = [(off, lst, g[5]) for off, lst in revs]
 
     def forward(self, xyz, points, geo=None):
         self._require_fused(xyz)
@@ -340,9 +381,9 @@ class PointNetSetAbstractionMsg(_FrozenFusedMixin, nn.Module):
         pts = _cl(points)
         B, N, C = xyz_t.shape
         S = self.npoint
-        revs = None
+        revs = ev_rev = None
         if geo is not None:
-            fps_idx, _, idxs, ev, revs = geo
+            fps_idx, _, idxs, ev, revs, ev_rev = geo[:6]
             torch.cuda.current_stream(xyz_t.device).wait_event(ev)
         else:
             fps_idx = ops.fps(xyz_t, S, _fps_start(B, N, xyz_t.device))
@@ -373,10 +414,12 @@ def geometry_chain(owner, xyz, layers):
         side.wait_stream(cur)
     out = []
     with torch.no_grad(), torch.cuda.stream(side if side is not None else cur):
-        for layer in layers:
-            g = layer.geometry(pts)
+        for layer in layers:             # the sampling chain first: layer l + 1 needs only the centres of layer l ...
+            g = layer.geometry(pts, with_rev=False)
             out.append(g)
             pts = g[1]
+        for layer, g in zip(layers, out):   # ... then the reverse indices, which only the backward reads
+            layer.geometry_rev(g)
     return out
 
 

@@ -2247,6 +2247,12 @@ LAYER2_SIGN_BITS = True
 SA_CHAIN = True
 
 
+# The chain's backward GEMM on W2^T and the groups pass of the first layer's backward as one launch
+# (pc3d_gemm_nt_groupsum_f32: the [B*S*ns, C1] gradient is written once and not read back for the sums), then the points
+# pass — bit-identical to the separate launches; False = those, for A/B timing.
+SA_CHAIN_BWD = True
+
+
 def sa_chain_supported(C1, C2, C3, ns):
     return (SA_CHAIN and ns in (32, 64, 128) and C1 in (32, 64, 128) and C2 % 32 == 0 and 32 <= C2 <= 128
             and C3 % 32 == 0 and LAYER2_SIGN_BITS)
@@ -2260,7 +2266,8 @@ class _GroupedMLPMaxFn(torch.autograd.Function):
     (pc3d_group_act_bwd_mask_f32). One [B,S,ns,C1] write and two reads fewer than group_act + mlp_relu_max."""
 
     @staticmethod
-    def forward(ctx, P, Bc, idx, w2, b2, w3, b3, rev_off, rev_lst):
+    def forward(ctx, P, Bc, idx, w2, b2, w3, b3, rev_off, rev_lst, rev_event=None):
+        ctx.rev_event = rev_event
         B, NA, C1 = P.shape
         S, ns = idx.shape[1], idx.shape[2]
         C2 = w2.shape[0]
@@ -2304,16 +2311,33 @@ class _GroupedMLPMaxFn(torch.autograd.Function):
             else:
                 _lib.call("pc3d_group_max_linear_bwd_f32", g.data_ptr(), out.data_ptr(), arg.data_ptr(), w3.data_ptr(),
                           B * S, ns, C2, w3.shape[0], H2.data_ptr(), gz.data_ptr(), _stream())
+        if SA_CHAIN_BWD and rev_off is not None and ns in (32, 64, 128) and C1 in (32, 64, 128) and C2 % 32 == 0:
+            dev = g.device
+            gh1 = torch.empty((B * S * ns, C1), dtype=torch.float32, device=dev)
+            gBc = torch.empty((B, S, C1), dtype=torch.float32, device=dev)
+            tail = torch.empty((B, S, C1), dtype=torch.float32, device=dev)
+            gP = torch.empty((B, NA, C1), dtype=torch.float32, device=dev)
+            w2t = _w_transposed(w2)
+            with torch.cuda.device(dev):
+                _lib.call("pc3d_gemm_nt_groupsum_f32", gz.data_ptr(), C2, w2t.data_ptr(), mask.data_ptr(), idx.data_ptr(),
+                          B, S, ns, C1, C2, gh1.data_ptr(), gBc.data_ptr(), tail.data_ptr(), _stream())
+                if ctx.rev_event is not None:    # built on the geometry stream, after the sampling chain (pointnet2_utils)
+                    torch.cuda.current_stream(dev).wait_event(ctx.rev_event)
+                _lib.call("pc3d_group_act_bwd_points_f32", gh1.data_ptr(), mask.data_ptr(), tail.data_ptr(), rev_off.data_ptr(),
+                          rev_lst.data_ptr(), B, NA, S, ns, C1, 0.0, gP.data_ptr(), _stream())
+            return gP, gBc, None, None, None, None, None, None, None, None
         gh1 = gemm_nt(gz, _w_transposed(w2))
         if rev_off is not None:        # gather through the reverse index of the grouping: no float atomics
+            if ctx.rev_event is not None:        # built on the geometry stream, after the sampling chain (pointnet2_utils)
+                torch.cuda.current_stream(g.device).wait_event(ctx.rev_event)
             gP, gBc = group_act_bwd_rev(gh1.view(B, S, ns, C1), None, mask, idx, (rev_off, rev_lst), NA, 0.0)
-            return gP, gBc, None, None, None, None, None, None, None
+            return gP, gBc, None, None, None, None, None, None, None, None
         gP = torch.empty((B, NA, C1), dtype=torch.float32, device=g.device)
         gBc = torch.empty((B, S, C1), dtype=torch.float32, device=g.device)
         with torch.cuda.device(g.device):
             _lib.call("pc3d_group_act_bwd_mask_f32", gh1.data_ptr(), mask.data_ptr(), idx.data_ptr(), B, NA, S, ns, C1,
                       0.0, gP.data_ptr(), gBc.data_ptr(), _det(), _stream())
-        return gP, gBc, None, None, None, None, None, None, None
+        return gP, gBc, None, None, None, None, None, None, None, None
 
 
 def grouped_mlp_max_supported(C1, ns, layers):
@@ -2333,9 +2357,10 @@ def grouped_mlp_max(P, Bc, idx, layers, rev=None):
             or Bc.shape != (P.shape[0], idx.shape[1], P.shape[2]):
         raise ValueError("grouped_mlp_max: unsupported shapes (see grouped_mlp_max_supported)")
     (w2, b2), (w3, b3) = layers
-    r0, r1 = rev if rev is not None else (None, None)
+    r0, r1 = (rev[0], rev[1]) if rev is not None else (None, None)
+    ev = rev[2] if rev is not None and len(rev) > 2 else None       # (off, lst[, event recorded after they were built])
     return _GroupedMLPMaxFn.apply(P.contiguous(), Bc.contiguous(), idx.contiguous(), w2.detach().contiguous(),
-                                  b2.detach().contiguous(), w3.detach().contiguous(), b3.detach().contiguous(), r0, r1)
+                                  b2.detach().contiguous(), w3.detach().contiguous(), b3.detach().contiguous(), r0, r1, ev)
 
 
 def mlp_relu_max(x, layers):

@@ -201,6 +201,22 @@ int pc3d_sa_chain_f32(const float* P, int64_t ldp, const float* Bc, const int32_
                       const float* W2, const float* b2, int C1, int C2, const float* W3, const float* b3, int C3,
                       uint8_t* mask1, uint32_t* mask2, float* out, int64_t* arg, void* stream);
 
+/* Y = X . Wt^T (pc3d_gemm_nt_f32 without bias / activation) AND the groups pass of pc3d_group_act_bwd_rev_f32 on Y in one
+ * launch — the backward of a set-abstraction chain's second layer and of the first layer's per-centre bias
+ * (model/pointnet2_utils.py:190-197): X = the gradient of the layer-2 pre-activation [B*S*ns, K] (row stride ldx),
+ * Wt [C1, K] = W2 transposed, Y [B*S*ns, C1] = the gradient of the generated layer-1 rows (NOT masked by mask1:
+ * pc3d_group_act_bwd_points_f32 applies it), gBc [B*S, C1] = per group the sum of mask1 * Y over its rows, tail [B*S, C1]
+ * the same sum over the rows j > 0 that repeat the group's first index (idx [B,S,ns]); mask1 [B*S*ns, C1/4] bytes from the
+ * forward. Results are bit-identical to the two launches (same summation orders); Y is written once and not read back.
+ * ns in {32, 64, 128}; C1 in {32, 64, 128}; K a multiple of 32.
+ * pc3d_group_act_bwd_points_f32: the points pass of pc3d_group_act_bwd_rev_f32 alone (gP [B,NA,C] from gH, its sign
+ * bytes, the groups pass's tail and the reverse index off / lst). */
+int pc3d_gemm_nt_groupsum_f32(const float* X, int64_t ldx, const float* Wt, const uint8_t* mask1, const int32_t* idx,
+                              int B, int S, int ns, int C1, int K, float* Y, float* gBc, float* tail, void* stream);
+int pc3d_group_act_bwd_points_f32(const float* gH, const uint8_t* mask, const float* tail, const int32_t* off,
+                                  const int32_t* lst, int B, int NA, int S, int K, int C, float slope, float* gP,
+                                  void* stream);
+
 /* The coordinate part of a set-abstraction layer's first 1x1 convolution (model/pointnet2_utils.py:118-135,190-197: the
  * Conv2d over [xyz_j - centre_s ; feat_j] is linear, so it splits into a per-POINT part P = Wx x + Wf f and a per-CENTRE
  * part Bc = b1 - Wx c; the Wf part is a GEMM with the coordinate part as its residual operand). Three-column products:

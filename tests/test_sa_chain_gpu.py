@@ -76,3 +76,28 @@ def test_sa_chain_vs_float64(ops, dev):
     np.testing.assert_allclose(out.cpu().numpy(), ref.detach().cpu().numpy(), rtol=2e-5, atol=2e-5)
     np.testing.assert_allclose(gp.cpu().numpy(), p.grad.cpu().numpy(), rtol=2e-4, atol=2e-5)
     np.testing.assert_allclose(gb.cpu().numpy(), bc.grad.cpu().numpy(), rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("B,N,S,ns,C1,C2,C3", [(8, 2048, 512, 32, 64, 64, 128),     # SSG SA1 (B reduced)
+                                                (8, 512, 128, 64, 128, 128, 256),    # SSG SA2
+                                                (3, 512, 128, 128, 64, 96, 128),     # MSG widest scale (K not a chunk multiple)
+                                                (2, 512, 100, 32, 32, 32, 64),       # narrow widths
+                                                (1, 300, 7, 64, 64, 128, 320),       # ragged last row tile
+                                                (2, 256, 9, 32, 128, 64, 96)])
+def test_sa_chain_backward_fused_gemm_groupsum_bitwise(ops, dev, B, N, S, ns, C1, C2, C3):
+    """pc3d_gemm_nt_groupsum_f32 + the points pass against GEMM on W2^T / groups pass / points pass: the gradients to P and
+    Bc are BIT-identical (same summation orders)."""
+    P, Bc, idx, layers, w = _case(ops, dev, B, N, S, ns, C1, C2, C3, seed=C3 + ns + 1, bad_idx=True)
+    if not ops.grouped_mlp_max_supported(C1, ns, layers):
+        pytest.skip("shape not on the fused path")
+    res = []
+    for fused in (True, False):
+        ops.SA_CHAIN_BWD = fused
+        try:
+            res.append(_run(ops, P, Bc, idx, layers, w, chain=True))
+        finally:
+            ops.SA_CHAIN_BWD = True
+    (o1, gp1, gb1), (o0, gp0, gb0) = res
+    assert torch.equal(o1, o0)
+    assert torch.equal(gb1, gb0), float((gb1 - gb0).abs().max())
+    assert torch.equal(gp1, gp0), float((gp1 - gp0).abs().max())
