@@ -168,50 +168,62 @@ class CWKNN:
         side = (_streams.side_stream(dev, _streams.TERMS)
                 if cur is not None and getattr(self, "dist_stream", True) and getattr(self.model, "sampling_chain_front", False)
                 else None)                      # ONE per process (see streams.py); only beside a sampling-chain victim
-        for iteration in range(self.num_iter):
-            if direct:
+        # A PointNet++ victim draws an FPS start per sampling layer and forward from the CPU generator (SURVEY A-4): the
+        # loop's draws are made here, in the same order, and uploaded once (pointnet2_utils.PredrawnFpsStarts)
+        from ...model import pointnet2_utils as _pn2
+        victim = getattr(self.model, "model", self.model)
+        predrawn = None
+        if adv_data.is_cuda and hasattr(victim, "sampling_input_sizes") and getattr(self, "predraw_starts", True):
+            predrawn = _pn2.PredrawnFpsStarts(victim.sampling_input_sizes(K), B, self.num_iter, dev, inner=_pn2.fps_start_source())
+            prev_source = _pn2.set_fps_start_source(predrawn)
+        try:
+            for iteration in range(self.num_iter):
+                if direct:
+                    if side is not None:
+                        side.wait_stream(cur)
+                        with torch.cuda.stream(side):
+                            terms = self.dist_func.per_sample_terms(adv_alias, ori_data, up_dist)   # channel-first, zero-copy
+                    logits = _logits_of(self.model(adv_data))
+                    a_term = self.adv_func.per_sample(logits.contiguous(), target, up_adv)
+                    if a_term is None:
+                        raise RuntimeError("CWKNN: the victim's logits changed shape / dtype between forwards")
+                    if side is not None:
+                        cur.wait_stream(side)
+                    else:
+                        terms = self.dist_func.per_sample_terms(adv_alias, ori_data, up_dist)
+                    adv_data.grad = None
+                    adv_alias.grad = None
+                    torch.autograd.backward([a_term] + terms, [ones] * (1 + len(terms)))
+                    ops.adam_clip_step(adv_data.data, adv_data.grad, exp_avg, exp_avg_sq, iteration + 1, self.attack_lr,
+                                       ori=ori_data, normal=normal if fc[1] else None, budget=fc[0], g2=adv_alias.grad)
+                    continue
                 if side is not None:
                     side.wait_stream(cur)
                     with torch.cuda.stream(side):
-                        terms = self.dist_func.per_sample_terms(adv_alias, ori_data, up_dist)   # channel-first, zero-copy
-                logits = _logits_of(self.model(adv_data))
-                a_term = self.adv_func.per_sample(logits.contiguous(), target, up_adv)
-                if a_term is None:
-                    raise RuntimeError("CWKNN: the victim's logits changed shape / dtype between forwards")
+                        # in the official tensorflow code they use sum instead of mean, hence * K (:119-123)
+                        dist_loss = self.dist_func(adv_data.transpose(1, 2).contiguous(), ori_t).mean() * K
+                logits = _logits_of(self.model(adv_data))  # [B, num_classes]
+                adv_loss = self.adv_func(logits, target).mean()
                 if side is not None:
                     cur.wait_stream(side)
                 else:
-                    terms = self.dist_func.per_sample_terms(adv_alias, ori_data, up_dist)
-                adv_data.grad = None
-                adv_alias.grad = None
-                torch.autograd.backward([a_term] + terms, [ones] * (1 + len(terms)))
-                ops.adam_clip_step(adv_data.data, adv_data.grad, exp_avg, exp_avg_sq, iteration + 1, self.attack_lr,
-                                   ori=ori_data, normal=normal if fc[1] else None, budget=fc[0], g2=adv_alias.grad)
-                continue
-            if side is not None:
-                side.wait_stream(cur)
-                with torch.cuda.stream(side):
-                    # in the official tensorflow code they use sum instead of mean, hence * K (:119-123)
                     dist_loss = self.dist_func(adv_data.transpose(1, 2).contiguous(), ori_t).mean() * K
-            logits = _logits_of(self.model(adv_data))  # [B, num_classes]
-            adv_loss = self.adv_func(logits, target).mean()
-            if side is not None:
-                cur.wait_stream(side)
-            else:
-                dist_loss = self.dist_func(adv_data.transpose(1, 2).contiguous(), ori_t).mean() * K
-            loss = adv_loss + dist_loss
-            if ratio != 1.0:
-                loss = loss * ratio            # batch means (:117-123) of a shard of a larger batch
-            if fc is None:
-                opt.zero_grad()
-                loss.backward()
-                opt.step()
-                adv_data.data = self.clip_func(adv_data.clone().detach(), ori_data, normal)
-            else:
-                adv_data.grad = None
-                loss.backward()
-                ops.adam_clip_step(adv_data.data, adv_data.grad, exp_avg, exp_avg_sq, iteration + 1, self.attack_lr,
-                                   ori=ori_data, normal=normal if fc[1] else None, budget=fc[0])
+                loss = adv_loss + dist_loss
+                if ratio != 1.0:
+                    loss = loss * ratio            # batch means (:117-123) of a shard of a larger batch
+                if fc is None:
+                    opt.zero_grad()
+                    loss.backward()
+                    opt.step()
+                    adv_data.data = self.clip_func(adv_data.clone().detach(), ori_data, normal)
+                else:
+                    adv_data.grad = None
+                    loss.backward()
+                    ops.adam_clip_step(adv_data.data, adv_data.grad, exp_avg, exp_avg_sq, iteration + 1, self.attack_lr,
+                                       ori=ori_data, normal=normal if fc[1] else None, budget=fc[0])
+        finally:
+            if predrawn is not None:
+                _pn2.set_fps_start_source(prev_source)
 
         # end of CW attack
         with torch.no_grad():

@@ -10,7 +10,13 @@ from .pointnet2_utils import PointNetSetAbstraction, PointNetSetAbstractionMsg, 
 
 
 class PointNet_Msg(_FrozenFusedMixin, nn.Module):
-    sampling_chain_front = True   # the forward starts with an FPS chain: attacks overlap their own searches with it
+    sampling_chain_front = True
+
+    def sampling_input_sizes(self, N):
+        """Points each farthest-point-sampling layer of ONE forward over N input points draws its start index from, in call
+        order (pointnet2_utils.PredrawnFpsStarts)."""
+        return [int(N), int(self.sa1.npoint)]
+   # the forward starts with an FPS chain: attacks overlap their own searches with it
 
     def __init__(self, num_class, normal_channel=True):
         super(PointNet_Msg, self).__init__()

@@ -10,7 +10,13 @@ from .pointnet2_utils import PointNetSetAbstraction, geometry_chain, geometry_jo
 
 
 class PointNet_Ssg(_FrozenFusedMixin, nn.Module):
-    sampling_chain_front = True   # the forward starts with an FPS chain: attacks overlap their own searches with it
+    sampling_chain_front = True
+
+    def sampling_input_sizes(self, N):
+        """Points each farthest-point-sampling layer of ONE forward over N input points draws its start index from, in call
+        order (pointnet2_utils.PredrawnFpsStarts)."""
+        return [int(N), int(self.sa1.npoint)]
+   # the forward starts with an FPS chain: attacks overlap their own searches with it
 
     def __init__(self, num_classes=40):
         super(PointNet_Ssg, self).__init__()

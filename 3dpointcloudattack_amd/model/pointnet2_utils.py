@@ -134,19 +134,63 @@ class SeededFpsStarts:
     def __init__(self, seeds):
         self.gens = [torch.Generator().manual_seed(int(s)) for s in seeds]
 
-    def __call__(self, B, N, device):
+    def draw_cpu(self, B, N):
         if B != len(self.gens):
             raise ValueError(f"SeededFpsStarts: batch of {B} clouds, {len(self.gens)} seeds")
-        vals = torch.tensor([int(torch.randint(0, N, (1,), generator=g)) for g in self.gens], dtype=torch.int32)
-        return ops.h2d(vals, device, torch.int32)
+        return torch.tensor([int(torch.randint(0, N, (1,), generator=g)) for g in self.gens], dtype=torch.int32)
+
+    def __call__(self, B, N, device):
+        return ops.h2d(self.draw_cpu(B, N), device, torch.int32)
+
+
+def _draw_cpu(source, B, N):
+    """One sampling layer's start indices on the host: the source's own draw, or the reference's — the first index from the
+    GLOBAL CPU generator (:72, SURVEY A-4); same call, same stream position -> same start indices under the same seed."""
+    if source is not None:
+        return source.draw_cpu(B, N)
+    return torch.randint(0, N, (B,), dtype=torch.long).to(torch.int32)
+
+
+class PredrawnFpsStarts:
+    """The start indices of `forwards` consecutive forwards of ONE victim, drawn ahead — from the source the live draws
+    would have used, in the order they would have been made: per forward one draw of B indices per sampling layer, layer l
+    over `layer_sizes[l]` points — and uploaded ONCE. An attack loop's forwards then read theirs from the device buffer: no
+    host draw and no host->device copy per sampling layer and forward (two per iteration for the single-scale classifier,
+    each a stream operation the launch queue has to thread through). When the buffer is used up the previous source is
+    live again at exactly the stream position it would have had; a call that does not fit the recorded pattern before that
+    is an error (the draws made ahead cannot be returned to the generator)."""
+
+    def __init__(self, layer_sizes, B, forwards, device, inner=None):
+        self.sizes, self.B, self.inner = [int(n) for n in layer_sizes], int(B), inner
+        rows = [_draw_cpu(inner, self.B, n) for _ in range(int(forwards)) for n in self.sizes]
+        self.total = len(rows)
+        self.buf = ops.h2d(torch.stack(rows), device, torch.int32) if rows else None      # [forwards * layers, B]
+        self.pos = 0
+
+    def draw_cpu(self, B, N):
+        if self.pos < self.total:
+            raise RuntimeError("PredrawnFpsStarts: host draw requested while pre-drawn indices are pending")
+        return _draw_cpu(self.inner, B, N)
+
+    def __call__(self, B, N, device):
+        if self.pos >= self.total:
+            return ops.h2d(_draw_cpu(self.inner, B, N), device, torch.int32)
+        if B != self.B or N != self.sizes[self.pos % len(self.sizes)] or self.buf.device != torch.device(device):
+            raise RuntimeError(f"PredrawnFpsStarts: call (B={B}, N={N}) does not fit the pre-drawn pattern "
+                               f"(B={self.B}, N={self.sizes[self.pos % len(self.sizes)]})")
+        row = self.buf[self.pos]
+        self.pos += 1
+        return row
+
+
+def fps_start_source():
+    return _FPS_START_SOURCE
 
 
 def _fps_start(B, N, device):
     if _FPS_START_SOURCE is not None:
         return _FPS_START_SOURCE(B, N, device)
-    # the reference draws the first index from the GLOBAL CPU generator every forward (:72, SURVEY A-4); same call,
-    # same stream position -> same start indices under the same seed
-    return ops.h2d(torch.randint(0, N, (B,), dtype=torch.long), device, torch.int32)     # no queue stall (ops.h2d)
+    return ops.h2d(_draw_cpu(None, B, N), device, torch.int32)     # no queue stall (ops.h2d)
 
 
 def farthest_point_sample(xyz, npoint, start=None):
