@@ -18,8 +18,7 @@ _KNN = namedtuple("KNN", "dists idx knn")
 
 def apply_knn(p1, p2, lengths1, lengths2, K, version, return_sorted):
     """knn_utils.py:10-20 — (values [B,N,K] ascending, positions [B,N,K] int64)."""
-    d, i = ops.knn(p1.float(), p2.float(), K)
-    return d, i.long()
+    return ops.knn(p1.float(), p2.float(), K, idx64=True)      # int64 positions like pytorch3d's (K = 1: from the search launch)
 
 
 def knn_points(p1: torch.Tensor, p2: torch.Tensor, lengths1: Union[torch.Tensor, None] = None,

@@ -34,6 +34,8 @@ struct ScatterArgs {
   int clamp;            // 1: targets are clamped into [0, N) (what the forward's gather did) instead of skipped
   const uint8_t* mbits; // [B, R, C/4] or null: the activation's sign as bits (bit c % 4 of byte c / 4), instead of `act`
   int64_t out_bs, out_cs;   // batch / channel stride of out in elements (a [B,3,N] gradient: ldo = 1, out_cs = N)
+  const float* row_bias;    // [B, N] or null  } a rank-1 term added on the way out: out[b,n,c] = sum + row_bias[b,n] * col_w[c]
+  const float* col_w;       // [C]             } (the guided walk's score term; a separate product, then a separate add)
 };
 
 // Lane = RECORD: a lane loads the CH contiguous channels of its record (one or two 16-byte loads when the slice is
@@ -115,6 +117,10 @@ __global__ __launch_bounds__(64 * W) void scatter_rows_own_kernel(ScatterArgs a)
 #pragma unroll
     for (int w = 1; w < W; ++w) sum += so_acc[(w * a.N + n) * ST + q];
     float* o = ob + (int64_t)n * a.ldo + (int64_t)q * a.out_cs;
+    if (a.row_bias) {
+      const float t = a.row_bias[(int64_t)b * a.N + n] * a.col_w[c0 + q];
+      sum = sum + t;
+    }
     *o = a.accumulate ? *o + sum : sum;
   }
 }
@@ -243,7 +249,7 @@ static hipError_t own_lds_optin(K kernel, size_t bytes) {
 
 int scatter_rows_det(const char* nm, const int32_t* tgt, const float* val, int64_t ldv, const float* act, int64_t lda, float slope,
                      int B, int R, int N, int C, float* out, int64_t ldo, int accumulate, int clamp, void* stream,
-                     const uint8_t* mbits, int64_t out_bs, int64_t out_cs) {
+                     const uint8_t* mbits, int64_t out_bs, int64_t out_cs, const float* row_bias, const float* col_w) {
   if (out_bs == 0) out_bs = (int64_t)N * ldo;
   PC3D_REQUIRE(B >= 0 && R >= 0 && N >= 1 && C >= 1 && ldv >= C && (ldo >= C || out_cs != 1) && (!act || lda >= C), "%s: bad sizes", nm);
   PC3D_REQUIRE(B <= 65535, "%s: B=%d exceeds grid.y limit", nm, B);
@@ -259,7 +265,7 @@ int scatter_rows_det(const char* nm, const int32_t* tgt, const float* val, int64
   PC3D_REQUIRE(own_bytes(N, ch) <= kOwnLdsMax, "%s: N=%d destination rows do not fit a CU's LDS (deterministic scatter)", nm, N);
   int w = 1;
   while (w < 8 && own_bytes(N, ch, 2 * w) <= kOwnLds && R >= 2 * w * 256) w *= 2;
-  ScatterArgs a{tgt, val, act, ldv, lda, slope, R, N, C, out, ldo, accumulate, clamp, mbits, out_bs, out_cs};
+  ScatterArgs a{tgt, val, act, ldv, lda, slope, R, N, C, out, ldo, accumulate, clamp, mbits, out_bs, out_cs, row_bias, col_w};
   const size_t lds = own_bytes(N, ch, w);
   const dim3 grid(cdiv(C, ch), B);
   hipStream_t st = as_stream(stream);

@@ -295,6 +295,7 @@ __global__ __launch_bounds__(LN_T) void linear16_pre_kernel(LinPreArgs a) {
 //   kind 0: UntargetedLogitsAdvLoss  mean_b max(real - other + kappa, 0)     (adv_utils.py:64-80)
 //   kind 1: LogitsAdvLoss            mean_b max(other - real + kappa, 0)     (adv_utils.py:17-33)
 //   kind 2: CrossEntropyAdvLoss      nll_loss(logp, target) (mean)           (adv_utils.py:42-51)
+//   kind 3: minus kind 2             (attack/GeoA3/GeoA3_attack.py:125-127: the untargeted classification loss -CE)
 // where real/other are taken on the model OUTPUT, i.e. on the log-probabilities, and
 // other = max_j ((1-onehot) logp - onehot * 10000).  scale multiplies the gradient (1/B for the batch mean).
 // ---------------------------------------------------------------------------------------------------------
@@ -346,9 +347,12 @@ __global__ __launch_bounds__(64) void cls_loss_kernel(const float* logits, int l
     const float mgn = other - real + kappa;
     lval = fmaxf(mgn, 0.f);
     if (mgn > 0.f) gt = -1.f, go = 1.f;
-  } else {
+  } else if (kind == 2) {
     lval = 0.f - real;
     gt = -1.f;
+  } else {                                 // kind 3: MINUS the cross-entropy (GeoA3's untargeted classification loss)
+    lval = real;
+    gt = 1.f;
   }
   if (lane == 0) {
     if (pred) pred[b] = am;
@@ -356,9 +360,9 @@ __global__ __launch_bounds__(64) void cls_loss_kernel(const float* logits, int l
   }
   if (g_logits) {
     // through log_softmax: g_z = g_lp - softmax * sum(g_lp)
-    const float gsum = gt + ((kind == 2) ? 0.f : go);
+    const float gsum = gt + ((kind >= 2) ? 0.f : go);
     for (int j = lane; j < ncls; j += 64) {
-      float g = (j == t ? gt : 0.f) + ((kind != 2 && j == ao) ? go : 0.f);
+      float g = (j == t ? gt : 0.f) + ((kind < 2 && j == ao) ? go : 0.f);
       if (!raw) g -= expf(z[j] - lse) * gsum;
       g_logits[(int64_t)b * ncls + j] = g * scale;
     }
@@ -532,7 +536,7 @@ extern "C" int pc3d_cls_loss_f32(const float* logits, int ld, int B, int ncls, c
                                  float kappa, float scale, float* logp, int64_t* pred, float* loss,
                                  float* g_logits, void* stream) {
   PC3D_REQUIRE(B >= 0 && ncls >= 2 && ld >= ncls, "pc3d_cls_loss_f32: bad sizes B=%d ncls=%d ld=%d", B, ncls, ld);
-  PC3D_REQUIRE(kind >= 0 && kind <= 6 && (kind & 3) != 3, "pc3d_cls_loss_f32: kind=%d not in {0,1,2} (+4)", kind);
+  PC3D_REQUIRE(kind >= 0 && kind <= 7, "pc3d_cls_loss_f32: kind=%d not in {0,1,2,3} (+4)", kind);
   if (B == 0) return PC3D_OK;
   PC3D_REQUIRE(logits && target, "pc3d_cls_loss_f32: null pointer");
   hipLaunchKernelGGL(cls_loss_kernel, dim3(B), dim3(64), 0, as_stream(stream), logits, ld, ncls, target, kind, kappa,

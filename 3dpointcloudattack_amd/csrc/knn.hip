@@ -18,6 +18,9 @@ struct KnnArgs {
   int N, M, K;
   float* d;    // [B,N,K]
   int32_t* i;  // [B,N,K]
+  int32_t* i_noself = nullptr;   // [B,N,K-1] or null: columns 1 .. K-1 of i
+  int32_t* i_first = nullptr;    // [B,N,k2] or null: columns 0 .. k2-1 of i
+  int k2 = 0;
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -140,6 +143,8 @@ __global__ __launch_bounds__(kKwWaves * 64) void knn_wave_kernel(KnnArgs a) {
       if (qi < N && lane < K) {
         if (a.d) a.d[((int64_t)b * N + qi) * K + lane] = __builtin_bit_cast(float, lk[p][u]);
         if (a.i) a.i[((int64_t)b * N + qi) * K + lane] = li[p][u];
+        if (a.i_noself && lane >= 1) a.i_noself[((int64_t)b * N + qi) * (K - 1) + lane - 1] = li[p][u];
+        if (a.i_first && lane < a.k2) a.i_first[((int64_t)b * N + qi) * a.k2 + lane] = li[p][u];
       }
     }
 }
@@ -383,6 +388,20 @@ extern "C" int pc3d_knn_bwd_f32(const float* q, int64_t q_bs, int64_t q_ps, int6
   KnnBwdArgs a{{q, q_bs, q_ps, q_cs}, {r, r_bs, r_ps, r_cs}, N, M, K, idx, w,
                {grad_q, gq_bs, gq_ps, gq_cs}, {grad_r, gr_bs, gr_ps, gr_cs}};
   return knn_bwd_launch("pc3d_knn_bwd_f32", a, B, grad_r, gr_bs, gr_ps, gr_cs, deterministic, det_ws, stream);
+}
+
+extern "C" int pc3d_knn_graph_i32(const float* pts, int64_t p_bs, int64_t p_ps, int64_t p_cs, int B, int N, int K, int32_t* idx,
+                                  int32_t* idx_noself, int32_t* idx_first, int k2, void* stream) {
+  const char* nm = "pc3d_knn_graph_i32";
+  PC3D_REQUIRE(B >= 0 && N >= 1 && K >= 2 && K <= 64 && K <= N && k2 >= 0 && k2 <= K, "%s: bad sizes B=%d N=%d K=%d k2=%d", nm, B, N, K, k2);
+  PC3D_REQUIRE(B <= 65535, "%s: B=%d exceeds grid.y limit", nm, B);
+  if (B == 0) return PC3D_OK;
+  PC3D_REQUIRE(pts && idx, "%s: null pointer", nm);
+  KnnArgs a{{pts, p_bs, p_ps, p_cs}, {pts, p_bs, p_ps, p_cs}, N, N, K, nullptr, idx};
+  a.i_noself = idx_noself, a.i_first = k2 > 0 ? idx_first : nullptr, a.k2 = k2;
+  hipLaunchKernelGGL((knn_wave_kernel<4, true>), dim3(cdiv(N, 16), B), dim3(256), 0, as_stream(stream), a);
+  PC3D_LAUNCH_CHECK(nm);
+  return PC3D_OK;
 }
 
 extern "C" int pc3d_knn_f32(const float* q, int64_t q_bs, int64_t q_ps, int64_t q_cs,

@@ -25,6 +25,7 @@ struct NNDir {
   int N, M;
   float* d;
   int32_t* i;
+  int64_t* i64 = nullptr;   // the same indices as 64-bit integers (the pytorch3d-style API hands out int64), or null
 };
 struct NNArgs {
   NNDir dir[2];
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(WAVES * 64) void nn_kernel(NNArgs args, int mt_cap)
     const int qi = q0 + t;
     if (qi < N) {
       if (D.d) D.d[(int64_t)b * N + qi] = bd;
-      if (D.i) {
+      if (D.i || D.i64) {
         // bi is the first index of the winning chunk: the arg-min is the first of its 8 points whose distance,
         // recomputed with the same instructions, equals the minimum (ties -> lowest index, as torch.min)
         const float* qp = qb + (int64_t)qi * D.q.ps;
@@ -173,7 +174,8 @@ __global__ __launch_bounds__(WAVES * 64) void nn_kernel(NNArgs args, int mt_cap)
             }
           }
         }
-        D.i[(int64_t)b * N + qi] = arg;
+        if (D.i) D.i[(int64_t)b * N + qi] = arg;
+        if (D.i64) D.i64[(int64_t)b * N + qi] = arg;
       }
     }
   }
@@ -800,6 +802,18 @@ extern "C" int pc3d_nn_f32(const float* q, int64_t q_bs, int64_t q_ps, int64_t q
   PC3D_REQUIRE(q && r, "pc3d_nn_f32: null input pointer");
   NNArgs a{};
   a.dir[0] = NNDir{{q, q_bs, q_ps, q_cs}, {r, r_bs, r_ps, r_cs}, N, M, min_d2, idx};
+  return nn_launch(a, 1, B, as_stream(stream));
+}
+
+extern "C" int pc3d_nn_i64_f32(const float* q, int64_t q_bs, int64_t q_ps, int64_t q_cs,
+                               const float* r, int64_t r_bs, int64_t r_ps, int64_t r_cs,
+                               int B, int N, int M, float* min_d2, int32_t* idx, int64_t* idx64, void* stream) {
+  PC3D_REQUIRE(B >= 0 && N >= 0 && M >= 1, "pc3d_nn_i64_f32: bad sizes B=%d N=%d M=%d (M must be >= 1)", B, N, M);
+  PC3D_REQUIRE(B <= 65535, "pc3d_nn_i64_f32: B=%d exceeds grid.y limit 65535", B);
+  if (B == 0 || N == 0) return PC3D_OK;
+  PC3D_REQUIRE(q && r, "pc3d_nn_i64_f32: null input pointer");
+  NNArgs a{};
+  a.dir[0] = NNDir{{q, q_bs, q_ps, q_cs}, {r, r_bs, r_ps, r_cs}, N, M, min_d2, idx, idx64};
   return nn_launch(a, 1, B, as_stream(stream));
 }
 

@@ -18,7 +18,8 @@ int gemm_nt_groupmax(const float* X, const float* W, const float* bias, int G, i
 int scatter_rows_det(const char* nm, const int32_t* tgt, const float* val, int64_t ldv, const float* act, int64_t lda, float slope,
                      int B, int R, int N, int C, float* out, int64_t ldo, int accumulate, int clamp, void* stream,
                      const uint8_t* mbits = nullptr,   // mbits [B,R,C/4]: the activation's sign as bits instead of `act`
-                     int64_t out_bs = 0, int64_t out_cs = 1);   // batch / channel strides of out (0: N * ldo)
+                     int64_t out_bs = 0, int64_t out_cs = 1,    // batch / channel strides of out (0: N * ldo)
+                     const float* row_bias = nullptr, const float* col_w = nullptr);   // + row_bias[b,n] * col_w[c] on the way out
 //   dst[b, arg[b,i,c], c] += w[b,i,c]  (mode 0: w = g; mode 1: w = g * leaky'(outv), dst = [dP | dQ] with dQ = w)
 int arg_scatter_det(const char* nm, const float* g, int64_t ldg, const float* outv, const int32_t* arg, int B, int S, int N, int C,
                     float slope, float* dst, int mode, void* stream, int slice = 0);

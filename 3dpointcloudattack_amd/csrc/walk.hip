@@ -377,11 +377,13 @@ extern "C" int pc3d_curve_walk_bwd_f32(const float* gcurves, const float* feats,
   a.rec_rt = reinterpret_cast<int*>(p), p += (int64_t)B * nrow;
   a.rec_ct = reinterpret_cast<int*>(p);
   if (int rc = pc3d::walk_dispatch(true, a, C, stream)) return rc;
-  if (int rc = pc3d::scatter_rows_det("pc3d_curve_walk_bwd_f32", a.rec_rt, a.rec_rv, C, nullptr, 0, 0.f, B, (int)nrow, N, C, gfeats,
-                                      C, 0, 1, stream))
+  // the per-point score coefficients first; the feature rows then leave with the rank-1 score term added on the way out
+  // (gfeats[b,n,c] = sum + coef[b,n] * agent_w[c]: every candidate row gets coef * w_nbr — an addcmul launch before)
+  if (int rc = pc3d::scatter_rows_det("pc3d_curve_walk_bwd_f32", a.rec_ct, a.rec_cv, 1, nullptr, 0, 0.f, B, (int)ncoef, N, 1, coef, 1, 0,
+                                      1, stream))
     return rc;
-  return pc3d::scatter_rows_det("pc3d_curve_walk_bwd_f32", a.rec_ct, a.rec_cv, 1, nullptr, 0, 0.f, B, (int)ncoef, N, 1, coef, 1, 0,
-                                1, stream);
+  return pc3d::scatter_rows_det("pc3d_curve_walk_bwd_f32", a.rec_rt, a.rec_rv, C, nullptr, 0, 0.f, B, (int)nrow, N, C, gfeats, C, 0, 1,
+                                stream, nullptr, 0, 1, coef, agent_w);
 }
 
 extern "C" int64_t pc3d_curve_walk_bwd_ws_floats(int B, int cn, int C, int L, int k, int deterministic) {

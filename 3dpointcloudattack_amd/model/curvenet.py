@@ -74,8 +74,7 @@ class CurveNet(_FrozenFusedMixin, nn.Module):
                 pts = sub
             key = (pts.shape[1], blk.k)
             if key not in graphs:
-                idx = ops.knn_raw(pts, pts, blk.k + 1)[1]
-                graphs[key] = (idx, idx[:, :, 1:].contiguous(), idx[:, :, :blk.k].contiguous())
+                graphs[key] = ops.knn_graph(pts, blk.k)     # (idx, idx[:, :, 1:], idx[:, :, :k]) from one launch
                 if with_grad:
                     # the LPFA blocks of this resolution gather through the first k columns; their deterministic backward
                     # gathers back through the sorted reverse index, built here once per graph, off the feature path

@@ -370,8 +370,7 @@ class CIC(nn.Module):
         if hit is not None and hit[0] is pts:
             return hit[1]
         pd = pts.detach()
-        idx = ops.knn_raw(pd, pd, self.k + 1)[1]
-        g = (idx, idx[:, :, 1:].contiguous(), idx[:, :, :self.k].contiguous())
+        g = ops.knn_graph(pd, self.k)                   # (idx, idx[:, :, 1:], idx[:, :, :k]) from one launch
         if torch.is_grad_enabled() and pts.requires_grad:
             ops.attach_rev_index(g[2], pts.shape[1])     # shared by the LPFA blocks of this resolution (deterministic backward)
         if cache is not None:

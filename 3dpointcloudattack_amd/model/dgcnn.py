@@ -51,6 +51,9 @@ def _fold_edge(conv, bn):
     return torch.cat((U, V), 0).contiguous(), torch.cat((torch.zeros_like(t), t)).contiguous()
 
 
+FIRST_LAYER_DIRECT = True      # the first EdgeConv's products and the input graph straight from the [B,3,N] input
+
+
 class DGCNN(_FrozenFusedMixin, nn.Module):
     """model/dgcnn.py:262-328. ``args`` needs ``k``, ``emb_dims``, ``dropout``."""
     deterministic_forward = True   # forward is a pure function of its input (no RNG): attack loops may share it
@@ -92,15 +95,24 @@ class DGCNN(_FrozenFusedMixin, nn.Module):
         self._require_fused(x)
         edges, c5, head = self.folded()
         B = x.size(0)
-        f = x.transpose(2, 1).contiguous().float()          # [B,N,3] channels-last from here on
+        x = x.float()
+        direct_in = FIRST_LAYER_DIRECT and x.is_cuda and edges[0][0].shape[0] % 4 == 0
+        f = x.permute(0, 2, 1) if direct_in else x.transpose(2, 1).contiguous()    # [B,N,3] channels-last from here on
         feats = []
         for li, (UV, tb) in enumerate(edges):
             with torch.no_grad():                           # graph indices are constants for autograd (topk indices)
                 fd = f.detach()
-                idx = ops.knn_raw(fd, fd, self.k)[1] if li == 0 else ops.knn_feat(fd, self.k)
                 if li == 0:
+                    # the input cloud is read in its [B,3,N] layout (search and first product take strides): no transposed
+                    # copy forward, no transposing copy of the gradient backward
+                    idx = ops.knn_raw(x.detach(), x.detach(), self.k, True, True)[1] if direct_in else ops.knn_raw(fd, fd, self.k)[1]
                     _graphed.note_input_knn(self, x, idx)       # the graph of the INPUT cloud: attacks may reuse it
-            PQ = ops.linear_act(f, UV, tb)                  # [U x | V x + t] in one fp32-MFMA launch
+                else:
+                    idx = ops.knn_feat(fd, self.k)
+            if li == 0 and direct_in:
+                PQ = ops.affine3(f, UV, tb)                 # [U x | V x + t]: three-column products (csrc/sa_front.hip)
+            else:
+                PQ = ops.linear_act(f, UV, tb)              # [U x | V x + t] in one fp32-MFMA launch
             f = ops.edge_max(PQ, idx, 0.2)                  # leaky(max_j P_j + Q_i) == max_j leaky(bn(conv(e_ij)))
             feats.append(f)
         g = torch.cat(feats, dim=2)                         # [B,N,512]

@@ -76,8 +76,9 @@ def _ptr(t):
 # ------------------------------------------------------------------------------------------------------
 # raw (non-differentiable) ops
 # ------------------------------------------------------------------------------------------------------
-def nn_raw(q, r, q_cf=False, r_cf=False, want_idx=True):
-    """Nearest reference point of every query: (min_d2 [B,N] f32, idx [B,N] i32)."""
+def nn_raw(q, r, q_cf=False, r_cf=False, want_idx=True, want_i64=False):
+    """Nearest reference point of every query: (min_d2 [B,N] f32, idx [B,N] i32); with want_i64 a third tensor, the same
+    indices as int64 written by the same launch."""
     qp, qbs, qps, qcs, B, N = _pts(q, q_cf, "q")
     rp, rbs, rps, rcs, B2, M = _pts(r, r_cf, "r")
     if B != B2:
@@ -86,6 +87,12 @@ def nn_raw(q, r, q_cf=False, r_cf=False, want_idx=True):
         raise ValueError("reference set is empty")
     d = torch.empty((B, N), dtype=torch.float32, device=q.device)
     i = torch.empty((B, N), dtype=torch.int32, device=q.device) if want_idx else None
+    if want_i64:
+        i64 = torch.empty((B, N), dtype=torch.int64, device=q.device)
+        with torch.cuda.device(q.device):
+            _lib.call("pc3d_nn_i64_f32", qp, qbs, qps, qcs, rp, rbs, rps, rcs, B, N, M, d.data_ptr(), _ptr(i), i64.data_ptr(),
+                      _stream())
+        return d, i, i64
     with torch.cuda.device(q.device):
         _lib.call("pc3d_nn_f32", qp, qbs, qps, qcs, rp, rbs, rps, rcs, B, N, M, d.data_ptr(), _ptr(i), _stream())
     return d, i
@@ -547,20 +554,40 @@ def knn_raw(q, r, K, q_cf=False, r_cf=False):
     return d, i
 
 
+def knn_graph(pts, k, cf=False):
+    """(idx [B,N,k+1] self first, idx[:, :, 1:], idx[:, :, :k]) — int32, contiguous — of the self-kNN graph of pts [B,N,3]:
+    the graph and the two views CurveNet's blocks gather through, written by ONE launch (pc3d_knn_graph_i32)."""
+    p, bs, ps, cs, B, N = _pts(pts, cf, "pts")
+    K = int(k) + 1
+    if not (2 <= K <= min(64, N)):
+        raise ValueError(f"knn_graph: k + 1 = {K} out of range [2, min(64, N={N})]")
+    idx = torch.empty((B, N, K), dtype=torch.int32, device=pts.device)
+    noself = torch.empty((B, N, K - 1), dtype=torch.int32, device=pts.device)
+    first = torch.empty((B, N, K - 1), dtype=torch.int32, device=pts.device)
+    with torch.cuda.device(pts.device):
+        _lib.call("pc3d_knn_graph_i32", p, bs, ps, cs, B, N, K, idx.data_ptr(), noself.data_ptr(), first.data_ptr(), K - 1, _stream())
+    return idx, noself, first
+
+
 class _KnnFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, r, K, q_cf, r_cf, deterministic):
-        d, i = knn_raw(q, r, K, q_cf, r_cf)
+    def forward(ctx, q, r, K, q_cf, r_cf, deterministic, idx64=False):
+        if idx64 and K == 1:                   # int64 indices from the search launch itself (no conversion launch)
+            d1, i1, i64 = nn_raw(q, r, q_cf, r_cf, want_i64=True)
+            d, i, iout = d1.unsqueeze(-1), i1.unsqueeze(-1), i64.unsqueeze(-1)
+        else:
+            d, i = knn_raw(q, r, K, q_cf, r_cf)
+            iout = i.long() if idx64 else i
         ctx.save_for_backward(q, r, i)
         ctx.cfg = (K, q_cf, r_cf, deterministic)
-        ctx.mark_non_differentiable(i)
+        ctx.mark_non_differentiable(iout)
         ctx.set_materialize_grads(False)      # no zero tensor for the index output's "gradient" (a fill launch per call)
-        return d, i
+        return d, iout
 
     @staticmethod
     def backward(ctx, gd, _gi):
         if gd is None:
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
         q, r, idx = ctx.saved_tensors
         K, q_cf, r_cf, det = ctx.cfg
         need_q, need_r = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
@@ -574,13 +601,13 @@ class _KnnFn(torch.autograd.Function):
         with torch.cuda.device(q.device):
             _lib.call("pc3d_knn_bwd_f32", *_pv(q, q_cf, "q"), *_pv(r, r_cf, "r"), B, N, M, K, idx.data_ptr(),
                       gd.data_ptr(), *_pv(gq, q_cf, "gq"), *_pv(gr, r_cf, "gr"), _det(det), _ptr(ws), _stream())
-        return gq, gr, None, None, None, None
+        return gq, gr, None, None, None, None, None
 
 
-def knn(q, r, K, q_cf=False, r_cf=False, deterministic=None):
-    """Differentiable K-NN: (dists [B,N,K], idx [B,N,K] int32). For self-kNN pass the same tensor twice
+def knn(q, r, K, q_cf=False, r_cf=False, deterministic=None, idx64=False):
+    """Differentiable K-NN: (dists [B,N,K], idx [B,N,K] int32 — int64 with idx64). For self-kNN pass the same tensor twice
     (autograd sums the two gradient roles)."""
-    return _KnnFn.apply(q, r, K, q_cf, r_cf, deterministic)
+    return _KnnFn.apply(q, r, K, q_cf, r_cf, deterministic, idx64)
 
 
 class _KnnOutlierFn(torch.autograd.Function):
@@ -858,9 +885,13 @@ def kappa_gather(pts, normal_src, nidx, idx):
 class _CrossEntropyFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, target, sign, gscale):
+        ctx.fixed = gscale is not None
+        if sign == -1.0:                  # minus the cross-entropy is a loss kind of the kernel: no scaling launch
+            _, _, loss, g = cls_loss(logits, target, 3, 0.0, 1.0 if gscale is None else gscale, want_grad=True)
+            ctx.save_for_backward(g)
+            return loss
         _, _, loss, g = cls_loss(logits, target, 2, 0.0, sign if gscale is None else sign * gscale, want_grad=True)
         ctx.save_for_backward(g)
-        ctx.fixed = gscale is not None
         return loss * sign if sign != 1.0 else loss
 
     @staticmethod
@@ -1780,10 +1811,13 @@ class _AttScaleFn(torch.autograd.Function):
             _lib.call("pc3d_att_scale_f32", x.data_ptr(), w.data_ptr(), M, C, xs.data_ptr(), att.data_ptr(), _stream())
         ctx.save_for_backward(x, w, att)
         ctx.mark_non_differentiable(att)
+        ctx.set_materialize_grads(False)      # no zero tensor for the score output's "gradient" (a fill launch per call)
         return xs, att
 
     @staticmethod
     def backward(ctx, g, _gatt):
+        if g is None:
+            return None, None
         x, w, att = ctx.saved_tensors
         C = x.shape[-1]
         g = g.contiguous()
@@ -1946,7 +1980,8 @@ class _CurveWalkFn(torch.autograd.Function):
                       ab.data_ptr(), mw.data_ptr(), mb.data_ptr(), B, N, C, k, cn, ctx.L, curves.data_ptr(),
                       nodes.data_ptr(), pick.data_ptr(), pre.data_ptr(), mom.data_ptr(), gF.data_ptr(),
                       coef.data_ptr(), ws.data_ptr(), det, _stream())
-        gF.addcmul_(coef.unsqueeze(-1), aw[:C])      # the rank-1 score term: every candidate row gets coef * w_nbr
+        if not det:                                  # (deterministic: added by the ordered scatter on its way out)
+            gF.addcmul_(coef.unsqueeze(-1), aw[:C])  # the rank-1 score term: every candidate row gets coef * w_nbr
         return gF, None, None, None, None, None, None, None
 
 

@@ -47,6 +47,12 @@ const char* pc3d_last_error(void);
 int pc3d_nn_f32(const float* q, int64_t q_bs, int64_t q_ps, int64_t q_cs,
                 const float* r, int64_t r_bs, int64_t r_ps, int64_t r_cs,
                 int B, int N, int M, float* min_d2, int32_t* idx, void* stream);
+/* pc3d_nn_f32 that also writes the indices as int64 (idx64 [B,N], may be NULL; idx may be NULL too): the pytorch3d-style
+ * knn_points of attack/GeoA3/knn_utils.py:22-55 returns int64 indices — written here instead of by a conversion launch. */
+int pc3d_nn_i64_f32(const float* q, int64_t q_bs, int64_t q_ps, int64_t q_cs,
+                    const float* r, int64_t r_bs, int64_t r_ps, int64_t r_cs,
+                    int B, int N, int M, float* min_d2, int32_t* idx, int64_t* idx64, void* stream);
+
 
 /* Both directions in ONE launch (grid.z = 2): a->b into (dA,iA) [B,N]; b->a into (dB,iB) [B,M]. */
 int pc3d_nn_bidir_f32(const float* a, int64_t a_bs, int64_t a_ps, int64_t a_cs,
@@ -361,7 +367,8 @@ int pc3d_linear_pre_f32(const float* parts, int P, int Jp, int J, const float* W
                         int K, const float* W, int O, const float* gate, int ldg, float* Y, int ldy, void* stream);
 
 /* log_softmax (model/pointnet.py:148) + argmax + adversarial loss on the log-probabilities and its gradient w.r.t.
- * the LOGITS, one launch. kind 0 = UntargetedLogitsAdvLoss, 1 = LogitsAdvLoss, 2 = CrossEntropyAdvLoss
+ * the LOGITS, one launch. kind 0 = UntargetedLogitsAdvLoss, 1 = LogitsAdvLoss, 2 = CrossEntropyAdvLoss, 3 = minus kind 2
+ * (GeoA3's untargeted classification loss, attack/GeoA3/GeoA3_attack.py:125-127)
  * (attack/CW/CW_utils/adv_utils.py:64-80, 17-33, 42-51); per-sample loss[b] (before the batch mean), pred[b],
  * logp [B,ncls], g_logits [B,ncls] = scale * dloss_b/dlogits (scale = 1/B reproduces .mean()). Outputs may be NULL.
  * kind + 4: the loss is taken on `logits` AS GIVEN (no log-softmax) — what the reference's functors compute on whatever the
@@ -420,6 +427,13 @@ int pc3d_pairwise_f32(const float* x, int64_t x_bs, int64_t x_ps, int64_t x_cs,
 int pc3d_knn_f32(const float* q, int64_t q_bs, int64_t q_ps, int64_t q_cs,
                  const float* r, int64_t r_bs, int64_t r_ps, int64_t r_cs,
                  int B, int N, int M, int K, float* dists, int32_t* idx, void* stream);
+/* The neighbour graph of ONE cloud set (self-kNN, K = k + 1 columns, self first) with the two views of it that
+ * CurveNet's blocks use (model/curvenet_util.py:10-17 `knn`, :232 `idx[:, :, :k]`, walk.py `idx[:, :, 1:]`) written by the
+ * same launch instead of two slicing copies per resolution: idx [B,N,K]; idx_noself [B,N,K-1] (may be NULL) = columns
+ * 1 .. K-1; idx_first [B,N,k2] (may be NULL, k2 <= K) = columns 0 .. k2-1. Same search and tie rule as pc3d_knn_f32. */
+int pc3d_knn_graph_i32(const float* pts, int64_t p_bs, int64_t p_ps, int64_t p_cs, int B, int N, int K, int32_t* idx,
+                       int32_t* idx_noself, int32_t* idx_first, int k2, void* stream);
+
 
 /* Backward of the K distances with upstream w [B,N,K]: grad_q dense, grad_r scattered (float atomics; when
  * deterministic != 0 in a fixed order: with det_ws = B*N*K*3 floats of scratch the edges' contributions are recorded
@@ -606,7 +620,8 @@ int pc3d_edge_max_bwd_slice_f32(const float* g, int64_t ldg, const float* out, c
  * Backward: gfeats [B,N,C] and coef [B,N] are ACCUMULATED into (zero them first); the full gradient is
  * gfeats + coef (x) agent_w[0:C] (the rank-1 score term is left to the caller as one dense pass). Float atomics.
  * deterministic = 1: the steps record their contributions in ws and the entry point sums them in record order with
- * the ordered LDS scatter (pc3d_scatter_rows_det_f32); gfeats and coef are then OVERWRITTEN.
+ * the ordered LDS scatter (pc3d_scatter_rows_det_f32); gfeats and coef are then OVERWRITTEN, and gfeats already
+ * INCLUDES the rank-1 term coef (x) agent_w[0:C] (added by the scatter on its way out: no dense pass for the caller).
  * ws: pc3d_curve_walk_bwd_ws_floats(B, cn, C, L, k, deterministic) floats of scratch (the gradients that travel from
  * step to step; in deterministic mode also the records). */
 int pc3d_curve_walk_fwd_f32(const float* feats, const int32_t* adj, const int32_t* start, const float* agent_w,

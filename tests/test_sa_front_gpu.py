@@ -310,3 +310,33 @@ def test_knn_attack_predrawn_fps_starts_equal_live_draws(dev, seeded):
     a = run(True)
     b = run(False)
     assert np.array_equal(a[0], b[0]) and a[1:] == b[1:]
+
+
+@pytest.mark.parametrize("B,N,k", [(2, 300, 20), (1, 64, 5), (3, 1024, 40)])
+def test_knn_graph_views_equal_slices(ops, dev, B, N, k):
+    """pc3d_knn_graph_i32: the self-kNN graph and the two views CurveNet's blocks use (model/curvenet_util.py:10-17,
+    idx[:, :, 1:], idx[:, :, :k]) from ONE launch — equal to the search + two slicing copies."""
+    rng = np.random.default_rng(N + k)
+    pts = torch.from_numpy(np.stack([unit_cloud(rng, N) for _ in range(B)])).to(dev)
+    idx, noself, first = ops.knn_graph(pts, k)
+    ref = ops.knn_raw(pts, pts, k + 1)[1]
+    assert torch.equal(idx, ref) and torch.equal(noself, ref[:, :, 1:]) and torch.equal(first, ref[:, :, :k])
+    assert noself.is_contiguous() and first.is_contiguous() and idx.dtype == torch.int32
+
+
+def test_nn_int64_indices_from_the_search_launch(ops, dev):
+    """knn_points (attack/GeoA3/knn_utils.py:22-55) hands out int64 positions: for K = 1 they come from the search launch
+    (pc3d_nn_i64_f32), equal to the int32 indices; the distances' gradient is unchanged."""
+    ku = M("3dpointcloudattack_amd.attack.GeoA3.knn_utils")
+    rng = np.random.default_rng(1)
+    a = torch.from_numpy(np.stack([unit_cloud(rng, 257) for _ in range(3)])).to(dev).requires_grad_()
+    b = torch.from_numpy(np.stack([unit_cloud(rng, 100) for _ in range(3)])).to(dev)
+    res = ku.knn_points(a, b, K=1)
+    d32, i32 = ops.nn_raw(a.detach(), b)
+    assert res.idx.dtype == torch.int64 and res.idx.shape == (3, 257, 1)
+    assert torch.equal(res.idx.squeeze(-1), i32.long()) and torch.equal(res.dists.squeeze(-1).detach(), d32)
+    res.dists.sum().backward()
+    nearest = torch.gather(b, 1, i32.long()[..., None].expand(-1, -1, 3))
+    np.testing.assert_allclose(a.grad.cpu().numpy(), (2 * (a.detach() - nearest)).cpu().numpy(), rtol=1e-5, atol=1e-6)
+    r3 = ku.knn_points(a.detach(), b, K=3)
+    assert r3.idx.dtype == torch.int64 and torch.equal(r3.idx[:, :, 0], i32.long())
