@@ -35,6 +35,8 @@ struct GroupSumArgs {
   const float* Wt;        // [C1, K]  (W2 transposed: the NT operand)
   const uint8_t* mask1;   // [M, C1/4]
   const int32_t* idx;     // [M]
+  const uint32_t* amask;  // [G, NS/32] or null: bit j of group g = "row (g, j) of X is not all zero (and was written)". Only
+                          // those rows are read, multiplied and written; the sums skip the others (exact zeros)
   int M, G, K;
   float* Y;               // [M, C1]
   float* gBc;             // [G, C1]
@@ -69,28 +71,55 @@ __device__ __forceinline__ void gs_step(gs_f32x16 (&acc)[TN], const float* __res
 
 // NS = rows per group (32 / 64 / 128), TN = C1 / 32 column tiles per wave
 template <int NS, int TN>
-__global__ __launch_bounds__(GS_T, 2) void gemm_groupsum_kernel(GroupSumArgs a) {
+__global__ __launch_bounds__(GS_T, (TN > 2 ? 2 : 3)) void gemm_groupsum_kernel(GroupSumArgs a) {
   constexpr int GPT = GS_BM / NS;                          // groups per tile
   constexpr int C1 = 32 * TN;
+  // weight-slice buffers: two for the widest layer; ONE for C1 <= 64, whose 48 KB of LDS then let three workgroups share a
+  // CU (the kernel waits on memory latency between its short phases: residency pays more than the saved barrier)
+  constexpr int NBUF = TN > 2 ? 2 : 1;
   extern __shared__ __attribute__((aligned(16))) float gs_lds[];
   float* AH = gs_lds;                                      // [128][GS_LDH]: a chunk of X, later a 64-column slab of Y
-  float* Ws = AH + GS_BM * GS_LDH;                          // [2][C1][GS_LDW]
-  uint8_t* m1s = reinterpret_cast<uint8_t*>(Ws + 2 * C1 * GS_LDW);       // [128][C1 / 4] layer-1 sign bits of the tile
+  float* Ws = AH + GS_BM * GS_LDH;                          // [NBUF][C1][GS_LDW]
+  uint8_t* m1s = reinterpret_cast<uint8_t*>(Ws + NBUF * C1 * GS_LDW);    // [128][C1 / 4] layer-1 sign bits of the tile
   uint32_t* s_rep = reinterpret_cast<uint32_t*>(m1s + GS_BM * (C1 / 4));  // [GPT][4] bit j: row j repeats the group's first index
+  int* rowmap = reinterpret_cast<int*>(s_rep + GPT * 4);                   // [128] compact row -> row of the tile
+  int* zlist = rowmap + GS_BM;                                             // [128] rows to be written as zeros (see below)
+  __shared__ int s_nzero;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int m0 = blockIdx.x * GS_BM;
   const int g_first = m0 / NS;
 
-  // the A chunk kc of the tile: 128 rows x 16 float4, eight per thread (rows / columns past the matrix read as zero)
+  // ---- the tile's ACTIVE rows, compacted in ascending order: word w of the tile covers its rows 32 w .. 32 w + 31
+  uint32_t aw[4];
+  int abase[5];
+  abase[0] = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const int g = g_first + (32 * w) / NS;
+    uint32_t word = 0u;
+    if (g < a.G) word = a.amask ? a.amask[(int64_t)g * (NS / 32) + ((32 * w) % NS) / 32] : 0xffffffffu;
+    aw[w] = word;
+    abase[w + 1] = abase[w] + __builtin_popcount(word);
+  }
+  const int n_act = abase[4];
+  if (tid < GS_BM) {
+    const int w = tid >> 5, bit = tid & 31;
+    const uint32_t word = w == 0 ? aw[0] : (w == 1 ? aw[1] : (w == 2 ? aw[2] : aw[3]));
+    const int bw = w == 0 ? abase[0] : (w == 1 ? abase[1] : (w == 2 ? abase[2] : abase[3]));
+    if ((word >> bit) & 1u) rowmap[bw + __builtin_popcount(word & ((1u << bit) - 1u))] = tid;
+  }
+  __syncthreads();
+
+  // the A chunk kc of the tile's active rows: <= 128 rows x 16 float4, eight per thread (the rest reads as zero)
   float4 xa[8];
   auto fetch_x = [&](int kc) {
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const int f = u * GS_T + tid, row = f >> 4, c4 = f & 15;
+      const int f = u * GS_T + tid, crow = f >> 4, c4 = f & 15;
       const int k = kc + 4 * c4;
-      xa[u] = (m0 + row < a.M && k < a.K) ? *reinterpret_cast<const float4*>(a.X + (int64_t)(m0 + row) * a.ldx + k)
-                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+      xa[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (crow < n_act && k < a.K) xa[u] = *reinterpret_cast<const float4*>(a.X + (int64_t)(m0 + rowmap[crow]) * a.ldx + k);
     }
   };
   auto stash_x = [&]() {
@@ -146,6 +175,7 @@ __global__ __launch_bounds__(GS_T, 2) void gemm_groupsum_kernel(GroupSumArgs a) 
   for (int j = 0; j < TN; ++j)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+  if (tid == 0) s_nzero = 0;
 
   // ---- Y tile = X tile . Wt^T, K in chunks of 64 (A) and slices of 32 (B)
   int cur = 0;
@@ -160,17 +190,29 @@ __global__ __launch_bounds__(GS_T, 2) void gemm_groupsum_kernel(GroupSumArgs a) 
       const int knext = kc + (ks + 1) * GS_BK;
       const bool more = knext < a.K;
       if (more) fetch_w(knext);
-      gs_step<TN>(acc, AH + (wave * 32 + r) * GS_LDH + ks * GS_BK + 4 * h, Ws + cur * C1 * GS_LDW + r * GS_LDW + 4 * h);
-      if (ks + 1 < nks) {                                   // the chunk's next slice into the other buffer
-        stash_w(Ws + (cur ^ 1) * C1 * GS_LDW);
+      if (wave * 32 < n_act)                                // (uniform) a wave whose 32 compact rows are all past the active ones idles
+        gs_step<TN>(acc, AH + (wave * 32 + r) * GS_LDH + ks * GS_BK + 4 * h, Ws + cur * C1 * GS_LDW + r * GS_LDW + 4 * h);
+      if (NBUF == 2) {
+        if (ks + 1 < nks) {                                 // the chunk's next slice into the other buffer
+          stash_w(Ws + (cur ^ 1) * C1 * GS_LDW);
+          __syncthreads();
+        }
+        cur ^= 1;                                           // (after the last slice: the next chunk's first goes to the other buffer)
+      } else if (ks + 1 < nks) {
+        __syncthreads();                                    // every wave has read the slice in the only buffer
+        stash_w(Ws);
         __syncthreads();
-        cur ^= 1;
-      } else {
-        cur ^= 1;                                           // (the next chunk's first slice goes to the other buffer: wb holds it)
       }
     }
   }
   __syncthreads();                                         // every wave has read the last chunk
+  if (a.amask && tid < GS_BM && m0 + tid < a.M) {           // (order in the list does not matter: rows of zeros)
+    const int t = tid, gl = t / NS, j = t - gl * NS;
+    const uint32_t word = (t >> 5) == 0 ? aw[0] : ((t >> 5) == 1 ? aw[1] : ((t >> 5) == 2 ? aw[2] : aw[3]));
+    if (!((word >> (t & 31)) & 1u) && !((s_rep[gl * 4 + (j >> 5)] >> (j & 31)) & 1u)) zlist[atomicAdd(&s_nzero, 1)] = t;
+  }
+  __syncthreads();
+  const int nzero = s_nzero;
 
   // ---- Y out through LDS, 64 columns at a time; group sums in ascending row order
   for (int hh = 0; hh < C1; hh += 64) {
@@ -184,22 +226,32 @@ __global__ __launch_bounds__(GS_T, 2) void gemm_groupsum_kernel(GroupSumArgs a) 
     __syncthreads();
     const int wcols = C1 - hh < 64 ? C1 - hh : 64;          // 32 or 64 columns in this slab
     for (int f = tid; f < GS_BM * 16; f += GS_T) {
-      const int row = f >> 4, c4 = f & 15;
-      if (4 * c4 < wcols && m0 + row < a.M)
-        *reinterpret_cast<float4*>(a.Y + (int64_t)(m0 + row) * C1 + hh + 4 * c4) =
-            *reinterpret_cast<const float4*>(AH + row * GS_LDH + 4 * c4);
+      const int crow = f >> 4, c4 = f & 15;
+      if (4 * c4 < wcols && crow < n_act)
+        *reinterpret_cast<float4*>(a.Y + (int64_t)(m0 + rowmap[crow]) * C1 + hh + 4 * c4) =
+            *reinterpret_cast<const float4*>(AH + crow * GS_LDH + 4 * c4);
+    }
+    // an inactive row that is NOT one of the group's padding copies is still in some point's reverse list: it reads as zero
+    // there (few rows: the copies, which the points pass reaches through `tail` only, are the bulk of the inactive)
+    for (int f = tid; f < nzero * 16; f += GS_T) {
+      const int t = zlist[f >> 4], c4 = f & 15;
+      if (4 * c4 < wcols) *reinterpret_cast<float4*>(a.Y + (int64_t)(m0 + t) * C1 + hh + 4 * c4) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     for (int t = tid; t < GPT * 64; t += GS_T) {
       const int gl = t >> 6, cl = t & 63;
       const int g = g_first + gl, col = hh + cl;
       if (cl < wcols && g < a.G) {
         float tot = 0.f, tl = 0.f;
-        const float* hp = AH + (gl * NS) * GS_LDH + cl;
-        const uint8_t* mp = m1s + (gl * NS) * (C1 / 4) + (col >> 2);
-#pragma unroll 8
-        for (int j = 0; j < NS; ++j) {
-          const float gv = hp[j * GS_LDH];
-          const bool pos = (mp[j * (C1 / 4)] >> (col & 3)) & 1;
+        // the group's active rows, ascending (the rows left out are exact zeros of the full sum)
+        const int w0 = gl * (NS / 32);
+        const int c_lo = w0 == 0 ? abase[0] : (w0 == 1 ? abase[1] : (w0 == 2 ? abase[2] : abase[3]));
+        const int w1 = w0 + NS / 32;
+        const int c_hi = w1 == 1 ? abase[1] : (w1 == 2 ? abase[2] : (w1 == 3 ? abase[3] : abase[4]));
+        const uint8_t* mp = m1s + (col >> 2);
+        for (int ci = c_lo; ci < c_hi; ++ci) {
+          const int row = rowmap[ci], j = row - gl * NS;
+          const float gv = AH[ci * GS_LDH + cl];
+          const bool pos = (mp[row * (C1 / 4)] >> (col & 3)) & 1;
           const float v = pos ? gv : gv * 0.f;
           tot += v;
           if ((s_rep[gl * 4 + (j >> 5)] >> (j & 31)) & 1u) tl += v;
@@ -217,7 +269,8 @@ __global__ __launch_bounds__(GS_T, 2) void gemm_groupsum_kernel(GroupSumArgs a) 
 using namespace pc3d;
 
 extern "C" int pc3d_gemm_nt_groupsum_f32(const float* X, int64_t ldx, const float* Wt, const uint8_t* mask1, const int32_t* idx,
-                                         int B, int S, int ns, int C1, int K, float* Y, float* gBc, float* tail, void* stream) {
+                                         const uint32_t* amask, int B, int S, int ns, int C1, int K, float* Y, float* gBc,
+                                         float* tail, void* stream) {
   const char* nm = "pc3d_gemm_nt_groupsum_f32";
   PC3D_REQUIRE(B >= 0 && S >= 1 && (ns == 32 || ns == 64 || ns == 128), "%s: bad sizes B=%d S=%d ns=%d (ns in {32,64,128})", nm, B, S, ns);
   PC3D_REQUIRE((C1 == 32 || C1 == 64 || C1 == 128) && K >= 32 && K % 32 == 0 && ldx >= K && ldx % 4 == 0,
@@ -228,9 +281,10 @@ extern "C" int pc3d_gemm_nt_groupsum_f32(const float* X, int64_t ldx, const floa
   PC3D_REQUIRE(((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Wt) | reinterpret_cast<uintptr_t>(Y) |
                  reinterpret_cast<uintptr_t>(mask1)) & 15) == 0, "%s: X / Wt / Y / mask1 must be 16-byte aligned", nm);
   const int G = B * S, M = G * ns;
-  GroupSumArgs a{X, ldx, Wt, mask1, idx, M, G, K, Y, gBc, tail};
+  GroupSumArgs a{X, ldx, Wt, mask1, idx, amask, M, G, K, Y, gBc, tail};
   const int gpt = GS_BM / ns;
-  const size_t lds = ((size_t)GS_BM * GS_LDH + (size_t)2 * C1 * GS_LDW) * sizeof(float) + (size_t)GS_BM * (C1 / 4) + (size_t)gpt * 16;
+  const size_t lds = ((size_t)GS_BM * GS_LDH + (size_t)(C1 > 64 ? 2 : 1) * C1 * GS_LDW) * sizeof(float) + (size_t)GS_BM * (C1 / 4) + (size_t)gpt * 16 +
+                     2 * GS_BM * sizeof(int);
   const dim3 grid(cdiv(M, GS_BM)), block(GS_T);
   hipStream_t st = as_stream(stream);
 #define PC3D_GS(NSV, TNV)                                                                                              \

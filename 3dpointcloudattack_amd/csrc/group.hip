@@ -438,6 +438,10 @@ struct GroupMaxBwdArgs {
                         // zeroed where xin <= 0, i.e. the previous layer's ReLU backward is applied on the way out
   const uint32_t* xmask = nullptr;   // [G*ns, C2/32] or null: the same signs as bits (bit k % 32 of word k / 32 of a row),
                                      // as pc3d_gemm_nt_gather_f32 writes them — 1/32 of the bytes of xin
+  uint32_t* amask = nullptr;         // [G, ceil(ns/32)] or null: bit j = "row j of the group won at least one channel". With
+                                     // it, ONLY those rows of gx are written (the others are all zero and nobody reads them:
+                                     // 58-65 % of the rows at SSG's levels — the ball query pads a group with copies of its
+                                     // first point, and a copy never wins the max)
 };
 
 // Thread = one input channel k of one group; its NS row accumulators live in REGISTERS and are addressed with the
@@ -465,11 +469,20 @@ __global__ __launch_bounds__(GMB_T) void group_max_linear_bwd_kernel(GroupMaxBwd
   extern __shared__ float gmb_lds[];
   float* s_g = gmb_lds;                                 // [C3]
   int* s_r = reinterpret_cast<int*>(gmb_lds + a.C3);    // [C3]
+  __shared__ uint32_t s_act[4];
+  if (threadIdx.x < 4) s_act[threadIdx.x] = 0u;
+  __syncthreads();
   for (int c = threadIdx.x; c < a.C3; c += blockDim.x) {
     s_g[c] = (a.out[base + c] > 0.f) ? a.gout[base + c] : 0.f;
-    s_r[c] = (int)a.arg[base + c];
+    const int rw = (int)a.arg[base + c];
+    s_r[c] = rw;
+    if (a.amask) atomicOr(&s_act[(rw >> 5) & 3], 1u << (rw & 31));
   }
   __syncthreads();
+  uint32_t act[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) act[v] = a.amask ? s_act[v] : 0xffffffffu;
+  if (a.amask && blockIdx.y == 0 && threadIdx.x < (a.ns + 31) / 32) a.amask[(int64_t)g * ((a.ns + 31) / 32) + threadIdx.x] = s_act[threadIdx.x];
   int c = 0;
   for (; c + 8 <= a.C3; c += 8) {
     int rr[8];
@@ -513,7 +526,7 @@ __global__ __launch_bounds__(GMB_T) void group_max_linear_bwd_kernel(GroupMaxBwd
       for (int e = 0; e < 32; ++e) {
         const uint32_t lo = __builtin_amdgcn_readlane(word, e), hi = __builtin_amdgcn_readlane(word, 32 + e);
         const uint32_t w = (lane & 32) ? hi : lo;
-        if (live && 32 * v + e < a.ns) o[(int64_t)(32 * v + e) * a.C2] = ((w >> (k & 31)) & 1u) ? acc[v][e] : 0.f;
+        if (live && 32 * v + e < a.ns && ((act[v] >> e) & 1u)) o[(int64_t)(32 * v + e) * a.C2] = ((w >> (k & 31)) & 1u) ? acc[v][e] : 0.f;
       }
     }
     return;
@@ -768,7 +781,10 @@ __global__ __launch_bounds__(256) void group_act_bwd_points_kernel(const float* 
                                                                    const uint8_t* __restrict__ mask,
                                                                    const float* __restrict__ tail, const int* __restrict__ off,
                                                                    const int* __restrict__ lst, int64_t L, int NA, int S,
-                                                                   int K, int C, float slope, float* __restrict__ gP) {
+                                                                   int K, int C, float slope, float* __restrict__ gP,
+                                                                   const uint32_t* __restrict__ amask = nullptr) {
+  // amask [B*S, ceil(K/32)] or null: bit j of group s = "row (s, j) of gH was written"; the other rows are all zero and
+  // are skipped (their memory is not even defined)
   const int b = blockIdx.y, lane = threadIdx.x & 63;
   const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (p >= NA) return;
@@ -785,9 +801,13 @@ __global__ __launch_bounds__(256) void group_act_bwd_points_kernel(const float* 
     bool pos[U][Q];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const bool live = t + u < t1;
+      bool live = t + u < t1;
       const int code = __builtin_amdgcn_readfirstlane(l[live ? t + u : t]);
       const bool is_tail = code >= SK;
+      if (amask && live && !is_tail) {                       // (uniform) a row the sparse producer did not write
+        const int sg = code / K, jj = code - sg * K;
+        live = (amask[((int64_t)b * S + sg) * ((K + 31) >> 5) + (jj >> 5)] >> (jj & 31)) & 1u;
+      }
       const int64_t row = (int64_t)b * SK + (is_tail ? 0 : code);
       const float* src = is_tail ? tail + ((int64_t)b * S + (code - SK)) * C : gH + row * C;
 #pragma unroll
@@ -947,13 +967,14 @@ extern "C" int pc3d_group_gather_bwd_f32(const float* g_out, const int32_t* idx,
 }
 
 static int group_max_linear_bwd_launch(const float* gout, const float* out, const int64_t* arg, const float* W, int G, int ns,
-                                       int C2, int C3, const float* xin, const uint32_t* xmask, float* gx, void* stream) {
+                                       int C2, int C3, const float* xin, const uint32_t* xmask, float* gx, void* stream,
+                                       uint32_t* amask = nullptr) {
   PC3D_REQUIRE(G >= 0 && ns >= 1 && ns <= GMB_MAXNS && C2 >= 1 && C3 >= 1 && C3 <= 4096,
                "pc3d_group_max_linear_bwd_f32: bad sizes G=%d ns=%d C2=%d C3=%d (ns <= 128, C3 <= 4096)", G, ns, C2, C3);
   PC3D_REQUIRE(!xmask || C2 % 32 == 0, "pc3d_group_max_linear_bwd_mask_f32: C2=%d must be a multiple of 32", C2);
   if (G == 0) return PC3D_OK;
   PC3D_REQUIRE(gout && out && arg && W && gx, "pc3d_group_max_linear_bwd_f32: null pointer");
-  GroupMaxBwdArgs a{gout, out, arg, W, ns, C2, C3, gx, xin, xmask};
+  GroupMaxBwdArgs a{gout, out, arg, W, ns, C2, C3, gx, xin, xmask, amask};
   const int bt = C2 <= 64 ? 64 : GMB_T;          // one wave per group when the layer is narrow
   const dim3 grid(G, cdiv(C2, bt)), block(bt);
   hipStream_t st = as_stream(stream);
@@ -975,6 +996,13 @@ extern "C" int pc3d_group_max_linear_bwd_mask_f32(const float* gout, const float
                                                   void* stream) {
   PC3D_REQUIRE(xmask != nullptr, "pc3d_group_max_linear_bwd_mask_f32: null mask");
   return group_max_linear_bwd_launch(gout, out, arg, W, G, ns, C2, C3, nullptr, xmask, gx, stream);
+}
+
+extern "C" int pc3d_group_max_linear_bwd_sparse_f32(const float* gout, const float* out, const int64_t* arg, const float* W,
+                                                    int G, int ns, int C2, int C3, const uint32_t* xmask, float* gx,
+                                                    uint32_t* amask, void* stream) {
+  PC3D_REQUIRE(xmask != nullptr && amask != nullptr, "pc3d_group_max_linear_bwd_sparse_f32: null mask");
+  return group_max_linear_bwd_launch(gout, out, arg, W, G, ns, C2, C3, nullptr, xmask, gx, stream, amask);
 }
 
 extern "C" int pc3d_group_act_f32(const float* P, const float* Bc, const int32_t* idx, int B, int NA, int S, int K, int C,
@@ -1088,8 +1116,8 @@ extern "C" int pc3d_group_act_bwd_rev_f32(const float* gH, const float* H, const
 
 // the points pass alone, for a caller that already has the groups pass's outputs (pc3d_sa_chain_bwd_f32 writes them)
 extern "C" int pc3d_group_act_bwd_points_f32(const float* gH, const uint8_t* mask, const float* tail, const int32_t* off,
-                                             const int32_t* lst, int B, int NA, int S, int K, int C, float slope, float* gP,
-                                             void* stream) {
+                                             const int32_t* lst, const uint32_t* amask, int B, int NA, int S, int K, int C,
+                                             float slope, float* gP, void* stream) {
   const char* nm = "pc3d_group_act_bwd_points_f32";
   PC3D_REQUIRE(B >= 0 && NA >= 1 && S >= 1 && K >= 1 && C >= 4 && C % 4 == 0 && C <= GAB_MAXC,
                "%s: bad sizes B=%d NA=%d S=%d K=%d C=%d (C %% 4 == 0, C <= %d)", nm, B, NA, S, K, C, GAB_MAXC);
@@ -1101,7 +1129,7 @@ extern "C" int pc3d_group_act_bwd_points_f32(const float* gH, const uint8_t* mas
   const dim3 gp(cdiv(NA, 4), B), blk(256);
   const float* H = nullptr;
 #define PC3D_GAP_LAUNCH(Q) \
-  hipLaunchKernelGGL(group_act_bwd_points_kernel<Q>, gp, blk, 0, st, gH, H, mask, tail, off, lst, L, NA, S, K, C, slope, gP)
+  hipLaunchKernelGGL(group_act_bwd_points_kernel<Q>, gp, blk, 0, st, gH, H, mask, tail, off, lst, L, NA, S, K, C, slope, gP, amask)
   if (C <= 64) { PC3D_GAP_LAUNCH(1); }
   else if (C <= 128) { PC3D_GAP_LAUNCH(2); }
   else if (C <= 256) { PC3D_GAP_LAUNCH(4); }

@@ -2286,6 +2286,9 @@ SA_CHAIN = True
 # (pc3d_gemm_nt_groupsum_f32: the [B*S*ns, C1] gradient is written once and not read back for the sums), then the points
 # pass — bit-identical to the separate launches; False = those, for A/B timing.
 SA_CHAIN_BWD = True
+# ... on the rows that won a channel of the group max only (pc3d_group_max_linear_bwd_sparse_f32 and the amask arguments
+# of the two launches after it): the other rows carry exact zeros. Bit-identical; False = full tensors, for A/B timing.
+SA_BWD_SPARSE = True
 
 
 def sa_chain_supported(C1, C2, C3, ns):
@@ -2338,15 +2341,21 @@ class _GroupedMLPMaxFn(torch.autograd.Function):
         S, ns = idx.shape[1], idx.shape[2]
         C2 = w2.shape[0]
         g = g.contiguous()
+        fused = SA_CHAIN_BWD and rev_off is not None and ns in (32, 64, 128) and C1 in (32, 64, 128) and C2 % 32 == 0
+        sparse = fused and m2 is not None and SA_BWD_SPARSE
         gz = torch.empty((B * S * ns, C2), dtype=torch.float32, device=g.device)
+        amask = torch.empty((B * S, (ns + 31) // 32), dtype=torch.int32, device=g.device) if sparse else None
         with torch.cuda.device(g.device):
-            if m2 is not None:
+            if sparse:                 # only the rows that won a channel of the max are written (and read below)
+                _lib.call("pc3d_group_max_linear_bwd_sparse_f32", g.data_ptr(), out.data_ptr(), arg.data_ptr(),
+                          w3.data_ptr(), B * S, ns, C2, w3.shape[0], m2.data_ptr(), gz.data_ptr(), amask.data_ptr(), _stream())
+            elif m2 is not None:
                 _lib.call("pc3d_group_max_linear_bwd_mask_f32", g.data_ptr(), out.data_ptr(), arg.data_ptr(),
                           w3.data_ptr(), B * S, ns, C2, w3.shape[0], m2.data_ptr(), gz.data_ptr(), _stream())
             else:
                 _lib.call("pc3d_group_max_linear_bwd_f32", g.data_ptr(), out.data_ptr(), arg.data_ptr(), w3.data_ptr(),
                           B * S, ns, C2, w3.shape[0], H2.data_ptr(), gz.data_ptr(), _stream())
-        if SA_CHAIN_BWD and rev_off is not None and ns in (32, 64, 128) and C1 in (32, 64, 128) and C2 % 32 == 0:
+        if fused:
             dev = g.device
             gh1 = torch.empty((B * S * ns, C1), dtype=torch.float32, device=dev)
             gBc = torch.empty((B, S, C1), dtype=torch.float32, device=dev)
@@ -2355,11 +2364,13 @@ class _GroupedMLPMaxFn(torch.autograd.Function):
             w2t = _w_transposed(w2)
             with torch.cuda.device(dev):
                 _lib.call("pc3d_gemm_nt_groupsum_f32", gz.data_ptr(), C2, w2t.data_ptr(), mask.data_ptr(), idx.data_ptr(),
-                          B, S, ns, C1, C2, gh1.data_ptr(), gBc.data_ptr(), tail.data_ptr(), _stream())
+                          _ptr(amask), B, S, ns, C1, C2, gh1.data_ptr(), gBc.data_ptr(), tail.data_ptr(), _stream())
                 if ctx.rev_event is not None:    # built on the geometry stream, after the sampling chain (pointnet2_utils)
                     torch.cuda.current_stream(dev).wait_event(ctx.rev_event)
+                # (no amask here: the rows the sparse launches leave unwritten are the ball query's padding copies, which the
+                # reverse lists do not contain — the few other inactive rows were written as zeros above)
                 _lib.call("pc3d_group_act_bwd_points_f32", gh1.data_ptr(), mask.data_ptr(), tail.data_ptr(), rev_off.data_ptr(),
-                          rev_lst.data_ptr(), B, NA, S, ns, C1, 0.0, gP.data_ptr(), _stream())
+                          rev_lst.data_ptr(), 0, B, NA, S, ns, C1, 0.0, gP.data_ptr(), _stream())
             return gP, gBc, None, None, None, None, None, None, None, None
         gh1 = gemm_nt(gz, _w_transposed(w2))
         if rev_off is not None:        # gather through the reverse index of the grouping: no float atomics

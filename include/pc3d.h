@@ -207,21 +207,33 @@ int pc3d_sa_chain_f32(const float* P, int64_t ldp, const float* Bc, const int32_
                       const float* W2, const float* b2, int C1, int C2, const float* W3, const float* b3, int C3,
                       uint8_t* mask1, uint32_t* mask2, float* out, int64_t* arg, void* stream);
 
-/* Y = X . Wt^T (pc3d_gemm_nt_f32 without bias / activation) AND the groups pass of pc3d_group_act_bwd_rev_f32 on Y in one
- * launch — the backward of a set-abstraction chain's second layer and of the first layer's per-centre bias
- * (model/pointnet2_utils.py:190-197): X = the gradient of the layer-2 pre-activation [B*S*ns, K] (row stride ldx),
- * Wt [C1, K] = W2 transposed, Y [B*S*ns, C1] = the gradient of the generated layer-1 rows (NOT masked by mask1:
- * pc3d_group_act_bwd_points_f32 applies it), gBc [B*S, C1] = per group the sum of mask1 * Y over its rows, tail [B*S, C1]
- * the same sum over the rows j > 0 that repeat the group's first index (idx [B,S,ns]); mask1 [B*S*ns, C1/4] bytes from the
- * forward. Results are bit-identical to the two launches (same summation orders); Y is written once and not read back.
- * ns in {32, 64, 128}; C1 in {32, 64, 128}; K a multiple of 32.
- * pc3d_group_act_bwd_points_f32: the points pass of pc3d_group_act_bwd_rev_f32 alone (gP [B,NA,C] from gH, its sign
- * bytes, the groups pass's tail and the reverse index off / lst). */
+/* The backward of a set-abstraction chain (pc3d_sa_chain_f32) from the max down to the points, on the ACTIVE rows only.
+ * A row of a group that wins no channel of the max carries no gradient — 58-65 % of the rows at the single-scale
+ * classifier's levels (the ball query pads a group with copies of its first point, and a copy never wins): the three
+ * launches below neither write, read nor multiply those rows (model/pointnet2_utils.py:190-198 differentiated).
+ *   pc3d_group_max_linear_bwd_sparse_f32 = pc3d_group_max_linear_bwd_mask_f32 that also writes amask [G, ceil(ns/32)] words
+ *       (bit j of group g = "row j won at least one channel") and stores ONLY those rows of gx [G*ns, C2]; the other
+ *       rows of gx stay undefined.
+ *   pc3d_gemm_nt_groupsum_f32: Y = X . Wt^T (pc3d_gemm_nt_f32 without bias / activation) AND the groups pass of
+ *       pc3d_group_act_bwd_rev_f32 on Y in one launch — X = gx above [B*S*ns, K] (row stride ldx), Wt [C1, K] = W2
+ *       transposed, Y [B*S*ns, C1] = the gradient of the generated layer-1 rows (NOT masked by mask1; written: the active
+ *       rows, and zeros for inactive rows that are not padding copies j > 0 with idx[g,j] == idx[g,0] — those copies are
+ *       not in the reverse lists of pc3d_group_reverse_i32, the points pass reaches them through `tail` only), gBc [B*S, C1] = per group the sum of mask1 * Y over its rows, tail [B*S, C1] the same sum over the rows
+ *       j > 0 that repeat the group's first index (idx [B,S,ns]); mask1 [B*S*ns, C1/4] bytes from the forward. amask NULL =
+ *       every row is active. A tile's active rows are compacted before the product (half the MFMA blocks at those
+ *       levels). Bit-identical to the separate launches on full tensors: the skipped terms are exact zeros, the others
+ *       are summed in the same order. ns in {32, 64, 128}; C1 in {32, 64, 128}; K a multiple of 32.
+ *   pc3d_group_act_bwd_points_f32: the points pass of pc3d_group_act_bwd_rev_f32 alone (gP [B,NA,C] from gH, its sign
+ *       bytes, the groups pass's tail and the reverse index off / lst); amask (may be NULL) [B*S, ceil(K/32)]: rows of gH
+ *       whose bit is clear are skipped. */
+int pc3d_group_max_linear_bwd_sparse_f32(const float* gout, const float* out, const int64_t* arg, const float* W, int G, int ns,
+                                         int C2, int C3, const uint32_t* xmask, float* gx, uint32_t* amask, void* stream);
 int pc3d_gemm_nt_groupsum_f32(const float* X, int64_t ldx, const float* Wt, const uint8_t* mask1, const int32_t* idx,
-                              int B, int S, int ns, int C1, int K, float* Y, float* gBc, float* tail, void* stream);
+                              const uint32_t* amask, int B, int S, int ns, int C1, int K, float* Y, float* gBc, float* tail,
+                              void* stream);
 int pc3d_group_act_bwd_points_f32(const float* gH, const uint8_t* mask, const float* tail, const int32_t* off,
-                                  const int32_t* lst, int B, int NA, int S, int K, int C, float slope, float* gP,
-                                  void* stream);
+                                  const int32_t* lst, const uint32_t* amask, int B, int NA, int S, int K, int C, float slope,
+                                  float* gP, void* stream);
 
 /* The coordinate part of a set-abstraction layer's first 1x1 convolution (model/pointnet2_utils.py:118-135,190-197: the
  * Conv2d over [xyz_j - centre_s ; feat_j] is linear, so it splits into a per-POINT part P = Wx x + Wf f and a per-CENTRE

@@ -85,19 +85,25 @@ def test_sa_chain_vs_float64(ops, dev):
                                                 (1, 300, 7, 64, 64, 128, 320),       # ragged last row tile
                                                 (2, 256, 9, 32, 128, 64, 96)])
 def test_sa_chain_backward_fused_gemm_groupsum_bitwise(ops, dev, B, N, S, ns, C1, C2, C3):
-    """pc3d_gemm_nt_groupsum_f32 + the points pass against GEMM on W2^T / groups pass / points pass: the gradients to P and
-    Bc are BIT-identical (same summation orders)."""
+    """The chain's backward in its three forms — (a) max-backward on the ACTIVE rows / GEMM on W2^T + groups pass in one
+    launch over the compacted active rows / points pass skipping the others, (b) the same on full tensors, (c) the four
+    separate launches: the gradients to P and Bc are BIT-identical (the skipped terms are exact zeros, everything else is
+    summed in the same order). The allocator's free blocks are filled with NaN first: a read of a row the sparse producer
+    did not write would show."""
     P, Bc, idx, layers, w = _case(ops, dev, B, N, S, ns, C1, C2, C3, seed=C3 + ns + 1, bad_idx=True)
     if not ops.grouped_mlp_max_supported(C1, ns, layers):
         pytest.skip("shape not on the fused path")
     res = []
-    for fused in (True, False):
-        ops.SA_CHAIN_BWD = fused
+    for fused, sparse in ((True, True), (True, False), (False, False)):
+        ops.SA_CHAIN_BWD, ops.SA_BWD_SPARSE = fused, sparse
         try:
+            junk = [torch.full((n,), float("nan"), device=dev) for n in (B * S * ns * C2, B * S * ns * C1, B * N * C1, 1 << 20)]
+            del junk
             res.append(_run(ops, P, Bc, idx, layers, w, chain=True))
         finally:
-            ops.SA_CHAIN_BWD = True
-    (o1, gp1, gb1), (o0, gp0, gb0) = res
-    assert torch.equal(o1, o0)
+            ops.SA_CHAIN_BWD, ops.SA_BWD_SPARSE = True, True
+    (o1, gp1, gb1), (o2, gp2, gb2), (o0, gp0, gb0) = res
+    assert torch.equal(o1, o0) and torch.isfinite(gp1).all() and torch.isfinite(gb1).all()
     assert torch.equal(gb1, gb0), float((gb1 - gb0).abs().max())
     assert torch.equal(gp1, gp0), float((gp1 - gp0).abs().max())
+    assert torch.equal(gb2, gb0) and torch.equal(gp2, gp0)

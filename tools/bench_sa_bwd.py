@@ -10,8 +10,8 @@ dev = torch.device("cuda:0")
 for name, (B, N, S, ns, C1, C2, C3) in (("SA1", (64, 2048, 512, 32, 64, 64, 128)), ("SA2", (64, 512, 128, 64, 128, 128, 256))):
     P, Bc, idx, layers, w = _case(ops, dev, B, N, S, ns, C1, C2, C3, seed=1)
     rev = ops.group_reverse(idx, N)
-    for fused in (True, False):
-        ops.SA_CHAIN_BWD = fused
+    for fused, sparse in ((True, True), (True, False), (False, False)):
+        ops.SA_CHAIN_BWD, ops.SA_BWD_SPARSE = fused, sparse
         ts = []
         for it in range(6):
             p, bc = P.clone().requires_grad_(), Bc.clone().requires_grad_()
@@ -24,5 +24,5 @@ for name, (B, N, S, ns, C1, C2, C3) in (("SA1", (64, 2048, 512, 32, 64, 64, 128)
             e1.record()
             e1.synchronize()
             ts.append(e0.elapsed_time(e1) * 1e3)
-        print(name, "fused" if fused else "four-launch", "backward us (incl. the loss's two ATen launches):", round(sorted(ts)[len(ts) // 2], 1), flush=True)
-ops.SA_CHAIN_BWD = True
+        print(name, ("sparse fused" if sparse else "fused") if fused else "four-launch", "backward us (incl. the loss's two ATen launches):", round(sorted(ts)[len(ts) // 2], 1), flush=True)
+ops.SA_CHAIN_BWD = ops.SA_BWD_SPARSE = True

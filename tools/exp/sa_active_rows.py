@@ -1,0 +1,31 @@
+"""EXPERIMENT: what fraction of the grouped rows of SSG's set-abstraction levels wins at least one channel of the group max
+(only those rows carry a gradient through the max), at B=64, N=2048 on unit clouds and seeded weights."""
+import importlib, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+from helpers import unit_cloud
+M = importlib.import_module
+dev = torch.device("cuda:0")
+ops = M("3dpointcloudattack_amd.ops")
+net = M("3dpointcloudattack_amd.model.pointnet2_SSG").PointNet_Ssg(40)
+net.load_state_dict(M("3dpointcloudattack_amd.seeding").seeded_state_dict(net, 0)); net = net.to(dev).eval()
+rng = np.random.default_rng(0)
+B, N = 64, 2048
+x = torch.from_numpy(np.stack([unit_cloud(rng, N) for _ in range(B)])).transpose(1, 2).contiguous().to(dev)
+res = []
+orig_apply = ops._GroupedMLPMaxFn.forward
+def fwd(ctx, P, Bc, idx, w2, b2, w3, b3, r0, r1, ev=None):
+    o = orig_apply(ctx, P, Bc, idx, w2, b2, w3, b3, r0, r1, ev)
+    arg = ctx.to_save[1]
+    Bv, S, ns = idx.shape
+    G, C3 = arg.shape
+    hit = torch.zeros((G, ns), dtype=torch.bool, device=dev)
+    hit.scatter_(1, arg.clamp(0, ns - 1), True)
+    res.append((ns, C3, float(hit.float().mean()), float(hit.sum(1).float().mean()), int(hit.sum(1).max())))
+    return o
+ops._GroupedMLPMaxFn.forward = staticmethod(fwd)
+out = net(x.clone().requires_grad_())[0]
+torch.cuda.synchronize()
+for ns, C3, frac, mean_rows, mx in res:
+    print(f"ns={ns} C3={C3}: active rows {frac:.3f} of all rows; per group mean {mean_rows:.1f}, max {mx}")
