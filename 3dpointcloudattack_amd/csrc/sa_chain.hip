@@ -88,6 +88,30 @@ __global__ __launch_bounds__(SC_T, 2) void sa_chain_kernel(SaChainArgs a) {
   const int m0 = blockIdx.x * SC_BM;
   const int lrow = tid >> 3, lk = (tid & 7) * 4;         // weight staging: 8 threads cover a row's 32 k
 
+  // ---- 32-row blocks that hold nothing but PADDING. The ball query lists a group's in-radius points first and fills the
+  // rest with copies of the first one (model/pointnet2_utils.py:84-104): a block of a group that starts past the listed
+  // points repeats row 0 of the group 32 times — identical values that can neither change the max nor win it (ties go to
+  // the lowest row). Such blocks are not generated, not multiplied and take no part in the max: with ns = 64 and ~22
+  // listed points per group (SSG's second level) that is the second block of most groups.
+  int* s_act = pi + 4 * 128;                             // [4] block b of the tile holds at least one listed point
+  if (wave < (SC_BM >> a.ns_shift)) {                    // one wavefront per group of the tile
+    const int g = (m0 >> a.ns_shift) + wave;
+    const bool gok = (int64_t)g << a.ns_shift < a.M;
+    const int32_t* id = a.idx + ((int64_t)g << a.ns_shift);
+    const int i0 = gok ? id[0] : 0;
+    for (int j0 = 0; j0 < a.ns; j0 += 64) {              // a block is kept when any of its rows is NOT a copy of row 0
+      const int j = j0 + lane;
+      const bool own = gok && j < a.ns && (j == 0 || id[j] != i0);
+      const unsigned long long bal = __builtin_amdgcn_ballot_w64(own);
+      if (lane == 0) {
+        s_act[wave * (a.ns >> 5) + (j0 >> 5)] = (uint32_t)bal != 0u;
+        if (j0 + 32 < a.ns) s_act[wave * (a.ns >> 5) + (j0 >> 5) + 1] = (uint32_t)(bal >> 32) != 0u;
+      }
+    }
+  }
+  __syncthreads();
+  const bool act = s_act[wm >> 5] != 0;                   // this wave's block (uniform per wave)
+
   // ---- gather + layer 1: AH[row][:] = relu(P[src(row)] + Bc[group(row)]), one sign bit per element to mask1
   {
     const int c4n = a.C1 >> 2;                           // float4 per row
@@ -101,6 +125,7 @@ __global__ __launch_bounds__(SC_T, 2) void sa_chain_kernel(SaChainArgs a) {
         const int f = f0 + u * SC_T;
         live[u] = f < SC_BM * c4n;
         const int row = live[u] ? f >> a.c4_shift : 0, c4 = live[u] ? f & (c4n - 1) : 0;
+        if (live[u] && !s_act[row >> 5]) live[u] = false;   // a block of padding copies: nobody will read these rows
         rowv[u] = row, c4v[u] = c4;
         v[u] = make_float4(0.f, 0.f, 0.f, 0.f), c[u] = v[u];
         const int gm = m0 + row;
@@ -156,7 +181,7 @@ __global__ __launch_bounds__(SC_T, 2) void sa_chain_kernel(SaChainArgs a) {
   for (int k0 = 0; k0 < a.C1; k0 += SC_BK) {
     const bool more = k0 + SC_BK < a.C1;
     if (more) fetch_w(a.W2, a.C2, a.C1, 0, k0 + SC_BK);
-    sc_step<TN2>(acc2, AH + (wm + r) * LDH + k0, Ws + cur * 128 * SC_LD, wn2, r, h);
+    if (act) sc_step<TN2>(acc2, AH + (wm + r) * LDH + k0, Ws + cur * 128 * SC_LD, wn2, r, h);
     if (more) stash_w(Ws + (cur ^ 1) * 128 * SC_LD);
     __syncthreads();                                     // (after the last step: every wave has finished reading AH)
     cur ^= 1;
@@ -166,6 +191,7 @@ __global__ __launch_bounds__(SC_T, 2) void sa_chain_kernel(SaChainArgs a) {
   // epilogue of layer 2 into AH: D[row][col]: lane holds column r of each 32-column tile, rows (e & 3) + 8 (e >> 2) + 4 h
 #pragma unroll
   for (int j = 0; j < TN2; ++j) {
+    if (!act) break;
     const int col = wn2 + j * 32 + r;
     const bool col_ok = col < a.C2;
     const float bj = col_ok ? a.b2[col] : 0.f;
@@ -196,7 +222,7 @@ __global__ __launch_bounds__(SC_T, 2) void sa_chain_kernel(SaChainArgs a) {
       const bool more_k = k0 + SC_BK < a.C2, more_n = n0 + 128 < a.C3;
       if (more_k) fetch_w(a.W3, a.C3, a.C2, n0, k0 + SC_BK);
       else if (more_n) fetch_w(a.W3, a.C3, a.C2, n0 + 128, 0);
-      sc_step<2>(acc3, AH + (wm + r) * LDH + k0, Ws + cur * 128 * SC_LD, wn3, r, h);
+      if (act) sc_step<2>(acc3, AH + (wm + r) * LDH + k0, Ws + cur * 128 * SC_LD, wn3, r, h);
       if (more_k || more_n) stash_w(Ws + (cur ^ 1) * 128 * SC_LD);
       __syncthreads();
       cur ^= 1;
@@ -210,7 +236,7 @@ __global__ __launch_bounds__(SC_T, 2) void sa_chain_kernel(SaChainArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int rl = wm + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (m0 + rl < a.M && acc3[j][e] > best) best = acc3[j][e], bi = rl;
+        if (act && m0 + rl < a.M && acc3[j][e] > best) best = acc3[j][e], bi = rl;     // (a padding block never wins)
       }
       const float ov = __shfl_xor(best, 32, 64);
       const int oi = __shfl_xor(bi, 32, 64);
@@ -512,7 +538,7 @@ extern "C" int pc3d_sa_chain_f32(const float* P, int64_t ldp, const float* Bc, c
       return PC3D_OK;
     }
   }
-  const size_t lds = ((size_t)SC_BM * ldh + 2 * 128 * SC_LD + 2 * 4 * 128) * sizeof(float);
+  const size_t lds = ((size_t)SC_BM * ldh + 2 * 128 * SC_LD + 2 * 4 * 128 + 4) * sizeof(float);
   const dim3 grid(cdiv(a.M, SC_BM)), block(SC_T);
   if (C2 <= 64) {
     if (lds > 64 * 1024)
