@@ -41,6 +41,8 @@ struct SaChainArgs {
   uint32_t* mask2;      // [M, C2/32]
   float* out;           // [M/ns, C3]
   int64_t* arg;         // [M/ns, C3]
+  const int32_t* tb = nullptr;      // [tiles][4] block table of the streaming kernel (see there) or null
+  const int32_t* ntiles = nullptr;  // [1] tiles in the table
 };
 
 // one K step of a 32 x (32 TN) wave tile: A from the resident buffer (row stride lda, k offset k0), B from the staged slice
@@ -88,52 +90,47 @@ __global__ __launch_bounds__(SC_T, 2) void sa_chain_kernel(SaChainArgs a) {
   const int m0 = blockIdx.x * SC_BM;
   const int lrow = tid >> 3, lk = (tid & 7) * 4;         // weight staging: 8 threads cover a row's 32 k
 
-  // ---- 32-row blocks that hold nothing but PADDING. The ball query lists a group's in-radius points first and fills the
-  // rest with copies of the first one (model/pointnet2_utils.py:84-104): a block of a group that starts past the listed
-  // points repeats row 0 of the group 32 times — identical values that can neither change the max nor win it (ties go to
-  // the lowest row). Such blocks are not generated, not multiplied and take no part in the max: with ns = 64 and ~22
-  // listed points per group (SSG's second level) that is the second block of most groups.
-  int* s_act = pi + 4 * 128;                             // [4] block b of the tile holds at least one listed point
-  if (wave < (SC_BM >> a.ns_shift)) {                    // one wavefront per group of the tile
-    const int g = (m0 >> a.ns_shift) + wave;
-    const bool gok = (int64_t)g << a.ns_shift < a.M;
-    const int32_t* id = a.idx + ((int64_t)g << a.ns_shift);
-    const int i0 = gok ? id[0] : 0;
-    for (int j0 = 0; j0 < a.ns; j0 += 64) {              // a block is kept when any of its rows is NOT a copy of row 0
-      const int j = j0 + lane;
-      const bool own = gok && j < a.ns && (j == 0 || id[j] != i0);
-      const unsigned long long bal = __builtin_amdgcn_ballot_w64(own);
-      if (lane == 0) {
-        s_act[wave * (a.ns >> 5) + (j0 >> 5)] = (uint32_t)bal != 0u;
-        if (j0 + 32 < a.ns) s_act[wave * (a.ns >> 5) + (j0 >> 5) + 1] = (uint32_t)(bal >> 32) != 0u;
-      }
-    }
+  // ---- the tile's four 32-row blocks in ORIGINAL row space: block k = rows 32 k .. 32 k + 31. Without a table the tile
+  // is blocks 4 t .. 4 t + 3; with one (a.tb, pc3d_sa_blocks_i32) it is up to four blocks of consecutive whole groups
+  // that hold at least one listed point — blocks of nothing but the ball query's padding copies are left out and the
+  // others move up, so a launch has fewer tiles, not idle waves (skipping them in place changed nothing: a tile waits
+  // for its active blocks).
+  int* s_blk = pi + 4 * 128;                             // [4] block ids (-1: empty slot), [4] their clouds
+  if (a.tb) {
+    if ((int)blockIdx.x >= a.ntiles[0]) return;          // (uniform, before any barrier)
+    if (tid < 4) s_blk[tid] = a.tb[blockIdx.x * 4 + tid];
+  } else if (tid < 4) {
+    const int k = (m0 >> 5) + tid;
+    s_blk[tid] = ((int64_t)k * 32 < a.M) ? k : -1;
   }
   __syncthreads();
-  const bool act = s_act[wm >> 5] != 0;                   // this wave's block (uniform per wave)
+  if (tid < 4) s_blk[4 + tid] = s_blk[tid] >= 0 ? ((s_blk[tid] * 32) >> a.ns_shift) / a.S : 0;
+  __syncthreads();
+  const int blk[4] = {s_blk[0], s_blk[1], s_blk[2], s_blk[3]};
+  const int bcl[4] = {s_blk[4], s_blk[5], s_blk[6], s_blk[7]};
+  auto pick4 = [](const int (&v)[4], int i) { return i == 0 ? v[0] : (i == 1 ? v[1] : (i == 2 ? v[2] : v[3])); };
+  const bool act = pick4(blk, wm >> 5) >= 0;              // this wave's block (uniform per wave)
 
   // ---- gather + layer 1: AH[row][:] = relu(P[src(row)] + Bc[group(row)]), one sign bit per element to mask1
   {
     const int c4n = a.C1 >> 2;                           // float4 per row
-    const int b_first = (m0 >> a.ns_shift) / a.S;        // uniform: one division per workgroup
     for (int f0 = tid; f0 < SC_BM * c4n; f0 += 4 * SC_T) {
       float4 v[4], c[4];
-      int rowv[4], c4v[4];
+      int gmv[4], rowv[4], c4v[4];
       bool live[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int f = f0 + u * SC_T;
         live[u] = f < SC_BM * c4n;
         const int row = live[u] ? f >> a.c4_shift : 0, c4 = live[u] ? f & (c4n - 1) : 0;
-        if (live[u] && !s_act[row >> 5]) live[u] = false;   // a block of padding copies: nobody will read these rows
-        rowv[u] = row, c4v[u] = c4;
+        const int kb = pick4(blk, row >> 5);
+        if (kb < 0) live[u] = false;                       // an empty slot: nobody will read these rows
+        const int gm = kb * 32 + (row & 31);
+        gmv[u] = gm, rowv[u] = row, c4v[u] = c4;
         v[u] = make_float4(0.f, 0.f, 0.f, 0.f), c[u] = v[u];
-        const int gm = m0 + row;
-        if (live[u] && gm < a.M) {
+        if (live[u]) {
           const int g = gm >> a.ns_shift, p = a.idx[gm];
-          // the cloud of group g: the tile's first group's cloud (one division per workgroup), + 1 per cloud boundary crossed
-          int bb = b_first;
-          for (int gs = (bb + 1) * a.S; g >= gs; gs += a.S) ++bb;          // (a tile of 128 rows spans <= 4 groups)
+          const int bb = pick4(bcl, row >> 5);
           c[u] = *reinterpret_cast<const float4*>(a.Bc + (int64_t)g * a.C1 + 4 * c4);
           if ((unsigned)p < (unsigned)a.NA)
             v[u] = *reinterpret_cast<const float4*>(a.P + ((int64_t)bb * a.NA + p) * a.ldp + 4 * c4);
@@ -143,10 +140,8 @@ __global__ __launch_bounds__(SC_T, 2) void sa_chain_kernel(SaChainArgs a) {
       for (int u = 0; u < 4; ++u) {
         if (!live[u]) continue;
         float4 x = make_float4(v[u].x + c[u].x, v[u].y + c[u].y, v[u].z + c[u].z, v[u].w + c[u].w);
-        const int gm = m0 + rowv[u];
-        if (gm < a.M)
-          a.mask1[(int64_t)gm * c4n + c4v[u]] =
-              (uint8_t)((x.x > 0.f ? 1 : 0) | (x.y > 0.f ? 2 : 0) | (x.z > 0.f ? 4 : 0) | (x.w > 0.f ? 8 : 0));
+        a.mask1[(int64_t)gmv[u] * c4n + c4v[u]] =
+            (uint8_t)((x.x > 0.f ? 1 : 0) | (x.y > 0.f ? 2 : 0) | (x.z > 0.f ? 4 : 0) | (x.w > 0.f ? 8 : 0));
         x.x = x.x > 0.f ? x.x : 0.f, x.y = x.y > 0.f ? x.y : 0.f, x.z = x.z > 0.f ? x.z : 0.f, x.w = x.w > 0.f ? x.w : 0.f;
         *reinterpret_cast<float4*>(AH + rowv[u] * LDH + 4 * c4v[u]) = x;
       }
@@ -200,8 +195,8 @@ __global__ __launch_bounds__(SC_T, 2) void sa_chain_kernel(SaChainArgs a) {
       const int row = wm + (e & 3) + 8 * (e >> 2) + 4 * h;
       const float v = acc2[j][e] + bj;
       const unsigned long long bal = __builtin_amdgcn_ballot_w64(v > 0.f && col_ok);
-      const int gm = m0 + row;
-      if (r == 0 && gm < a.M && wn2 + j * 32 < a.C2)      // (C2 % 32 == 0: a 32-column tile is all in or all out)
+      const int gm = pick4(blk, wm >> 5) * 32 + (row & 31);
+      if (r == 0 && wn2 + j * 32 < a.C2)                  // (C2 % 32 == 0: a 32-column tile is all in or all out)
         a.mask2[(int64_t)gm * (a.C2 >> 5) + ((wn2 + j * 32) >> 5)] = (uint32_t)(h ? (bal >> 32) : bal);
       if (col_ok) AH[row * LDH + col] = v > 0.f ? v : 0.f;
     }
@@ -236,15 +231,15 @@ __global__ __launch_bounds__(SC_T, 2) void sa_chain_kernel(SaChainArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int rl = wm + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (act && m0 + rl < a.M && acc3[j][e] > best) best = acc3[j][e], bi = rl;     // (a padding block never wins)
+        if (act && acc3[j][e] > best) best = acc3[j][e], bi = rl;     // (an empty slot never wins)
       }
       const float ov = __shfl_xor(best, 32, 64);
       const int oi = __shfl_xor(bi, 32, 64);
       if (ov > best || (ov == best && oi < bi)) best = ov, bi = oi;
       const int col = n0 + wn3 + j * 32 + r;
-      if (tpg == 1) {                                    // ns == 32: the tile IS the group
-        const int64_t grp = (int64_t)((m0 + wm) >> a.ns_shift);
-        if (h == 0 && m0 + wm < a.M && col < a.C3) {
+      if (tpg == 1) {                                    // ns == 32: the block IS the group
+        const int64_t grp = pick4(blk, wm >> 5);
+        if (h == 0 && act && col < a.C3) {
           a.out[grp * a.C3 + col] = fmaxf(best + a.b3[col], 0.f);
           a.arg[grp * a.C3 + col] = bi - wm;
         }
@@ -254,20 +249,26 @@ __global__ __launch_bounds__(SC_T, 2) void sa_chain_kernel(SaChainArgs a) {
       }
     }
     if (tpg > 1) {
+      // a group's blocks sit in consecutive slots of ONE tile, its block 0 (always kept) first: slot sb heads a group when
+      // its block id is a multiple of tpg; the group's other kept blocks follow in ascending row order (strict >: lowest row)
       __syncthreads();
-      for (int t = tid; t < (SC_BM >> a.ns_shift) * 128; t += SC_T) {
-        const int g = t >> 7, cl = t & 127;
-        float best = pv[g * tpg * 128 + cl];
-        int bi = pi[g * tpg * 128 + cl];
-        for (int w = 1; w < tpg; ++w) {                  // ascending tile = ascending rows: strict >
-          const float v = pv[(g * tpg + w) * 128 + cl];
-          if (v > best) best = v, bi = pi[(g * tpg + w) * 128 + cl];
+      for (int t = tid; t < 4 * 128; t += SC_T) {
+        const int sb = t >> 7, cl = t & 127;
+        const int kb = pick4(blk, sb);
+        if (kb < 0 || (kb & (tpg - 1)) != 0) continue;
+        float best = pv[sb * 128 + cl];
+        int bi = pi[sb * 128 + cl] - 32 * sb;              // row inside the group: 32 * (block of the group) + row of the block
+        for (int s2 = sb + 1; s2 < 4; ++s2) {
+          const int k2 = pick4(blk, s2);
+          if (k2 < 0 || (k2 >> (a.ns_shift - 5)) != (kb >> (a.ns_shift - 5))) break;
+          const float v = pv[s2 * 128 + cl];
+          if (v > best) best = v, bi = pi[s2 * 128 + cl] - 32 * s2 + 32 * (k2 - kb);
         }
-        const int64_t grp = (int64_t)(m0 >> a.ns_shift) + g;
+        const int64_t grp = kb >> (a.ns_shift - 5);
         const int col = n0 + cl;
-        if ((int64_t)m0 + ((int64_t)g << a.ns_shift) < a.M && col < a.C3) {
+        if (col < a.C3) {
           a.out[grp * a.C3 + col] = fmaxf(best + a.b3[col], 0.f);
-          a.arg[grp * a.C3 + col] = bi - (g << a.ns_shift);
+          a.arg[grp * a.C3 + col] = bi;
         }
       }
       __syncthreads();                                   // pv / pi are rewritten by the next column tile
@@ -494,14 +495,101 @@ __global__ __launch_bounds__(SR_T, 2) void sa_chain_res_kernel(SaChainArgs a, in
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Block table of the streaming kernel: which 32-row blocks of the grouped rows hold at least one LISTED point, packed
+// four to a tile without splitting a group over two tiles.
+//   sa_block_flags_kernel : a wavefront per group; bit b of flags[g] = block b of the group has a row that is not a copy
+//                           of row 0 (block 0 always); the table is filled with -1 on the way.
+//   sa_block_pack_kernel  : ONE workgroup packs the groups in order (a group with `a` kept blocks opens a new tile when
+//                           the current one has fewer than `a` free slots). The packing is sequential by nature; it is
+//                           run as a scan over per-thread chunks: each thread first maps every possible fill level at its
+//                           chunk's start to (tiles opened, fill level at its end), thread 0 chains the 256 maps, then
+//                           every thread replays its chunk from its true start and writes its slots.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sa_block_flags_kernel(const int32_t* __restrict__ idx, int G, int ns, uint8_t* __restrict__ flags,
+                                                             int32_t* __restrict__ tb, int tb_len) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < tb_len; i += gridDim.x * 256) tb[i] = -1;
+  const int lane = threadIdx.x & 63;
+  const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (g >= G) return;
+  const int32_t* id = idx + (int64_t)g * ns;
+  const int i0 = id[0];
+  unsigned fl = 0;
+  for (int j0 = 0; j0 < ns; j0 += 64) {
+    const int j = j0 + lane;
+    const bool own = j < ns && (j == 0 || id[j] != i0);
+    const unsigned long long bal = __builtin_amdgcn_ballot_w64(own);
+    if ((uint32_t)bal) fl |= 1u << (j0 >> 5);
+    if ((uint32_t)(bal >> 32)) fl |= 1u << ((j0 >> 5) + 1);
+  }
+  if (lane == 0) flags[g] = (uint8_t)fl;
+}
+
+__global__ __launch_bounds__(256) void sa_block_pack_kernel(const uint8_t* __restrict__ flags, int G, int bpg, int32_t* __restrict__ tb,
+                                                            int32_t* __restrict__ ntiles) {
+  extern __shared__ uint8_t s_cnt[];                      // [G] kept blocks per group (staged once: the loops below are serial)
+  __shared__ int s_dt[256][5], s_fo[256][5], s_tile[256], s_fill[256];
+  const int t = threadIdx.x;
+  for (int g = t; g < G; g += 256) s_cnt[g] = (uint8_t)__builtin_popcount((unsigned)flags[g]);
+  __syncthreads();
+  const int per = (G + 255) / 256, lo = t * per, hi = min(lo + per, G);
+  int tl[5] = {0, 0, 0, 0, 0}, fl[5] = {0, 1, 2, 3, 4};    // the five possible fill levels at the chunk's start, side by side
+  for (int g = lo; g < hi; ++g) {
+    const int a = s_cnt[g];
+#pragma unroll
+    for (int f0 = 0; f0 < 5; ++f0) {
+      const bool open = fl[f0] + a > 4;
+      tl[f0] += open ? 1 : 0;
+      fl[f0] = (open ? 0 : fl[f0]) + a;
+    }
+  }
+#pragma unroll
+  for (int f0 = 0; f0 < 5; ++f0) s_dt[t][f0] = tl[f0], s_fo[t][f0] = fl[f0];
+  __syncthreads();
+  if (t == 0) {
+    int tile = 0, fill = 0;
+    for (int c = 0; c < 256; ++c) {
+      s_tile[c] = tile, s_fill[c] = fill;
+      const int f0 = fill;
+      tile += s_dt[c][f0], fill = s_fo[c][f0];
+    }
+    ntiles[0] = tile + (fill > 0 ? 1 : 0);
+  }
+  __syncthreads();
+  int tile = s_tile[t], fill = s_fill[t];
+  for (int g = lo; g < hi; ++g) {
+    const unsigned fb = flags[g];
+    const int a = s_cnt[g];
+    if (fill + a > 4) ++tile, fill = 0;
+    for (int b = 0; b < bpg; ++b)
+      if ((fb >> b) & 1u) tb[tile * 4 + fill++] = g * bpg + b;
+  }
+}
+
 }  // namespace pc3d
 
 using namespace pc3d;
 
-extern "C" int pc3d_sa_chain_f32(const float* P, int64_t ldp, const float* Bc, const int32_t* idx, int B, int NA, int S, int ns,
-                                 const float* W2, const float* b2, int C1, int C2, const float* W3, const float* b3, int C3,
-                                 uint8_t* mask1, uint32_t* mask2, float* out, int64_t* arg, void* stream) {
-  const char* nm = "pc3d_sa_chain_f32";
+extern "C" int pc3d_sa_blocks_i32(const int32_t* idx, int B, int S, int ns, uint8_t* flags, int32_t* tb, int32_t* ntiles,
+                                  void* stream) {
+  const char* nm = "pc3d_sa_blocks_i32";
+  PC3D_REQUIRE(B >= 0 && S >= 1 && (ns == 32 || ns == 64 || ns == 128) && (int64_t)B * S * ns <= 0x7fffffffLL,
+               "%s: bad sizes B=%d S=%d ns=%d (ns in {32,64,128})", nm, B, S, ns);
+  if (B == 0) return PC3D_OK;
+  PC3D_REQUIRE(idx && flags && tb && ntiles, "%s: null pointer", nm);
+  const int G = B * S, M = G * ns, tb_len = cdiv(M, SC_BM) * 4;
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(sa_block_flags_kernel, dim3(cdiv(G, 4)), dim3(256), 0, st, idx, G, ns, flags, tb, tb_len);
+  PC3D_REQUIRE(G <= 48 * 1024, "%s: B * S = %d groups exceed the packing kernel's staging buffer", nm, G);
+  hipLaunchKernelGGL(sa_block_pack_kernel, dim3(1), dim3(256), (size_t)G, st, flags, G, ns / 32, tb, ntiles);
+  PC3D_LAUNCH_CHECK(nm);
+  return PC3D_OK;
+}
+
+static int sa_chain_launch(const char* nm, const float* P, int64_t ldp, const float* Bc, const int32_t* idx, int B, int NA, int S, int ns,
+                           const float* W2, const float* b2, int C1, int C2, const float* W3, const float* b3, int C3,
+                           uint8_t* mask1, uint32_t* mask2, float* out, int64_t* arg, const int32_t* tb, const int32_t* ntiles,
+                           void* stream) {
   PC3D_REQUIRE(B >= 0 && NA >= 1 && S >= 1 && (ns == 32 || ns == 64 || ns == 128), "%s: bad sizes B=%d NA=%d S=%d ns=%d (ns in {32,64,128})",
                nm, B, NA, S, ns);
   PC3D_REQUIRE((C1 == 32 || C1 == 64 || C1 == 128) && C2 >= 32 && C2 <= 128 && C2 % 32 == 0 && C3 >= 32 && C3 % 32 == 0,
@@ -513,7 +601,7 @@ extern "C" int pc3d_sa_chain_f32(const float* P, int64_t ldp, const float* Bc, c
   PC3D_REQUIRE(((reinterpret_cast<uintptr_t>(P) | reinterpret_cast<uintptr_t>(Bc) | reinterpret_cast<uintptr_t>(W2) |
                  reinterpret_cast<uintptr_t>(W3)) & 15) == 0, "%s: operands must be 16-byte aligned", nm);
   SaChainArgs a{P, Bc, idx, W2, b2, W3, b3, ldp, B * S * ns, NA, S, ns, C1, C2, C3, ns == 32 ? 5 : (ns == 64 ? 6 : 7),
-                C1 == 32 ? 3 : (C1 == 64 ? 4 : 5), mask1, mask2, out, arg};
+                C1 == 32 ? 3 : (C1 == 64 ? 4 : 5), mask1, mask2, out, arg, tb, ntiles};
   const int ldh = (C1 > C2 ? C1 : C2) + 4;
   hipStream_t st = as_stream(stream);
   if ((C1 == 32 || C1 == 64) && (C2 == 32 || C2 == 64) && ns <= 64) {
@@ -538,7 +626,7 @@ extern "C" int pc3d_sa_chain_f32(const float* P, int64_t ldp, const float* Bc, c
       return PC3D_OK;
     }
   }
-  const size_t lds = ((size_t)SC_BM * ldh + 2 * 128 * SC_LD + 2 * 4 * 128 + 4) * sizeof(float);
+  const size_t lds = ((size_t)SC_BM * ldh + 2 * 128 * SC_LD + 2 * 4 * 128 + 8) * sizeof(float);
   const dim3 grid(cdiv(a.M, SC_BM)), block(SC_T);
   if (C2 <= 64) {
     if (lds > 64 * 1024)
@@ -553,4 +641,20 @@ extern "C" int pc3d_sa_chain_f32(const float* P, int64_t ldp, const float* Bc, c
   }
   PC3D_LAUNCH_CHECK(nm);
   return PC3D_OK;
+}
+
+extern "C" int pc3d_sa_chain_f32(const float* P, int64_t ldp, const float* Bc, const int32_t* idx, int B, int NA, int S, int ns,
+                                 const float* W2, const float* b2, int C1, int C2, const float* W3, const float* b3, int C3,
+                                 uint8_t* mask1, uint32_t* mask2, float* out, int64_t* arg, void* stream) {
+  return sa_chain_launch("pc3d_sa_chain_f32", P, ldp, Bc, idx, B, NA, S, ns, W2, b2, C1, C2, W3, b3, C3, mask1, mask2, out, arg,
+                         nullptr, nullptr, stream);
+}
+
+extern "C" int pc3d_sa_chain_tb_f32(const float* P, int64_t ldp, const float* Bc, const int32_t* idx, int B, int NA, int S, int ns,
+                                    const float* W2, const float* b2, int C1, int C2, const float* W3, const float* b3, int C3,
+                                    uint8_t* mask1, uint32_t* mask2, float* out, int64_t* arg, const int32_t* tb,
+                                    const int32_t* ntiles, void* stream) {
+  PC3D_REQUIRE((tb == nullptr) == (ntiles == nullptr), "pc3d_sa_chain_tb_f32: tb and ntiles go together");
+  return sa_chain_launch("pc3d_sa_chain_tb_f32", P, ldp, Bc, idx, B, NA, S, ns, W2, b2, C1, C2, W3, b3, C3, mask1, mask2, out, arg,
+                         tb, ntiles, stream);
 }

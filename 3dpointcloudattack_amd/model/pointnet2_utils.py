@@ -49,11 +49,11 @@ def _front_supported(first, layers, ns):
     return C1 % 4 == 0 and C1 <= ops.GROUP_ACT_MAX_C and len(layers) >= 2 and ns <= ops.GROUP_MAX_NS
 
 
-def _grouped_tail(P, Bc, idx, layers, rev=None):
+def _grouped_tail(P, Bc, idx, layers, rev=None, blocks=None):
     """relu(P[idx] + Bc) -> the remaining layers -> max over the group: [B,S,C_last]."""
     C1 = P.shape[2]
     if FUSE_LAYERS_1_2 and ops.grouped_mlp_max_supported(C1, idx.shape[2], layers[1:]):
-        return ops.grouped_mlp_max(P, Bc, idx, layers[1:], rev=rev)   # layer 1 generated inside layer 2's GEMM
+        return ops.grouped_mlp_max(P, Bc, idx, layers[1:], rev=rev, blocks=blocks)   # layer 1 generated inside layer 2's GEMM
     h1 = ops.group_act(P, Bc, idx, 0.0)                               # [B,S,ns,C1] = relu(layer 1)
     return ops.mlp_relu_max(h1, layers[1:])
 
@@ -299,9 +299,11 @@ class PointNetSetAbstraction(_FrozenFusedMixin, nn.Module):
         fps_idx = ops.fps(xyz_t, self.npoint, _fps_start(B, N, xyz_t.device))                       # [B,S] i32
         centres = ops.group_gather(xyz_t, None, fps_idx.view(B, self.npoint, 1)).view(B, self.npoint, 3)
         idx = ops.ball_query(self.radius, self.nsample, xyz_t, centres)                              # [B,S,ns] i32
+        # groups of 64+ rows: which 32-row blocks hold listed points at all (the chain launch packs those; ops.sa_blocks)
+        blocks = ops.sa_blocks(idx) if (self.nsample >= 64 and self.nsample % 32 == 0 and self.nsample <= 128) else None
         ev = torch.cuda.Event()
         ev.record()                      # what the layer's FORWARD waits for
-        g = [fps_idx, centres, idx, ev, None, None, N]
+        g = [fps_idx, centres, idx, ev, None, None, N, blocks]
         if with_rev:
             self.geometry_rev(g)
         return g
@@ -340,9 +342,10 @@ class PointNetSetAbstraction(_FrozenFusedMixin, nn.Module):
         else:
             B, N, _ = xyz_t.shape
             rev = None
-            ev_rev = None
+            ev_rev = blocks = None
             if geo is not None:
                 fps_idx, _, idx, ev, rev, ev_rev = geo[:6]
+                blocks = geo[7] if len(geo) > 7 else None
                 torch.cuda.current_stream(xyz_t.device).wait_event(ev)
             else:
                 fps_idx = ops.fps(xyz_t, self.npoint, _fps_start(B, N, xyz_t.device))                   # [B,S] i32
@@ -352,7 +355,7 @@ class PointNetSetAbstraction(_FrozenFusedMixin, nn.Module):
                 new_xyz, P, Bc = ops.sa_front(xyz_t, pts, fps_idx, *first)
                 if idx is None:
                     idx = ops.ball_query(self.radius, self.nsample, xyz_t, new_xyz.detach())
-                new_points = _grouped_tail(P, Bc, idx, layers, rev)
+                new_points = _grouped_tail(P, Bc, idx, layers, rev, blocks)
             else:
                 new_xyz = ops.group_gather(xyz_t, None, fps_idx.view(B, self.npoint, 1)).view(B, self.npoint, 3)
                 if idx is None:

@@ -2289,6 +2289,25 @@ SA_CHAIN_BWD = True
 # ... on the rows that won a channel of the group max only (pc3d_group_max_linear_bwd_sparse_f32 and the amask arguments
 # of the two launches after it): the other rows carry exact zeros. Bit-identical; False = full tensors, for A/B timing.
 SA_BWD_SPARSE = True
+# The chain launch over a block table (ops.sa_blocks): 32-row blocks of nothing but padding copies are left out and the rest
+# packed into fewer tiles (same results; False = every block, for A/B timing).
+SA_BLOCK_TABLE = True
+
+
+def sa_blocks(idx):
+    """Block table of a grouping idx [B,S,ns] int32 (ns in {64, 128}) for the chain launch: (tb, ntiles) — the 32-row blocks
+    that hold at least one listed point, packed four to a tile (pc3d_sa_blocks_i32). Depends on idx only: the geometry chain
+    builds it right after the ball query."""
+    if idx.dtype != torch.int32 or idx.dim() != 3 or not idx.is_cuda or not idx.is_contiguous():
+        raise ValueError("sa_blocks: idx must be a contiguous int32 [B,S,ns] GPU tensor")
+    B, S, ns = idx.shape
+    dev = idx.device
+    flags = torch.empty((B * S,), dtype=torch.uint8, device=dev)
+    tb = torch.empty((((B * S * ns + 127) // 128) * 4,), dtype=torch.int32, device=dev)
+    nt = torch.empty((1,), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.call("pc3d_sa_blocks_i32", idx.data_ptr(), B, S, ns, flags.data_ptr(), tb.data_ptr(), nt.data_ptr(), _stream())
+    return tb, nt
 
 
 def sa_chain_supported(C1, C2, C3, ns):
@@ -2304,7 +2323,7 @@ class _GroupedMLPMaxFn(torch.autograd.Function):
     (pc3d_group_act_bwd_mask_f32). One [B,S,ns,C1] write and two reads fewer than group_act + mlp_relu_max."""
 
     @staticmethod
-    def forward(ctx, P, Bc, idx, w2, b2, w3, b3, rev_off, rev_lst, rev_event=None):
+    def forward(ctx, P, Bc, idx, w2, b2, w3, b3, rev_off, rev_lst, rev_event=None, blocks=None):
         ctx.rev_event = rev_event
         B, NA, C1 = P.shape
         S, ns = idx.shape[1], idx.shape[2]
@@ -2315,10 +2334,11 @@ class _GroupedMLPMaxFn(torch.autograd.Function):
             m2 = torch.empty((B * S * ns, C2 // 32), dtype=torch.int32, device=P.device)
             out = torch.empty((B * S, C3), dtype=torch.float32, device=P.device)
             arg = torch.empty((B * S, C3), dtype=torch.int64, device=P.device)
+            tb, nt = blocks if (blocks is not None and ns >= 64) else (None, None)
             with torch.cuda.device(P.device):
-                _lib.call("pc3d_sa_chain_f32", P.data_ptr(), P.stride(1), Bc.data_ptr(), idx.data_ptr(), B, NA, S, ns,
+                _lib.call("pc3d_sa_chain_tb_f32", P.data_ptr(), P.stride(1), Bc.data_ptr(), idx.data_ptr(), B, NA, S, ns,
                           w2.data_ptr(), b2.data_ptr(), C1, C2, w3.data_ptr(), b3.data_ptr(), C3, mask.data_ptr(),
-                          m2.data_ptr(), out.data_ptr(), arg.data_ptr(), _stream())
+                          m2.data_ptr(), out.data_ptr(), arg.data_ptr(), _ptr(tb), _ptr(nt), _stream())
             ctx.save_for_backward(out, arg, None, m2, mask, idx, w2, w3, rev_off, rev_lst)
             ctx.dims = (B, NA, C1)
             return out.view(B, S, -1)
@@ -2371,19 +2391,19 @@ class _GroupedMLPMaxFn(torch.autograd.Function):
                 # reverse lists do not contain — the few other inactive rows were written as zeros above)
                 _lib.call("pc3d_group_act_bwd_points_f32", gh1.data_ptr(), mask.data_ptr(), tail.data_ptr(), rev_off.data_ptr(),
                           rev_lst.data_ptr(), 0, B, NA, S, ns, C1, 0.0, gP.data_ptr(), _stream())
-            return gP, gBc, None, None, None, None, None, None, None, None
+            return gP, gBc, None, None, None, None, None, None, None, None, None
         gh1 = gemm_nt(gz, _w_transposed(w2))
         if rev_off is not None:        # gather through the reverse index of the grouping: no float atomics
             if ctx.rev_event is not None:        # built on the geometry stream, after the sampling chain (pointnet2_utils)
                 torch.cuda.current_stream(g.device).wait_event(ctx.rev_event)
             gP, gBc = group_act_bwd_rev(gh1.view(B, S, ns, C1), None, mask, idx, (rev_off, rev_lst), NA, 0.0)
-            return gP, gBc, None, None, None, None, None, None, None, None
+            return gP, gBc, None, None, None, None, None, None, None, None, None
         gP = torch.empty((B, NA, C1), dtype=torch.float32, device=g.device)
         gBc = torch.empty((B, S, C1), dtype=torch.float32, device=g.device)
         with torch.cuda.device(g.device):
             _lib.call("pc3d_group_act_bwd_mask_f32", gh1.data_ptr(), mask.data_ptr(), idx.data_ptr(), B, NA, S, ns, C1,
                       0.0, gP.data_ptr(), gBc.data_ptr(), _det(), _stream())
-        return gP, gBc, None, None, None, None, None, None, None, None
+        return gP, gBc, None, None, None, None, None, None, None, None, None
 
 
 def grouped_mlp_max_supported(C1, ns, layers):
@@ -2394,7 +2414,7 @@ def grouped_mlp_max_supported(C1, ns, layers):
     return C2 % 8 == 0 and C2 <= 128 and C3 % 32 == 0 and C3 <= 4096
 
 
-def grouped_mlp_max(P, Bc, idx, layers, rev=None):
+def grouped_mlp_max(P, Bc, idx, layers, rev=None, blocks=None):
     """max_j relu(W3 relu(W2 relu(P[b,idx[b,s,j]] + Bc[b,s]) + b2) + b3) -> [B,S,C3]; P [B,NA,C1], Bc [B,S,C1], idx
     [B,S,ns] int32, layers = [(W2,b2),(W3,b3)] frozen. Differentiable in P and Bc. rev = group_reverse(idx, NA): the
     backward gathers through it instead of scattering with float atomics."""
@@ -2406,7 +2426,8 @@ def grouped_mlp_max(P, Bc, idx, layers, rev=None):
     r0, r1 = (rev[0], rev[1]) if rev is not None else (None, None)
     ev = rev[2] if rev is not None and len(rev) > 2 else None       # (off, lst[, event recorded after they were built])
     return _GroupedMLPMaxFn.apply(P.contiguous(), Bc.contiguous(), idx.contiguous(), w2.detach().contiguous(),
-                                  b2.detach().contiguous(), w3.detach().contiguous(), b3.detach().contiguous(), r0, r1, ev)
+                                  b2.detach().contiguous(), w3.detach().contiguous(), b3.detach().contiguous(), r0, r1, ev,
+                                  blocks if SA_BLOCK_TABLE else None)
 
 
 def mlp_relu_max(x, layers):
