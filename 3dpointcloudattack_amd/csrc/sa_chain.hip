@@ -495,6 +495,194 @@ __global__ __launch_bounds__(SR_T, 2) void sa_chain_res_kernel(SaChainArgs a, in
   }
 }
 
+// The resident kernel over a table of 16-row UNITS (pc3d_sa_blocks_i32 with unit = 16): at SSG's first level a group
+// lists 13.5 points of 32 on average, so the second half of most groups is nothing but padding copies; those units are
+// left out and the rest packed four to a 64-row tile, whole groups per tile. A wave's 32-row MFMA block is then two units
+// of possibly different groups: the group max is taken per unit (registers 0-7 / 8-15 of an accumulator tile) and the
+// units of a group are combined through LDS in ascending row order. Same results as the kernel above.
+template <int C1, int C2>
+__global__ __launch_bounds__(SR_T, 2) void sa_chain_res_tb_kernel(SaChainArgs a, int tiles_max) {
+  extern __shared__ __attribute__((aligned(16))) float sc_lds[];
+  constexpr int LDH = (C1 > C2 ? C1 : C2) + 4, LD2 = C1 + 4, LD3 = C2 + 4;
+  constexpr int c4n = C1 / 4, G4 = C1 / 16;              // float4 per generated row / per thread (64 rows x c4n = 256 x G4)
+  float* W2s = sc_lds;                                   // [64][LD2] (rows past C2 are zero)
+  float* W3s = W2s + 64 * LD2;                            // [round128(C3)][LD3] (rows past C3 are zero)
+  const int C3p = (a.C3 + 127) & ~127;
+  float* AH = W3s + C3p * LD3;                            // [64][LDH]
+  float* pv = AH + SR_BM * LDH;                           // [4][128]: a unit's (16 rows) maximum per column of the tile
+  int* pi = reinterpret_cast<int*>(pv + 4 * 128);
+  float* b2s = reinterpret_cast<float*>(pi + 4 * 128);     // [64] + [C3p]: the biases, read by every tile's epilogues
+  float* b3s = b2s + 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wm = (wave >> 1) * 32;
+
+  for (int f = tid; f < 64 * c4n; f += SR_T) {            // weights + biases: once per workgroup
+    const int row = f / c4n, c4 = f % c4n;
+    *reinterpret_cast<float4*>(W2s + row * LD2 + 4 * c4) =
+        row < C2 ? *reinterpret_cast<const float4*>(a.W2 + (int64_t)row * C1 + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int f = tid; f < C3p * (C2 / 4); f += SR_T) {
+    const int row = f / (C2 / 4), c4 = f % (C2 / 4);
+    *reinterpret_cast<float4*>(W3s + row * LD3 + 4 * c4) =
+        row < a.C3 ? *reinterpret_cast<const float4*>(a.W3 + (int64_t)row * C2 + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int c = tid; c < 64; c += SR_T) b2s[c] = c < C2 ? a.b2[c] : 0.f;
+  for (int c = tid; c < C3p; c += SR_T) b3s[c] = c < a.C3 ? a.b3[c] : 0.f;
+
+  // The tile's four 16-row UNITS in original row space (unit k = rows 16 k .. 16 k + 15), from the table of
+  // pc3d_sa_blocks_i32: units of nothing but padding copies are left out, whole groups per tile. Three-stage prefetch: the
+  // units of tile i+3, the INDICES of tile i+2 and the ROWS of tile i+1 are in flight while tile i computes.
+  const int tiles = min(tiles_max, a.ntiles[0]);
+  auto load_units = [&](int tile, int (&U)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) U[q] = tile < tiles ? a.tb[tile * 4 + q] : -1;
+  };
+  auto unit_of = [](const int (&U)[4], int q) { return q == 0 ? U[0] : (q == 1 ? U[1] : (q == 2 ? U[2] : U[3])); };
+  float4 gv[G4], gc[G4];
+  int nidx[G4];
+  auto load_idx = [&](const int (&U)[4]) {
+#pragma unroll
+    for (int u = 0; u < G4; ++u) {
+      const int row = (u * SR_T + tid) / c4n;
+      const int ub = unit_of(U, row >> 4);
+      nidx[u] = ub >= 0 ? a.idx[ub * 16 + (row & 15)] : -1;
+    }
+  };
+  auto load_rows = [&](const int (&U)[4]) {
+    const int b_first = U[0] >= 0 ? ((U[0] * 16) >> a.ns_shift) / a.S : 0;     // uniform: one division per tile
+#pragma unroll
+    for (int u = 0; u < G4; ++u) {
+      const int f = u * SR_T + tid, row = f / c4n, c4 = f % c4n;
+      const int ub = unit_of(U, row >> 4);
+      gv[u] = make_float4(0.f, 0.f, 0.f, 0.f), gc[u] = gv[u];
+      if (ub >= 0) {
+        const int g = (ub * 16) >> a.ns_shift, p = nidx[u];
+        const int bb = b_first + (g >= (b_first + 1) * a.S ? 1 : 0);       // a tile's <= 4 consecutive groups: one boundary (S >= 4)
+        gc[u] = *reinterpret_cast<const float4*>(a.Bc + (int64_t)g * C1 + 4 * c4);
+        if ((unsigned)p < (unsigned)a.NA)
+          gv[u] = *reinterpret_cast<const float4*>(a.P + ((int64_t)bb * a.NA + p) * a.ldp + 4 * c4);
+      }
+    }
+  };
+  int tile = blockIdx.x;
+  const int step = gridDim.x;
+  int Ua[4], Ub[4], Uc[4];
+  load_units(tile, Ua);
+  load_units(tile + step, Ub);
+  load_units(tile + 2 * step, Uc);
+  if (tile < tiles) {
+    load_idx(Ua);
+    load_rows(Ua);
+    load_idx(Ub);
+  }
+  const int wn2 = (wave & 1) * 32, wn3 = (wave & 1) * 64;
+  const float* Ap = AH + (wm + r) * LDH + 4 * h;           // this lane's A-operand row (both layers)
+  const int upg = a.ns >> 4;                               // units per group
+  for (; tile < tiles; tile += step) {
+    __syncthreads();                                      // the previous tile's layer 3 has finished reading AH (first trip: weights are in)
+#pragma unroll
+    for (int u = 0; u < G4; ++u) {
+      const int f = u * SR_T + tid, row = f / c4n, c4 = f % c4n;
+      float4 x = make_float4(gv[u].x + gc[u].x, gv[u].y + gc[u].y, gv[u].z + gc[u].z, gv[u].w + gc[u].w);
+      const int ub = unit_of(Ua, row >> 4);
+      if (ub >= 0)
+        a.mask1[(int64_t)(ub * 16 + (row & 15)) * c4n + c4] = (uint8_t)((x.x > 0.f ? 1 : 0) | (x.y > 0.f ? 2 : 0) | (x.z > 0.f ? 4 : 0) | (x.w > 0.f ? 8 : 0));
+      x.x = x.x > 0.f ? x.x : 0.f, x.y = x.y > 0.f ? x.y : 0.f, x.z = x.z > 0.f ? x.z : 0.f, x.w = x.w > 0.f ? x.w : 0.f;
+      *reinterpret_cast<float4*>(AH + row * LDH + 4 * c4) = x;
+    }
+    __syncthreads();
+    int Ud[4];
+    load_units(tile + 3 * step, Ud);
+    if (tile + step < tiles) {                             // in flight under this tile's MFMAs
+      load_rows(Ub);                                      // (their indices arrived during the previous tile)
+      if (tile + 2 * step < tiles) load_idx(Uc);
+    }
+    // ---- layer 2: wave tile 32 x 32 (columns wn2 ..)
+    sc_f32x16 acc2[1];
+    sc_mm<1, C1 / 32, LDH, LD2>(acc2, Ap, W2s + (wn2 + r) * LD2 + 4 * h);
+    __syncthreads();                                      // every wave has finished reading the generated rows
+    {
+      const int col = wn2 + r;
+      const float bj = b2s[col];
+      float* hp = AH + (wm + 4 * h) * LDH + col;           // rows (e & 3) + 8 (e >> 2) of this lane's column
+      if (col < C2) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float v = acc2[0][e] + bj;
+          hp[((e & 3) + 8 * (e >> 2)) * LDH] = v > 0.f ? v : 0.f;
+        }
+      }
+    }
+    __syncthreads();
+    // the layer-2 signs, one word per row and 32 columns: relu(v) > 0 iff v > 0, so they are read back from the tile just
+    // written (a packed pass: 8 ds_read_b128 + 32 compares per word) instead of a ballot, an address and a two-lane store
+    // per accumulator register in the epilogue above
+    for (int t = tid; t < SR_BM * (C2 / 32); t += SR_T) {
+      const int row = t & (SR_BM - 1), w = t >> 6;        // consecutive lanes: consecutive rows (conflict-free reads)
+      const float* hp = AH + row * LDH + 32 * w;
+      uint32_t bits = 0;
+#pragma unroll
+      for (int c = 0; c < 32; c += 4) {
+        const float4 x = *reinterpret_cast<const float4*>(hp + c);
+        bits |= (x.x > 0.f ? 1u : 0u) << c | (x.y > 0.f ? 2u : 0u) << c | (x.z > 0.f ? 4u : 0u) << c | (x.w > 0.f ? 8u : 0u) << c;
+      }
+      const int ub = unit_of(Ua, row >> 4);
+      if (ub >= 0) a.mask2[(int64_t)(ub * 16 + (row & 15)) * (C2 / 32) + w] = bits;
+    }
+    // ---- layer 3 + group max: wave tile 32 x 64 of every 128-column tile; the wave's 32 rows are TWO units
+    const int us0 = unit_of(Ua, wm >> 4), us1 = unit_of(Ua, (wm >> 4) + 1);
+    for (int n0 = 0; n0 < a.C3; n0 += 128) {
+      sc_f32x16 acc3[2];
+      sc_mm<2, C2 / 32, LDH, LD3>(acc3, Ap, W3s + (n0 + wn3 + r) * LD3 + 4 * h);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {             // rows 16 half .. 16 half + 15 of the wave's block: registers 8 half ..
+          float best = -__builtin_inff();
+          int bi = 0;
+#pragma unroll
+          for (int e = 8 * half; e < 8 * half + 8; ++e)
+            if (acc3[j][e] > best) best = acc3[j][e], bi = (e & 3) + 8 * ((e >> 2) & 1) + 4 * h;     // row inside the unit
+          const float ov = __shfl_xor(best, 32, 64);
+          const int oi = __shfl_xor(bi, 32, 64);
+          if (ov > best || (ov == best && oi < bi)) best = ov, bi = oi;
+          if (h == 0) {
+            const int slot = (wm >> 4) + half;
+            pv[slot * 128 + wn3 + j * 32 + r] = (half == 0 ? us0 : us1) >= 0 ? best : -__builtin_inff();   // (an empty slot never wins)
+            pi[slot * 128 + wn3 + j * 32 + r] = bi;
+          }
+        }
+      }
+      // a group's units sit in consecutive slots of ONE tile, its unit 0 (always kept) first: slot s heads a group when its
+      // unit id is a multiple of upg; the group's other kept units follow in ascending row order (strict >: lowest row)
+      __syncthreads();
+      for (int t = tid; t < 4 * 128; t += SR_T) {
+        const int sb = t >> 7, cl = t & 127;
+        const int ub = unit_of(Ua, sb);
+        if (ub < 0 || (ub & (upg - 1)) != 0) continue;
+        float best = pv[sb * 128 + cl];
+        int bi = pi[sb * 128 + cl];
+        for (int s2 = sb + 1; s2 < 4; ++s2) {
+          const int u2 = unit_of(Ua, s2);
+          if (u2 < 0 || (u2 >> (a.ns_shift - 4)) != (ub >> (a.ns_shift - 4))) break;
+          const float v = pv[s2 * 128 + cl];
+          if (v > best) best = v, bi = pi[s2 * 128 + cl] + 16 * (u2 - ub);
+        }
+        const int64_t grp = ub >> (a.ns_shift - 4);
+        const int col = n0 + cl;
+        if (col < a.C3) {
+          a.out[grp * a.C3 + col] = fmaxf(best + b3s[col], 0.f);
+          a.arg[grp * a.C3 + col] = bi;
+        }
+      }
+      __syncthreads();                                    // pv / pi are rewritten by the next column tile / tile
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) Ua[q] = Ub[q], Ub[q] = Uc[q], Uc[q] = Ud[q];
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Block table of the streaming kernel: which 32-row blocks of the grouped rows hold at least one LISTED point, packed
 // four to a tile without splitting a group over two tiles.
@@ -506,8 +694,8 @@ __global__ __launch_bounds__(SR_T, 2) void sa_chain_res_kernel(SaChainArgs a, in
 //                           chunk's start to (tiles opened, fill level at its end), thread 0 chains the 256 maps, then
 //                           every thread replays its chunk from its true start and writes its slots.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sa_block_flags_kernel(const int32_t* __restrict__ idx, int G, int ns, uint8_t* __restrict__ flags,
-                                                             int32_t* __restrict__ tb, int tb_len) {
+__global__ __launch_bounds__(256) void sa_block_flags_kernel(const int32_t* __restrict__ idx, int G, int ns, int unit,
+                                                             uint8_t* __restrict__ flags, int32_t* __restrict__ tb, int tb_len) {
   for (int i = blockIdx.x * 256 + threadIdx.x; i < tb_len; i += gridDim.x * 256) tb[i] = -1;
   const int lane = threadIdx.x & 63;
   const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -519,69 +707,108 @@ __global__ __launch_bounds__(256) void sa_block_flags_kernel(const int32_t* __re
     const int j = j0 + lane;
     const bool own = j < ns && (j == 0 || id[j] != i0);
     const unsigned long long bal = __builtin_amdgcn_ballot_w64(own);
-    if ((uint32_t)bal) fl |= 1u << (j0 >> 5);
-    if ((uint32_t)(bal >> 32)) fl |= 1u << ((j0 >> 5) + 1);
+    for (int q = 0; q < 64 / unit; ++q) {                  // unit = 16 or 32 rows
+      const unsigned long long m = unit == 32 ? 0xffffffffull : 0xffffull;
+      if ((bal >> (q * unit)) & m) fl |= 1u << (j0 / unit + q);
+    }
   }
   if (lane == 0) flags[g] = (uint8_t)fl;
 }
 
-__global__ __launch_bounds__(256) void sa_block_pack_kernel(const uint8_t* __restrict__ flags, int G, int bpg, int32_t* __restrict__ tb,
-                                                            int32_t* __restrict__ ntiles) {
-  extern __shared__ uint8_t s_cnt[];                      // [G] kept blocks per group (staged once: the loops below are serial)
-  __shared__ int s_dt[256][5], s_fo[256][5], s_tile[256], s_fill[256];
-  const int t = threadIdx.x;
-  for (int g = t; g < G; g += 256) s_cnt[g] = (uint8_t)__builtin_popcount((unsigned)flags[g]);
-  __syncthreads();
-  const int per = (G + 255) / 256, lo = t * per, hi = min(lo + per, G);
-  int tl[5] = {0, 0, 0, 0, 0}, fl[5] = {0, 1, 2, 3, 4};    // the five possible fill levels at the chunk's start, side by side
-  for (int g = lo; g < hi; ++g) {
-    const int a = s_cnt[g];
+constexpr int SP_T = 1024;
+
+// a chunk of groups as a map: fill level at its start (0 .. 4) -> (tiles opened << 3 | fill level at its end)
+struct SpMap {
+  int m[5];
+};
+__device__ __forceinline__ int sp_pick(const SpMap& a, int f) {
+  return f == 0 ? a.m[0] : (f == 1 ? a.m[1] : (f == 2 ? a.m[2] : (f == 3 ? a.m[3] : a.m[4])));
+}
+__device__ __forceinline__ SpMap sp_then(const SpMap& a, const SpMap& b) {     // first a, then b
+  SpMap c;
 #pragma unroll
-    for (int f0 = 0; f0 < 5; ++f0) {
-      const bool open = fl[f0] + a > 4;
-      tl[f0] += open ? 1 : 0;
-      fl[f0] = (open ? 0 : fl[f0]) + a;
+  for (int f = 0; f < 5; ++f) {
+    const int x = a.m[f], y = sp_pick(b, x & 7);
+    c.m[f] = (((x >> 3) + (y >> 3)) << 3) | (y & 7);
+  }
+  return c;
+}
+
+__global__ __launch_bounds__(SP_T) void sa_block_pack_kernel(const uint8_t* __restrict__ flags, int G, int bpg, int32_t* __restrict__ tb,
+                                                             int32_t* __restrict__ ntiles) {
+  extern __shared__ uint8_t s_fl[];                       // [G] the groups' unit flags (staged once: the loops below are serial)
+  __shared__ int s_wave[SP_T / 64][5];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  for (int g = t; g < G; g += SP_T) s_fl[g] = flags[g];
+  __syncthreads();
+  const int per = (G + SP_T - 1) / SP_T, lo = min(t * per, G), hi = min(lo + per, G);
+  SpMap mine;                                             // the five possible fill levels at the chunk's start, side by side
+#pragma unroll
+  for (int f = 0; f < 5; ++f) mine.m[f] = f;
+  for (int g = lo; g < hi; ++g) {
+    const int a = __builtin_popcount((unsigned)s_fl[g]);
+#pragma unroll
+    for (int f = 0; f < 5; ++f) {
+      const int fill = mine.m[f] & 7, til = mine.m[f] >> 3;
+      const bool open = fill + a > 4;
+      mine.m[f] = ((til + (open ? 1 : 0)) << 3) | ((open ? 0 : fill) + a);
     }
   }
+  // inclusive scan of the maps over the lanes of a wave, then over the waves
+  SpMap inc = mine;
 #pragma unroll
-  for (int f0 = 0; f0 < 5; ++f0) s_dt[t][f0] = tl[f0], s_fo[t][f0] = fl[f0];
-  __syncthreads();
-  if (t == 0) {
-    int tile = 0, fill = 0;
-    for (int c = 0; c < 256; ++c) {
-      s_tile[c] = tile, s_fill[c] = fill;
-      const int f0 = fill;
-      tile += s_dt[c][f0], fill = s_fo[c][f0];
-    }
-    ntiles[0] = tile + (fill > 0 ? 1 : 0);
+  for (int d = 1; d < 64; d <<= 1) {
+    SpMap o;
+#pragma unroll
+    for (int f = 0; f < 5; ++f) o.m[f] = __shfl_up(inc.m[f], d, 64);
+    if (lane >= d) inc = sp_then(o, inc);
   }
+  if (lane == 63)
+#pragma unroll
+    for (int f = 0; f < 5; ++f) s_wave[wave][f] = inc.m[f];
   __syncthreads();
-  int tile = s_tile[t], fill = s_fill[t];
+  int tile = 0, fill = 0;                                  // state at this wave's start
+  for (int w = 0; w < wave; ++w) {
+    const int y = s_wave[w][fill];
+    tile += y >> 3, fill = y & 7;
+  }
+  {                                                        // ... at this thread's start: the lanes before it
+    SpMap ex;
+#pragma unroll
+    for (int f = 0; f < 5; ++f) ex.m[f] = __shfl_up(inc.m[f], 1, 64);
+    if (lane > 0) {
+      const int y = sp_pick(ex, fill);
+      tile += y >> 3, fill = y & 7;
+    }
+  }
   for (int g = lo; g < hi; ++g) {
-    const unsigned fb = flags[g];
-    const int a = s_cnt[g];
+    const unsigned fb = s_fl[g];
+    const int a = __builtin_popcount(fb);
     if (fill + a > 4) ++tile, fill = 0;
     for (int b = 0; b < bpg; ++b)
       if ((fb >> b) & 1u) tb[tile * 4 + fill++] = g * bpg + b;
   }
+  if (t == SP_T - 1) ntiles[0] = tile + (fill > 0 ? 1 : 0);
 }
 
 }  // namespace pc3d
 
 using namespace pc3d;
 
-extern "C" int pc3d_sa_blocks_i32(const int32_t* idx, int B, int S, int ns, uint8_t* flags, int32_t* tb, int32_t* ntiles,
+extern "C" int pc3d_sa_blocks_i32(const int32_t* idx, int B, int S, int ns, int unit, uint8_t* flags, int32_t* tb, int32_t* ntiles,
                                   void* stream) {
   const char* nm = "pc3d_sa_blocks_i32";
   PC3D_REQUIRE(B >= 0 && S >= 1 && (ns == 32 || ns == 64 || ns == 128) && (int64_t)B * S * ns <= 0x7fffffffLL,
                "%s: bad sizes B=%d S=%d ns=%d (ns in {32,64,128})", nm, B, S, ns);
+  PC3D_REQUIRE((unit == 16 || unit == 32) && ns / unit >= 1 && ns / unit <= 4,
+               "%s: unit=%d rows (16 or 32) with at most four units per group (ns=%d)", nm, unit, ns);
   if (B == 0) return PC3D_OK;
   PC3D_REQUIRE(idx && flags && tb && ntiles, "%s: null pointer", nm);
-  const int G = B * S, M = G * ns, tb_len = cdiv(M, SC_BM) * 4;
+  const int G = B * S, M = G * ns, tb_len = cdiv(M, 4 * unit) * 4;
   hipStream_t st = as_stream(stream);
-  hipLaunchKernelGGL(sa_block_flags_kernel, dim3(cdiv(G, 4)), dim3(256), 0, st, idx, G, ns, flags, tb, tb_len);
+  hipLaunchKernelGGL(sa_block_flags_kernel, dim3(cdiv(G, 4)), dim3(256), 0, st, idx, G, ns, unit, flags, tb, tb_len);
   PC3D_REQUIRE(G <= 48 * 1024, "%s: B * S = %d groups exceed the packing kernel's staging buffer", nm, G);
-  hipLaunchKernelGGL(sa_block_pack_kernel, dim3(1), dim3(256), (size_t)G, st, flags, G, ns / 32, tb, ntiles);
+  hipLaunchKernelGGL(sa_block_pack_kernel, dim3(1), dim3(SP_T), (size_t)G, st, flags, G, ns / unit, tb, ntiles);
   PC3D_LAUNCH_CHECK(nm);
   return PC3D_OK;
 }
@@ -589,7 +816,7 @@ extern "C" int pc3d_sa_blocks_i32(const int32_t* idx, int B, int S, int ns, uint
 static int sa_chain_launch(const char* nm, const float* P, int64_t ldp, const float* Bc, const int32_t* idx, int B, int NA, int S, int ns,
                            const float* W2, const float* b2, int C1, int C2, const float* W3, const float* b3, int C3,
                            uint8_t* mask1, uint32_t* mask2, float* out, int64_t* arg, const int32_t* tb, const int32_t* ntiles,
-                           void* stream) {
+                           int unit, void* stream) {
   PC3D_REQUIRE(B >= 0 && NA >= 1 && S >= 1 && (ns == 32 || ns == 64 || ns == 128), "%s: bad sizes B=%d NA=%d S=%d ns=%d (ns in {32,64,128})",
                nm, B, NA, S, ns);
   PC3D_REQUIRE((C1 == 32 || C1 == 64 || C1 == 128) && C2 >= 32 && C2 <= 128 && C2 % 32 == 0 && C3 >= 32 && C3 % 32 == 0,
@@ -608,8 +835,10 @@ static int sa_chain_launch(const char* nm, const float* P, int64_t ldp, const fl
     // small weights: the persistent resident-weight kernel, when its LDS (weights padded to 64 / 128 rows, a 64-row
     // tile) leaves room for two workgroups per CU
     const int c3p = (C3 + 127) & ~127;
-    const size_t lds_r = ((size_t)64 * (C1 + 4) + (size_t)c3p * (C2 + 4) + (size_t)SR_BM * ldh + 2 * 2 * 128 + 64 + c3p) * sizeof(float);
+    const size_t lds_r = ((size_t)64 * (C1 + 4) + (size_t)c3p * (C2 + 4) + (size_t)SR_BM * ldh + (tb ? 4 : 2) * 2 * 128 + 64 + c3p) * sizeof(float);
     if (lds_r <= 80 * 1024) {
+      PC3D_REQUIRE(!tb || S >= 4, "%s: the unit table needs at least four groups per cloud (S=%d)", nm, S);
+      PC3D_REQUIRE(!tb || unit == 16, "%s: this shape runs on the resident kernel, whose table has 16-row units (unit=%d)", nm, unit);
       const int tiles = cdiv(a.M, SR_BM);
       const int grid_r = tiles < 512 ? tiles : 512;
       auto launch = [&](auto kern) -> int {
@@ -619,13 +848,19 @@ static int sa_chain_launch(const char* nm, const float* P, int64_t ldp, const fl
         hipLaunchKernelGGL(kern, dim3(grid_r), dim3(SR_T), lds_r, st, a, tiles);
         return PC3D_OK;
       };
-      int rc = C1 == 32 ? (C2 == 32 ? launch(sa_chain_res_kernel<32, 32>) : launch(sa_chain_res_kernel<32, 64>))
-                        : (C2 == 32 ? launch(sa_chain_res_kernel<64, 32>) : launch(sa_chain_res_kernel<64, 64>));
+      int rc;
+      if (tb)
+        rc = C1 == 32 ? (C2 == 32 ? launch(sa_chain_res_tb_kernel<32, 32>) : launch(sa_chain_res_tb_kernel<32, 64>))
+                      : (C2 == 32 ? launch(sa_chain_res_tb_kernel<64, 32>) : launch(sa_chain_res_tb_kernel<64, 64>));
+      else
+        rc = C1 == 32 ? (C2 == 32 ? launch(sa_chain_res_kernel<32, 32>) : launch(sa_chain_res_kernel<32, 64>))
+                      : (C2 == 32 ? launch(sa_chain_res_kernel<64, 32>) : launch(sa_chain_res_kernel<64, 64>));
       if (rc) return rc;
       PC3D_LAUNCH_CHECK(nm);
       return PC3D_OK;
     }
   }
+  PC3D_REQUIRE(!tb || unit == 32, "%s: this shape runs on the streaming kernel, whose table has 32-row blocks (unit=%d)", nm, unit);
   const size_t lds = ((size_t)SC_BM * ldh + 2 * 128 * SC_LD + 2 * 4 * 128 + 8) * sizeof(float);
   const dim3 grid(cdiv(a.M, SC_BM)), block(SC_T);
   if (C2 <= 64) {
@@ -643,18 +878,36 @@ static int sa_chain_launch(const char* nm, const float* P, int64_t ldp, const fl
   return PC3D_OK;
 }
 
+// rows per unit of the table pc3d_sa_chain_tb_f32 expects for a shape (the dispatch rule of sa_chain_launch): 16 = the
+// resident kernel, 32 = the streaming kernel with groups of 64+ rows, 0 = a table would change nothing
+extern "C" int pc3d_sa_chain_table_unit(int S, int ns, int C1, int C2, int C3) {
+  if (!(ns == 32 || ns == 64 || ns == 128) || !(C1 == 32 || C1 == 64 || C1 == 128) || C2 < 32 || C2 > 128 || C2 % 32 || C3 < 32 || C3 % 32)
+    return 0;
+  if ((C1 == 32 || C1 == 64) && (C2 == 32 || C2 == 64) && ns <= 64 && S >= 4) {
+    const int c3p = (C3 + 127) & ~127, ldh = (C1 > C2 ? C1 : C2) + 4;
+    const size_t lds_r = ((size_t)64 * (C1 + 4) + (size_t)c3p * (C2 + 4) + (size_t)SR_BM * ldh + 4 * 2 * 128 + 64 + c3p) * sizeof(float);
+    if (lds_r <= 80 * 1024) return 16;
+  }
+  if ((C1 == 32 || C1 == 64) && (C2 == 32 || C2 == 64) && ns <= 64) {          // resident without a table (S < 4) or streaming
+    const int c3p = (C3 + 127) & ~127, ldh = (C1 > C2 ? C1 : C2) + 4;
+    const size_t lds_r = ((size_t)64 * (C1 + 4) + (size_t)c3p * (C2 + 4) + (size_t)SR_BM * ldh + 2 * 2 * 128 + 64 + c3p) * sizeof(float);
+    if (lds_r <= 80 * 1024) return 0;
+  }
+  return ns >= 64 ? 32 : 0;
+}
+
 extern "C" int pc3d_sa_chain_f32(const float* P, int64_t ldp, const float* Bc, const int32_t* idx, int B, int NA, int S, int ns,
                                  const float* W2, const float* b2, int C1, int C2, const float* W3, const float* b3, int C3,
                                  uint8_t* mask1, uint32_t* mask2, float* out, int64_t* arg, void* stream) {
   return sa_chain_launch("pc3d_sa_chain_f32", P, ldp, Bc, idx, B, NA, S, ns, W2, b2, C1, C2, W3, b3, C3, mask1, mask2, out, arg,
-                         nullptr, nullptr, stream);
+                         nullptr, nullptr, 0, stream);
 }
 
 extern "C" int pc3d_sa_chain_tb_f32(const float* P, int64_t ldp, const float* Bc, const int32_t* idx, int B, int NA, int S, int ns,
                                     const float* W2, const float* b2, int C1, int C2, const float* W3, const float* b3, int C3,
                                     uint8_t* mask1, uint32_t* mask2, float* out, int64_t* arg, const int32_t* tb,
-                                    const int32_t* ntiles, void* stream) {
+                                    const int32_t* ntiles, int unit, void* stream) {
   PC3D_REQUIRE((tb == nullptr) == (ntiles == nullptr), "pc3d_sa_chain_tb_f32: tb and ntiles go together");
   return sa_chain_launch("pc3d_sa_chain_tb_f32", P, ldp, Bc, idx, B, NA, S, ns, W2, b2, C1, C2, W3, b3, C3, mask1, mask2, out, arg,
-                         tb, ntiles, stream);
+                         tb, ntiles, unit, stream);
 }

@@ -299,10 +299,17 @@ class PointNetSetAbstraction(_FrozenFusedMixin, nn.Module):
         fps_idx = ops.fps(xyz_t, self.npoint, _fps_start(B, N, xyz_t.device))                       # [B,S] i32
         centres = ops.group_gather(xyz_t, None, fps_idx.view(B, self.npoint, 1)).view(B, self.npoint, 3)
         idx = ops.ball_query(self.radius, self.nsample, xyz_t, centres)                              # [B,S,ns] i32
-        # groups of 64+ rows: which 32-row blocks hold listed points at all (the chain launch packs those; ops.sa_blocks)
-        blocks = ops.sa_blocks(idx) if (self.nsample >= 64 and self.nsample % 32 == 0 and self.nsample <= 128) else None
         ev = torch.cuda.Event()
-        ev.record()                      # what the layer's FORWARD waits for
+        ev.record()                      # what the layer's FORWARD waits for (its front: centres and group indices)
+        # which 16- / 32-row units of the grouped rows hold listed points at all (the chain launch packs those; ops.sa_blocks):
+        # needed by the chain launch only, which waits for the table's own event after the layer's front has been queued
+        blocks = None
+        if self.nsample in (32, 64, 128) and len(self.mlp_convs) == 3:
+            unit = ops.sa_chain_table_unit(self.npoint, self.nsample, *[c.out_channels for c in self.mlp_convs])
+            if unit:
+                ev_tb = torch.cuda.Event()
+                blocks = ops.sa_blocks(idx, unit) + (ev_tb,)
+                ev_tb.record()
         g = [fps_idx, centres, idx, ev, None, None, N, blocks]
         if with_rev:
             self.geometry_rev(g)

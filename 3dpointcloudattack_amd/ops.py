@@ -2294,20 +2294,26 @@ SA_BWD_SPARSE = True
 SA_BLOCK_TABLE = True
 
 
-def sa_blocks(idx):
-    """Block table of a grouping idx [B,S,ns] int32 (ns in {64, 128}) for the chain launch: (tb, ntiles) — the 32-row blocks
-    that hold at least one listed point, packed four to a tile (pc3d_sa_blocks_i32). Depends on idx only: the geometry chain
-    builds it right after the ball query."""
+def sa_chain_table_unit(S, ns, C1, C2, C3):
+    """Rows per unit (16 / 32) of the table the chain launch takes for this shape, or 0 when a table would change nothing
+    (pc3d_sa_chain_table_unit: the library's own dispatch rule)."""
+    return int(_lib.load().pc3d_sa_chain_table_unit(int(S), int(ns), int(C1), int(C2), int(C3)))
+
+
+def sa_blocks(idx, unit):
+    """Unit table of a grouping idx [B,S,ns] int32 for the chain launch: (tb, ntiles, unit) — the 16- / 32-row units that
+    hold at least one listed point, packed four to a tile, whole groups per tile (pc3d_sa_blocks_i32). Depends on idx only:
+    the geometry chain builds it right after the ball query."""
     if idx.dtype != torch.int32 or idx.dim() != 3 or not idx.is_cuda or not idx.is_contiguous():
         raise ValueError("sa_blocks: idx must be a contiguous int32 [B,S,ns] GPU tensor")
     B, S, ns = idx.shape
     dev = idx.device
     flags = torch.empty((B * S,), dtype=torch.uint8, device=dev)
-    tb = torch.empty((((B * S * ns + 127) // 128) * 4,), dtype=torch.int32, device=dev)
+    tb = torch.empty((((B * S * ns + 4 * unit - 1) // (4 * unit)) * 4,), dtype=torch.int32, device=dev)
     nt = torch.empty((1,), dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
-        _lib.call("pc3d_sa_blocks_i32", idx.data_ptr(), B, S, ns, flags.data_ptr(), tb.data_ptr(), nt.data_ptr(), _stream())
-    return tb, nt
+        _lib.call("pc3d_sa_blocks_i32", idx.data_ptr(), B, S, ns, int(unit), flags.data_ptr(), tb.data_ptr(), nt.data_ptr(), _stream())
+    return tb, nt, int(unit)
 
 
 def sa_chain_supported(C1, C2, C3, ns):
@@ -2334,11 +2340,16 @@ class _GroupedMLPMaxFn(torch.autograd.Function):
             m2 = torch.empty((B * S * ns, C2 // 32), dtype=torch.int32, device=P.device)
             out = torch.empty((B * S, C3), dtype=torch.float32, device=P.device)
             arg = torch.empty((B * S, C3), dtype=torch.int64, device=P.device)
-            tb, nt = blocks if (blocks is not None and ns >= 64) else (None, None)
+            tb = nt = None
+            unit = 0
+            if blocks is not None and blocks[2] == sa_chain_table_unit(S, ns, C1, C2, C3):
+                tb, nt, unit = blocks[:3]
+                if len(blocks) > 3 and blocks[3] is not None:      # built on the geometry stream: its own event
+                    torch.cuda.current_stream(P.device).wait_event(blocks[3])
             with torch.cuda.device(P.device):
                 _lib.call("pc3d_sa_chain_tb_f32", P.data_ptr(), P.stride(1), Bc.data_ptr(), idx.data_ptr(), B, NA, S, ns,
                           w2.data_ptr(), b2.data_ptr(), C1, C2, w3.data_ptr(), b3.data_ptr(), C3, mask.data_ptr(),
-                          m2.data_ptr(), out.data_ptr(), arg.data_ptr(), _ptr(tb), _ptr(nt), _stream())
+                          m2.data_ptr(), out.data_ptr(), arg.data_ptr(), _ptr(tb), _ptr(nt), unit, _stream())
             ctx.save_for_backward(out, arg, None, m2, mask, idx, w2, w3, rev_off, rev_lst)
             ctx.dims = (B, NA, C1)
             return out.view(B, S, -1)

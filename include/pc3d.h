@@ -206,21 +206,24 @@ int pc3d_group_act_bwd_mask_f32(const float* gH, const uint8_t* mask, const int3
 int pc3d_sa_chain_f32(const float* P, int64_t ldp, const float* Bc, const int32_t* idx, int B, int NA, int S, int ns,
                       const float* W2, const float* b2, int C1, int C2, const float* W3, const float* b3, int C3,
                       uint8_t* mask1, uint32_t* mask2, float* out, int64_t* arg, void* stream);
-/* The same launch over a BLOCK TABLE: the 32-row blocks of the grouped rows that hold nothing but the ball query's padding
- * (copies of a group's first point, model/pointnet2_utils.py:84-104 — they can neither change nor win the group max) are
- * left out and the others packed four to a tile, whole groups per tile: fewer tiles instead of wasted products (with 64
- * rows per group and ~22 listed points, SSG's second level, the second block of most groups). Same out / arg; mask1 /
- * mask2 are written for the kept blocks only (the backward never reads the others: their rows carry exact zeros).
- *   pc3d_sa_blocks_i32: builds the table from idx [B,S,ns] — flags [B*S] bytes (scratch: bit b = block b of the group is
- *   kept), tb [ceil(B*S*ns/128)*4] int32 block ids (-1 = empty slot), ntiles [1] — two small launches, off the forward's
- *   path (idx is known as soon as the ball query has run).
- *   pc3d_sa_chain_tb_f32: tb / ntiles NULL = pc3d_sa_chain_f32; the table is used by the streaming kernel (wide layers). */
-int pc3d_sa_blocks_i32(const int32_t* idx, int B, int S, int ns, uint8_t* flags, int32_t* tb, int32_t* ntiles, void* stream);
+/* The same launch over a TABLE of row units: the 16- / 32-row units of the grouped rows that hold nothing but the ball
+ * query's padding (copies of a group's first point, model/pointnet2_utils.py:84-104 — they can neither change nor win the
+ * group max) are left out and the others packed four to a tile, whole groups per tile: fewer tiles instead of wasted
+ * products (SSG: 13.5 of 32 and 22 of 64 rows per group are listed points). Same out / arg; mask1 / mask2 are written for
+ * the kept units only (the backward never reads the others: their rows carry exact zeros).
+ *   pc3d_sa_chain_table_unit: rows per unit the launch expects for a shape — 16 (the resident-weight kernel, 64-row tiles),
+ *   32 (the streaming kernel, groups of 64+ rows), 0 (a table would change nothing).
+ *   pc3d_sa_blocks_i32: builds the table from idx [B,S,ns] — flags [B*S] bytes (scratch: bit u = unit u of the group is
+ *   kept), tb [ceil(B*S*ns/(4*unit))*4] int32 unit ids in original row space (-1 = empty slot), ntiles [1] — two small
+ *   launches, off the forward's path (idx is known as soon as the ball query has run). At most four units per group.
+ *   pc3d_sa_chain_tb_f32: tb / ntiles NULL = pc3d_sa_chain_f32; `unit` must be what pc3d_sa_chain_table_unit says. */
+int pc3d_sa_chain_table_unit(int S, int ns, int C1, int C2, int C3);
+int pc3d_sa_blocks_i32(const int32_t* idx, int B, int S, int ns, int unit, uint8_t* flags, int32_t* tb, int32_t* ntiles,
+                       void* stream);
 int pc3d_sa_chain_tb_f32(const float* P, int64_t ldp, const float* Bc, const int32_t* idx, int B, int NA, int S, int ns,
                          const float* W2, const float* b2, int C1, int C2, const float* W3, const float* b3, int C3,
                          uint8_t* mask1, uint32_t* mask2, float* out, int64_t* arg, const int32_t* tb, const int32_t* ntiles,
-                         void* stream);
-
+                         int unit, void* stream);
 
 /* The backward of a set-abstraction chain (pc3d_sa_chain_f32) from the max down to the points, on the ACTIVE rows only.
  * A row of a group that wins no channel of the max carries no gradient — 58-65 % of the rows at the single-scale

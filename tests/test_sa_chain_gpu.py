@@ -109,22 +109,26 @@ def test_sa_chain_backward_fused_gemm_groupsum_bitwise(ops, dev, B, N, S, ns, C1
     assert torch.equal(gb2, gb0) and torch.equal(gp2, gp0)
 
 
-@pytest.mark.parametrize("B,N,S,ns,C1,C2,C3", [(8, 512, 128, 64, 128, 128, 256),    # SSG SA2
-                                                (3, 512, 128, 128, 64, 96, 128),    # MSG widest scale
+@pytest.mark.parametrize("B,N,S,ns,C1,C2,C3", [(8, 512, 128, 64, 128, 128, 256),    # SSG SA2: streaming kernel, 32-row units
+                                                (8, 2048, 512, 32, 64, 64, 128),    # SSG SA1: resident kernel, 16-row units
+                                                (3, 512, 128, 64, 32, 64, 96),      # resident, four units per group
                                                 (1, 300, 7, 64, 64, 128, 320),      # ragged last tile
-                                                (2, 256, 40, 64, 128, 64, 96)])
+                                                (2, 256, 40, 64, 128, 64, 96),
+                                                (2, 512, 9, 32, 32, 32, 64)])
 def test_sa_chain_block_table_equals_full_launch_bitwise(ops, dev, B, N, S, ns, C1, C2, C3):
     """pc3d_sa_chain_tb_f32 over the block table of pc3d_sa_blocks_i32 (32-row blocks of nothing but padding copies left
     out, the others packed into fewer tiles) against the launch over every block: outputs and both gradients BIT-identical;
     the table lists every block that holds a listed point exactly once, whole groups per tile."""
     P, Bc, idx, layers, w = _case(ops, dev, B, N, S, ns, C1, C2, C3, seed=ns + C1, bad_idx=True)
-    tb, nt = ops.sa_blocks(idx)
+    unit = ops.sa_chain_table_unit(S, ns, C1, C2, C3)
+    assert unit in (16, 32)
+    tb, nt, _ = ops.sa_blocks(idx, unit)
     torch.cuda.synchronize()
     tbn, ntv = tb.cpu().numpy().reshape(-1, 4), int(nt.item())
-    bpg = ns // 32
+    bpg = ns // unit
     ii = idx.cpu().numpy().reshape(B * S, ns)
     want = sorted(g * bpg + b for g in range(B * S) for b in range(bpg)
-                  if b == 0 or (ii[g, 32 * b:32 * b + 32] != ii[g, 0]).any())
+                  if b == 0 or (ii[g, unit * b:unit * b + unit] != ii[g, 0]).any())
     got = [int(k) for k in tbn[:ntv].ravel() if k >= 0]
     assert got == want and (tbn[ntv:] == -1).all()
     for row in tbn[:ntv]:                                   # a group's blocks never straddle two tiles
@@ -139,7 +143,7 @@ def test_sa_chain_block_table_equals_full_launch_bitwise(ops, dev, B, N, S, ns, 
         try:
             p, bc = P.clone().requires_grad_(), Bc.clone().requires_grad_()
             rev = ops.group_reverse(idx, P.shape[1])
-            out = ops.grouped_mlp_max(p, bc, idx, layers, rev=rev, blocks=(tb, nt))
+            out = ops.grouped_mlp_max(p, bc, idx, layers, rev=rev, blocks=(tb, nt, unit))
             (out * w).sum().backward()
             return out.detach(), p.grad, bc.grad
         finally:

@@ -20,6 +20,14 @@ if os.environ.get("PC3D_FUSE12") == "0":      # A/B switch for the experiment re
     M("3dpointcloudattack_amd.model.pointnet2_utils").FUSE_LAYERS_1_2 = False
 if os.environ.get("PC3D_L2_BITS") == "0":
     M("3dpointcloudattack_amd.ops").LAYER2_SIGN_BITS = False
+if os.environ.get("PC3D_SA_TABLE") == "0":
+    M("3dpointcloudattack_amd.ops").SA_BLOCK_TABLE = False
+if os.environ.get("PC3D_SA_TABLE") == "32":      # unit tables for the streaming kernel only
+    _ops = M("3dpointcloudattack_amd.ops")
+    _orig_unit = _ops.sa_chain_table_unit
+    _ops.sa_chain_table_unit = lambda *a: (_orig_unit(*a) if _orig_unit(*a) == 32 else 0)
+if os.environ.get("PC3D_SA_SPARSE") == "0":
+    M("3dpointcloudattack_amd.ops").SA_BWD_SPARSE = False
 if os.environ.get("PC3D_REV_INDEX") == "0":
     M("3dpointcloudattack_amd.model.pointnet2_utils").REVERSE_INDEX = False
 res = {}
