@@ -451,10 +451,16 @@ struct GroupMaxBwdArgs {
 using gmb_f32x32 = __attribute__((ext_vector_type(32))) float;
 using gmb_f32x16 = __attribute__((ext_vector_type(16))) float;
 
-template <int NS>
-__global__ __launch_bounds__(GMB_T) void group_max_linear_bwd_kernel(GroupMaxBwdArgs a) {
+// KS > 1 (few groups: a classifier's group-all layer has ONE group per cloud and 1024 channels to walk): the channels are
+// split over KS thread groups of the workgroup (threadIdx.y), each with its own accumulators; the partial sums are added
+// in chunk order through LDS, one 32-row register vector at a time. The order of a row's sum is then "chunk by chunk" —
+// fixed for a given KS, which the HOST chooses from the per-cloud shape (ops.gmb_ksplit), never from the batch.
+template <int NS, int KS = 1>
+__global__ __launch_bounds__(GMB_T * KS) void group_max_linear_bwd_kernel(GroupMaxBwdArgs a) {
   constexpr int NV = (NS + 31) / 32;          // accumulators as 32-wide register vectors: a uniform dynamic index into
   const int g = blockIdx.x;                    // one of those lowers to M0-relative register addressing (v_movrel)
+  const int q = KS > 1 ? threadIdx.y : 0;      // channel chunk of this thread group
+  const int tlin = threadIdx.y * blockDim.x + threadIdx.x, nthr = blockDim.x * blockDim.y;
   const int k = blockIdx.y * blockDim.x + threadIdx.x;
   const bool live = k < a.C2;
   const float* wcol = a.W + (live ? k : 0);
@@ -470,9 +476,9 @@ __global__ __launch_bounds__(GMB_T) void group_max_linear_bwd_kernel(GroupMaxBwd
   float* s_g = gmb_lds;                                 // [C3]
   int* s_r = reinterpret_cast<int*>(gmb_lds + a.C3);    // [C3]
   __shared__ uint32_t s_act[4];
-  if (threadIdx.x < 4) s_act[threadIdx.x] = 0u;
+  if (tlin < 4) s_act[tlin] = 0u;
   __syncthreads();
-  for (int c = threadIdx.x; c < a.C3; c += blockDim.x) {
+  for (int c = tlin; c < a.C3; c += nthr) {
     s_g[c] = (a.out[base + c] > 0.f) ? a.gout[base + c] : 0.f;
     const int rw = (int)a.arg[base + c];
     s_r[c] = rw;
@@ -482,9 +488,10 @@ __global__ __launch_bounds__(GMB_T) void group_max_linear_bwd_kernel(GroupMaxBwd
   uint32_t act[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) act[v] = a.amask ? s_act[v] : 0xffffffffu;
-  if (a.amask && blockIdx.y == 0 && threadIdx.x < (a.ns + 31) / 32) a.amask[(int64_t)g * ((a.ns + 31) / 32) + threadIdx.x] = s_act[threadIdx.x];
-  int c = 0;
-  for (; c + 8 <= a.C3; c += 8) {
+  if (a.amask && blockIdx.y == 0 && tlin < (a.ns + 31) / 32) a.amask[(int64_t)g * ((a.ns + 31) / 32) + tlin] = s_act[tlin];
+  const int cper = a.C3 / KS, cend = (q + 1) * cper;   // (the entry point checks C3 % (8 KS) == 0 for KS > 1)
+  int c = q * cper;
+  for (; c + 8 <= cend; c += 8) {
     int rr[8];
     float gg[8], ww[8];
 #pragma unroll
@@ -502,13 +509,30 @@ __global__ __launch_bounds__(GMB_T) void group_max_linear_bwd_kernel(GroupMaxBwd
         if (hi == v) acc[v][lo] = __builtin_fmaf(gg[e], ww[e], acc[v][lo]);
     }
   }
-  for (; c < a.C3; ++c) {
+  for (; c < cend; ++c) {
     const int r = __builtin_amdgcn_readfirstlane(s_r[c]);
     const float gv = s_g[c], w = wcol[(int64_t)c * a.C2];
     const int hi = r >> 5, lo = r & 31;
 #pragma unroll
     for (int v = 0; v < NV; ++v)
       if (hi == v) acc[v][lo] = __builtin_fmaf(gv, w, acc[v][lo]);
+  }
+  if (KS > 1) {
+    float* comb = gmb_lds + 2 * a.C3;                    // [KS - 1][32][blockDim.x]
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      if (q > 0)
+#pragma unroll
+        for (int e = 0; e < 32; ++e) comb[((q - 1) * 32 + e) * blockDim.x + threadIdx.x] = acc[v][e];
+      __syncthreads();
+      if (q == 0)
+#pragma unroll
+        for (int e = 0; e < 32; ++e)
+#pragma unroll
+          for (int p = 0; p < KS - 1; ++p) acc[v][e] += comb[(p * 32 + e) * blockDim.x + threadIdx.x];
+      __syncthreads();
+    }
+    if (q > 0) return;
   }
   if (a.xmask) {
     // sign bits instead of the stored activation: the wave's 32 rows x 2 words of a register vector are ONE load (lane l
@@ -968,7 +992,7 @@ extern "C" int pc3d_group_gather_bwd_f32(const float* g_out, const int32_t* idx,
 
 static int group_max_linear_bwd_launch(const float* gout, const float* out, const int64_t* arg, const float* W, int G, int ns,
                                        int C2, int C3, const float* xin, const uint32_t* xmask, float* gx, void* stream,
-                                       uint32_t* amask = nullptr) {
+                                       uint32_t* amask = nullptr, int ksplit = 1) {
   PC3D_REQUIRE(G >= 0 && ns >= 1 && ns <= GMB_MAXNS && C2 >= 1 && C3 >= 1 && C3 <= 4096,
                "pc3d_group_max_linear_bwd_f32: bad sizes G=%d ns=%d C2=%d C3=%d (ns <= 128, C3 <= 4096)", G, ns, C2, C3);
   PC3D_REQUIRE(!xmask || C2 % 32 == 0, "pc3d_group_max_linear_bwd_mask_f32: C2=%d must be a multiple of 32", C2);
@@ -979,6 +1003,16 @@ static int group_max_linear_bwd_launch(const float* gout, const float* out, cons
   const dim3 grid(G, cdiv(C2, bt)), block(bt);
   hipStream_t st = as_stream(stream);
   const size_t lds = 2 * (size_t)C3 * sizeof(float);
+  if (ksplit > 1) {
+    PC3D_REQUIRE(ksplit == 4 && C3 % 32 == 0, "pc3d_group_max_linear_bwd_ks_f32: ksplit=%d (1 or 4; C3 %% 32 == 0)", ksplit);
+    const size_t lds4 = lds + (size_t)3 * 32 * bt * sizeof(float);
+    const dim3 block4(bt, 4);
+    if (ns <= 32) hipLaunchKernelGGL((group_max_linear_bwd_kernel<32, 4>), grid, block4, lds4, st, a);
+    else if (ns <= 64) hipLaunchKernelGGL((group_max_linear_bwd_kernel<64, 4>), grid, block4, lds4, st, a);
+    else hipLaunchKernelGGL((group_max_linear_bwd_kernel<128, 4>), grid, block4, lds4, st, a);
+    PC3D_LAUNCH_CHECK("pc3d_group_max_linear_bwd_ks_f32");
+    return PC3D_OK;
+  }
   if (ns <= 32) hipLaunchKernelGGL(group_max_linear_bwd_kernel<32>, grid, block, lds, st, a);
   else if (ns <= 64) hipLaunchKernelGGL(group_max_linear_bwd_kernel<64>, grid, block, lds, st, a);
   else hipLaunchKernelGGL(group_max_linear_bwd_kernel<128>, grid, block, lds, st, a);
@@ -989,6 +1023,12 @@ static int group_max_linear_bwd_launch(const float* gout, const float* out, cons
 extern "C" int pc3d_group_max_linear_bwd_f32(const float* gout, const float* out, const int64_t* arg, const float* W,
                                              int G, int ns, int C2, int C3, const float* xin, float* gx, void* stream) {
   return group_max_linear_bwd_launch(gout, out, arg, W, G, ns, C2, C3, xin, nullptr, gx, stream);
+}
+
+extern "C" int pc3d_group_max_linear_bwd_ks_f32(const float* gout, const float* out, const int64_t* arg, const float* W,
+                                                int G, int ns, int C2, int C3, const float* xin, float* gx, int ksplit,
+                                                void* stream) {
+  return group_max_linear_bwd_launch(gout, out, arg, W, G, ns, C2, C3, xin, nullptr, gx, stream, nullptr, ksplit);
 }
 
 extern "C" int pc3d_group_max_linear_bwd_mask_f32(const float* gout, const float* out, const int64_t* arg, const float* W,
@@ -1142,14 +1182,16 @@ extern "C" int pc3d_group_act_bwd_points_f32(const float* gH, const uint8_t* mas
 // kernel: 0 = choose, 1 = a workgroup per group, 2 = the tiled GEMM main loop with the group-max epilogue (ns = 32 / 64 / 128)
 static int group_linear_max_launch(int kernel, const float* x, const float* W, const float* b, int G, int ns, int C2, int C3,
                                    float* out, int64_t* arg, void* stream) {
-  PC3D_REQUIRE(G >= 0 && ns >= 1 && ns <= 128 && C2 >= 8 && C2 <= 128 && C2 % 8 == 0 && C3 >= 32 && C3 % 32 == 0 && C3 <= 4096,
-               "pc3d_group_linear_max_f32: unsupported sizes ns=%d C2=%d C3=%d (ns <= 128, C2 %% 8 == 0 <= 128, C3 %% 32 == 0)",
-               ns, C2, C3);
+  // groups of 32 / 64 / 128 rows: the tiled GEMM main loop (operands through LDS, 128 rows share a weight tile) with a
+  // group-max epilogue — measured against the one-workgroup-per-group kernel below in tools/bench_glm.py. It takes any
+  // input width; the per-group kernel keeps a group's rows in registers (C2 <= 128).
+  const bool gemm_ok = (ns == 32 || ns == 64 || ns == 128) && (int64_t)G * ns <= 0x7fffffff;
+  PC3D_REQUIRE(G >= 0 && ns >= 1 && ns <= 128 && C2 >= 8 && C2 % 8 == 0 && (C2 <= 128 || (gemm_ok && kernel != 1)) && C3 >= 32 &&
+                   C3 % 32 == 0 && C3 <= 4096,
+               "pc3d_group_linear_max_f32: unsupported sizes ns=%d C2=%d C3=%d (ns <= 128, C2 %% 8 == 0, C2 <= 128 unless ns in "
+               "{32, 64, 128}, C3 %% 32 == 0)", ns, C2, C3);
   if (G == 0) return PC3D_OK;
   PC3D_REQUIRE(x && W && b && out && arg, "pc3d_group_linear_max_f32: null pointer");
-  // groups of 32 / 64 / 128 rows: the tiled GEMM main loop (operands through LDS, 128 rows share a weight tile) with a
-  // group-max epilogue — measured against the one-workgroup-per-group kernel below in tools/bench_glm.py
-  const bool gemm_ok = (ns == 32 || ns == 64 || ns == 128) && (int64_t)G * ns <= 0x7fffffff;
   PC3D_REQUIRE(kernel != 2 || gemm_ok, "pc3d_group_linear_max_kernel_f32: the GEMM form needs ns in {32, 64, 128} (ns=%d)", ns);
   if (kernel != 1 && gemm_ok) return gemm_nt_groupmax(x, W, b, G, ns, C2, C3, out, arg, stream);
   GroupLinMaxArgs a{x, W, b, ns, C2, C3, out, arg};

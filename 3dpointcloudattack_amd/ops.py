@@ -2046,7 +2046,7 @@ def _group_linear_max_fwd(x, w, b):
     """(out [G,C3], arg [G,C3] int64) of max_r relu(x[g,r,:] @ w.T + b): fused MFMA kernel when the shape fits it."""
     G, ns, C2 = x.shape
     C3 = w.shape[0]
-    if C2 % 8 == 0 and C2 <= 128 and C3 % 32 == 0 and C3 <= 4096:
+    if C2 % 8 == 0 and (C2 <= 128 or ns in (32, 64, 128)) and C3 % 32 == 0 and C3 <= 4096:
         out = torch.empty((G, C3), dtype=torch.float32, device=x.device)
         arg = torch.empty((G, C3), dtype=torch.int64, device=x.device)
         with torch.cuda.device(x.device):
@@ -2061,6 +2061,16 @@ def _group_linear_max_fwd(x, w, b):
     return out, arg
 
 
+def gmb_ksplit(groups_per_cloud, C2, C3):
+    """Channel split (1 or 4) of the max-backward launch for a layer with `groups_per_cloud` groups per cloud: 4 when a
+    nominal batch of GEMM_NOMINAL_BATCH clouds leaves the chip mostly idle (a group-all layer). From the per-cloud shape
+    only: the split changes the order of a row's sum."""
+    if C3 % 32 or groups_per_cloud is None:
+        return 1
+    wgs = GEMM_NOMINAL_BATCH * int(groups_per_cloud) * ((C2 + (63 if C2 <= 64 else 127)) // (64 if C2 <= 64 else 128))
+    return 4 if wgs < 512 else 1
+
+
 class _MLPReLUMaxFn(torch.autograd.Function):
     """The whole shared MLP of a set-abstraction layer + the max over the group, x [G,ns,C0] -> [G,C_last], with a
     hand-written backward: hidden layers run on pc3d_gemm_nt_f32 (fp32 MFMA, bias + ReLU in the epilogue); the last
@@ -2069,8 +2079,9 @@ class _MLPReLUMaxFn(torch.autograd.Function):
     ReLU's mask while loading dY — no separate mask pass over the [G*ns, C] tensors. Frozen weights: only dL/dx."""
 
     @staticmethod
-    def forward(ctx, x, *wb):
+    def forward(ctx, x, gpc, *wb):
         G, ns, C0 = x.shape
+        ctx.gpc = gpc
         ws, bs = wb[0::2], wb[1::2]
         acts = [x.reshape(G * ns, C0)]
         for w, b in zip(ws[:-1], bs[:-1]):
@@ -2091,13 +2102,14 @@ class _MLPReLUMaxFn(torch.autograd.Function):
         gx = torch.empty((G * ns, C2), dtype=torch.float32, device=g.device)
         last_hidden = acts[-1] if nl > 1 else None                     # ReLU output feeding the last layer (or raw x)
         with torch.cuda.device(g.device):
-            _lib.call("pc3d_group_max_linear_bwd_f32", g.data_ptr(), out.data_ptr(), arg.data_ptr(), ws[-1].data_ptr(),
-                      G, ns, C2, ws[-1].shape[0], _ptr(last_hidden), gx.data_ptr(), _stream())
+            _lib.call("pc3d_group_max_linear_bwd_ks_f32", g.data_ptr(), out.data_ptr(), arg.data_ptr(), ws[-1].data_ptr(),
+                      G, ns, C2, ws[-1].shape[0], _ptr(last_hidden), gx.data_ptr(), gmb_ksplit(ctx.gpc, C2, ws[-1].shape[0]),
+                      _stream())
         for li in range(nl - 2, -1, -1):                                # hidden layers, last to first
             # gradient wrt that layer's input; the incoming gradient is masked by the layer's own ReLU on load (the
             # last hidden layer's mask was applied by the max-backward kernel above)
             gx = gemm_nt(gx, _w_transposed(ws[li]), gate=(acts[li] if li < nl - 2 else None), gate_slope=0.0)
-        return (gx.view(G, ns, C0),) + (None,) * (2 * nl)
+        return (gx.view(G, ns, C0), None) + (None,) * (2 * nl)
 
 
 def group_reverse(idx, NA):
@@ -2448,7 +2460,10 @@ def mlp_relu_max(x, layers):
     if ns > GROUP_MAX_NS:
         raise ValueError(f"mlp_relu_max: group size {ns} exceeds {GROUP_MAX_NS}")
     flat = [t.contiguous() for wb in layers for t in wb]
-    out = _MLPReLUMaxFn.apply(x.reshape(-1, ns, C0).contiguous(), *flat)
+    gpc = 1
+    for d in lead[1:]:
+        gpc *= int(d)
+    out = _MLPReLUMaxFn.apply(x.reshape(-1, ns, C0).contiguous(), gpc if len(lead) >= 2 else None, *flat)
     return out.view(*lead, layers[-1][0].shape[0])
 
 

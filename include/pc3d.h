@@ -186,6 +186,12 @@ int pc3d_group_act_bwd_f32(const float* gH, const float* H, const int32_t* idx, 
 int pc3d_gemm_nt_gather_f32(const float* P, int64_t ldp, const float* Bc, const int32_t* idx, int B, int NA, int S, int ns,
                             float slope_in, const float* W, const float* bias, int N, int K, int act, float slope, float* Y,
                             int64_t ldy, uint8_t* mask, uint32_t* ymask, void* stream);
+/* pc3d_group_max_linear_bwd_f32 with the channels split over `ksplit` (1 or 4) thread groups of a workgroup, the partial
+ * sums added in chunk order: for launches with few groups (a group-all layer: ONE group per cloud, C3 = 1024 channels to
+ * walk serially). A row's summation order depends on ksplit, so the caller chooses it from the per-cloud shape, never
+ * from the batch. C3 % 32 == 0. */
+int pc3d_group_max_linear_bwd_ks_f32(const float* gout, const float* out, const int64_t* arg, const float* W, int G, int ns,
+                                     int C2, int C3, const float* xin, float* gx, int ksplit, void* stream);
 /* ymask (may be NULL; needs N % 32 == 0): [B*S*ns, N/32] words, bit n % 32 of word n / 32 of a row = "Y[row, n] > 0 before
  * the activation" — the sign of layer 2's output for ITS backward, so that Y itself need not be kept after the next
  * layer has consumed it:  pc3d_group_max_linear_bwd_mask_f32 = pc3d_group_max_linear_bwd_f32 with that mask for xin. */
