@@ -15,8 +15,8 @@ B, N = 64, 2048
 x = torch.from_numpy(np.stack([unit_cloud(rng, N) for _ in range(B)])).transpose(1, 2).contiguous().to(dev)
 res = []
 orig_apply = ops._GroupedMLPMaxFn.forward
-def fwd(ctx, P, Bc, idx, w2, b2, w3, b3, r0, r1, ev=None):
-    o = orig_apply(ctx, P, Bc, idx, w2, b2, w3, b3, r0, r1, ev)
+def fwd(ctx, P, Bc, idx, w2, b2, w3, b3, r0, r1, ev=None, blocks=None):
+    o = orig_apply(ctx, P, Bc, idx, w2, b2, w3, b3, r0, r1, ev, blocks)
     arg = ctx.to_save[1]
     Bv, S, ns = idx.shape
     G, C3 = arg.shape
