@@ -509,14 +509,32 @@ def main():
             torch.manual_seed(5 + rank)
             np.random.seed(5 + rank)
             atk.attack(d4, l4)
-        x4 = torch.relu(torch.randn(B4 * 128 * 64, 128, device=dev))
-        w4 = torch.randn(128, 128, device=dev) / 128 ** 0.5
-        b4 = torch.randn(128, device=dev)
-        whole(f"cfg4_knn_ssg_B{B4}_N2048", knn_run, 8, 40,
-              kernel_roof("gemm_nt_kernel (SA2 layer 2, [524288,128,128])", lambda: ops.gemm_nt(x4, w4, b4, "relu"),
-                          flops=2.0 * B4 * 128 * 64 * 128 * 128,
-                          note="K = 128: also HBM-bound on reading + writing [M,128] fp32 rows (537 MB)"))
-        del x4, w4, b4
+        # dominant kernel of the iteration: the second level's set-abstraction chain (gather -> layers 1-2-3 -> group max, one
+        # launch over the table of 32-row blocks that hold listed points), stand-alone on a grouping with the real padding
+        # structure: 512-point clouds, 128 FPS centres, ball query r = 0.4 / 64 samples
+        c4 = clouds(B4, 512, 4242).to(dev)
+        with torch.no_grad():
+            f4 = ops.fps(c4, 128, None)
+            ctr4 = torch.gather(c4, 1, f4.long()[..., None].expand(-1, -1, 3)).contiguous()
+            idx4 = ops.ball_query(0.4, 64, c4, ctr4)
+            P4, Bc4 = torch.randn(B4, 512, 128, device=dev), torch.randn(B4, 128, 128, device=dev)
+            L4 = [(torch.randn(128, 128, device=dev) / 128 ** 0.5, torch.randn(128, device=dev)),
+                  (torch.randn(256, 128, device=dev) / 128 ** 0.5, torch.randn(256, device=dev))]
+            blk4 = ops.sa_blocks(idx4, 32)
+            kept4 = int((blk4[0][:int(blk4[1].item()) * 4] >= 0).sum().item())
+        per_row = 2.0 * (128 * 128 + 128 * 256)
+
+        def sa2_chain():
+            with torch.no_grad():
+                ops.grouped_mlp_max(P4, Bc4, idx4, L4, blocks=blk4)
+        roof4 = kernel_roof("sa_chain_kernel<2> (SSG SA2: 8192 groups x 64 rows, 128 -> 128 -> 256, over the block table)",
+                            sa2_chain, flops=per_row * 32 * kept4,
+                            note=f"flops of the {kept4} kept 32-row blocks of {B4 * 128 * 2} (the others are padding copies of a "
+                                 "group's first point); the reference's count for every row is alg_flops_all_rows")
+        roof4["alg_flops_all_rows"] = per_row * B4 * 128 * 64
+        roof4["frac_all_rows"] = roof4["alg_flops_all_rows"] / roof4["launch_us"] / 1e6 / MFMA_F32_PEAK_TFLOPS
+        whole(f"cfg4_knn_ssg_B{B4}_N2048", knn_run, 8, 40, roof4)
+        del c4, P4, Bc4, idx4, blk4
 
         d5 = clouds(B, 4096, 999)
         p5 = d5.to(dev)
