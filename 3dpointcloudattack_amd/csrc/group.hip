@@ -25,14 +25,14 @@ struct FpsArgs {
   int32_t* out;          // [B,S]
 };
 
-template <int PER>
-__global__ __launch_bounds__(FPS_T) void fps_kernel(FpsArgs a) {
+template <int PER, int T = FPS_T>
+__global__ __launch_bounds__(T) void fps_kernel(FpsArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* sx = lds;                 // [N] staged coordinates (winner lookup)
   float* sy = lds + a.N;
   float* sz = lds + 2 * a.N;
-  __shared__ float red_v[2][FPS_T / 64];
-  __shared__ int red_i[2][FPS_T / 64];
+  __shared__ float red_v[2][T / 64 > 1 ? T / 64 : 1];
+  __shared__ int red_i[2][T / 64 > 1 ? T / 64 : 1];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // A chain of dependent steps on one wavefront per SIMD, usually beside a chip-filling kernel of another stream (the
   // previous layer's MLP, the attack's searches): its instructions go first in the SIMD's issue arbitration.
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(FPS_T) void fps_kernel(FpsArgs a) {
   float px[PER], py[PER], pz[PER], dist[PER];
 #pragma unroll
   for (int e = 0; e < PER; ++e) {
-    const int i = e * FPS_T + tid;  // strided ownership: coalesced loads, ascending index within a thread
+    const int i = e * T + tid;  // strided ownership: coalesced loads, ascending index within a thread
     float x = 0.f, y = 0.f, z = 0.f;
     if (i < a.N) {
       const float* p = xb + (int64_t)i * a.x.ps;
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(FPS_T) void fps_kernel(FpsArgs a) {
       dist[e] = nd;
       if (nd > bv) {  // ascending index inside the thread: strict > keeps the lowest index
         bv = nd;
-        bi = e * FPS_T + tid;
+        bi = e * T + tid;
       }
     }
     // wave arg-max on DPP (the shuffle version cost ~800 cycles of LDS-crossbar latency per step): the maximum
@@ -80,16 +80,20 @@ __global__ __launch_bounds__(FPS_T) void fps_kernel(FpsArgs a) {
       bi = wave_min_dpp_i32(bv == wv ? bi : 0x7fffffff);
       bv = wv;
     }
-    const int buf = s & 1;  // double-buffered exchange: one barrier per step
-    if (lane == 0) red_v[buf][wave] = bv, red_i[buf][wave] = bi;
-    __syncthreads();
-    float fv = red_v[buf][0];
-    int fi = red_i[buf][0];
+    float fv = bv;
+    int fi = bi;
+    if (T > 64) {           // (one wavefront per cloud: the wave's arg-max is the cloud's — no exchange, no barrier)
+      const int buf = s & 1;  // double-buffered exchange: one barrier per step
+      if (lane == 0) red_v[buf][wave] = bv, red_i[buf][wave] = bi;
+      __syncthreads();
+      fv = red_v[buf][0];
+      fi = red_i[buf][0];
 #pragma unroll
-    for (int w = 1; w < FPS_T / 64; ++w) {
-      const float ov = red_v[buf][w];
-      const int oi = red_i[buf][w];
-      if (ov > fv || (ov == fv && oi < fi)) fv = ov, fi = oi;
+      for (int w = 1; w < T / 64; ++w) {
+        const float ov = red_v[buf][w];
+        const int oi = red_i[buf][w];
+        if (ov > fv || (ov == fv && oi < fi)) fv = ov, fi = oi;
+      }
     }
     if (fi != 0x7fffffff) far = fi;  // no finite candidate (NaN cloud): stay put instead of indexing LDS at 2^31
   }
@@ -861,24 +865,51 @@ __global__ __launch_bounds__(256) void group_act_bwd_points_kernel(const float* 
 
 using namespace pc3d;
 
-extern "C" int pc3d_fps_f32(const float* xyz, int64_t x_bs, int64_t x_ps, int64_t x_cs, int B, int N, int S,
-                            const int32_t* start, int32_t* out, void* stream) {
-  PC3D_REQUIRE(B >= 0 && N >= 1 && S >= 1, "pc3d_fps_f32: bad sizes B=%d N=%d S=%d", B, N, S);
-  PC3D_REQUIRE(N <= FPS_T * FPS_MAXPER, "pc3d_fps_f32: N=%d exceeds %d", N, FPS_T * FPS_MAXPER);
+static int fps_launch(const char* nm, int threads, const float* xyz, int64_t x_bs, int64_t x_ps, int64_t x_cs, int B, int N, int S,
+                      const int32_t* start, int32_t* out, void* stream) {
+  PC3D_REQUIRE(B >= 0 && N >= 1 && S >= 1, "%s: bad sizes B=%d N=%d S=%d", nm, B, N, S);
+  PC3D_REQUIRE(threads == 64 || threads == 128 || threads == 256 || threads == 512 || threads == 1024,
+               "%s: threads=%d (64, 128, 256, 512 or 1024)", nm, threads);
+  PC3D_REQUIRE(N <= threads * FPS_MAXPER && N <= FPS_T * FPS_MAXPER, "%s: N=%d exceeds %d (threads * %d)", nm, N,
+               threads * FPS_MAXPER < FPS_T * FPS_MAXPER ? threads * FPS_MAXPER : FPS_T * FPS_MAXPER, FPS_MAXPER);
   if (B == 0) return PC3D_OK;
-  PC3D_REQUIRE(xyz && out, "pc3d_fps_f32: null pointer");
+  PC3D_REQUIRE(xyz && out, "%s: null pointer", nm);
   FpsArgs a{{xyz, x_bs, x_ps, x_cs}, N, S, start, out};
   const size_t lds = (size_t)3 * N * sizeof(float);
   hipStream_t st = as_stream(stream);
-  const int per = cdiv(N, FPS_T);
-  if (per <= 1) hipLaunchKernelGGL(fps_kernel<1>, dim3(B), dim3(FPS_T), lds, st, a);
-  else if (per <= 2) hipLaunchKernelGGL(fps_kernel<2>, dim3(B), dim3(FPS_T), lds, st, a);
-  else if (per <= 4) hipLaunchKernelGGL(fps_kernel<4>, dim3(B), dim3(FPS_T), lds, st, a);
-  else if (per <= 8) hipLaunchKernelGGL(fps_kernel<8>, dim3(B), dim3(FPS_T), lds, st, a);
-  else if (per <= 16) hipLaunchKernelGGL(fps_kernel<16>, dim3(B), dim3(FPS_T), lds, st, a);
-  else hipLaunchKernelGGL(fps_kernel<32>, dim3(B), dim3(FPS_T), lds, st, a);
-  PC3D_LAUNCH_CHECK("pc3d_fps_f32");
+  const int per = cdiv(N, threads);
+#define PC3D_FPS(TV)                                                                                 \
+  do {                                                                                               \
+    if (per <= 1) hipLaunchKernelGGL((fps_kernel<1, TV>), dim3(B), dim3(TV), lds, st, a);            \
+    else if (per <= 2) hipLaunchKernelGGL((fps_kernel<2, TV>), dim3(B), dim3(TV), lds, st, a);       \
+    else if (per <= 4) hipLaunchKernelGGL((fps_kernel<4, TV>), dim3(B), dim3(TV), lds, st, a);       \
+    else if (per <= 8) hipLaunchKernelGGL((fps_kernel<8, TV>), dim3(B), dim3(TV), lds, st, a);       \
+    else if (per <= 16) hipLaunchKernelGGL((fps_kernel<16, TV>), dim3(B), dim3(TV), lds, st, a);     \
+    else hipLaunchKernelGGL((fps_kernel<32, TV>), dim3(B), dim3(TV), lds, st, a);                    \
+  } while (0)
+  if (threads == 64) PC3D_FPS(64);
+  else if (threads == 128) PC3D_FPS(128);
+  else if (threads == 256) PC3D_FPS(256);
+  else if (threads == 512) PC3D_FPS(512);
+  else PC3D_FPS(1024);
+#undef PC3D_FPS
+  PC3D_LAUNCH_CHECK(nm);
   return PC3D_OK;
+}
+
+extern "C" int pc3d_fps_f32(const float* xyz, int64_t x_bs, int64_t x_ps, int64_t x_cs, int B, int N, int S,
+                            const int32_t* start, int32_t* out, void* stream) {
+  // threads per cloud by N (tools/bench_fps.py, ns per step at 64 / 128 / 256 / 512 threads): N = 512: 390 / 463 / 561 / 856;
+  // 1024: 521 / 519 / 580 / 858; 2048: 966 / 671 / 650 / 957; 4096: - / 1106 / 799 / 1091 — a step is a latency chain (update,
+  // wave arg-max, exchange + barrier, winner's coordinates): fewer wavefronts shorten the exchange until the per-lane work takes over
+  const int threads = N <= 512 ? 64 : (N <= 1024 ? 128 : FPS_T);
+  return fps_launch("pc3d_fps_f32", threads, xyz, x_bs, x_ps, x_cs, B, N, S, start, out, stream);
+}
+
+// the same sampling with the workgroup size named (256 / 512 / 1024 threads per cloud): for tests and measurements
+extern "C" int pc3d_fps_threads_f32(int threads, const float* xyz, int64_t x_bs, int64_t x_ps, int64_t x_cs, int B, int N, int S,
+                                    const int32_t* start, int32_t* out, void* stream) {
+  return fps_launch("pc3d_fps_threads_f32", threads, xyz, x_bs, x_ps, x_cs, B, N, S, start, out, stream);
 }
 
 // kernel: 0 = choose, 1 = a wavefront per centre, 2 = a centre per lane (error when its limits are exceeded)

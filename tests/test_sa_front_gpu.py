@@ -340,3 +340,21 @@ def test_nn_int64_indices_from_the_search_launch(ops, dev):
     np.testing.assert_allclose(a.grad.cpu().numpy(), (2 * (a.detach() - nearest)).cpu().numpy(), rtol=1e-5, atol=1e-6)
     r3 = ku.knn_points(a.detach(), b, K=3)
     assert r3.idx.dtype == torch.int64 and torch.equal(r3.idx[:, :, 0], i32.long())
+
+
+@pytest.mark.parametrize("B,N,S", [(3, 512, 128), (2, 1000, 256), (2, 2048, 64), (1, 37, 37)])
+def test_fps_same_indices_for_every_workgroup_size(ops, dev, B, N, S):
+    """pc3d_fps_threads_f32: the sampling with 64 ... 1024 threads per cloud gives the indices of pc3d_fps_f32 (which picks
+    the size by N) — the arg-max tie rule (lowest index) does not depend on how the points are spread over the lanes."""
+    lib = M("3dpointcloudattack_amd._lib")
+    rng = np.random.default_rng(N)
+    x = torch.from_numpy(np.round(rng.standard_normal((B, N, 3)) * 4).astype(np.float32) / 4).to(dev)     # many exact ties
+    start = torch.from_numpy(rng.integers(0, N, B).astype(np.int32)).to(dev)
+    ref = ops.fps(x, S, start)
+    for thr in (64, 128, 256, 512, 1024):
+        if N > 32 * thr:
+            continue
+        out = torch.empty((B, S), dtype=torch.int32, device=dev)
+        lib.call("pc3d_fps_threads_f32", thr, x.data_ptr(), x.stride(0), x.stride(1), x.stride(2), B, N, S, start.data_ptr(),
+                 out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        assert torch.equal(out, ref), thr

@@ -13,3 +13,17 @@ for B, N, S in ((32, 4096, 1024), (64, 2048, 512), (64, 512, 128), (32, 1024, 25
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 10 * 1e3
     print(f"B={B} N={N} S={S}: {us:.1f} us, {us / S * 1e3:.0f} ns per step", flush=True)
+    lib = importlib.import_module("3dpointcloudattack_amd._lib")
+    out = torch.empty((B, S), dtype=torch.int32, device=dev)
+    ref = ops.fps(x, S, None)
+    for thr in (64, 128, 256, 512):
+        if N > thr * 32:
+            continue
+        call = lambda: lib.call("pc3d_fps_threads_f32", thr, x.data_ptr(), x.stride(0), x.stride(1), x.stride(2), B, N, S, 0,
+                                out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        for _ in range(3): call()
+        e0.record()
+        for _ in range(10): call()
+        e1.record(); torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / 10 * 1e3
+        print(f"    {thr} threads: {us:.1f} us, {us / S * 1e3:.0f} ns per step, equal {bool(torch.equal(out, ref))}", flush=True)
