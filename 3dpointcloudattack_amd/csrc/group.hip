@@ -577,6 +577,128 @@ __global__ __launch_bounds__(GMB_T * KS) void group_max_linear_bwd_kernel(GroupM
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// The same backward with the group's channels SORTED BY WINNING ROW first (a counting sort in LDS by the wavefront that
+// owns the group): a row's gradient is then a plain register sum over a contiguous run of (channel, gradient) pairs and
+// leaves in one store — no register array addressed through M0 (the form above spends ~15 instructions per channel, ten of
+// them on the indexed read-modify-write), channels whose masked gradient is zero drop out (a third to a half of them: the
+// max was not positive), and only rows that won something are visited. Order: the slots of the sort are handed out by
+// ds_add_rtn of ONE wavefront in channel order (chunks of 64, inside a chunk the hardware's fixed lane order), so a row's
+// channels are summed in one order for given inputs.
+// Workgroup = one wavefront = (group, 64 input channels); needs the sign-bit mask form (xmask) and writes amask.
+// ---------------------------------------------------------------------------------------------------------
+template <int NS>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void group_max_bwd_csr_kernel(GroupMaxBwdArgs a) {
+  extern __shared__ float gmc_lds[];
+  float2* s_e = reinterpret_cast<float2*>(gmc_lds);              // [C3] (channel | row << 16, gradient), sorted by row
+  int* s_off = reinterpret_cast<int*>(s_e + 2 * a.C3);           // [NS + 1] row offsets
+  int* s_cur = s_off + NS + 1;                                    // [NS] fill cursors
+  const int g = blockIdx.x, lane = threadIdx.x;
+  const int k = blockIdx.y * 64 + lane;
+  const bool live = k < a.C2;
+  const int64_t base = (int64_t)g * a.C3;
+  for (int j = lane; j <= NS; j += 64) s_off[j] = 0;
+  wave_lds_sync();
+  // pass 1: the group's kept (row, gradient) pairs, parked unsorted in LDS; row histogram
+  float2* s_t = s_e + a.C3;                                       // [C3] parking area (behind the sorted list)
+  for (int c0 = 0; c0 < a.C3; c0 += 64) {
+    const int c = c0 + lane;
+    float x = 0.f;
+    int rw = -1;
+    if (c < a.C3) {
+      x = (a.out[base + c] > 0.f) ? a.gout[base + c] : 0.f;
+      if (x != 0.f) {
+        rw = (int)a.arg[base + c] & (NS - 1);
+        atomicAdd(&s_off[rw + 1], 1);
+      }
+      s_t[c] = make_float2(__builtin_bit_cast(float, rw), x);
+    }
+  }
+  wave_lds_sync();
+  {   // inclusive scan of s_off[1 .. NS] (NS <= 128: two bins per lane)
+    const int e0 = 2 * lane + 1, e1 = 2 * lane + 2;
+    const int v0 = e0 <= NS ? s_off[e0] : 0, v1 = e1 <= NS ? s_off[e1] : 0;
+    int sc = v0 + v1;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(sc, d, 64);
+      if (lane >= d) sc += o;
+    }
+    const int excl = sc - (v0 + v1);
+    wave_lds_sync();
+    if (e0 <= NS) s_off[e0] = excl + v0, s_cur[e0 - 1] = excl;
+    if (e1 <= NS) s_off[e1] = excl + v0 + v1, s_cur[e1 - 1] = excl + v0;
+  }
+  wave_lds_sync();
+  // pass 2: slots in channel order
+  for (int c0 = 0; c0 < a.C3; c0 += 64) {
+    const int c = c0 + lane;
+    if (c < a.C3) {
+      const float2 pr = s_t[c];
+      const int rw = __builtin_bit_cast(int, pr.x);
+      if (rw >= 0) {
+        const int slot = atomicAdd(&s_cur[rw], 1);
+        s_e[slot] = make_float2(__builtin_bit_cast(float, c | (rw << 16)), pr.y);
+      }
+    }
+  }
+  wave_lds_sync();
+  const int nent = s_off[NS];
+  // rows that won something; the first wavefront column of the group publishes them
+  constexpr int NW = NS / 32;
+  uint32_t act[NW];
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    const int j = 32 * w + (lane & 31);
+    const unsigned long long bal = __builtin_amdgcn_ballot_w64(lane < 32 && s_off[j + 1] > s_off[j]);
+    act[w] = (uint32_t)bal;
+  }
+  if (a.amask && blockIdx.y == 0 && lane < NW) a.amask[(int64_t)g * NW + lane] = lane == 0 ? act[0] : (lane == 1 ? act[NW > 1 ? 1 : 0] : (lane == 2 ? act[NW > 2 ? 2 : 0] : act[NW > 3 ? 3 : 0]));
+  // the rows' layer-2 sign words for this wavefront's 64 columns: lane l holds the word of row (l & 31) + 32 w, column half l >> 5
+  const int wpr = a.C2 >> 5, kw = (blockIdx.y * 64) >> 5;
+  uint32_t mword[NW];
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    const int wrow = 32 * w + (lane & 31), wcol = kw + (lane >> 5);
+    mword[w] = (wrow < a.ns && wcol < wpr) ? a.xmask[((int64_t)g * a.ns + wrow) * wpr + wcol] : 0u;
+  }
+  const float* wcol = a.W + (live ? k : 0);
+  float* o = a.gx + (int64_t)g * a.ns * a.C2 + k;
+  auto flush = [&](int row, float acc) {          // row: uniform
+    uint32_t lo = 0u, hi = 0u;
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+      if ((row >> 5) == w) lo = __builtin_amdgcn_readlane(mword[w], row & 31), hi = __builtin_amdgcn_readlane(mword[w], 32 + (row & 31));
+    const uint32_t wd = (lane & 32) ? hi : lo;
+    if (live && row < a.ns) o[(int64_t)row * a.C2] = ((wd >> (k & 31)) & 1u) ? acc : 0.f;
+  };
+  float acc = 0.f;
+  int cur_row = -1;
+  for (int t0 = 0; t0 < nent; t0 += 8) {
+    float2 e2[8];
+    float ww[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int t = t0 + u < nent ? t0 + u : nent - 1;
+      e2[u] = s_e[t];
+      const int code = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, e2[u].x));
+      ww[u] = wcol[(int64_t)(code & 0xffff) * a.C2];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (t0 + u < nent) {
+        const int row = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, e2[u].x)) >> 16;
+        if (row != cur_row) {
+          if (cur_row >= 0) flush(cur_row, acc);
+          acc = 0.f, cur_row = row;
+        }
+        acc = __builtin_fmaf(e2[u].y, ww[u], acc);
+      }
+    }
+  }
+  if (cur_row >= 0) flush(cur_row, acc);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Forward of the same operator: out[g,c] = max_r relu(x[g,r,:] . W[c,:] + b[c]), arg[g,c] = winning row — the last
 // 1x1 conv + ReLU + max over the group of a set-abstraction layer (model/pointnet2_utils.py:190-197) WITHOUT writing
 // the [G*ns, C3] activation (537 MB per layer at SSG's B=64, N=2048) and reading it back for the max.
@@ -1034,6 +1156,16 @@ static int group_max_linear_bwd_launch(const float* gout, const float* out, cons
   const dim3 grid(G, cdiv(C2, bt)), block(bt);
   hipStream_t st = as_stream(stream);
   const size_t lds = 2 * (size_t)C3 * sizeof(float);
+  if (amask && xmask && (ns == 32 || ns == 64 || ns == 128) && C3 <= 1024 && C3 <= 65535) {
+    // the sparse form: channels sorted by winning row (group_max_bwd_csr_kernel), one wavefront per (group, 64 columns)
+    const dim3 gridc(G, cdiv(C2, 64));
+    const size_t ldsc = (size_t)2 * C3 * sizeof(float2) + (size_t)(2 * ns + 1) * sizeof(int);
+    if (ns == 32) hipLaunchKernelGGL(group_max_bwd_csr_kernel<32>, gridc, dim3(64), ldsc, st, a);
+    else if (ns == 64) hipLaunchKernelGGL(group_max_bwd_csr_kernel<64>, gridc, dim3(64), ldsc, st, a);
+    else hipLaunchKernelGGL(group_max_bwd_csr_kernel<128>, gridc, dim3(64), ldsc, st, a);
+    PC3D_LAUNCH_CHECK("pc3d_group_max_linear_bwd_sparse_f32");
+    return PC3D_OK;
+  }
   if (ksplit > 1) {
     PC3D_REQUIRE(ksplit == 4 && C3 % 32 == 0, "pc3d_group_max_linear_bwd_ks_f32: ksplit=%d (1 or 4; C3 %% 32 == 0)", ksplit);
     const size_t lds4 = lds + (size_t)3 * 32 * bt * sizeof(float);
