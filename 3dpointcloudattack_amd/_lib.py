@@ -59,6 +59,7 @@ SIGNATURES = {
     "pc3d_scatter_points_det_f32": [_P, _P, _I, _I, _I] + _PTS + [_P],
     "pc3d_rows_max_f32": [_P, _L, _I, _I, _P, _P, _P],
     "pc3d_gemm_nt_groupsum_f32": [_P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P],
+    "pc3d_gemm_nt_groupsum_packed_f32": [_P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "pc3d_group_act_bwd_points_f32": [_P] * 6 + [_I] * 5 + [_F, _P, _P],
     "pc3d_group_max_linear_bwd_ks_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _I, _P],
     "pc3d_group_max_linear_bwd_sparse_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P],

@@ -2301,6 +2301,9 @@ SA_CHAIN_BWD = True
 # ... on the rows that won a channel of the group max only (pc3d_group_max_linear_bwd_sparse_f32 and the amask arguments
 # of the two launches after it): the other rows carry exact zeros. Bit-identical; False = full tensors, for A/B timing.
 SA_BWD_SPARSE = True
+# ... with the GEMM + groups launch over tiles PACKED with whole groups' active rows (pc3d_gemm_nt_groupsum_packed_f32)
+# instead of 128 consecutive rows. Bit-identical; False = consecutive rows, for A/B timing.
+SA_BWD_PACKED = True
 # The chain launch over a block table (ops.sa_blocks): 32-row blocks of nothing but padding copies are left out and the rest
 # packed into fewer tiles (same results; False = every block, for A/B timing).
 SA_BLOCK_TABLE = True
@@ -2406,8 +2409,15 @@ class _GroupedMLPMaxFn(torch.autograd.Function):
             gP = torch.empty((B, NA, C1), dtype=torch.float32, device=dev)
             w2t = _w_transposed(w2)
             with torch.cuda.device(dev):
-                _lib.call("pc3d_gemm_nt_groupsum_f32", gz.data_ptr(), C2, w2t.data_ptr(), mask.data_ptr(), idx.data_ptr(),
-                          _ptr(amask), B, S, ns, C1, C2, gh1.data_ptr(), gBc.data_ptr(), tail.data_ptr(), _stream())
+                if sparse and SA_BWD_PACKED and ns <= 64:
+                    G = B * S
+                    scratch = torch.empty((G + 4 + (G + 3) // 4,), dtype=torch.int32, device=dev)
+                    _lib.call("pc3d_gemm_nt_groupsum_packed_f32", gz.data_ptr(), C2, w2t.data_ptr(), mask.data_ptr(),
+                              idx.data_ptr(), amask.data_ptr(), B, S, ns, C1, C2, gh1.data_ptr(), gBc.data_ptr(),
+                              tail.data_ptr(), scratch.data_ptr(), _stream())
+                else:
+                    _lib.call("pc3d_gemm_nt_groupsum_f32", gz.data_ptr(), C2, w2t.data_ptr(), mask.data_ptr(), idx.data_ptr(),
+                              _ptr(amask), B, S, ns, C1, C2, gh1.data_ptr(), gBc.data_ptr(), tail.data_ptr(), _stream())
                 if ctx.rev_event is not None:    # built on the geometry stream, after the sampling chain (pointnet2_utils)
                     torch.cuda.current_stream(dev).wait_event(ctx.rev_event)
                 # (no amask here: the rows the sparse launches leave unwritten are the ball query's padding copies, which the

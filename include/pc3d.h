@@ -255,6 +255,13 @@ int pc3d_group_max_linear_bwd_sparse_f32(const float* gout, const float* out, co
 int pc3d_gemm_nt_groupsum_f32(const float* X, int64_t ldx, const float* Wt, const uint8_t* mask1, const int32_t* idx,
                               const uint32_t* amask, int B, int S, int ns, int C1, int K, float* Y, float* gBc, float* tail,
                               void* stream);
+/* pc3d_gemm_nt_groupsum_f32 with amask over PACKED tiles: a tile is a run of whole groups whose active rows fill 128 rows
+ * (a first one-workgroup launch assigns groups to tiles from amask's bit counts), instead of 128 consecutive rows of
+ * which a third are active. Same results bit for bit. scratch: B*S + 4 + ceil(B*S / 4) int32 (overwritten). ns in {32, 64};
+ * amask must not be NULL. */
+int pc3d_gemm_nt_groupsum_packed_f32(const float* X, int64_t ldx, const float* Wt, const uint8_t* mask1, const int32_t* idx,
+                                     const uint32_t* amask, int B, int S, int ns, int C1, int K, float* Y, float* gBc,
+                                     float* tail, int32_t* scratch, void* stream);
 int pc3d_group_act_bwd_points_f32(const float* gH, const uint8_t* mask, const float* tail, const int32_t* off,
                                   const int32_t* lst, const uint32_t* amask, int B, int NA, int S, int K, int C, float slope,
                                   float* gP, void* stream);

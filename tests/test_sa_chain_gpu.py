@@ -85,7 +85,7 @@ def test_sa_chain_vs_float64(ops, dev):
                                                 (1, 300, 7, 64, 64, 128, 320),       # ragged last row tile
                                                 (2, 256, 9, 32, 128, 64, 96)])
 def test_sa_chain_backward_fused_gemm_groupsum_bitwise(ops, dev, B, N, S, ns, C1, C2, C3):
-    """The chain's backward in its three forms — (a) max-backward on the ACTIVE rows / GEMM on W2^T + groups pass in one
+    """The chain's backward in its forms — (a) max-backward on the ACTIVE rows / GEMM on W2^T + groups pass in one
     launch over the compacted active rows / points pass skipping the others, (b) the same on full tensors, (c) the four
     separate launches: the gradients to P and Bc are BIT-identical (the skipped terms are exact zeros, everything else is
     summed in the same order). The allocator's free blocks are filled with NaN first: a read of a row the sparse producer
@@ -94,19 +94,22 @@ def test_sa_chain_backward_fused_gemm_groupsum_bitwise(ops, dev, B, N, S, ns, C1
     if not ops.grouped_mlp_max_supported(C1, ns, layers):
         pytest.skip("shape not on the fused path")
     res = []
-    for fused, sparse in ((True, True), (True, False), (False, False)):
-        ops.SA_CHAIN_BWD, ops.SA_BWD_SPARSE = fused, sparse
+    for fused, sparse, packed in ((True, True, True), (True, True, False), (True, False, False), (False, False, False)):
+        ops.SA_CHAIN_BWD, ops.SA_BWD_SPARSE, ops.SA_BWD_PACKED = fused, sparse, packed
         try:
             junk = [torch.full((n,), float("nan"), device=dev) for n in (B * S * ns * C2, B * S * ns * C1, B * N * C1, 1 << 20)]
             del junk
             res.append(_run(ops, P, Bc, idx, layers, w, chain=True))
         finally:
-            ops.SA_CHAIN_BWD, ops.SA_BWD_SPARSE = True, True
-    (o1, gp1, gb1), (o2, gp2, gb2), (o0, gp0, gb0) = res
+            ops.SA_CHAIN_BWD, ops.SA_BWD_SPARSE, ops.SA_BWD_PACKED = True, True, True
+    (o3, gp3, gb3), (o1, gp1, gb1), (o2, gp2, gb2), (o0, gp0, gb0) = res
     assert torch.equal(o1, o0) and torch.isfinite(gp1).all() and torch.isfinite(gb1).all()
     assert torch.equal(gb1, gb0), float((gb1 - gb0).abs().max())
     assert torch.equal(gp1, gp0), float((gp1 - gp0).abs().max())
     assert torch.equal(gb2, gb0) and torch.equal(gp2, gp0)
+    assert torch.isfinite(gp3).all() and torch.isfinite(gb3).all()       # tiles packed with whole groups' active rows
+    assert torch.equal(gb3, gb0), float((gb3 - gb0).abs().max())
+    assert torch.equal(gp3, gp0), float((gp3 - gp0).abs().max())
 
 
 @pytest.mark.parametrize("B,N,S,ns,C1,C2,C3", [(8, 512, 128, 64, 128, 128, 256),    # SSG SA2: streaming kernel, 32-row units

@@ -28,6 +28,8 @@ if os.environ.get("PC3D_SA_TABLE") == "32":      # unit tables for the streaming
     _ops.sa_chain_table_unit = lambda *a: (_orig_unit(*a) if _orig_unit(*a) == 32 else 0)
 if os.environ.get("PC3D_SA_SPARSE") == "0":
     M("3dpointcloudattack_amd.ops").SA_BWD_SPARSE = False
+if os.environ.get("PC3D_SA_PACKED") == "0":
+    M("3dpointcloudattack_amd.ops").SA_BWD_PACKED = False
 if os.environ.get("PC3D_REV_INDEX") == "0":
     M("3dpointcloudattack_amd.model.pointnet2_utils").REVERSE_INDEX = False
 res = {}
