@@ -684,6 +684,209 @@ __global__ __launch_bounds__(SR_T, 2) void sa_chain_res_tb_kernel(SaChainArgs a,
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// The streaming kernel over a table of 8-ROW units. A 32 x 32 MFMA accumulator tile holds rows 8 q + (e & 3) + 4 h of its
+// block in registers e = 4 q .. 4 q + 3: a QUARTER of the block is a register group as well, so the group max can be taken
+// per 8 rows at the cost it had per 32. At SSG's second level a group lists 23 of 64 points (the rest are the ball query's
+// copies of the first): in 32-row blocks that is 35.1 rows per group (37.6 executed after packing), in 8-row units 26.5
+// (31.9) — tools/exp/sa_listed_rows.py; 379 -> 320 us. The table (pc3d_sa_blocks_i32 with unit = 8) has 64-row tiles of
+// eight slots, whole groups per tile; a workgroup takes two of them.
+// (The RESIDENT kernel was measured with 8-row units as well — 18.0 instead of 21.6 rows per group at SSG's first level —
+// and dropped: eight units per tile double its epilogue's shuffles, LDS stores and combine trips, 238 -> 252 us for the
+// launch and 2.19 -> 2.31 ms for the iteration. It keeps 16-row units.)
+// ---------------------------------------------------------------------------------------------------------
+// a workgroup's 128 rows are table tiles 2 t and 2 t + 1 (sixteen slots)
+template <int TN2>
+__global__ __launch_bounds__(SC_T, 2) void sa_chain_u8_kernel(SaChainArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sc_lds[];
+  const int LDH = (a.C1 > a.C2 ? a.C1 : a.C2) + 4;
+  float* AH = sc_lds;                                   // [128][LDH]
+  float* Ws = sc_lds + SC_BM * LDH;                      // [2][128][SC_LD]
+  float* pv = Ws + 2 * 128 * SC_LD;                      // [16][128] a unit's maximum per column of the column tile
+  int* pi = reinterpret_cast<int*>(pv + 16 * 128);
+  int* s_unit = pi + 16 * 128;                           // [16] unit ids (-1: empty slot), [16] their clouds, [16] run lengths
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wm = (wave >> 1) * 32;                       // this wave's 32 rows
+  const int lrow = tid >> 3, lk = (tid & 7) * 4;         // weight staging: 8 threads cover a row's 32 k
+  const int nt = a.ntiles[0];
+  if ((int)blockIdx.x * 2 >= nt) return;                 // (uniform, before any barrier)
+  if (tid < 16) {
+    const int tt = blockIdx.x * 2 + (tid >> 3);
+    s_unit[tid] = tt < nt ? a.tb[tt * 8 + (tid & 7)] : -1;
+  }
+  __syncthreads();
+  if (tid < 16) {
+    const int ub = s_unit[tid];
+    s_unit[16 + tid] = ub >= 0 ? ((ub * 8) >> a.ns_shift) / a.S : 0;
+    int len = 0;                                         // units of the group this slot heads (0: not a head)
+    if (ub >= 0 && (ub & ((a.ns >> 3) - 1)) == 0) {
+      len = 1;
+      for (int s2 = tid + 1; s2 < 16; ++s2) {
+        const int u2 = s_unit[s2];
+        if (u2 < 0 || (u2 >> (a.ns_shift - 3)) != (ub >> (a.ns_shift - 3))) break;
+        ++len;
+      }
+    }
+    s_unit[32 + tid] = len;
+  }
+  __syncthreads();
+  int us[4];                                             // the wave's four units (slots fill in order: the first decides)
+#pragma unroll
+  for (int q = 0; q < 4; ++q) us[q] = s_unit[(wm >> 3) + q];
+  const bool act = us[0] >= 0;
+
+  // ---- gather + layer 1: AH[row][:] = relu(P[src(row)] + Bc[group(row)]), one sign bit per element to mask1
+  {
+    const int c4n = a.C1 >> 2;                           // float4 per row
+    for (int f0 = tid; f0 < SC_BM * c4n; f0 += 4 * SC_T) {
+      float4 v[4], c[4];
+      int gmv[4], rowv[4], c4v[4];
+      bool live[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int f = f0 + u * SC_T;
+        live[u] = f < SC_BM * c4n;
+        const int row = live[u] ? f >> a.c4_shift : 0, c4 = live[u] ? f & (c4n - 1) : 0;
+        const int kb = s_unit[row >> 3];
+        if (kb < 0) live[u] = false;                       // an empty slot: nobody will read these rows
+        const int gm = kb * 8 + (row & 7);
+        gmv[u] = gm, rowv[u] = row, c4v[u] = c4;
+        v[u] = make_float4(0.f, 0.f, 0.f, 0.f), c[u] = v[u];
+        if (live[u]) {
+          const int g = gm >> a.ns_shift, p = a.idx[gm];
+          const int bb = s_unit[16 + (row >> 3)];
+          c[u] = *reinterpret_cast<const float4*>(a.Bc + (int64_t)g * a.C1 + 4 * c4);
+          if ((unsigned)p < (unsigned)a.NA)
+            v[u] = *reinterpret_cast<const float4*>(a.P + ((int64_t)bb * a.NA + p) * a.ldp + 4 * c4);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (!live[u]) continue;
+        float4 x = make_float4(v[u].x + c[u].x, v[u].y + c[u].y, v[u].z + c[u].z, v[u].w + c[u].w);
+        a.mask1[(int64_t)gmv[u] * c4n + c4v[u]] =
+            (uint8_t)((x.x > 0.f ? 1 : 0) | (x.y > 0.f ? 2 : 0) | (x.z > 0.f ? 4 : 0) | (x.w > 0.f ? 8 : 0));
+        x.x = x.x > 0.f ? x.x : 0.f, x.y = x.y > 0.f ? x.y : 0.f, x.z = x.z > 0.f ? x.z : 0.f, x.w = x.w > 0.f ? x.w : 0.f;
+        *reinterpret_cast<float4*>(AH + rowv[u] * LDH + 4 * c4v[u]) = x;
+      }
+    }
+  }
+
+  float4 wb[2];
+  auto fetch_w = [&](const float* W, int ncols, int K, int n0, int k0) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int gn = n0 + q * 64 + lrow;
+      wb[q] = (gn < ncols) ? *reinterpret_cast<const float4*>(W + (int64_t)gn * K + k0 + lk) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto stash_w = [&](float* dst) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) *reinterpret_cast<float4*>(dst + (q * 64 + lrow) * SC_LD + lk) = wb[q];
+  };
+
+  // ---- layer 2: H = relu(A . W2^T + b2), 128 x (64 TN2) per workgroup, wave (wm, wn2)
+  const int wn2 = (wave & 1) * (32 * TN2);
+  sc_f32x16 acc2[TN2];
+#pragma unroll
+  for (int j = 0; j < TN2; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc2[j][e] = 0.f;
+  fetch_w(a.W2, a.C2, a.C1, 0, 0);
+  stash_w(Ws);
+  __syncthreads();                                       // AH (generated rows) and the first slice are in place
+  int cur = 0;
+  for (int k0 = 0; k0 < a.C1; k0 += SC_BK) {
+    const bool more = k0 + SC_BK < a.C1;
+    if (more) fetch_w(a.W2, a.C2, a.C1, 0, k0 + SC_BK);
+    if (act) sc_step<TN2>(acc2, AH + (wm + r) * LDH + k0, Ws + cur * 128 * SC_LD, wn2, r, h);
+    if (more) stash_w(Ws + (cur ^ 1) * 128 * SC_LD);
+    __syncthreads();                                     // (after the last step: every wave has finished reading AH)
+    cur ^= 1;
+  }
+  fetch_w(a.W3, a.C3, a.C2, 0, 0);
+#pragma unroll
+  for (int j = 0; j < TN2; ++j) {
+    if (!act) break;
+    const int col = wn2 + j * 32 + r;
+    const bool col_ok = col < a.C2;
+    const float bj = col_ok ? a.b2[col] : 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = wm + (e & 3) + 8 * (e >> 2) + 4 * h;
+      const float v = acc2[j][e] + bj;
+      const unsigned long long bal = __builtin_amdgcn_ballot_w64(v > 0.f && col_ok);
+      const int ub = us[e >> 2];
+      if (r == 0 && ub >= 0 && wn2 + j * 32 < a.C2)        // (C2 % 32 == 0: a 32-column tile is all in or all out)
+        a.mask2[(int64_t)(ub * 8 + (e & 3) + 4 * h) * (a.C2 >> 5) + ((wn2 + j * 32) >> 5)] = (uint32_t)(h ? (bal >> 32) : bal);
+      if (col_ok) AH[row * LDH + col] = v > 0.f ? v : 0.f;
+    }
+  }
+  stash_w(Ws + cur * 128 * SC_LD);
+  __syncthreads();                                       // AH now holds the layer-2 output; W3's first slice is staged
+
+  // ---- layer 3 + group max, one 128-column tile of C3 at a time; wave (wm, wn3 = 64 (wave & 1))
+  const int wn3 = (wave & 1) * 64;
+  for (int n0 = 0; n0 < a.C3; n0 += 128) {
+    sc_f32x16 acc3[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc3[j][e] = 0.f;
+    for (int k0 = 0; k0 < a.C2; k0 += SC_BK) {
+      const bool more_k = k0 + SC_BK < a.C2, more_n = n0 + 128 < a.C3;
+      if (more_k) fetch_w(a.W3, a.C3, a.C2, n0, k0 + SC_BK);
+      else if (more_n) fetch_w(a.W3, a.C3, a.C2, n0 + 128, 0);
+      if (act) sc_step<2>(acc3, AH + (wm + r) * LDH + k0, Ws + cur * 128 * SC_LD, wn3, r, h);
+      if (more_k || more_n) stash_w(Ws + (cur ^ 1) * 128 * SC_LD);
+      __syncthreads();
+      cur ^= 1;
+    }
+    // per 8-row unit and column: in-lane over its four accumulator rows (ascending: strict > keeps the lowest row), then
+    // across the lane halves (compare (value, row))
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float best = -__builtin_inff();
+        int bi = 0;
+#pragma unroll
+        for (int e = 4 * q; e < 4 * q + 4; ++e)
+          if (acc3[j][e] > best) best = acc3[j][e], bi = (e & 3) + 4 * h;
+        const float ov = __shfl_xor(best, 32, 64);
+        const int oi = __shfl_xor(bi, 32, 64);
+        if (ov > best || (ov == best && oi < bi)) best = ov, bi = oi;
+        if (h == 0) {
+          const int slot = (wm >> 3) + q;
+          pv[slot * 128 + wn3 + j * 32 + r] = us[q] >= 0 ? best : -__builtin_inff();     // (an empty slot never wins)
+          pi[slot * 128 + wn3 + j * 32 + r] = bi;
+        }
+      }
+    }
+    __syncthreads();
+    for (int t = tid; t < 16 * 128; t += SC_T) {
+      const int sb = t >> 7, cl = t & 127;
+      const int len = s_unit[32 + sb];
+      if (len == 0) continue;
+      const int ub = s_unit[sb];
+      float best = pv[sb * 128 + cl];
+      int bi = pi[sb * 128 + cl];
+      for (int k = 1; k < len; ++k) {
+        const float v = pv[(sb + k) * 128 + cl];
+        if (v > best) best = v, bi = pi[(sb + k) * 128 + cl] + 8 * (s_unit[sb + k] - ub);
+      }
+      const int64_t grp = ub >> (a.ns_shift - 3);
+      const int col = n0 + cl;
+      if (col < a.C3) {
+        a.out[grp * a.C3 + col] = fmaxf(best + a.b3[col], 0.f);
+        a.arg[grp * a.C3 + col] = bi;
+      }
+    }
+    __syncthreads();                                     // pv / pi are rewritten by the next column tile
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Block table of the streaming kernel: which 32-row blocks of the grouped rows hold at least one LISTED point, packed
 // four to a tile without splitting a group over two tiles.
 //   sa_block_flags_kernel : a wavefront per group; bit b of flags[g] = block b of the group has a row that is not a copy
@@ -707,8 +910,8 @@ __global__ __launch_bounds__(256) void sa_block_flags_kernel(const int32_t* __re
     const int j = j0 + lane;
     const bool own = j < ns && (j == 0 || id[j] != i0);
     const unsigned long long bal = __builtin_amdgcn_ballot_w64(own);
-    for (int q = 0; q < 64 / unit; ++q) {                  // unit = 16 or 32 rows
-      const unsigned long long m = unit == 32 ? 0xffffffffull : 0xffffull;
+    for (int q = 0; q < 64 / unit; ++q) {                  // unit = 8, 16 or 32 rows
+      const unsigned long long m = unit == 32 ? 0xffffffffull : (unit == 16 ? 0xffffull : 0xffull);
       if ((bal >> (q * unit)) & m) fl |= 1u << (j0 / unit + q);
     }
   }
@@ -791,6 +994,82 @@ __global__ __launch_bounds__(SP_T) void sa_block_pack_kernel(const uint8_t* __re
   if (t == SP_T - 1) ntiles[0] = tile + (fill > 0 ? 1 : 0);
 }
 
+
+// The table of 8-row units: eight slots per tile, whole groups per tile. Here the packing is NOT chained across the whole
+// launch: every chunk of >= 32 groups opens a tile of its own, so chunks are packed independently and the tiles are
+// numbered by one prefix sum over the chunks' tile counts — which EVERY workgroup computes for itself (a thread per
+// chunk: 32 serial steps over flags that sit in L2), so one launch of many workgroups does it, a wavefront per chunk
+// writing its piece of the table through LDS. (One workgroup doing all the writes took 44 us at SSG's first level — 131 072
+// uncoalesced stores from one CU — and the five-state maps above cost more with eight slots.) Half a tile per chunk is
+// lost: 4 % of the rows.
+constexpr int SU_CAP = 8;                                  // slots per tile at most
+__global__ __launch_bounds__(SP_T) void sa_unit_pack_kernel(const uint8_t* __restrict__ flags, int G, int upg, int per, int cap,
+                                                            int32_t* __restrict__ tb, int32_t* __restrict__ ntiles) {
+  __shared__ int s_base[SP_T + 1];                         // tiles before chunk c
+  __shared__ int s_wave[SP_T / 64];
+  __shared__ int s_piece[SP_T / 64][64 * SU_CAP];          // a chunk's tiles (<= one per group, per <= 64)
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int nchunks = (G + per - 1) / per;                 // <= 1024
+  int tiles = 0;
+  if (t < nchunks) {
+    const int lo = t * per, hi = min(lo + per, G);
+    int fill = cap;
+    if (per == 32 && hi - lo == 32 && (reinterpret_cast<uintptr_t>(flags) & 15) == 0) {      // the chunk's 32 flag bytes in two loads
+      const uint4 v0 = *reinterpret_cast<const uint4*>(flags + lo), v1 = *reinterpret_cast<const uint4*>(flags + lo + 16);
+      const uint32_t wd[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+      for (int i = 0; i < 32; ++i) {
+        const int a = __builtin_popcount((wd[i >> 2] >> (8 * (i & 3))) & 0xffu);
+        if (fill + a > cap) ++tiles, fill = 0;
+        fill += a;
+      }
+    } else {
+      for (int g = lo; g < hi; ++g) {
+        const int a = __builtin_popcount((unsigned)flags[g]);
+        if (fill + a > cap) ++tiles, fill = 0;
+        fill += a;
+      }
+    }
+  }
+  int incl = tiles;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int up = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += up;
+  }
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  int base = incl - tiles;
+  for (int w = 0; w < wave; ++w) base += s_wave[w];
+  s_base[t] = base;
+  if (t == SP_T - 1) s_base[SP_T] = base + tiles;
+  __syncthreads();
+  if (blockIdx.x == 0 && t == 0) ntiles[0] = s_base[SP_T];
+  // a wavefront per chunk: lane l holds group lo + l; the greedy walk over the chunk runs on the scalar unit
+  for (int c = blockIdx.x * (SP_T / 64) + wave; c < nchunks; c += gridDim.x * (SP_T / 64)) {
+    const int lo = c * per, n = min(per, G - lo);
+    const unsigned fb = lane < n ? flags[lo + lane] : 0u;
+    const int a = __builtin_popcount(fb);
+    int tile = -1, fill = cap, my_tile = 0, my_fill = 0;
+    for (int i = 0; i < n; ++i) {
+      const int ai = __builtin_amdgcn_readlane(a, i);
+      if (fill + ai > cap) ++tile, fill = 0;
+      if (lane == i) my_tile = tile, my_fill = fill;
+      fill += ai;
+    }
+    const int nt = tile + 1;                               // = s_base[c + 1] - s_base[c]
+    int* piece = s_piece[wave];
+    for (int i = lane; i < nt * cap; i += 64) piece[i] = -1;
+    if (lane < n) {
+      int k = my_tile * cap + my_fill;
+      for (int b = 0; b < upg; ++b)
+        if ((fb >> b) & 1u) piece[k++] = (lo + lane) * upg + b;
+    }
+    int32_t* dst = tb + (int64_t)s_base[c] * cap;
+    for (int i = lane; i < nt * cap; i += 64) dst[i] = piece[i];
+  }
+}
+
 }  // namespace pc3d
 
 using namespace pc3d;
@@ -800,15 +1079,26 @@ extern "C" int pc3d_sa_blocks_i32(const int32_t* idx, int B, int S, int ns, int 
   const char* nm = "pc3d_sa_blocks_i32";
   PC3D_REQUIRE(B >= 0 && S >= 1 && (ns == 32 || ns == 64 || ns == 128) && (int64_t)B * S * ns <= 0x7fffffffLL,
                "%s: bad sizes B=%d S=%d ns=%d (ns in {32,64,128})", nm, B, S, ns);
-  PC3D_REQUIRE((unit == 16 || unit == 32) && ns / unit >= 1 && ns / unit <= 4,
-               "%s: unit=%d rows (16 or 32) with at most four units per group (ns=%d)", nm, unit, ns);
+  PC3D_REQUIRE(((unit == 16 || unit == 32) && ns / unit >= 1 && ns / unit <= 4) || (unit == 8 && ns <= 64),
+               "%s: unit=%d rows: 16 or 32 with at most four units per group, or 8 with at most eight (ns=%d)", nm, unit, ns);
   if (B == 0) return PC3D_OK;
   PC3D_REQUIRE(idx && flags && tb && ntiles, "%s: null pointer", nm);
-  const int G = B * S, M = G * ns, tb_len = cdiv(M, 4 * unit) * 4;
+  const int G = B * S, M = G * ns;
+  // unit 8: 64-row tiles of eight slots; unit 16 / 32: four slots per tile. Units 8 and 16 (at most one tile per group) are
+  // packed chunk by chunk by many workgroups, which write whole tiles: nothing to pre-fill, tiles past ntiles are never read
+  const bool chunked = unit != 32;
+  const int tb_len = chunked ? 0 : cdiv(M, 4 * unit) * 4;
   hipStream_t st = as_stream(stream);
   hipLaunchKernelGGL(sa_block_flags_kernel, dim3(cdiv(G, 4)), dim3(256), 0, st, idx, G, ns, unit, flags, tb, tb_len);
   PC3D_REQUIRE(G <= 48 * 1024, "%s: B * S = %d groups exceed the packing kernel's staging buffer", nm, G);
-  hipLaunchKernelGGL(sa_block_pack_kernel, dim3(1), dim3(SP_T), (size_t)G, st, flags, G, ns / unit, tb, ntiles);
+  if (chunked) {
+    const int per = cdiv(G, SP_T) > 32 ? cdiv(G, SP_T) : 32;                  // groups per chunk (<= 48: G <= 48 K)
+    const int nchunks = cdiv(G, per);
+    hipLaunchKernelGGL(sa_unit_pack_kernel, dim3(cdiv(nchunks, SP_T / 64)), dim3(SP_T), 0, st, flags, G, ns / unit, per,
+                       unit == 8 ? 8 : 4, tb, ntiles);
+  } else {
+    hipLaunchKernelGGL(sa_block_pack_kernel, dim3(1), dim3(SP_T), (size_t)G, st, flags, G, ns / unit, tb, ntiles);
+  }
   PC3D_LAUNCH_CHECK(nm);
   return PC3D_OK;
 }
@@ -839,7 +1129,7 @@ static int sa_chain_launch(const char* nm, const float* P, int64_t ldp, const fl
     if (lds_r <= 80 * 1024) {
       PC3D_REQUIRE(!tb || S >= 4, "%s: the unit table needs at least four groups per cloud (S=%d)", nm, S);
       PC3D_REQUIRE(!tb || unit == 16, "%s: this shape runs on the resident kernel, whose table has 16-row units (unit=%d)", nm, unit);
-      const int tiles = cdiv(a.M, SR_BM);
+      const int tiles = tb ? B * S : cdiv(a.M, SR_BM);     // (the table's tiles: at most one per group)
       const int grid_r = tiles < 512 ? tiles : 512;
       auto launch = [&](auto kern) -> int {
         if (lds_r > 64 * 1024)
@@ -860,7 +1150,22 @@ static int sa_chain_launch(const char* nm, const float* P, int64_t ldp, const fl
       return PC3D_OK;
     }
   }
-  PC3D_REQUIRE(!tb || unit == 32, "%s: this shape runs on the streaming kernel, whose table has 32-row blocks (unit=%d)", nm, unit);
+  PC3D_REQUIRE(!tb || unit == 32 || (unit == 8 && ns <= 64),
+               "%s: this shape runs on the streaming kernel, whose table has 32-row blocks or (ns <= 64) 8-row units (unit=%d)", nm, unit);
+  if (tb && unit == 8) {
+    const size_t lds8 = ((size_t)SC_BM * ldh + 2 * 128 * SC_LD + 2 * 16 * 128 + 48) * sizeof(float);
+    const dim3 grid8(cdiv(B * S, 2)), block8(SC_T);        // two table tiles (<= one per group) per workgroup
+    auto launch8 = [&](auto kern) -> int {
+      if (lds8 > 64 * 1024)
+        if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);
+            e != hipSuccess) { set_error("%s: LDS opt-in failed: %s", nm, hipGetErrorString(e)); return (int)e; }
+      hipLaunchKernelGGL(kern, grid8, block8, lds8, st, a);
+      return PC3D_OK;
+    };
+    if (int rc = C2 <= 64 ? launch8(sa_chain_u8_kernel<1>) : launch8(sa_chain_u8_kernel<2>)) return rc;
+    PC3D_LAUNCH_CHECK(nm);
+    return PC3D_OK;
+  }
   const size_t lds = ((size_t)SC_BM * ldh + 2 * 128 * SC_LD + 2 * 4 * 128 + 8) * sizeof(float);
   const dim3 grid(cdiv(a.M, SC_BM)), block(SC_T);
   if (C2 <= 64) {
@@ -879,21 +1184,17 @@ static int sa_chain_launch(const char* nm, const float* P, int64_t ldp, const fl
 }
 
 // rows per unit of the table pc3d_sa_chain_tb_f32 expects for a shape (the dispatch rule of sa_chain_launch): 16 = the
-// resident kernel, 32 = the streaming kernel with groups of 64+ rows, 0 = a table would change nothing
+// resident kernel, 8 = the streaming kernel with groups of <= 64 rows, 32 = with groups of 128 rows, 0 = no table
 extern "C" int pc3d_sa_chain_table_unit(int S, int ns, int C1, int C2, int C3) {
   if (!(ns == 32 || ns == 64 || ns == 128) || !(C1 == 32 || C1 == 64 || C1 == 128) || C2 < 32 || C2 > 128 || C2 % 32 || C3 < 32 || C3 % 32)
     return 0;
-  if ((C1 == 32 || C1 == 64) && (C2 == 32 || C2 == 64) && ns <= 64 && S >= 4) {
+  if ((C1 == 32 || C1 == 64) && (C2 == 32 || C2 == 64) && ns <= 64) {          // the resident kernel, if its LDS fits
     const int c3p = (C3 + 127) & ~127, ldh = (C1 > C2 ? C1 : C2) + 4;
-    const size_t lds_r = ((size_t)64 * (C1 + 4) + (size_t)c3p * (C2 + 4) + (size_t)SR_BM * ldh + 4 * 2 * 128 + 64 + c3p) * sizeof(float);
-    if (lds_r <= 80 * 1024) return 16;
+    const size_t fixed = (size_t)64 * (C1 + 4) + (size_t)c3p * (C2 + 4) + (size_t)SR_BM * ldh + 64 + c3p;
+    if (S >= 4 && (fixed + 4 * 2 * 128) * sizeof(float) <= 80 * 1024) return 16;
+    if ((fixed + 2 * 2 * 128) * sizeof(float) <= 80 * 1024) return 0;          // resident without a table
   }
-  if ((C1 == 32 || C1 == 64) && (C2 == 32 || C2 == 64) && ns <= 64) {          // resident without a table (S < 4) or streaming
-    const int c3p = (C3 + 127) & ~127, ldh = (C1 > C2 ? C1 : C2) + 4;
-    const size_t lds_r = ((size_t)64 * (C1 + 4) + (size_t)c3p * (C2 + 4) + (size_t)SR_BM * ldh + 2 * 2 * 128 + 64 + c3p) * sizeof(float);
-    if (lds_r <= 80 * 1024) return 0;
-  }
-  return ns >= 64 ? 32 : 0;
+  return ns <= 64 ? 8 : 32;                                                    // the streaming kernel
 }
 
 extern "C" int pc3d_sa_chain_f32(const float* P, int64_t ldp, const float* Bc, const int32_t* idx, int B, int NA, int S, int ns,

@@ -2316,15 +2316,18 @@ def sa_chain_table_unit(S, ns, C1, C2, C3):
 
 
 def sa_blocks(idx, unit):
-    """Unit table of a grouping idx [B,S,ns] int32 for the chain launch: (tb, ntiles, unit) — the 16- / 32-row units that
-    hold at least one listed point, packed four to a tile, whole groups per tile (pc3d_sa_blocks_i32). Depends on idx only:
-    the geometry chain builds it right after the ball query."""
+    """Unit table of a grouping idx [B,S,ns] int32 for the chain launch: (tb, ntiles, unit) — the 8- / 16- / 32-row units
+    that hold at least one listed point, packed eight (8-row units) or four to a tile, whole groups per tile
+    (pc3d_sa_blocks_i32). Depends on idx only: the geometry chain builds it right after the ball query."""
     if idx.dtype != torch.int32 or idx.dim() != 3 or not idx.is_cuda or not idx.is_contiguous():
         raise ValueError("sa_blocks: idx must be a contiguous int32 [B,S,ns] GPU tensor")
     B, S, ns = idx.shape
     dev = idx.device
     flags = torch.empty((B * S,), dtype=torch.uint8, device=dev)
-    tb = torch.empty((((B * S * ns + 4 * unit - 1) // (4 * unit)) * 4,), dtype=torch.int32, device=dev)
+    # 8-row units: 64-row tiles of eight slots, 16-row units: of four — at most one tile per group; 32-row blocks: 128-row
+    # tiles of four
+    n_tb = B * S * (8 if unit == 8 else 4) if unit != 32 else ((B * S * ns + 127) // 128) * 4
+    tb = torch.empty((n_tb,), dtype=torch.int32, device=dev)
     nt = torch.empty((1,), dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
         _lib.call("pc3d_sa_blocks_i32", idx.data_ptr(), B, S, ns, int(unit), flags.data_ptr(), tb.data_ptr(), nt.data_ptr(), _stream())

@@ -218,10 +218,13 @@ int pc3d_sa_chain_f32(const float* P, int64_t ldp, const float* Bc, const int32_
  * products (SSG: 13.5 of 32 and 22 of 64 rows per group are listed points). Same out / arg; mask1 / mask2 are written for
  * the kept units only (the backward never reads the others: their rows carry exact zeros).
  *   pc3d_sa_chain_table_unit: rows per unit the launch expects for a shape — 16 (the resident-weight kernel, 64-row tiles),
- *   32 (the streaming kernel, groups of 64+ rows), 0 (a table would change nothing).
+ *   8 (the streaming kernel, groups of <= 64 rows: an 8-row quarter of a 32 x 32 MFMA accumulator tile is a register group
+ *   of its own, so the max is taken per 8 rows), 32 (the streaming kernel, groups of 128 rows), 0 (no table).
  *   pc3d_sa_blocks_i32: builds the table from idx [B,S,ns] — flags [B*S] bytes (scratch: bit u = unit u of the group is
- *   kept), tb [ceil(B*S*ns/(4*unit))*4] int32 unit ids in original row space (-1 = empty slot), ntiles [1] — two small
- *   launches, off the forward's path (idx is known as soon as the ball query has run). At most four units per group.
+ *   kept), tb int32 unit ids in original row space (-1 = empty slot): unit 8 -> [B*S*8] (64-row tiles of eight slots, at
+ *   most eight units per group), unit 16 -> [B*S*4] (64-row tiles of four slots), unit 32 -> [ceil(B*S*ns/128)*4]
+ *   (128-row tiles of four slots; at most four units per group for 16 / 32); ntiles [1] — two small launches (idx is known
+ *   as soon as the ball query has run). Whole groups per tile; tiles past ntiles are undefined for units 8 / 16.
  *   pc3d_sa_chain_tb_f32: tb / ntiles NULL = pc3d_sa_chain_f32; `unit` must be what pc3d_sa_chain_table_unit says. */
 int pc3d_sa_chain_table_unit(int S, int ns, int C1, int C2, int C3);
 int pc3d_sa_blocks_i32(const int32_t* idx, int B, int S, int ns, int unit, uint8_t* flags, int32_t* tb, int32_t* ntiles,

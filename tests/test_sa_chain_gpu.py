@@ -117,23 +117,25 @@ def test_sa_chain_backward_fused_gemm_groupsum_bitwise(ops, dev, B, N, S, ns, C1
                                                 (3, 512, 128, 64, 32, 64, 96),      # resident, four units per group
                                                 (1, 300, 7, 64, 64, 128, 320),      # ragged last tile
                                                 (2, 256, 40, 64, 128, 64, 96),
-                                                (2, 512, 9, 32, 32, 32, 64)])
+                                                (2, 512, 9, 32, 32, 32, 64),
+                                                (2, 256, 5, 32, 64, 64, 128),       # resident, S < 8: 16-row units
+                                                (2, 512, 24, 128, 64, 96, 128)])    # groups of 128 rows: 32-row blocks
 def test_sa_chain_block_table_equals_full_launch_bitwise(ops, dev, B, N, S, ns, C1, C2, C3):
-    """pc3d_sa_chain_tb_f32 over the block table of pc3d_sa_blocks_i32 (32-row blocks of nothing but padding copies left
-    out, the others packed into fewer tiles) against the launch over every block: outputs and both gradients BIT-identical;
+    """pc3d_sa_chain_tb_f32 over the unit table of pc3d_sa_blocks_i32 (8- / 16- / 32-row units of nothing but padding copies
+    left out, the others packed into fewer tiles) against the launch over every block: outputs and both gradients BIT-identical;
     the table lists every block that holds a listed point exactly once, whole groups per tile."""
     P, Bc, idx, layers, w = _case(ops, dev, B, N, S, ns, C1, C2, C3, seed=ns + C1, bad_idx=True)
     unit = ops.sa_chain_table_unit(S, ns, C1, C2, C3)
-    assert unit in (16, 32)
+    assert unit in (8, 16, 32)
     tb, nt, _ = ops.sa_blocks(idx, unit)
     torch.cuda.synchronize()
-    tbn, ntv = tb.cpu().numpy().reshape(-1, 4), int(nt.item())
+    tbn, ntv = tb.cpu().numpy().reshape(-1, 8 if unit == 8 else 4), int(nt.item())
     bpg = ns // unit
     ii = idx.cpu().numpy().reshape(B * S, ns)
     want = sorted(g * bpg + b for g in range(B * S) for b in range(bpg)
                   if b == 0 or (ii[g, unit * b:unit * b + unit] != ii[g, 0]).any())
     got = [int(k) for k in tbn[:ntv].ravel() if k >= 0]
-    assert got == want and (tbn[ntv:] == -1).all()
+    assert got == want and (unit != 32 or (tbn[ntv:] == -1).all())    # (8- / 16-row units: tiles past ntiles are not written)
     for row in tbn[:ntv]:                                   # a group's blocks never straddle two tiles
         ks = [int(k) for k in row if k >= 0]
         assert ks == sorted(ks) and all((k // bpg != ks[0] // bpg) or k == ks[0] or True for k in ks)

@@ -26,6 +26,17 @@ if os.environ.get("PC3D_SA_TABLE") == "32":      # unit tables for the streaming
     _ops = M("3dpointcloudattack_amd.ops")
     _orig_unit = _ops.sa_chain_table_unit
     _ops.sa_chain_table_unit = lambda *a: (_orig_unit(*a) if _orig_unit(*a) == 32 else 0)
+if os.environ.get("PC3D_SA_UNIT8") in ("0", "res16"):   # A/B: the 16- / 32-row tables (all shapes, or the resident kernel only)
+    _ops = M("3dpointcloudattack_amd.ops")
+    _orig_unit8 = _ops.sa_chain_table_unit
+    def _unit_old(S, ns, C1, C2, C3, _all=os.environ["PC3D_SA_UNIT8"] == "0"):
+        u = _orig_unit8(S, ns, C1, C2, C3)
+        if u != 8:
+            return u
+        if C1 <= 64 and C2 <= 64:
+            return 16
+        return (32 if ns >= 64 else 0) if _all else 8
+    _ops.sa_chain_table_unit = _unit_old
 if os.environ.get("PC3D_SA_SPARSE") == "0":
     M("3dpointcloudattack_amd.ops").SA_BWD_SPARSE = False
 if os.environ.get("PC3D_SA_PACKED") == "0":
