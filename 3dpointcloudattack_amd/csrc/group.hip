@@ -76,8 +76,12 @@ __global__ __launch_bounds__(T) void fps_kernel(FpsArgs a) {
     // wave arg-max on DPP (the shuffle version cost ~800 cycles of LDS-crossbar latency per step): the maximum
     // first, then the lowest index among the lanes that hold it (= the reference's first-index tie rule)
     {
+      // the lanes that hold the maximum by ballot: ONE lane unless two points are exactly equidistant — then its index comes
+      // by readlane, and only a tie takes the second DPP reduction
       const float wv = wave_max_dpp(bv);
-      bi = wave_min_dpp_i32(bv == wv ? bi : 0x7fffffff);
+      const unsigned long long tie = __builtin_amdgcn_ballot_w64(bv == wv);
+      if (__builtin_popcountll(tie) == 1) bi = __builtin_amdgcn_readlane(bi, __builtin_ctzll(tie));
+      else bi = wave_min_dpp_i32(bv == wv ? bi : 0x7fffffff);
       bv = wv;
     }
     float fv = bv;
