@@ -510,7 +510,7 @@ def main():
             np.random.seed(5 + rank)
             atk.attack(d4, l4)
         # dominant kernel of the iteration: the second level's set-abstraction chain (gather -> layers 1-2-3 -> group max, one
-        # launch over the table of 32-row blocks that hold listed points), stand-alone on a grouping with the real padding
+        # launch over the table of 8-row units that hold listed points), stand-alone on a grouping with the real padding
         # structure: 512-point clouds, 128 FPS centres, ball query r = 0.4 / 64 samples
         c4 = clouds(B4, 512, 4242).to(dev)
         with torch.no_grad():
@@ -520,17 +520,18 @@ def main():
             P4, Bc4 = torch.randn(B4, 512, 128, device=dev), torch.randn(B4, 128, 128, device=dev)
             L4 = [(torch.randn(128, 128, device=dev) / 128 ** 0.5, torch.randn(128, device=dev)),
                   (torch.randn(256, 128, device=dev) / 128 ** 0.5, torch.randn(256, device=dev))]
-            blk4 = ops.sa_blocks(idx4, 32)
-            kept4 = int((blk4[0][:int(blk4[1].item()) * 4] >= 0).sum().item())
+            unit4 = ops.sa_chain_table_unit(128, 64, 128, 128, 256)        # rows per unit of the table this shape takes (8)
+            blk4 = ops.sa_blocks(idx4, unit4)
+            kept4 = int((blk4[0][:int(blk4[1].item()) * (8 if unit4 == 8 else 4)] >= 0).sum().item())
         per_row = 2.0 * (128 * 128 + 128 * 256)
 
         def sa2_chain():
             with torch.no_grad():
                 ops.grouped_mlp_max(P4, Bc4, idx4, L4, blocks=blk4)
-        roof4 = kernel_roof("sa_chain_kernel<2> (SSG SA2: 8192 groups x 64 rows, 128 -> 128 -> 256, over the block table)",
-                            sa2_chain, flops=per_row * 32 * kept4,
-                            note=f"flops of the {kept4} kept 32-row blocks of {B4 * 128 * 2} (the others are padding copies of a "
-                                 "group's first point); the reference's count for every row is alg_flops_all_rows")
+        roof4 = kernel_roof("sa_chain_u8_kernel<2> (SSG SA2: 8192 groups x 64 rows, 128 -> 128 -> 256, over the unit table)",
+                            sa2_chain, flops=per_row * unit4 * kept4,
+                            note=f"flops of the {kept4} kept {unit4}-row units of {B4 * 128 * 64 // unit4} (the others are padding "
+                                 "copies of a group's first point); the reference's count for every row is alg_flops_all_rows")
         roof4["alg_flops_all_rows"] = per_row * B4 * 128 * 64
         roof4["frac_all_rows"] = roof4["alg_flops_all_rows"] / roof4["launch_us"] / 1e6 / MFMA_F32_PEAK_TFLOPS
         whole(f"cfg4_knn_ssg_B{B4}_N2048", knn_run, 8, 40, roof4)
