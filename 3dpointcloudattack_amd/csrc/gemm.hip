@@ -344,9 +344,7 @@ __global__ __launch_bounds__(WM * WN * KS * 64, OCC) void gemm_nt_kernel(GemmArg
           const int rl = wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
           if (m0 + rl < a.M && acc[i][j][e] > best) best = acc[i][j][e], bi = rl;
         }
-        const float ov = __shfl_xor(best, 32, 64);
-        const int oi = __shfl_xor(bi, 32, 64);
-        if (ov > best || (ov == best && oi < bi)) best = ov, bi = oi;
+        argmax_xor32(best, bi);
         if (h == 0) {
           pv[((wm >> 5) + i) * BN + wn + j * 32 + r] = best;
           pi[((wm >> 5) + i) * BN + wn + j * 32 + r] = bi;

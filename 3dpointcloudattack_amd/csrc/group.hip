@@ -760,9 +760,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
       const int rr = r0 + (e & 3) + 8 * (e >> 2) + 4 * h;          // ascending in e for fixed h
       if (rr < a.ns && acc[e] > best) best = acc[e], bi = rr;
     }
-    const float ov = __shfl_xor(best, 32, 64);
-    const int oi = __shfl_xor(bi, 32, 64);
-    if (ov > best || (ov == best && oi < bi)) best = ov, bi = oi;
+    argmax_xor32(best, bi);
     const int ch = cb * 32 + r;
     if (nw == 1) {
       if (h == 0) {

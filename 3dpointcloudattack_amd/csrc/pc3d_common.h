@@ -126,6 +126,19 @@ __device__ __forceinline__ float wave_max_dpp(float v) {
   PC3D_DPP_STEP_F(fmaxf, v, 0x143);  // row_bcast:31 -> lane 63 holds the wave maximum
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+// (value, index) of lanes l and l ^ 32 combined IN BOTH lanes: the larger value, the lower index on a tie. One
+// v_permlane32_swap_b32 (gfx950) per operand — a VALU instruction — instead of a ds_bpermute round trip through LDS each.
+// `best` must not be NaN (the arg-max loops that call this start from -inf and update on a strict >).
+__device__ __forceinline__ void argmax_xor32(float& best, int& bi) {
+  const unsigned bv = __builtin_bit_cast(unsigned, best), bu = (unsigned)bi;
+  const auto rv = __builtin_amdgcn_permlane32_swap(bv, bv, false, false);     // [0]: the low half's value, [1]: the high half's
+  const auto ri = __builtin_amdgcn_permlane32_swap(bu, bu, false, false);
+  const float lv = __builtin_bit_cast(float, (unsigned)rv[0]), hv = __builtin_bit_cast(float, (unsigned)rv[1]);
+  const int li = (int)ri[0], hi = (int)ri[1];
+  const bool high = hv > lv || (hv == lv && hi < li);
+  best = high ? hv : lv;
+  bi = high ? hi : li;
+}
 __device__ __forceinline__ int imin_(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int wave_min_dpp_i32(int v) {
   PC3D_DPP_STEP_I(imin_, v, 0x111);

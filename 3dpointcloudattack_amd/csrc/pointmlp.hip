@@ -249,12 +249,7 @@ __global__ __launch_bounds__(PM_FT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         bi = pt;
       }
     }
-    const float ov = __shfl_xor(best, 32, 64);
-    const int oi = __shfl_xor(bi, 32, 64);
-    if (ov > best || (ov == best && oi < bi)) {
-      best = ov;
-      bi = oi;
-    }
+    argmax_xor32(best, bi);
     if (h == 0) {
       pv[ptile * a.C3 + ch] = best;
       pi[ptile * a.C3 + ch] = bi;

@@ -233,9 +233,7 @@ __global__ __launch_bounds__(SC_T, 2) void sa_chain_kernel(SaChainArgs a) {
         const int rl = wm + (e & 3) + 8 * (e >> 2) + 4 * h;
         if (act && acc3[j][e] > best) best = acc3[j][e], bi = rl;     // (an empty slot never wins)
       }
-      const float ov = __shfl_xor(best, 32, 64);
-      const int oi = __shfl_xor(bi, 32, 64);
-      if (ov > best || (ov == best && oi < bi)) best = ov, bi = oi;
+      argmax_xor32(best, bi);
       const int col = n0 + wn3 + j * 32 + r;
       if (tpg == 1) {                                    // ns == 32: the block IS the group
         const int64_t grp = pick4(blk, wm >> 5);
@@ -460,9 +458,7 @@ __global__ __launch_bounds__(SR_T, 2) void sa_chain_res_kernel(SaChainArgs a, in
             if (m0 + rl < a.M && acc3[j][e] > best) best = acc3[j][e], bi = rl;
           }
         }
-        const float ov = __shfl_xor(best, 32, 64);
-        const int oi = __shfl_xor(bi, 32, 64);
-        if (ov > best || (ov == best && oi < bi)) best = ov, bi = oi;
+        argmax_xor32(best, bi);
         const int col = n0 + wn3 + j * 32 + r;
         if (tpg == 1) {
           const int64_t grp = (int64_t)((m0 + wm) >> a.ns_shift);
@@ -644,9 +640,7 @@ __global__ __launch_bounds__(SR_T, 2) void sa_chain_res_tb_kernel(SaChainArgs a,
 #pragma unroll
           for (int e = 8 * half; e < 8 * half + 8; ++e)
             if (acc3[j][e] > best) best = acc3[j][e], bi = (e & 3) + 8 * ((e >> 2) & 1) + 4 * h;     // row inside the unit
-          const float ov = __shfl_xor(best, 32, 64);
-          const int oi = __shfl_xor(bi, 32, 64);
-          if (ov > best || (ov == best && oi < bi)) best = ov, bi = oi;
+          argmax_xor32(best, bi);
           if (h == 0) {
             const int slot = (wm >> 4) + half;
             pv[slot * 128 + wn3 + j * 32 + r] = (half == 0 ? us0 : us1) >= 0 ? best : -__builtin_inff();   // (an empty slot never wins)
@@ -853,9 +847,7 @@ __global__ __launch_bounds__(SC_T, 2) void sa_chain_u8_kernel(SaChainArgs a) {
 #pragma unroll
         for (int e = 4 * q; e < 4 * q + 4; ++e)
           if (acc3[j][e] > best) best = acc3[j][e], bi = (e & 3) + 4 * h;
-        const float ov = __shfl_xor(best, 32, 64);
-        const int oi = __shfl_xor(bi, 32, 64);
-        if (ov > best || (ov == best && oi < bi)) best = ov, bi = oi;
+        argmax_xor32(best, bi);
         if (h == 0) {
           const int slot = (wm >> 3) + q;
           pv[slot * 128 + wn3 + j * 32 + r] = us[q] >= 0 ? best : -__builtin_inff();     // (an empty slot never wins)
