@@ -239,16 +239,20 @@ __global__ __launch_bounds__(PM_FT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     }
     const int ch = cb * 32 + r;
     float best = -__builtin_inff();
-    int bi = n0 + ptile * 32;
+    // the winning accumulator row as an inline constant per select; the point index is formed once after the loop (and the
+    // bounds test only runs in a ragged last tile): the epilogue's VALU instructions do not overlap the other wave's MFMAs
+    int be = 0;
+    const int base = n0 + ptile * 32;
+    if (base + 32 <= a.N) {             // (uniform)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int pt = n0 + ptile * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;  // ascending in e for fixed h
-      const float v = acc[e];
-      if (pt < a.N && v > best) {
-        best = v;
-        bi = pt;
-      }
+      for (int e = 0; e < 16; ++e)      // ascending point index in e for fixed h: strict > keeps the lowest
+        if (acc[e] > best) best = acc[e], be = (e & 3) + 8 * (e >> 2);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        if (base + (e & 3) + 8 * (e >> 2) + 4 * h < a.N && acc[e] > best) best = acc[e], be = (e & 3) + 8 * (e >> 2);
     }
+    int bi = best == -__builtin_inff() ? base : base + be + 4 * h;
     argmax_xor32(best, bi);
     if (h == 0) {
       pv[ptile * a.C3 + ch] = best;
