@@ -112,6 +112,42 @@ def test_sa_chain_backward_fused_gemm_groupsum_bitwise(ops, dev, B, N, S, ns, C1
     assert torch.equal(gp3, gp0), float((gp3 - gp0).abs().max())
 
 
+@pytest.mark.parametrize("B,N,S,ns,C1,C2,C3,mode", [(4, 512, 128, 64, 128, 128, 256, "zero_groups"),
+                                                     (4, 1024, 256, 32, 64, 64, 128, "zero_groups"),
+                                                     (2, 512, 64, 64, 64, 64, 128, "zero_all"),
+                                                     (2, 256, 40, 32, 32, 64, 96, "dense"),       # no padding copies: every row listed
+                                                     (2, 256, 24, 64, 64, 128, 256, "dense")])
+def test_sa_chain_backward_packed_tiles_edge_cases_bitwise(ops, dev, B, N, S, ns, C1, C2, C3, mode):
+    """The packed-tile backward where its tiling is least regular: groups whose upstream gradient is all zero (no active
+    row: the group still owns its weight in a tile and its sums are exact zeros), a gradient that is zero everywhere, and
+    groupings without a single padding copy (up to ns active rows per group: the widest weights the tiling sees) — against
+    the four-launch form, bit for bit."""
+    P, Bc, idx, layers, w = _case(ops, dev, B, N, S, ns, C1, C2, C3, seed=ns + C2 + B)
+    if mode == "zero_groups":
+        w = w.clone()
+        w[:, ::3] = 0.0
+        w[0, : S // 2] = 0.0
+    elif mode == "zero_all":
+        w = torch.zeros_like(w)
+    else:
+        rng = np.random.default_rng(5)
+        idx = torch.from_numpy(np.stack([np.stack([rng.choice(N, ns, replace=False) for _ in range(S)]) for _ in range(B)])
+                               .astype(np.int32)).to(dev)
+    res = []
+    for fused, sparse, packed in ((True, True, True), (False, False, False)):
+        ops.SA_CHAIN_BWD, ops.SA_BWD_SPARSE, ops.SA_BWD_PACKED = fused, sparse, packed
+        try:
+            junk = [torch.full((n,), float("nan"), device=dev) for n in (B * S * ns * C2, B * S * ns * C1, B * N * C1, 1 << 20)]
+            del junk
+            res.append(_run(ops, P, Bc, idx, layers, w, chain=True))
+        finally:
+            ops.SA_CHAIN_BWD, ops.SA_BWD_SPARSE, ops.SA_BWD_PACKED = True, True, True
+    (o1, gp1, gb1), (o0, gp0, gb0) = res
+    assert torch.equal(o1, o0) and torch.isfinite(gp1).all() and torch.isfinite(gb1).all()
+    assert torch.equal(gb1, gb0), float((gb1 - gb0).abs().max())
+    assert torch.equal(gp1, gp0), float((gp1 - gp0).abs().max())
+
+
 @pytest.mark.parametrize("B,N,S,ns,C1,C2,C3", [(8, 512, 128, 64, 128, 128, 256),    # SSG SA2: streaming kernel, 32-row units
                                                 (8, 2048, 512, 32, 64, 64, 128),    # SSG SA1: resident kernel, 16-row units
                                                 (3, 512, 128, 64, 32, 64, 96),      # resident, four units per group
