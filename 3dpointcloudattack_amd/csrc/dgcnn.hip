@@ -125,7 +125,7 @@ __global__ __launch_bounds__(KF_T) void knn_feat_kernel(KnnFeatArgs a) {
         }
       }
       if (NT != 16 && blk + 1 < nblk) first_rows(blk + 1);   // (C = 128: the operand would stay live through the scan: 136 VGPRs)
-      rn += __shfl_xor(rn, 32, 64);            // |r_j|^2 for column j = r
+      rn = sum_xor32(rn);                      // |r_j|^2 for column j = r (the two lane halves hold the two k halves)
       // model/dgcnn.py:195-197 ranks the references of a query by 2 q.r - |q|^2 - |r|^2, largest first. |q|^2 is the
       // same for every candidate of a query, so the key is that of |r|^2 - 2 q.r, smallest first (never -0: x - x is +0;
       // NaN -> +inf by v_min_f32, which returns its other operand for a quiet NaN): 6 VALU per element instead of 10 and

@@ -139,6 +139,12 @@ __device__ __forceinline__ void argmax_xor32(float& best, int& bi) {
   best = high ? hv : lv;
   bi = high ? hi : li;
 }
+// v(lane l) + v(lane l ^ 32) in both lanes, on one v_permlane32_swap_b32 (low half + high half: the same sum in either lane)
+__device__ __forceinline__ float sum_xor32(float v) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
 __device__ __forceinline__ int imin_(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int wave_min_dpp_i32(int v) {
   PC3D_DPP_STEP_I(imin_, v, 0x111);

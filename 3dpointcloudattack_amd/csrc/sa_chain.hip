@@ -689,33 +689,36 @@ __global__ __launch_bounds__(SR_T, 2) void sa_chain_res_tb_kernel(SaChainArgs a,
 // launch and 2.19 -> 2.31 ms for the iteration. It keeps 16-row units.)
 // ---------------------------------------------------------------------------------------------------------
 // a workgroup's 128 rows are table tiles 2 t and 2 t + 1 (sixteen slots)
-template <int TN2>
-__global__ __launch_bounds__(SC_T, 2) void sa_chain_u8_kernel(SaChainArgs a) {
+// BM rows per workgroup: 128 (eight waves, two table tiles) or 64 (four waves, one table tile: 80 KB of LDS, so that TWO
+// workgroups share a CU and one's barriers and epilogues run under the other's MFMAs)
+template <int TN2, int BM>
+__global__ __launch_bounds__(4 * BM, BM == 64 ? 2 : 1) void sa_chain_u8_kernel(SaChainArgs a) {
+  constexpr int NT = 4 * BM, SLOTS = BM / 8, TT = BM / 64;   // threads, unit slots, table tiles per workgroup
   extern __shared__ __attribute__((aligned(16))) float sc_lds[];
   const int LDH = (a.C1 > a.C2 ? a.C1 : a.C2) + 4;
   float* AH = sc_lds;                                   // [128][LDH]
-  float* Ws = sc_lds + SC_BM * LDH;                      // [2][128][SC_LD]
-  float* pv = Ws + 2 * 128 * SC_LD;                      // [16][128] a unit's maximum per column of the column tile
-  int* pi = reinterpret_cast<int*>(pv + 16 * 128);
-  int* s_unit = pi + 16 * 128;                           // [16] unit ids (-1: empty slot), [16] their clouds, [16] run lengths
+  float* Ws = sc_lds + BM * LDH;                         // [2][128][SC_LD]
+  float* pv = Ws + 2 * 128 * SC_LD;                      // [SLOTS][128] a unit's maximum per column of the column tile
+  int* pi = reinterpret_cast<int*>(pv + SLOTS * 128);
+  int* s_unit = pi + SLOTS * 128;                        // [16] unit ids (-1: empty slot), [16] their clouds, [16] run lengths
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int wm = (wave >> 1) * 32;                       // this wave's 32 rows
   const int lrow = tid >> 3, lk = (tid & 7) * 4;         // weight staging: 8 threads cover a row's 32 k
   const int nt = a.ntiles[0];
-  if ((int)blockIdx.x * 2 >= nt) return;                 // (uniform, before any barrier)
-  if (tid < 16) {
-    const int tt = blockIdx.x * 2 + (tid >> 3);
+  if ((int)blockIdx.x * TT >= nt) return;                // (uniform, before any barrier)
+  if (tid < SLOTS) {
+    const int tt = blockIdx.x * TT + (tid >> 3);
     s_unit[tid] = tt < nt ? a.tb[tt * 8 + (tid & 7)] : -1;
   }
   __syncthreads();
-  if (tid < 16) {
+  if (tid < SLOTS) {
     const int ub = s_unit[tid];
     s_unit[16 + tid] = ub >= 0 ? ((ub * 8) >> a.ns_shift) / a.S : 0;
     int len = 0;                                         // units of the group this slot heads (0: not a head)
     if (ub >= 0 && (ub & ((a.ns >> 3) - 1)) == 0) {
       len = 1;
-      for (int s2 = tid + 1; s2 < 16; ++s2) {
+      for (int s2 = tid + 1; s2 < SLOTS; ++s2) {
         const int u2 = s_unit[s2];
         if (u2 < 0 || (u2 >> (a.ns_shift - 3)) != (ub >> (a.ns_shift - 3))) break;
         ++len;
@@ -732,14 +735,14 @@ __global__ __launch_bounds__(SC_T, 2) void sa_chain_u8_kernel(SaChainArgs a) {
   // ---- gather + layer 1: AH[row][:] = relu(P[src(row)] + Bc[group(row)]), one sign bit per element to mask1
   {
     const int c4n = a.C1 >> 2;                           // float4 per row
-    for (int f0 = tid; f0 < SC_BM * c4n; f0 += 4 * SC_T) {
+    for (int f0 = tid; f0 < BM * c4n; f0 += 4 * NT) {
       float4 v[4], c[4];
       int gmv[4], rowv[4], c4v[4];
       bool live[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int f = f0 + u * SC_T;
-        live[u] = f < SC_BM * c4n;
+        const int f = f0 + u * NT;
+        live[u] = f < BM * c4n;
         const int row = live[u] ? f >> a.c4_shift : 0, c4 = live[u] ? f & (c4n - 1) : 0;
         const int kb = s_unit[row >> 3];
         if (kb < 0) live[u] = false;                       // an empty slot: nobody will read these rows
@@ -766,17 +769,18 @@ __global__ __launch_bounds__(SC_T, 2) void sa_chain_u8_kernel(SaChainArgs a) {
     }
   }
 
-  float4 wb[2];
+  constexpr int NQ = 1024 / NT, QR = NT / 8;             // float4 per thread of a [128][32] weight slice, rows per pass
+  float4 wb[NQ];
   auto fetch_w = [&](const float* W, int ncols, int K, int n0, int k0) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int gn = n0 + q * 64 + lrow;
+    for (int q = 0; q < NQ; ++q) {
+      const int gn = n0 + q * QR + lrow;
       wb[q] = (gn < ncols) ? *reinterpret_cast<const float4*>(W + (int64_t)gn * K + k0 + lk) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   auto stash_w = [&](float* dst) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) *reinterpret_cast<float4*>(dst + (q * 64 + lrow) * SC_LD + lk) = wb[q];
+    for (int q = 0; q < NQ; ++q) *reinterpret_cast<float4*>(dst + (q * QR + lrow) * SC_LD + lk) = wb[q];
   };
 
   // ---- layer 2: H = relu(A . W2^T + b2), 128 x (64 TN2) per workgroup, wave (wm, wn2)
@@ -856,7 +860,7 @@ __global__ __launch_bounds__(SC_T, 2) void sa_chain_u8_kernel(SaChainArgs a) {
       }
     }
     __syncthreads();
-    for (int t = tid; t < 16 * 128; t += SC_T) {
+    for (int t = tid; t < SLOTS * 128; t += NT) {
       const int sb = t >> 7, cl = t & 127;
       const int len = s_unit[32 + sb];
       if (len == 0) continue;
@@ -1145,8 +1149,12 @@ static int sa_chain_launch(const char* nm, const float* P, int64_t ldp, const fl
   PC3D_REQUIRE(!tb || unit == 32 || (unit == 8 && ns <= 64),
                "%s: this shape runs on the streaming kernel, whose table has 32-row blocks or (ns <= 64) 8-row units (unit=%d)", nm, unit);
   if (tb && unit == 8) {
-    const size_t lds8 = ((size_t)SC_BM * ldh + 2 * 128 * SC_LD + 2 * 16 * 128 + 48) * sizeof(float);
-    const dim3 grid8(cdiv(B * S, 2)), block8(SC_T);        // two table tiles (<= one per group) per workgroup
+    // 64 rows per workgroup when two such workgroups fit a CU's LDS (<= 80 KB each), else 128
+    const size_t lds64 = ((size_t)64 * ldh + 2 * 128 * SC_LD + 2 * 8 * 128 + 48) * sizeof(float);
+    const bool half = lds64 <= 80 * 1024;        // (SSG's second level: 319 -> 311 us)
+    const int bm = half ? 64 : 128;
+    const size_t lds8 = half ? lds64 : ((size_t)128 * ldh + 2 * 128 * SC_LD + 2 * 16 * 128 + 48) * sizeof(float);
+    const dim3 grid8(cdiv(B * S, bm / 64)), block8(4 * bm);  // (table tiles: <= one per group)
     auto launch8 = [&](auto kern) -> int {
       if (lds8 > 64 * 1024)
         if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);
@@ -1154,7 +1162,10 @@ static int sa_chain_launch(const char* nm, const float* P, int64_t ldp, const fl
       hipLaunchKernelGGL(kern, grid8, block8, lds8, st, a);
       return PC3D_OK;
     };
-    if (int rc = C2 <= 64 ? launch8(sa_chain_u8_kernel<1>) : launch8(sa_chain_u8_kernel<2>)) return rc;
+    int rc;
+    if (half) rc = C2 <= 64 ? launch8(sa_chain_u8_kernel<1, 64>) : launch8(sa_chain_u8_kernel<2, 64>);
+    else rc = C2 <= 64 ? launch8(sa_chain_u8_kernel<1, 128>) : launch8(sa_chain_u8_kernel<2, 128>);
+    if (rc) return rc;
     PC3D_LAUNCH_CHECK(nm);
     return PC3D_OK;
   }
