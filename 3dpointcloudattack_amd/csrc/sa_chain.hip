@@ -1149,12 +1149,10 @@ static int sa_chain_launch(const char* nm, const float* P, int64_t ldp, const fl
   PC3D_REQUIRE(!tb || unit == 32 || (unit == 8 && ns <= 64),
                "%s: this shape runs on the streaming kernel, whose table has 32-row blocks or (ns <= 64) 8-row units (unit=%d)", nm, unit);
   if (tb && unit == 8) {
-    // 64 rows per workgroup when two such workgroups fit a CU's LDS (<= 80 KB each), else 128
-    const size_t lds64 = ((size_t)64 * ldh + 2 * 128 * SC_LD + 2 * 8 * 128 + 48) * sizeof(float);
-    const bool half = lds64 <= 80 * 1024;        // (SSG's second level: 319 -> 311 us)
-    const int bm = half ? 64 : 128;
-    const size_t lds8 = half ? lds64 : ((size_t)128 * ldh + 2 * 128 * SC_LD + 2 * 16 * 128 + 48) * sizeof(float);
-    const dim3 grid8(cdiv(B * S, bm / 64)), block8(4 * bm);  // (table tiles: <= one per group)
+    // 64 rows per workgroup: 79 KB of LDS at the widest shape (128 -> 128), two workgroups per CU (128-row workgroups, one
+    // per CU, were 319 instead of 311 us at SSG's second level)
+    const size_t lds8 = ((size_t)64 * ldh + 2 * 128 * SC_LD + 2 * 8 * 128 + 48) * sizeof(float);
+    const dim3 grid8(B * S), block8(256);                  // (table tiles: <= one per group)
     auto launch8 = [&](auto kern) -> int {
       if (lds8 > 64 * 1024)
         if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);
@@ -1162,9 +1160,7 @@ static int sa_chain_launch(const char* nm, const float* P, int64_t ldp, const fl
       hipLaunchKernelGGL(kern, grid8, block8, lds8, st, a);
       return PC3D_OK;
     };
-    int rc;
-    if (half) rc = C2 <= 64 ? launch8(sa_chain_u8_kernel<1, 64>) : launch8(sa_chain_u8_kernel<2, 64>);
-    else rc = C2 <= 64 ? launch8(sa_chain_u8_kernel<1, 128>) : launch8(sa_chain_u8_kernel<2, 128>);
+    const int rc = C2 <= 64 ? launch8(sa_chain_u8_kernel<1, 64>) : launch8(sa_chain_u8_kernel<2, 64>);
     if (rc) return rc;
     PC3D_LAUNCH_CHECK(nm);
     return PC3D_OK;
