@@ -683,12 +683,11 @@ __global__ __launch_bounds__(SR_T, 2) void sa_chain_res_tb_kernel(SaChainArgs a,
 // per 8 rows at the cost it had per 32. At SSG's second level a group lists 23 of 64 points (the rest are the ball query's
 // copies of the first): in 32-row blocks that is 35.1 rows per group (37.6 executed after packing), in 8-row units 26.5
 // (31.9) — tools/exp/sa_listed_rows.py; 379 -> 320 us. The table (pc3d_sa_blocks_i32 with unit = 8) has 64-row tiles of
-// eight slots, whole groups per tile; a workgroup takes two of them.
+// eight slots, whole groups per tile; a (four-wave) workgroup takes one of them.
 // (The RESIDENT kernel was measured with 8-row units as well — 18.0 instead of 21.6 rows per group at SSG's first level —
 // and dropped: eight units per tile double its epilogue's shuffles, LDS stores and combine trips, 238 -> 252 us for the
 // launch and 2.19 -> 2.31 ms for the iteration. It keeps 16-row units.)
 // ---------------------------------------------------------------------------------------------------------
-// a workgroup's 128 rows are table tiles 2 t and 2 t + 1 (sixteen slots)
 // BM rows per workgroup: 128 (eight waves, two table tiles) or 64 (four waves, one table tile: 80 KB of LDS, so that TWO
 // workgroups share a CU and one's barriers and epilogues run under the other's MFMAs)
 template <int TN2, int BM>
