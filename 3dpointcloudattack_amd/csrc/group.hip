@@ -1030,7 +1030,7 @@ extern "C" int pc3d_fps_f32(const float* xyz, int64_t x_bs, int64_t x_ps, int64_
   return fps_launch("pc3d_fps_f32", threads, xyz, x_bs, x_ps, x_cs, B, N, S, start, out, stream);
 }
 
-// the same sampling with the workgroup size named (256 / 512 / 1024 threads per cloud): for tests and measurements
+// the same sampling with the workgroup size named (64 / 128 / 256 / 512 / 1024 threads per cloud): for tests and measurements
 extern "C" int pc3d_fps_threads_f32(int threads, const float* xyz, int64_t x_bs, int64_t x_ps, int64_t x_cs, int B, int N, int S,
                                     const int32_t* start, int32_t* out, void* stream) {
   return fps_launch("pc3d_fps_threads_f32", threads, xyz, x_bs, x_ps, x_cs, B, N, S, start, out, stream);
