@@ -251,8 +251,8 @@ def _geoA3_attack(net, pt_model, ptm_model, pts_model, dgcnn_model, cur_model, p
         transfer.append(m)
     targeted = cfg.attack_method != 'untarget'
     # a victim with a deterministic forward replays its forward/backward from hipGraphs (graphed.py; the wrapper is
-    # kept on the model, so every batch of a run reuses the captures). cfg.graph_victim = False launches eagerly.
-    net = _graphed.wrap(net, enable=getattr(cfg, "graph_victim", True))
+    # kept on the model, so every batch of a run reuses the captures). cfg.graph_victim = False launches eagerly, True replays, unset = the victim's graph_replay_default.
+    net = _graphed.wrap(net, enable=getattr(cfg, "graph_victim", None))
 
     pc = pc.transpose(2, 1).float().to(dev)
     normal = estimate_normal(pc, k=3)

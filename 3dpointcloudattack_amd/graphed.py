@@ -306,7 +306,11 @@ class GraphedVictim(nn.Module):
 
 
 def wrap(model, enable=True):
-    """``GraphedVictim(model)`` for victims that declare a deterministic forward, the model itself otherwise."""
+    """``GraphedVictim(model)`` for victims that declare a deterministic forward, the model itself otherwise. enable:
+    True / False, or None = the victim's own ``graph_replay_default`` (True unless it says otherwise: for a victim of a
+    few dozen chip-filling launches the replay's static-buffer copies and per-node cost outweigh what the host saves)."""
+    if enable is None:
+        enable = getattr(model, "graph_replay_default", True)
     if not enable or isinstance(model, GraphedVictim) or not getattr(model, "deterministic_forward", False):
         return model
     g = model.__dict__.get("_pc3d_graphed")

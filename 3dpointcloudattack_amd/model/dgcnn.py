@@ -57,6 +57,10 @@ FIRST_LAYER_DIRECT = True      # the first EdgeConv's products and the input gra
 class DGCNN(_FrozenFusedMixin, nn.Module):
     """model/dgcnn.py:262-328. ``args`` needs ``k``, ``emb_dims``, ``dropout``."""
     deterministic_forward = True   # forward is a pure function of its input (no RNG): attack loops may share it
+    # GeoA3 at B=32, N=1024, same box: 1.974 / 1.977 ms per iteration launched eagerly against 2.001 / 2.005 replayed as
+    # two hipGraphs (about sixty chip-filling launches: the host keeps ahead of them, and a replay adds four static-buffer
+    # copies and a per-node cost) — unlike CurveNet's 250 small launches, where eager timings scatter by 1 ms
+    graph_replay_default = False
 
     def __init__(self, args, output_channels=105 + 1):
         super(DGCNN, self).__init__()

@@ -1,6 +1,6 @@
 """Whole-attack wall time per iteration for BASELINE.json configs[2] (GeoA3 on DGCNN, B=32 N=1024), configs[3]
 (KNN attack on PointNet++ SSG, B=64 N=2048) and one GPU's share of configs[4] (CW and GeoA3 on CurveNet, B=32
-N=4096), short runs; prints JSON. PC3D_GRAPH_VICTIM=0 launches the victims eagerly."""
+N=4096), short runs; prints JSON. PC3D_GRAPH_VICTIM=0 / 1 launches every victim eagerly / from hipGraphs (unset: each victim's default)."""
 import importlib, sys, os, json, time, types
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -15,7 +15,8 @@ def mk(modname, cls, seed=0, **kw):
     m.load_state_dict(seeded_state_dict(m, seed)); return m.to(dev).eval()
 rng = np.random.default_rng(0)
 which = sys.argv[1:] or ["geoa3", "knn", "aof"]
-GRAPH = os.environ.get("PC3D_GRAPH_VICTIM", "1") != "0"
+_gv = os.environ.get("PC3D_GRAPH_VICTIM")      # unset: every victim's own default (graphed.wrap)
+GRAPH = None if _gv is None else _gv != "0"
 if os.environ.get("PC3D_FUSE12") == "0":      # A/B switch for the experiment recorded in DESIGN.md
     M("3dpointcloudattack_amd.model.pointnet2_utils").FUSE_LAYERS_1_2 = False
 if os.environ.get("PC3D_L2_BITS") == "0":
@@ -57,7 +58,7 @@ if "cw_curvenet" in which:
     ts = []
     for it in (6, 6, 6 + IT, 6 + 2 * IT, 6 + 3 * IT):      # three slopes, the median is reported (as for the KNN attack)
         atk = cw.CW(net, net, adv.UntargetedLogitsAdvLoss(kappa=0.), cu.ClipPointsLinf(budget=0.18), du.ChamferDist(method='adv2ori'),
-                    attack_lr=1e-2, binary_step=1, num_iter=it, graph=GRAPH)
+                    attack_lr=1e-2, binary_step=1, num_iter=it, graph=True if GRAPH is None else GRAPH)
         torch.manual_seed(0); np.random.seed(0)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         atk.attack(pcs, lab)
