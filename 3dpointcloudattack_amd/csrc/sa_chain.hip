@@ -1084,10 +1084,11 @@ extern "C" int pc3d_sa_blocks_i32(const int32_t* idx, int B, int S, int ns, int 
   const bool chunked = unit != 32;
   const int tb_len = chunked ? 0 : cdiv(M, 4 * unit) * 4;
   hipStream_t st = as_stream(stream);
+  // (checked before any launch by ops.sa_blocks, which then builds no table: the chain launch takes every row)
+  PC3D_REQUIRE(G <= (chunked ? 64 : 48) * 1024, "%s: B * S = %d groups exceed the packing kernel's limit (%d K)", nm, G, chunked ? 64 : 48);
   hipLaunchKernelGGL(sa_block_flags_kernel, dim3(cdiv(G, 4)), dim3(256), 0, st, idx, G, ns, unit, flags, tb, tb_len);
-  PC3D_REQUIRE(G <= 48 * 1024, "%s: B * S = %d groups exceed the packing kernel's staging buffer", nm, G);
   if (chunked) {
-    const int per = cdiv(G, SP_T) > 32 ? cdiv(G, SP_T) : 32;                  // groups per chunk (<= 48: G <= 48 K)
+    const int per = cdiv(G, SP_T) > 32 ? cdiv(G, SP_T) : 32;                  // groups per chunk (<= 64: a lane per group)
     const int nchunks = cdiv(G, per);
     hipLaunchKernelGGL(sa_unit_pack_kernel, dim3(cdiv(nchunks, SP_T / 64)), dim3(SP_T), 0, st, flags, G, ns / unit, per,
                        unit == 8 ? 8 : 4, tb, ntiles);

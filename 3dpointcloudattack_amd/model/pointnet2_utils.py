@@ -306,9 +306,10 @@ class PointNetSetAbstraction(_FrozenFusedMixin, nn.Module):
         blocks = None
         if self.nsample in (32, 64, 128) and len(self.mlp_convs) == 3:
             unit = ops.sa_chain_table_unit(self.npoint, self.nsample, *[c.out_channels for c in self.mlp_convs])
-            if unit:
+            tbl = ops.sa_blocks(idx, unit) if unit else None          # (None: too many groups for the packing launches)
+            if tbl is not None:
                 ev_tb = torch.cuda.Event()
-                blocks = ops.sa_blocks(idx, unit) + (ev_tb,)
+                blocks = tbl + (ev_tb,)
                 ev_tb.record()
         g = [fps_idx, centres, idx, ev, None, None, N, blocks]
         if with_rev:

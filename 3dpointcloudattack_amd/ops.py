@@ -2318,11 +2318,14 @@ def sa_chain_table_unit(S, ns, C1, C2, C3):
 def sa_blocks(idx, unit):
     """Unit table of a grouping idx [B,S,ns] int32 for the chain launch: (tb, ntiles, unit) — the 8- / 16- / 32-row units
     that hold at least one listed point, packed eight (8-row units) or four to a tile, whole groups per tile
-    (pc3d_sa_blocks_i32). Depends on idx only: the geometry chain builds it right after the ball query."""
+    (pc3d_sa_blocks_i32). Depends on idx only: the geometry chain builds it right after the ball query. None when B * S
+    exceeds what the packing launches take (64 K groups; 48 K for 32-row blocks)."""
     if idx.dtype != torch.int32 or idx.dim() != 3 or not idx.is_cuda or not idx.is_contiguous():
         raise ValueError("sa_blocks: idx must be a contiguous int32 [B,S,ns] GPU tensor")
     B, S, ns = idx.shape
     dev = idx.device
+    if B * S > (48 if unit == 32 else 64) * 1024:         # the packing launches' limit: no table, the chain takes every row
+        return None
     flags = torch.empty((B * S,), dtype=torch.uint8, device=dev)
     # 8-row units: 64-row tiles of eight slots, 16-row units: of four — at most one tile per group; 32-row blocks: 128-row
     # tiles of four

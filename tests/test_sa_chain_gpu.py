@@ -116,7 +116,9 @@ def test_sa_chain_backward_fused_gemm_groupsum_bitwise(ops, dev, B, N, S, ns, C1
                                                      (4, 1024, 256, 32, 64, 64, 128, "zero_groups"),
                                                      (2, 512, 64, 64, 64, 64, 128, "zero_all"),
                                                      (2, 256, 40, 32, 32, 64, 96, "dense"),       # no padding copies: every row listed
-                                                     (2, 256, 24, 64, 64, 128, 256, "dense")])
+                                                     (2, 256, 24, 64, 64, 128, 256, "dense"),
+                                                     (100, 512, 500, 32, 32, 32, 64, "zero_groups")])   # 50 000 groups: past the
+                                                                                                        # tile pass's LDS staging
 def test_sa_chain_backward_packed_tiles_edge_cases_bitwise(ops, dev, B, N, S, ns, C1, C2, C3, mode):
     """The packed-tile backward where its tiling is least regular: groups whose upstream gradient is all zero (no active
     row: the group still owns its weight in a tile and its sums are exact zeros), a gradient that is zero everywhere, and
@@ -193,3 +195,28 @@ def test_sa_chain_block_table_equals_full_launch_bitwise(ops, dev, B, N, S, ns, 
     a, b_ = run(True), run(False)
     assert ntv <= tbn.shape[0]
     assert all(torch.equal(u, v) for u, v in zip(a, b_))
+
+
+@pytest.mark.parametrize("G,ns,unit", [(40960, 32, 16), (65536, 32, 8), (33000, 64, 8), (5000, 32, 16)])
+def test_unit_table_of_many_groups(ops, dev, G, ns, unit):
+    """pc3d_sa_blocks_i32 where a packing chunk is longer than 32 groups (B * S > 32 K, up to the launches' 64 K limit): every
+    unit that holds a listed point exactly once, in order, whole groups per tile; beyond the limit no table is built."""
+    rng = np.random.default_rng(G + unit)
+    cnt = rng.integers(1, ns + 1, size=G)                              # listed points per group: a prefix, then copies
+    base = rng.integers(0, 1000, size=(G, 1))
+    ii = np.where(np.arange(ns)[None, :] < cnt[:, None], base + 1 + np.arange(ns)[None, :], base + 1).astype(np.int32)
+    idx = torch.from_numpy(ii.reshape(1, G, ns)).to(dev)
+    tb, nt, _ = ops.sa_blocks(idx, unit)
+    torch.cuda.synchronize()
+    slots = 8 if unit == 8 else 4
+    ntv = int(nt.item())
+    tbn = tb.cpu().numpy().reshape(-1, slots)[:ntv]
+    upg = ns // unit
+    kept = -(-cnt // unit)                                             # units of a group that hold a listed point
+    want = np.concatenate([g * upg + np.arange(k) for g, k in enumerate(kept)])
+    got = tbn[tbn >= 0]
+    assert np.array_equal(got, want)
+    grp = np.where(tbn >= 0, tbn // upg, -1)
+    first, last = np.where(grp >= 0, grp, G + 1).min(1), grp.max(1)
+    assert (first[1:] > last[:-1]).all()                               # a group never straddles two tiles
+    assert ops.sa_blocks(torch.zeros((1, 70000, 32), dtype=torch.int32, device=dev), 16) is None
