@@ -224,7 +224,8 @@ int pc3d_sa_chain_f32(const float* P, int64_t ldp, const float* Bc, const int32_
  *   kept), tb int32 unit ids in original row space (-1 = empty slot): unit 8 -> [B*S*8] (64-row tiles of eight slots, at
  *   most eight units per group), unit 16 -> [B*S*4] (64-row tiles of four slots), unit 32 -> [ceil(B*S*ns/128)*4]
  *   (128-row tiles of four slots; at most four units per group for 16 / 32); ntiles [1] — two small launches (idx is known
- *   as soon as the ball query has run). Whole groups per tile; tiles past ntiles are undefined for units 8 / 16.
+ *   as soon as the ball query has run). Whole groups per tile; tiles past ntiles are undefined for units 8 / 16. B*S <= 64 K
+ *   groups (48 K for unit 32): beyond that the entry point fails and the caller launches pc3d_sa_chain_f32 over every row.
  *   pc3d_sa_chain_tb_f32: tb / ntiles NULL = pc3d_sa_chain_f32; `unit` must be what pc3d_sa_chain_table_unit says. */
 int pc3d_sa_chain_table_unit(int S, int ns, int C1, int C2, int C3);
 int pc3d_sa_blocks_i32(const int32_t* idx, int B, int S, int ns, int unit, uint8_t* flags, int32_t* tb, int32_t* ntiles,
