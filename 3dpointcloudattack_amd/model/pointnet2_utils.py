@@ -301,7 +301,7 @@ class PointNetSetAbstraction(_FrozenFusedMixin, nn.Module):
         idx = ops.ball_query(self.radius, self.nsample, xyz_t, centres)                              # [B,S,ns] i32
         ev = torch.cuda.Event()
         ev.record()                      # what the layer's FORWARD waits for (its front: centres and group indices)
-        # which 16- / 32-row units of the grouped rows hold listed points at all (the chain launch packs those; ops.sa_blocks):
+        # which 8- / 16- / 32-row units of the grouped rows hold listed points at all (the chain launch packs those; ops.sa_blocks):
         # needed by the chain launch only, which waits for the table's own event after the layer's front has been queued
         blocks = None
         if self.nsample in (32, 64, 128) and len(self.mlp_convs) == 3:

@@ -2304,13 +2304,13 @@ SA_BWD_SPARSE = True
 # ... with the GEMM + groups launch over tiles PACKED with whole groups' active rows (pc3d_gemm_nt_groupsum_packed_f32)
 # instead of 128 consecutive rows. Bit-identical; False = consecutive rows, for A/B timing.
 SA_BWD_PACKED = True
-# The chain launch over a block table (ops.sa_blocks): 32-row blocks of nothing but padding copies are left out and the rest
+# The chain launch over a unit table (ops.sa_blocks): 8- / 16- / 32-row units of nothing but padding copies are left out and the rest
 # packed into fewer tiles (same results; False = every block, for A/B timing).
 SA_BLOCK_TABLE = True
 
 
 def sa_chain_table_unit(S, ns, C1, C2, C3):
-    """Rows per unit (16 / 32) of the table the chain launch takes for this shape, or 0 when a table would change nothing
+    """Rows per unit (8 / 16 / 32) of the table the chain launch takes for this shape, or 0 when a table would change nothing
     (pc3d_sa_chain_table_unit: the library's own dispatch rule)."""
     return int(_lib.load().pc3d_sa_chain_table_unit(int(S), int(ns), int(C1), int(C2), int(C3)))
 
