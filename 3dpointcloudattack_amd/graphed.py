@@ -57,7 +57,8 @@ def capture_guard():
     try:
         yield keep
     finally:
-        _KEEP_STACK.remove(keep)
+        assert _KEEP_STACK and _KEEP_STACK[-1] is keep      # guards nest strictly; pop by identity, never by list equality
+        _KEEP_STACK.pop()
         if was:
             gc.enable()
 
@@ -271,7 +272,8 @@ class GraphedVictim(nn.Module):
             object.__setattr__(self, "_input_knn", model.__dict__.get("_input_knn"))
             return out
         with_grad = torch.is_grad_enabled() and x.requires_grad
-        key = (tuple(x.shape), x.dtype, x.device, with_grad, self._weights_key())
+        from . import ops as _ops               # the backward kernel flavour (ordered sums / float atomics) is baked into a capture
+        key = (tuple(x.shape), x.dtype, x.device, with_grad, bool(_ops._det()), self._weights_key())
         slots = self._slots.get(key)
         if slots is None:
             while len(self._slots) >= MAX_CAPTURES:

@@ -209,6 +209,12 @@ def const_vec(device, n, value):
     device = torch.device(device)
     key = (device.type, device.index, int(n), float(np.float32(value)))
     t = _CONST_VECS.get(key)
+    if t is None and torch.cuda.is_current_stream_capturing():
+        # a miss inside a capture: the fill below is only RECORDED, so the tensor is valid inside this graph's replays and
+        # nowhere else — it belongs to the capture (keep-alive list) and never enters the process-wide cache
+        t = torch.full((int(n),), float(np.float32(value)), dtype=torch.float32, device=device)
+        _graphed.note_captured(t)
+        return t
     if t is None:
         if len(_CONST_VECS) >= 256:
             _CONST_VECS.pop(next(iter(_CONST_VECS)))
@@ -998,6 +1004,11 @@ def geoa3_loss_grad(device, B, value):
     (value = 1/B for the batch mean): cached, never written again."""
     key = (torch.device(device).index, int(B), float(np.float32(value)))
     t = _GEO_GFIX.get(key)
+    if t is None and torch.cuda.is_current_stream_capturing():      # as const_vec: owned by the capture, not cached
+        t = torch.zeros((5, int(B)), dtype=torch.float32, device=device)
+        t[4].fill_(float(np.float32(value)))
+        _graphed.note_captured(t)
+        return t
     if t is None:
         if len(_GEO_GFIX) >= 64:
             _GEO_GFIX.pop(next(iter(_GEO_GFIX)))
@@ -1056,6 +1067,10 @@ def _w_transposed(w):
     every point-wise layer re-transposed its weight: 7 copies per DGCNN backward, ~60 per CurveNet backward.)"""
     key = (w.data_ptr(), w._version, tuple(w.shape))
     hit = _WT_CACHE.get(key)
+    if hit is None and torch.cuda.is_current_stream_capturing():    # as const_vec: the transposing copy is only recorded
+        wt = w.t().contiguous()
+        _graphed.note_captured(w, wt)
+        return wt
     if hit is None:
         while len(_WT_CACHE) >= WT_CACHE_MAX:             # oldest entry out, one at a time — never wholesale: a captured
             _WT_CACHE.pop(next(iter(_WT_CACHE)))          # graph that used it holds its own reference (note_captured)

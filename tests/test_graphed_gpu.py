@@ -126,3 +126,25 @@ def test_leaf_grad_accumulates_across_replays(dev):
         (model(leaf)[0] * w2).sum().backward()
     assert g.stats["replayed"] >= 2
     assert (xg.grad - xe.grad).norm() <= 2e-3 * xe.grad.norm()
+
+
+def test_mode_switch_recaptures(dev):
+    """The backward kernel flavour (ordered sums / float atomics) is baked into a capture: a graphed victim used with
+    deterministic=False must not hand that capture to a later deterministic call of the same shape. After an
+    atomic-mode pass, deterministic passes through the SAME wrapper are bit-equal to each other and to the eager victim."""
+    ops = importlib.import_module("3dpointcloudattack_amd.ops")
+    m = _victim(dev, "dgcnn")
+    g = graphed.wrap(m)
+    gen = torch.Generator().manual_seed(5)
+    w = torch.randn(4, 40, generator=gen).to(dev)
+    x = (torch.rand(4, 3, 1024, generator=gen) - 0.5).to(dev)
+    with ops.deterministic(False):
+        _grad(g, x, w)
+        _grad(g, x, w)
+    caps = g.stats["captures"]
+    with ops.deterministic(True):
+        _, g1, _ = _grad(g, x, w)
+        _, g2, _ = _grad(g, x, w)
+        _, ge, _ = _grad(m, x, w)
+    assert g.stats["captures"] == caps + 1, g.stats       # its own capture, not the atomic one's
+    assert torch.equal(g1, g2) and torch.equal(g1, ge)
