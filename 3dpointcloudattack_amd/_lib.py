@@ -54,6 +54,7 @@ SIGNATURES = {
     "pc3d_group_act_bwd_mask_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _I, _P],
     "pc3d_knn_graph_i32": _PTS + [_I, _I, _I, _P, _P, _P, _I, _P],
     "pc3d_fps_threads_f32": [_I] + _PTS + [_I, _I, _I, _P, _P, _P],
+    "pc3d_fps_pruned_f32": _PTS + [_I, _I, _I, _P, _P, _P],
     "pc3d_affine3_f32": _PTS + [_I, _I, _P, _P, _F, _I, _P, _L, _P],
     "pc3d_affine3_bwd_f32": [_P, _L, _I, _I, _I, _P, _F] + _PTS + _PTS + [_P],
     "pc3d_scatter_points_det_f32": [_P, _P, _I, _I, _I] + _PTS + [_P],
@@ -97,6 +98,8 @@ SIGNATURES = {
     "pc3d_gather_max_f32": [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
     "pc3d_gather_max_bwd_f32": [_P, _P, _I, _I, _I, _P, _I, _P],
     "pc3d_graph_laplacian_f32": _PTS + [_P, _I, _I, _I, _P, _P],
+    "pc3d_spectral_reproject_f32": [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
+    "pc3d_rowdot3_f32": [_P, _P, _I, _I, _I, _I, _P, _P, _P],
     "pc3d_clip_f32": _PTS + _PTS + _PTS + [_I, _I, _I, _F] + _PTS + [_P],
     "pc3d_adam_clip_step_f32": _PTS + _PTS + _PTS + [_P, _P] + _PTS + _PTS + [_I, _I, _D, _D, _D, _D, _F, _P, _I, _P],
     "pc3d_i32_add": [_P, _I, _P],

@@ -105,10 +105,9 @@ class CWTAOF:
         for binary_step in range(self.binary_step if fk is None else 0):
             adv_data = ori_data.clone().detach() + torch.randn((B, 3, K)).to(dev) * 1e-7
             Evs, V = get_Laplace_from_pc(adv_data)
-            V_lo, V_hi = V[..., :lp].contiguous(), V[..., lp:].contiguous()
-            projs = torch.bmm(adv_data, V)  # (B, 3, N)
-            hfc = torch.bmm(projs[..., lp:], V_hi.transpose(2, 1)).detach().clone()
-            lfc = torch.bmm(projs[..., :lp], V_lo.transpose(2, 1)).detach().clone()
+            V = V.float().contiguous()
+            Vt = V.transpose(2, 1).contiguous()     # constant for the whole binary step
+            lfc, hfc = ops.spectral_reproject(adv_data.contiguous(), V, Vt, lp)     # :114-126
             lfc.requires_grad_()
             opt = optim.Adam([lfc], lr=self.attack_lr, weight_decay=0.)
 
@@ -125,9 +124,7 @@ class CWTAOF:
                     adv_data = lfc.detach() + hfc
                     if self.clip_func is not None:
                         adv_data = self.clip_func(adv_data.detach().clone(), ori_data)
-                    coeff = torch.bmm(adv_data, V)
-                    hfc = torch.bmm(coeff[..., lp:], V_hi.transpose(2, 1))
-                    lfc.data = torch.bmm(coeff[..., :lp], V_lo.transpose(2, 1))
+                    lfc.data, hfc = ops.spectral_reproject(adv_data.contiguous(), V, Vt, lp)     # :164-170
                     pred = torch.argmax(_logits_of(self.model(adv_data)), dim=1)
                     lfc_pred = torch.argmax(_logits_of(self.model(lfc)), dim=1)
                     dist_val = torch.sqrt(torch.sum((adv_data - ori_data) ** 2, dim=[1, 2]))
@@ -159,8 +156,8 @@ class CWTAOF:
         B, _, K = ori_data.shape
         ffw = importlib_fused_forward()
         st = dict(
-            V=torch.empty((B, K, K), device=dev), V_lo_t=torch.empty((B, lp, K), device=dev),
-            V_hi_t=torch.empty((B, K - lp, K), device=dev), lfc=torch.empty((B, 3, K), device=dev),
+            V=torch.empty((B, K, K), device=dev), Vt=torch.empty((B, K, K), device=dev),
+            coeff=torch.empty((B, 3, K), device=dev), lfc=torch.empty((B, 3, K), device=dev),
             hfc=torch.empty((B, 3, K), device=dev), adv=torch.empty((B, 3, K), device=dev),
             m=torch.zeros((B, 3, K), device=dev), v=torch.zeros((B, 3, K), device=dev),
             step=torch.zeros((1,), dtype=torch.int32, device=dev),
@@ -172,12 +169,8 @@ class CWTAOF:
             if not reuse_basis:      # the eigen-decomposition is the expensive part (~55 ms at B=32, N=1024)
                 _, V = get_Laplace_from_pc(adv0)
                 st["V"].copy_(V)
-                st["V_lo_t"].copy_(V[..., :lp].transpose(2, 1))
-                st["V_hi_t"].copy_(V[..., lp:].transpose(2, 1))
-            V = st["V"]
-            projs = torch.bmm(adv0, V)
-            st["hfc"].copy_(torch.bmm(projs[..., lp:], st["V_hi_t"]))
-            st["lfc"].copy_(torch.bmm(projs[..., :lp], st["V_lo_t"]))
+                st["Vt"].copy_(V.transpose(2, 1))
+            ops.spectral_reproject(adv0.contiguous(), st["V"], st["Vt"], lp, st["lfc"], st["hfc"], st["coeff"])
             st["m"].zero_(), st["v"].zero_(), st["step"].zero_()
 
         def iterate():
@@ -191,9 +184,7 @@ class CWTAOF:
                 adv = lfc + hfc
                 if self.clip_func is not None:
                     adv = self.clip_func(adv, ori_data)
-                coeff = torch.bmm(adv, st["V"])
-                hfc.copy_(torch.bmm(coeff[..., lp:], st["V_hi_t"]))
-                lfc.copy_(torch.bmm(coeff[..., :lp], st["V_lo_t"]))
+                ops.spectral_reproject(adv.contiguous(), st["V"], st["Vt"], lp, lfc, hfc, st["coeff"])     # V, V^T read once each
                 pred = torch.argmax(ffw(self.model, adv)[0], dim=1)
                 lfc_pred = torch.argmax(ffw(self.model, lfc)[0], dim=1)
                 dist_val = torch.sqrt(torch.sum((adv - ori_data) ** 2, dim=[1, 2]))

@@ -30,6 +30,10 @@ int rev_gather_sum(const char* nm, const float* val, int64_t ldv, const float* a
                    const int32_t* lst, int B, int E, int NA, int C, float* out, int64_t ldo, void* stream);
 bool own_fits(int N);   // N destination rows fit the LDS tile of the owner-wave kernels
 
+// fps_pruned.hip: farthest-point sampling on one wavefront per cloud with exact pruning (N <= 4096)
+int fps_pruned_launch(const char* nm, const float* xyz, int64_t x_bs, int64_t x_ps, int64_t x_cs, int B, int N, int S,
+                      const int32_t* start, int32_t* out, void* stream);
+
 // Element strides of a [B, n_points, 3] fp32 point set in caller memory.
 struct PtsView {
   const float* p;

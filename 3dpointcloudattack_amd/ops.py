@@ -2029,6 +2029,28 @@ def graph_laplacian(xyz, k=30, cf=True):
     return L
 
 
+def spectral_reproject(adv, V, Vt, low_pass, lfc=None, hfc=None, coeff=None):
+    """AOF's re-projection of adv [B,3,N] onto the graph-frequency bands of the basis V [B,N,N] (Vt = its transpose, kept
+    beside it): returns (lfc, hfc) = (adv V)[..., :lp] V[..., :lp]^T, (adv V)[..., lp:] V[..., lp:]^T, written into the
+    given buffers when passed (TAOF_attack.py:114-126,164-170). No gradient (the reference runs it under no_grad)."""
+    for nm, t in (("adv", adv), ("V", V), ("Vt", Vt)):
+        _check(t, nm)
+        if not t.is_contiguous():
+            raise ValueError(f"spectral_reproject: {nm} must be contiguous")
+    B, three, N = adv.shape
+    if three != 3 or V.shape != (B, N, N) or Vt.shape != (B, N, N):
+        raise ValueError("spectral_reproject: adv [B,3,N], V and Vt [B,N,N] expected")
+    mk = lambda t: torch.empty((B, 3, N), dtype=torch.float32, device=adv.device) if t is None else t
+    lfc, hfc, coeff = mk(lfc), mk(hfc), mk(coeff)
+    for nm, t in (("lfc", lfc), ("hfc", hfc), ("coeff", coeff)):
+        if t.shape != (B, 3, N) or t.dtype != torch.float32 or not t.is_contiguous() or t.device != adv.device:
+            raise ValueError(f"spectral_reproject: {nm} must be a contiguous fp32 [B,3,N] tensor on adv's device")
+    with torch.cuda.device(adv.device):
+        _lib.call("pc3d_spectral_reproject_f32", adv.data_ptr(), V.data_ptr(), Vt.data_ptr(), B, N, int(low_pass),
+                  coeff.data_ptr(), lfc.data_ptr(), hfc.data_ptr(), _stream())
+    return lfc, hfc
+
+
 # ------------------------------------------------------------------------------------------------------
 # Last 1x1 conv + ReLU + max over the group of a set-abstraction layer, with the sparse backward
 # ------------------------------------------------------------------------------------------------------

@@ -546,6 +546,12 @@ int pc3d_fps_f32(const float* xyz, int64_t x_bs, int64_t x_ps, int64_t x_cs, int
  * are identical; pc3d_fps_f32 takes 64 up to N = 512, 128 up to 1024, else 256): for tests and measurements. */
 int pc3d_fps_threads_f32(int threads, const float* xyz, int64_t x_bs, int64_t x_ps, int64_t x_cs, int B, int N, int S,
                          const int32_t* start, int32_t* out, void* stream);
+/* The same sampling on ONE wavefront per cloud with exact pruning (csrc/fps_pruned.hip): the cloud is split into rows of 64
+ * spatially close points (a k-d partition built inside the launch), and a step updates only the rows whose bounding box is
+ * closer to the new centre than the row's largest running distance. Same arithmetic per point, ties to the lowest index:
+ * the index sequence equals pc3d_fps_threads_f32's bit for bit. N <= 4096. pc3d_fps_f32 chooses between the two. */
+int pc3d_fps_pruned_f32(const float* xyz, int64_t x_bs, int64_t x_ps, int64_t x_cs, int B, int N, int S,
+                        const int32_t* start, int32_t* out, void* stream);
 
 
 /* K6  ball query (model/pointnet2_utils.py:84-104): out[b,s,:] = the first `nsample` point indices in ascending
@@ -768,6 +774,18 @@ int pc3d_lpfa_prep_bwd_f32(const float* gA, const float* gBc, const float* G1, c
  * in the reference's topk); L [B,N,N] f32 is overwritten. Only the N*K graph edges are evaluated. */
 int pc3d_graph_laplacian_f32(const float* xyz, int64_t x_bs, int64_t x_ps, int64_t x_cs,
                              const int32_t* idx, int B, int N, int K, float* L, void* stream);
+
+/* K12b  AOF's per-iteration spectral re-projection (attack/AOF/TAOF_attack.py:114-126 at the start of a binary step,
+ * :164-170 after every optimiser step): coeff = adv . V, lfc = coeff[..., :lp] . V[..., :lp]^T, hfc = coeff[..., lp:] .
+ * V[..., lp:]^T — three torch.bmm with a 3-row left operand in the reference. Here two HBM-bound launches that read V^T
+ * and V once each: adv, coeff (scratch), lfc, hfc [B,3,N] contiguous; V [B,N,N] (column j = eigenvector j, as
+ * torch.symeig / torch.linalg.eigh return it) and Vt = V^T [B,N,N], both contiguous. Sums in a fixed order. */
+int pc3d_spectral_reproject_f32(const float* adv, const float* V, const float* Vt, int B, int N, int lp, float* coeff,
+                                float* lfc, float* hfc, void* stream);
+/* The building block: out[b,c,r] = sum_k vec[b,c,k] * mat[b,r,k] for the 3 rows of vec [B,3,K] against every row of
+ * mat [B,R,K]; with out_hi != NULL the columns k < split go to out_lo and the others to out_hi (both [B,3,R]). */
+int pc3d_rowdot3_f32(const float* mat, const float* vec, int B, int R, int K, int split, float* out_lo, float* out_hi,
+                     void* stream);
 
 /* Classifier tail in one launch: logits = c2 W3^T + b3 (fc3), log_softmax / pred / adversarial loss as
  * pc3d_cls_loss_f32, and g_c2 = (g_logits W3) * (c2 > 0) (fc3 backward + ReLU mask of fc2's activation). K2 <= 256,

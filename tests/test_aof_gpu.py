@@ -92,3 +92,31 @@ def test_taof_graph_replay_equals_eager(dev):
         torch.manual_seed(4)
         outs.append(atk.attack(pcs, tgt, y))
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]) and outs[0][2] == outs[1][2]
+
+
+@pytest.mark.parametrize("B,N,lp", [(2, 1024, 100), (3, 512, 40), (2, 256, 0), (2, 256, 256), (2, 1000, 101), (1, 130, 7),
+                                    (1, 1030, 100), (2, 2048, 100)])
+def test_spectral_reproject_vs_float64_product(ops, dev, B, N, lp):
+    """pc3d_spectral_reproject_f32 (TAOF_attack.py:114-126,164-170) against the float64 products on an orthonormal basis:
+    both bands within fp32 summation error (1e-5 of the band's largest entry); lfc + hfc gives the cloud back; the
+    register form (N % 4 == 0, N <= 1024), the generic form and every position of the band edge are covered."""
+    gen = torch.Generator().manual_seed(N + lp)
+    q, _ = torch.linalg.qr(torch.randn(B, N, N, generator=gen, dtype=torch.float64))
+    adv = torch.randn(B, 3, N, generator=gen, dtype=torch.float64) * 0.4
+    V = q.float().contiguous().to(dev)
+    Vt = V.transpose(1, 2).contiguous()
+    a32 = adv.float().contiguous().to(dev)
+    lfc, hfc = ops.spectral_reproject(a32, V, Vt, lp)
+    V64, a64 = V.double().cpu(), a32.double().cpu()
+    co = a64 @ V64
+    lref = co[..., :lp] @ V64[..., :lp].transpose(1, 2)
+    href = co[..., lp:] @ V64[..., lp:].transpose(1, 2)
+    for got, ref in ((lfc, lref), (hfc, href)):
+        err = (got.double().cpu() - ref).abs().max().item()
+        assert err <= 1e-5 * max(ref.abs().max().item(), 1.0), (err, ref.abs().max().item())
+    torch.testing.assert_close((lfc + hfc).cpu(), a32.cpu(), rtol=0, atol=2e-5)
+    # out= buffers, and a second call gives the same bits (fixed summation tree)
+    l2, h2, c2 = (torch.empty_like(a32) for _ in range(3))
+    ops.spectral_reproject(a32, V, Vt, lp, l2, h2, c2)
+    assert torch.equal(l2, lfc) and torch.equal(h2, hfc)
+    torch.testing.assert_close(c2.double().cpu(), co, rtol=0, atol=1e-5 * max(co.abs().max().item(), 1.0))
