@@ -57,29 +57,33 @@ __device__ __forceinline__ float wave_min_f_dpp(float v) { return -wave_max_dpp(
 // hazard recogniser)
 extern "C" __device__ int fpsp_writelane(int value, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
 
-// Wave maximum of values that are never NaN, wave-uniform result: ONE v_max_f32 with a DPP operand per level (the C++ form
-// compiles to move + DPP move + two canonicalising maxima per level). A DPP instruction needs two wait states after the
-// VALU write of its source, v_readlane one after the last write; the trailing nops cover a VALU read of the SGPR result.
-__device__ __forceinline__ float wave_max_chain(float v) {
-  float r;
+// two rows at once: the chains alternate, so a row's next level is two instructions behind its previous one (the other row's
+// instruction + s_nop 0 = the two wait states a DPP read needs after the VALU write of its source)
+__device__ __forceinline__ void wave_max_chain2(float a, float b, float& ra, float& rb) {
   asm volatile(
       "s_nop 1\n\t"
-      "v_max_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-      "s_nop 1\n\t"
-      "v_max_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-      "s_nop 1\n\t"
-      "v_max_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-      "s_nop 1\n\t"
-      "v_max_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-      "s_nop 1\n\t"
-      "v_max_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xf bank_mask:0xf\n\t"
-      "s_nop 1\n\t"
-      "v_max_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xf bank_mask:0xf\n\t"
-      "s_nop 1\n\t"
-      "v_readlane_b32 %0, %1, 63\n\t"
-      "s_nop 3"
-      : "=s"(r), "+v"(v));
-  return r;
+      "v_max_f32_dpp %2, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %3, %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_max_f32_dpp %2, %2, %2 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %3, %3, %3 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_max_f32_dpp %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %3, %3, %3 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_max_f32_dpp %2, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %3, %3, %3 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_max_f32_dpp %2, %2, %2 row_bcast:15 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %3, %3, %3 row_bcast:15 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_max_f32_dpp %2, %2, %2 row_bcast:31 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %3, %3, %3 row_bcast:31 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_readlane_b32 %0, %2, 63\n\t"
+      "v_readlane_b32 %1, %3, 63\n\t"
+      "s_nop 1"
+      : "=s"(ra), "=s"(rb), "+v"(a), "+v"(b));
 }
 
 // the same over lanes 0..15 (DPP row 0): four levels, the result in lane 15
@@ -96,7 +100,7 @@ __device__ __forceinline__ float wave_max16_chain(float v) {
       "v_max_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
       "s_nop 1\n\t"
       "v_readlane_b32 %0, %1, 15\n\t"
-      "s_nop 3"
+      "s_nop 1"
       : "=s"(r), "+v"(v));
   return r;
 }
@@ -350,41 +354,78 @@ __global__ __launch_bounds__(FPSP_T) void fps_pruned_kernel(FpsPrunedArgs a) {
 #ifdef FPSP_DIAG
     dg[5] += __builtin_popcount(act);
 #endif
-#define FPSP_ROW(j)                                                                                                          \
-  if (act & (1u << (j))) {                                                                                                   \
+    int tiec = 0;          // the largest number of lanes that tied for a row's maximum in this step (1: no tie anywhere)
+#define FPSP_UPD(j, n)                                                                                                       \
+  float n;                                                                                                                   \
+  {                                                                                                                          \
     const float dx = px[j] - cx, dy = py[j] - cy, dz = pz[j] - cz;                                                           \
     const float d = (dx * dx + dy * dy) + dz * dz;                                                                           \
-    float n; /* v_min_f32 returns the other operand for a NaN: exactly (d < dist) ? d : dist, as fps_kernel */               \
+    /* v_min_f32 returns the other operand for a NaN: exactly (d < dist) ? d : dist, as fps_kernel */                        \
     asm("v_min_f32_e32 %0, %1, %2" : "=v"(n) : "v"(d), "v"(dd[j]));                                                          \
     dd[j] = n;                                                                                                               \
-    const float m = wave_max_chain(n);                                                                                       \
-    const unsigned long long t = __builtin_amdgcn_ballot_w64(n == m);                                                        \
-    int am = __builtin_ctzll(t);                                                                                             \
-    if (t & (t - 1)) { /* equidistant points inside a row: the lowest original index */                                      \
-      const int o = orig[(wave + 4 * (j)) * 64 + lane];                                                                      \
-      const int mo = wave_min_dpp_i32(n == m ? o : 0x7fffffff);                                                              \
-      am = __builtin_ctzll(__builtin_amdgcn_ballot_w64(n == m && o == mo));                                                  \
-    }                                                                                                                        \
-    rmax_i = fpsp_writelane(__builtin_bit_cast(int, m), (j), rmax_i);                                                        \
-    rarg = fpsp_writelane(am, (j), rarg);                                                                                    \
   }
+#define FPSP_REC(j, n, m)                                                                                                    \
+  {                                                                                                                          \
+    const unsigned long long t = __builtin_amdgcn_ballot_w64(n == m);                                                        \
+    const int c = __builtin_popcountll(t);                                                                                   \
+    tiec = tiec > c ? tiec : c;                                                                                              \
+    rmax_i = fpsp_writelane(__builtin_bit_cast(int, m), (j), rmax_i);                                                        \
+    rarg = fpsp_writelane(__builtin_ctzll(t), (j), rarg);                                                                    \
+  }
+#define FPSP_ROW(j)                                                                                                          \
+  {                                                                                                                          \
+    FPSP_UPD(j, n_)                                                                                                          \
+    const float m_ = wave_max_chain(n_);                                                                                     \
+    FPSP_REC(j, n_, m_)                                                                                                      \
+  }
+  // two rows with their reductions interleaved (the DPP wait states of one are the other's instructions)
+#define FPSP_ROW2(j, k)                                                                                                      \
+  {                                                                                                                          \
+    FPSP_UPD(j, na_)                                                                                                         \
+    FPSP_UPD(k, nb_)                                                                                                         \
+    float ma_, mb_;                                                                                                          \
+    wave_max_chain2(na_, nb_, ma_, mb_);                                                                                     \
+    FPSP_REC(j, na_, ma_)                                                                                                    \
+    FPSP_REC(k, nb_, mb_)                                                                                                    \
+  }
+#define FPSP_PAIR(j)                                                                                                         \
+  if ((j) + 1 < PER) {                                                                                                       \
+    const unsigned sw_ = (act >> (j)) & 3u;                                                                                  \
+    if (sw_ == 3u) FPSP_ROW2(j, (j) + 1 < PER ? (j) + 1 : (j))                                                               \
+    else if (sw_ == 1u) FPSP_ROW(j)                                                                                          \
+    else if (sw_ == 2u) FPSP_ROW((j) + 1 < PER ? (j) + 1 : (j))                                                              \
+  } else if (act & (1u << (j))) FPSP_ROW(j)
 #pragma unroll
     for (int j4 = 0; j4 < PER; j4 += 4) {
       if (PER <= 4 || (act & (0xfu << j4))) {
-        FPSP_ROW(j4)
-        if (j4 + 1 < PER) { FPSP_ROW(j4 + 1) }
-        if (j4 + 2 < PER) { FPSP_ROW(j4 + 2) }
-        if (j4 + 3 < PER) { FPSP_ROW(j4 + 3) }
+        FPSP_PAIR(j4)
+        if (j4 + 2 < PER) { FPSP_PAIR(j4 + 2) }
       }
     }
+    if (__builtin_expect(tiec > 1, 0)) {
+      // equidistant points inside one of the rows just updated: that row's arg-max is the lowest ORIGINAL index among the
+      // tied lanes (the row's maximum is in lane j of the table)
+#pragma unroll
+      for (int j = 0; j < PER; ++j)
+        if (act & (1u << j)) {
+          const float m = __builtin_bit_cast(float, __builtin_amdgcn_readlane(rmax_i, j));
+          const int o = orig[(wave + 4 * j) * 64 + lane];
+          const int mo = wave_min_dpp_i32(dd[j] == m ? o : 0x7fffffff);
+          rarg = fpsp_writelane(__builtin_ctzll(__builtin_amdgcn_ballot_w64(dd[j] == m && o == mo)), j, rarg);
+        }
+    }
+#undef FPSP_PAIR
+#undef FPSP_ROW2
 #undef FPSP_ROW
+#undef FPSP_REC
+#undef FPSP_UPD
     FPSP_STAMP(1);
     // the wave's best row
     const float rmax = __builtin_bit_cast(float, rmax_i);
     const float g = wave_max16_chain(rmax);
     const unsigned tg = (unsigned)__builtin_amdgcn_ballot_w64(rmax == g) & 0xffffu;
     int jw = __builtin_ctz(tg | 0x10000u);
-    if (tg & (tg - 1)) {                                     // rows tie: the lowest original index among their arg-max points
+    if (__builtin_expect((tg & (tg - 1)) != 0, 0)) {         // rows tie: the lowest original index among their arg-max points
       const int o = (live && rmax == g) ? (int)orig[(wave + 4 * lane) * 64 + rarg] : 0x7fffffff;
       const int mo = wave_min_dpp_i32(o);
       jw = __builtin_ctzll(__builtin_amdgcn_ballot_w64(o == mo));
@@ -415,7 +456,7 @@ __global__ __launch_bounds__(FPSP_T) void fps_pruned_kernel(FpsPrunedArgs a) {
     const int p0 = y0 & 4095, p1 = y1 & 4095, p2 = y2 & 4095, p3 = y3 & 4095;
     const int nt = (v0 == gm) + (v1 == gm) + (v2 == gm) + (v3 == gm);
     int np = v0 == gm ? p0 : (v1 == gm ? p1 : (v2 == gm ? p2 : p3));
-    if (nt > 1) {                                            // waves tie: the lowest original index
+    if (__builtin_expect(nt > 1, 0)) {                       // waves tie: the lowest original index
       const int o0 = v0 == gm ? (int)orig[p0] : 0x7fffffff, o1 = v1 == gm ? (int)orig[p1] : 0x7fffffff;
       const int o2 = v2 == gm ? (int)orig[p2] : 0x7fffffff, o3 = v3 == gm ? (int)orig[p3] : 0x7fffffff;
       int bo = o0;

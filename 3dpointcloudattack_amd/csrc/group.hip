@@ -78,7 +78,7 @@ __global__ __launch_bounds__(T) void fps_kernel(FpsArgs a) {
     {
       // the lanes that hold the maximum by ballot: ONE lane unless two points are exactly equidistant — then its index comes
       // by readlane, and only a tie takes the second DPP reduction
-      const float wv = wave_max_dpp(bv);
+      const float wv = wave_max_chain(bv);     // (bv is a running distance or -2: never NaN)
       const unsigned long long tie = __builtin_amdgcn_ballot_w64(bv == wv);
       if (__builtin_popcountll(tie) == 1) bi = __builtin_amdgcn_readlane(bi, __builtin_ctzll(tie));
       else bi = wave_min_dpp_i32(bv == wv ? bi : 0x7fffffff);
@@ -1023,10 +1023,12 @@ static int fps_launch(const char* nm, int threads, const float* xyz, int64_t x_b
 
 extern "C" int pc3d_fps_f32(const float* xyz, int64_t x_bs, int64_t x_ps, int64_t x_cs, int B, int N, int S,
                             const int32_t* start, int32_t* out, void* stream) {
-  // threads per cloud by N (tools/bench_fps.py, ns per step at 64 / 128 / 256 / 512 threads): N = 512: 390 / 463 / 561 / 856;
-  // 1024: 521 / 519 / 580 / 858; 2048: 966 / 671 / 650 / 957; 4096: - / 1106 / 799 / 1091 — a step is a latency chain (update,
-  // wave arg-max, exchange + barrier, winner's coordinates): fewer wavefronts shorten the exchange until the per-lane work takes over
-  const int threads = N <= 512 ? 64 : (N <= 1024 ? 128 : FPS_T);
+  // threads per cloud by N (tools/bench_fps.py, ns per step at 64 / 128 / 256 / 512 threads, round 4 with the one-instruction-
+  // per-level DPP maximum): N = 512: 325 / 429 / 508 / 786; 1024: 468 / 493 / 556 / 816; 2048: 908 / 617 / 610 / 875; 4096:
+  // - / 1068 / 750 / 1003 — a step is a latency chain (update, wave arg-max, exchange + barrier, winner's coordinates): fewer
+  // wavefronts shorten the exchange until the per-lane work takes over. The pruned form (fps_pruned.hip, pc3d_fps_pruned_f32)
+  // gives the same picks at 788 / 699 / 672 / 636 ns per step for N = 4096 / 2048 / 1024 / 512: not faster, so not chosen here
+  const int threads = N <= 1024 ? 64 : FPS_T;
   return fps_launch("pc3d_fps_f32", threads, xyz, x_bs, x_ps, x_cs, B, N, S, start, out, stream);
 }
 

@@ -130,6 +130,31 @@ __device__ __forceinline__ float wave_max_dpp(float v) {
   PC3D_DPP_STEP_F(fmaxf, v, 0x143);  // row_bcast:31 -> lane 63 holds the wave maximum
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+// Wave maximum of values that are never NaN, wave-uniform result: ONE v_max_f32 with a DPP operand per level (the C++ form
+// compiles to move + DPP move + two canonicalising maxima per level). A DPP instruction needs two wait states after the
+// VALU write of its source, v_readlane one after the last write; the trailing nops cover a VALU read of the SGPR result.
+__device__ __forceinline__ float wave_max_chain(float v) {
+  float r;
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_readlane_b32 %0, %1, 63\n\t"
+      "s_nop 1"
+      : "=s"(r), "+v"(v));
+  return r;
+}
+
 // (value, index) of lanes l and l ^ 32 combined IN BOTH lanes: the larger value, the lower index on a tie. One
 // v_permlane32_swap_b32 (gfx950) per operand — a VALU instruction — instead of a ds_bpermute round trip through LDS each.
 // `best` must not be NaN (the arg-max loops that call this start from -inf and update on a strict >).

@@ -27,7 +27,7 @@ for B, N, S in ((32, 4096, 1024), (64, 2048, 512), (64, 512, 128), (32, 1024, 25
         for _ in range(10): call()
         e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / 10 * 1e3
-        print(f"    pruned (one wavefront): {us:.1f} us, {us / S * 1e3:.0f} ns per step, equal {bool(torch.equal(out, ref))}", flush=True)
+        print(f"    pruned (pc3d_fps_pruned_f32): {us:.1f} us, {us / S * 1e3:.0f} ns per step, equal {bool(torch.equal(out, ref))}", flush=True)
         call1 = lambda: lib.call("pc3d_fps_pruned_f32", x.data_ptr(), x.stride(0), x.stride(1), x.stride(2), B, N, 1, 0,
                                  out.data_ptr(), torch.cuda.current_stream().cuda_stream)
         for _ in range(3): call1()
