@@ -14,3 +14,35 @@ for B, N, K in ((32, 4096, 20), (32, 1024, 21), (32, 1024, 20), (64, 2048, 5), (
     for _ in range(20): ops.knn_raw(x, x, K)
     e1.record(); torch.cuda.synchronize()
     print(json.dumps({"B": B, "N": N, "K": K, "us": round(e0.elapsed_time(e1) / 20 * 1e3, 1)}), flush=True)
+
+# ---- CurveNet's graphs: the plain search (values + indices) against pc3d_knn_graph_i32 (indices + the two views its blocks
+# gather through, written by the same launch) — both as 10 calls per replayed hipGraph (round-3 review: knn_wave_kernel<4,true>
+# went 124 -> 160 us average inside the cfg5 loop when the views moved into the launch; stand-alone A/B)
+def graph_us(fn, reps=10, rounds=10):
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            fn()
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(reps):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(rounds):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / (reps * rounds)
+
+
+for B, N in ((32, 4096), (32, 1024), (32, 256), (32, 64)):
+    torch.manual_seed(N)
+    x = torch.rand(B, N, 3, device=dev)
+    t_plain = graph_us(lambda: ops.knn_raw(x, x, 21))
+    t_graph = graph_us(lambda: ops.knn_graph(x, 20))
+    print(json.dumps({"B": B, "N": N, "k": 20, "knn_raw_us": round(t_plain, 1), "knn_graph_us": round(t_graph, 1)}), flush=True)
