@@ -1231,6 +1231,9 @@ def linear_act(x, w, b=None, act=None, slope=0.0):
 # ------------------------------------------------------------------------------------------------------
 # K5/K6/K7: PointNet++ sampling & grouping
 # ------------------------------------------------------------------------------------------------------
+FPS_THREADS_OVERRIDE = int(os.environ.get("PC3D_FPS_THREADS", "0"))     # 0: the library's choice
+
+
 def fps(xyz, npoint, start=None, cf=False):
     """Farthest-point sampling: xyz [B,N,3] (or [B,3,N] with cf) -> int32 [B,npoint]. start: int32 [B] or None (0)."""
     p, bs, ps, cs, B, N = _pts(xyz, cf, "xyz")
@@ -1238,7 +1241,11 @@ def fps(xyz, npoint, start=None, cf=False):
     if start is not None and (start.dtype != torch.int32 or not start.is_cuda):
         raise TypeError("fps: start must be an int32 GPU tensor")
     with torch.cuda.device(xyz.device):
-        _lib.call("pc3d_fps_f32", p, bs, ps, cs, B, N, int(npoint), _ptr(start), out.data_ptr(), _stream())
+        if FPS_THREADS_OVERRIDE and N <= 32 * FPS_THREADS_OVERRIDE:     # diagnostics only (tools/exp/cw_curvenet_race.py)
+            _lib.call("pc3d_fps_threads_f32", FPS_THREADS_OVERRIDE, p, bs, ps, cs, B, N, int(npoint), _ptr(start), out.data_ptr(),
+                      _stream())
+        else:
+            _lib.call("pc3d_fps_f32", p, bs, ps, cs, B, N, int(npoint), _ptr(start), out.data_ptr(), _stream())
     return out
 
 
