@@ -14,7 +14,7 @@ import torch  # noqa: F401,E402
 from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpc3d_hip.so")
+LIB_PATH = os.environ.get("PC3D_LIB_PATH") or os.path.join(_HERE, "libpc3d_hip.so")     # (the override: A/B builds in tools/)
 
 _P = c_void_p
 _I = c_int

@@ -125,7 +125,11 @@ __global__ __launch_bounds__(KF_T) void knn_feat_kernel(KnnFeatArgs a) {
         }
       }
       if (NT != 16 && blk + 1 < nblk) first_rows(blk + 1);   // (C = 128: the operand would stay live through the scan: 136 VGPRs)
-      rn = sum_xor32(rn);                      // |r_j|^2 for column j = r (the two lane halves hold the two k halves)
+      // |r_j|^2 for column j = r (the two lane halves hold the two k halves). A/B in round 4 (tools/bench_knn_feat.py, B=32,
+      // N=1024, K=20 / K=1): this ds_swizzle-backed shuffle 111.4 / 65.1 us, sum_xor32 (v_permlane32_swap, round 3) 137.4 / 74.1 —
+      // the swap's result is needed by the very next VALU instruction of every lane, and its wait states stall the wave where the
+      // LDS round trip of the shuffle is overlapped with the next block's loads
+      rn += __shfl_xor(rn, 32, 64);
       // model/dgcnn.py:195-197 ranks the references of a query by 2 q.r - |q|^2 - |r|^2, largest first. |q|^2 is the
       // same for every candidate of a query, so the key is that of |r|^2 - 2 q.r, smallest first (never -0: x - x is +0;
       // NaN -> +inf by v_min_f32, which returns its other operand for a quiet NaN): 6 VALU per element instead of 10 and
