@@ -13,6 +13,8 @@ Same constructor / ``attack(data, target)`` signature and return values as the r
   user callables still work through the generic path (same protocol as the reference:
   ``adv_func(logits, target)``, ``dist_func(adv[B,3,K], ori[B,3,K], weights[B])``, ``clip_func(pc, ori)``).
 """
+import os
+
 import numpy as np
 import torch
 import torch.optim as optim
@@ -98,6 +100,10 @@ class CW:
         self.trans_fail = 0
         self.attack_fail = 0
         self.verbose = verbose
+        # the fused PointNet iteration's adv -> ori search forked beside the head launches: measured SLOWER in round 4 (headline
+        # 0.310-0.315 ms per iteration forked after the STN tower, 0.309-0.313 after the trunk tower, 0.288 in line: a second
+        # branch in the replayed graph costs ~25 us of cross-queue hand-off for the 12 us it hides), so off unless asked for
+        self.overlap_search = os.environ.get("PC3D_OVERLAP_SEARCH", "0") == "1"
         self.fused = fused
         self.graph = graph
         self.sample_seeds = sample_seeds
@@ -263,10 +269,28 @@ class CW:
                 cur = adv_data.detach()
                 if hasattr(self.model, "fused_attack_grad") and st["K"] <= ops.CW_UPDATE_MAX_POINTS:
                     # 17 launches: the classifier tail writes pred + advances the step word, one update launch
+                    nn_box = []
+                    fork = None
+                    if dk == 2 and getattr(self, "overlap_search", False):
+                        # the adv -> ori search depends on the iterate only: forked onto the TERMS stream right after the
+                        # first tower launch, it runs beside the STN head's fold + two linear launches (a few CUs each)
+                        # instead of behind the whole victim; joined before the update launch. Inside a captured iteration
+                        # the fork and the join become graph edges.
+                        main = torch.cuda.current_stream(cur.device)
+                        side_s = _streams.side_stream(cur.device, _streams.TERMS)
+
+                        def fork():
+                            side_s.wait_stream(main)
+                            with torch.cuda.stream(side_s):
+                                nn_box.append(ops.nn_raw(cur, ori_data, True, True)[1])
                     _, _, gx_model = self.model.fused_attack_grad(cur, st["target"], *fml, pred_out=st["pred"],
-                                                                  step=st["step"], scale=st["ratio"] / st["B"])
+                                                                  step=st["step"], scale=st["ratio"] / st["B"],
+                                                                  after_stn_tower=fork)
                     nn_idx = None
-                    if dk == 2:
+                    if fork is not None:
+                        main.wait_stream(side_s)
+                        nn_idx = nn_box[0]
+                    elif dk == 2:
                         _, nn_idx = ops.nn_raw(cur, ori_data, True, True)
                     ops.cw_update(cur, ori_data, st["pred"], label, self.attack_method == 'untarget', st["bestdist"],
                                   st["bestscore"], st["o_bestdist"], st["o_bestscore"], st["o_bestattack"], gx_model,

@@ -8,6 +8,8 @@ weights once, and each tower (3 -> 64 -> 128 -> 1024 + max over points) is ONE f
 
 Reference: STN3d model/pointnet.py:14-48, PointNetfeat :89-128, PointNetCls :130-148.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -178,10 +180,12 @@ class PointNetCls(_FrozenFusedMixin, nn.Module):
                                                   scale=1.0 / x.shape[0] if scale is None else scale)
         return logp, pred, loss, fused_input_grad(ctx, g_logits)
 
-    def fused_attack_grad(self, x, target, kind, kappa=0.0, pred_out=None, step=None, scale=None):
+    def fused_attack_grad(self, x, target, kind, kappa=0.0, pred_out=None, step=None, scale=None, after_stn_tower=None):
         """fused_loss_and_grad for the attack loops: the classifier tail (fc3, loss, fc3 backward) is one launch that
-        also writes the prediction into `pred_out` and advances the device step word. Returns (pred, loss, dL/dx)."""
-        _, ctx = fused_forward(self, x, tail=False)
+        also writes the prediction into `pred_out` and advances the device step word. Returns (pred, loss, dL/dx).
+        after_stn_tower: called right after the first tower launch has been queued — the caller's chance to fork work
+        that does not depend on the victim (the attack's nearest-neighbour search) beside the few-CU head launches."""
+        _, ctx = fused_forward(self, x, tail=False, after_stn_tower=after_stn_tower)
         c2, pk = ctx[9], ctx[1]
         _, pred, loss, g_c2 = ops.cls_tail(c2, pk["c"][4], pk["c"][5], target, kind, kappa,
                                            scale=1.0 / x.shape[0] if scale is None else scale,
@@ -231,7 +235,10 @@ def _fused_pack(model):
                 s_t=(_t(w1s), _t(w2s), w3s_t.contiguous()), c_t=(_t(w1c), _t(w2c), _t(w3c)))
 
 
-def fused_forward(model, x, tail=True):
+FORK_AFTER_TRUNK = os.environ.get("PC3D_FORK_AFTER_TRUNK", "0") == "1"      # experiment switch
+
+
+def fused_forward(model, x, tail=True, after_stn_tower=None):
     """Launch-minimal forward of PointNetCls: 2 tower launches (+2 folds) + 5 head launches, no autograd graph.
     Returns (logits [B,k] PRE-softmax, ctx) — ctx feeds fused_input_grad."""
     model._require_fused(x)
@@ -239,10 +246,14 @@ def fused_forward(model, x, tail=True):
     w1s, b1s, w2s, b2s, w3s, b3s = pk["s"]
     w1c, b1c, w2c, b2c, w3c, b3c = pk["c"]
     pooled_s, idx_s, masks_s = ops.pointmlp3_max_fwd_raw(x, pk["tower_s"], True, want_masks=True)
+    if after_stn_tower is not None and not FORK_AFTER_TRUNK:
+        after_stn_tower()
     a1 = ops.linear(pooled_s, w1s, b1s, relu=True)
     a2 = ops.linear(a1, w2s, b2s, relu=True)
     # the transform (STN fc3 + identity, [B,9]) is computed in the trunk tower's prologue: no launch of its own
     pooled, idx, masks, trans = ops.pointmlp3_max_fwd_raw(x, pk["tower_c"], False, want_masks=True, T_head=(a2, w3s, b3s))
+    if after_stn_tower is not None and FORK_AFTER_TRUNK:
+        after_stn_tower()
     c1 = ops.linear(pooled, w1c, b1c, relu=True)
     c2 = ops.linear(c1, w2c, b2c, relu=True)
     logits = ops.linear(c2, w3c, b3c) if tail else None
