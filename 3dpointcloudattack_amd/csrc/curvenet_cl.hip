@@ -98,7 +98,7 @@ __global__ __launch_bounds__(1024) void topk_desc_kernel(const float* __restrict
   __syncthreads();
   // A stage with partner distance j <= 64 keeps every pair of a wavefront's 64 consecutive i inside one aligned block of
   // 128 keys, and so do the stages after it down to j = 1: those need no workgroup barrier, only the wavefront's own
-  // LDS order. A barrier follows a stage only when the NEXT stage reaches across blocks (j > 64): 6 barriers instead of
+  // LDS order. A barrier follows a stage only when it or the NEXT stage reaches across blocks (j > 64): 9 barriers instead of
   // 55 for 1024 keys (18.4 -> 16.3 us: the launch is one workgroup per cloud, and what is left is 55 dependent LDS
   // round trips).
   for (int k = 2; k <= npow2; k <<= 1) {
@@ -110,7 +110,12 @@ __global__ __launch_bounds__(1024) void topk_desc_kernel(const float* __restrict
         if ((a > c) == asc) tk_keys[lo] = c, tk_keys[hi] = a;
       }
       const int jn = j > 1 ? (j >> 1) : k;      // partner distance of the next stage (k: first stage of size 2k)
-      if (jn > 64) __syncthreads();
+      // Workgroup barrier when THIS stage wrote into other wavefronts' blocks (j > 64) or the NEXT one reads from them
+      // (jn > 64). Until round 4 only the second condition was tested: after the j = 128 stage of every merge of 256 or
+      // more keys, the j = 64 stage read keys a neighbouring wavefront might still be writing. With the 16 wavefronts in
+      // step it never showed; beside a single high-priority wavefront that delays one SIMD (fps_kernel<16,64> on the
+      // geometry branch of a replayed CurveNet graph) one cloud in ~800 got other start points.
+      if (jn > 64 || j > 64) __syncthreads();
       else wave_lds_sync();
     }
   }

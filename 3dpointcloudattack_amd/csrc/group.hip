@@ -1026,13 +1026,13 @@ extern "C" int pc3d_fps_f32(const float* xyz, int64_t x_bs, int64_t x_ps, int64_
   // threads per cloud by N (tools/bench_fps.py, ns per step at 64 / 128 / 256 / 512 threads, round 4 with the one-instruction-
   // per-level DPP maximum): N = 512: 325 / 429 / 508 / 786; 1024: 468 / 493 / 556 / 816; 2048: 908 / 617 / 610 / 875; 4096:
   // - / 1068 / 750 / 1003 — a step is a latency chain (update, wave arg-max, exchange + barrier, winner's coordinates): fewer
-  // wavefronts shorten the exchange until the per-lane work takes over. N = 1024 stays on 128 threads although 64 measure 5 %
-  // faster: with 64 the hipGraph-replayed CurveNet loop (B = 32, N = 4096) stopped being run == run in about one run of
-  // twelve (tools/exp/cw_curvenet_poison.py), while the kernel itself returns the same indices in 200 of 200 launches beside
-  // a stream of GEMMs (tools/exp/fps_determinism_under_load.py) and the eager loop stays bit-equal — a change of timing that
-  // exposes something else; not found yet, DESIGN.md §3.9. The pruned form (fps_pruned.hip, pc3d_fps_pruned_f32) gives the
-  // same picks at 788 / 699 / 672 / 636 ns per step for N = 4096 / 2048 / 1024 / 512: not faster, so not chosen here
-  const int threads = N <= 512 ? 64 : (N <= 1024 ? 128 : FPS_T);
+  // wavefronts shorten the exchange until the per-lane work takes over. (Taking 64 threads at N = 1024 first made the
+  // hipGraph-replayed CurveNet loop lose run == run in one run of twelve: the single high-priority wavefront per CU skews the
+  // wavefronts of whatever shares the CU, and topk_desc_kernel's bitonic sort was missing a workgroup barrier — fixed in
+  // curvenet_cl.hip, tools/exp/curvenet_graph_race.py; 0 of 600 replays differ since.) The pruned form (fps_pruned.hip,
+  // pc3d_fps_pruned_f32) gives the same picks at 788 / 699 / 672 / 636 ns per step for N = 4096 / 2048 / 1024 / 512: not
+  // faster, so not chosen here
+  const int threads = N <= 1024 ? 64 : FPS_T;
   return fps_launch("pc3d_fps_f32", threads, xyz, x_bs, x_ps, x_cs, B, N, S, start, out, stream);
 }
 

@@ -139,3 +139,28 @@ def test_lpfa_fused(ops, dev, B, N, K, C):
     (ref * up.double()).sum().backward()
     assert _rel(out, ref) < 2e-6
     assert _rel(Aa.grad, Ad.grad) < 1e-5 and _rel(Ba.grad, Bd.grad) < 1e-5
+
+
+def test_topk_desc_beside_a_sampling_chain(ops, dev):
+    """pc3d_topk_desc_f32 (model/curvenet_util.py:457) returns the same start points whatever shares the chip. Until round 4
+    the bitonic network skipped the workgroup barrier between its j = 128 and j = 64 stages; with the sixteen wavefronts in
+    step that never showed, but beside the sampling chain's single high-priority wavefront per CU (the geometry branch of
+    a replayed CurveNet graph) about one cloud in 800 got other start points — found as a run != run of the graphed
+    CurveNet loop (tools/exp/curvenet_graph_race.py). 300 launches x 32 clouds beside pc3d_fps_f32 on another stream,
+    each compared with a stable descending sort."""
+    g = torch.Generator().manual_seed(8)
+    score = torch.rand(32, 1024, generator=g).to(dev)
+    score[:, 100:140] = score[:, 99:100]                       # ties: the lower index first
+    want = torch.sort(score, dim=1, descending=True, stable=True)[1][:, :100].to(torch.int32)
+    pts = torch.rand(32, 1024, 3, generator=g).to(dev)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    bad = 0
+    for it in range(300):
+        with torch.cuda.stream(side):
+            ops.fps(pts, 256, None)
+        got = ops.topk_desc(score, 100)
+        bad += int(not torch.equal(got, want))
+    torch.cuda.synchronize()
+    torch.cuda.current_stream().wait_stream(side)
+    assert bad == 0, f"{bad} of 300 launches returned other start points"
