@@ -31,8 +31,9 @@ __global__ __launch_bounds__(T) void fps_kernel(FpsArgs a) {
   float* sx = lds;                 // [N] staged coordinates (winner lookup)
   float* sy = lds + a.N;
   float* sz = lds + 2 * a.N;
-  __shared__ float red_v[2][T / 64 > 1 ? T / 64 : 1];
-  __shared__ int red_i[2][T / 64 > 1 ? T / 64 : 1];
+  // one 8-byte key per wave and step parity: (value bits as a signed word : 0x7fffffff - index) — a signed 64-bit maximum
+  // is the larger value, the lower index on a tie (values are running distances >= 0 or the -1 / -2 of padding, never NaN)
+  __shared__ __attribute__((aligned(16))) long long red_k[2][T / 64 > 1 ? T / 64 : 1];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // A chain of dependent steps on one wavefront per SIMD, usually beside a chip-filling kernel of another stream (the
   // previous layer's MLP, the attack's searches): its instructions go first in the SIMD's issue arbitration.
@@ -42,22 +43,29 @@ __global__ __launch_bounds__(T) void fps_kernel(FpsArgs a) {
 #pragma unroll
   for (int e = 0; e < PER; ++e) {
     const int i = e * T + tid;  // strided ownership: coalesced loads, ascending index within a thread
-    float x = 0.f, y = 0.f, z = 0.f;
-    if (i < a.N) {
-      const float* p = xb + (int64_t)i * a.x.ps;
-      x = p[0], y = p[a.x.cs], z = p[2 * a.x.cs];
-      sx[i] = x, sy[i] = y, sz[i] = z;
-    }
+    // Slots past the cloud hold COPIES of its last point: a copy has that point's running distance at every step and a
+    // higher index, so the lowest-index tie rule never picks it (inside a lane, between lanes, between waves) — and every
+    // running distance is then >= +0, which is what lets the arg-max below compare float bits as integers.
+    const float* p = xb + (int64_t)(i < a.N ? i : a.N - 1) * a.x.ps;
+    const float x = p[0], y = p[a.x.cs], z = p[2 * a.x.cs];
+    if (i < a.N) sx[i] = x, sy[i] = y, sz[i] = z;
     px[e] = x, py[e] = y, pz[e] = z;
-    dist[e] = (i < a.N) ? 1e10f : -1.f;  // padding can never win the arg-max
+    dist[e] = 1e10f;
   }
   int far = a.start ? a.start[b] : 0;
   far = far < 0 ? 0 : (far >= a.N ? a.N - 1 : far);  // a start index outside the cloud cannot fault the launch
   __syncthreads();
+  int keep = 0;
   for (int s = 0; s < a.S; ++s) {
-    if (tid == 0) a.out[(int64_t)b * a.S + s] = far;
+    // the picks leave 64 at a time: lane (s % 64) of wave 0 keeps step s's pick, a coalesced store every 64 steps
+    keep = (lane == (s & 63)) ? far : keep;
+    if ((s & 63) == 63 && wave == 0) a.out[(int64_t)b * a.S + (s - 63) + lane] = keep;
     const float cx = sx[far], cy = sy[far], cz = sz[far];
-    float bv = -2.f;
+    // Per-lane arg-max on the BITS of the running distances (all >= +0, never NaN, so they order like the values; best
+    // starts at -1): the float compare + two selects of round 3 (v_cmp_gt_f32_e64 into an SGPR pair, v_cndmask twice, each
+    // two wait states behind it) were 30 of the 62 s_nop in the compiled step; an integer maximum and ONE select on VCC
+    // remain. 707 -> 640 us for 4096 -> 1024. Ascending e inside the lane and the strict > keep the lowest index on ties.
+    int bvi = -1;
     int bi = 0x7fffffff;
 #pragma unroll
     for (int e = 0; e < PER; ++e) {
@@ -68,11 +76,15 @@ __global__ __launch_bounds__(T) void fps_kernel(FpsArgs a) {
       float nd;
       asm("v_min_f32_e32 %0, %1, %2" : "=v"(nd) : "v"(d), "v"(dist[e]));
       dist[e] = nd;
-      if (nd > bv) {  // ascending index inside the thread: strict > keeps the lowest index
-        bv = nd;
-        bi = e * T + tid;
-      }
+      const int ndi = __builtin_bit_cast(int, nd);
+      // (hipcc turns this idiom back into v_cmp_lt_i32 + v_cndmask on VCC — 37 s_nop per step instead of 62 — and that is
+      // the faster form: forced through inline asm as sub / ashr / max / bfi, the select becomes one more dependent link
+      // per row: 737 us against 640 for 4096 -> 1024)
+      const int gt = (bvi - ndi) >> 31;                 // -1: nd > best so far
+      bvi = bvi > ndi ? bvi : ndi;
+      bi = (gt & (e * T + tid)) | (~gt & bi);
     }
+    float bv = __builtin_bit_cast(float, bvi);
     // wave arg-max on DPP (the shuffle version cost ~800 cycles of LDS-crossbar latency per step): the maximum
     // first, then the lowest index among the lanes that hold it (= the reference's first-index tie rule)
     {
@@ -88,19 +100,21 @@ __global__ __launch_bounds__(T) void fps_kernel(FpsArgs a) {
     int fi = bi;
     if (T > 64) {           // (one wavefront per cloud: the wave's arg-max is the cloud's — no exchange, no barrier)
       const int buf = s & 1;  // double-buffered exchange: one barrier per step
-      if (lane == 0) red_v[buf][wave] = bv, red_i[buf][wave] = bi;
+      if (lane == 0)
+        red_k[buf][wave] = ((long long)__builtin_bit_cast(int, bv) << 32) | (long long)(unsigned)(0x7fffffff - bi);
       __syncthreads();
-      fv = red_v[buf][0];
-      fi = red_i[buf][0];
+      long long best = red_k[buf][0];
 #pragma unroll
       for (int w = 1; w < T / 64; ++w) {
-        const float ov = red_v[buf][w];
-        const int oi = red_i[buf][w];
-        if (ov > fv || (ov == fv && oi < fi)) fv = ov, fi = oi;
+        const long long o = red_k[buf][w];
+        best = o > best ? o : best;
       }
+      fv = __builtin_bit_cast(float, (int)(best >> 32));
+      fi = 0x7fffffff - (int)(unsigned)(best & 0xffffffffll);
     }
     if (fi != 0x7fffffff) far = fi;  // no finite candidate (NaN cloud): stay put instead of indexing LDS at 2^31
   }
+  if ((a.S & 63) != 0 && wave == 0 && lane < (a.S & 63)) a.out[(int64_t)b * a.S + (a.S & ~63) + lane] = keep;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1032,7 +1046,7 @@ extern "C" int pc3d_fps_f32(const float* xyz, int64_t x_bs, int64_t x_ps, int64_
   // curvenet_cl.hip, tools/exp/curvenet_graph_race.py; 0 of 600 replays differ since.) The pruned form (fps_pruned.hip,
   // pc3d_fps_pruned_f32) gives the same picks at 788 / 699 / 672 / 636 ns per step for N = 4096 / 2048 / 1024 / 512: not
   // faster, so not chosen here
-  const int threads = N <= 1024 ? 64 : FPS_T;
+  const int threads = N <= 512 ? 64 : FPS_T;
   return fps_launch("pc3d_fps_f32", threads, xyz, x_bs, x_ps, x_cs, B, N, S, start, out, stream);
 }
 
