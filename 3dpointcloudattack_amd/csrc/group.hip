@@ -15,6 +15,8 @@ namespace pc3d {
 // FPS.  distance[i] = min(distance[i], |p_i - p_far|^2) ; far = argmax distance (lowest index on ties).
 // Arithmetic = the reference's: ((dx*dx + dy*dy) + dz*dz) in fp32 without contraction, distance init 1e10.
 // ---------------------------------------------------------------------------------------------------------
+typedef float fps_f2 __attribute__((ext_vector_type(2)));
+
 constexpr int FPS_T = 256;
 constexpr int FPS_MAXPER = 32;  // points per thread -> N <= 8192
 
@@ -67,23 +69,63 @@ __global__ __launch_bounds__(T) void fps_kernel(FpsArgs a) {
     // remain. 707 -> 640 us for 4096 -> 1024. Ascending e inside the lane and the strict > keep the lowest index on ties.
     int bvi = -1;
     int bi = 0x7fffffff;
+    // ROW PAIRS on packed fp32 (v_pk_add_f32 / v_pk_mul_f32: the same IEEE operations per component, in the reference's
+    // order): a single wavefront issues an instruction every four clocks whatever its width, so a packed instruction is
+    // two rows for the price of one — 8 per pair instead of the 12 the compiler's own SLP leaves (it packs two
+    // coordinates of ONE row). 640 -> see DESIGN.md §3.9.
+    constexpr int PP = PER / 2;
+    const fps_f2 cX = {cx, cx}, cY = {cy, cy}, cZ = {cz, cz};
+    // (hipcc turns the idiom below back into v_cmp_lt_i32 + v_cndmask on VCC, and that is the faster form: forced through
+    // inline asm as sub / ashr / max / bfi the select becomes one more dependent link per row, 737 us against 640)
+#define FPS_TRACK(eu, ndv)                                                                          \
+  {                                                                                                 \
+    const int ndi_ = __builtin_bit_cast(int, ndv);                                                  \
+    const int gt_ = (bvi - ndi_) >> 31; /* -1: nd > best so far */                                  \
+    bvi = bvi > ndi_ ? bvi : ndi_;                                                                  \
+    bi = (gt_ & ((eu) * T + tid)) | (~gt_ & bi);                                                    \
+  }
+    // Two pairs per trip, written interleaved: 244 -> 230 us at 8 rows per lane (2048 -> 512), 105 -> 104 at 4, but 585 -> 595
+    // at 16 (and 606 with the order forced through inline asm) — so only up to 8 rows per lane. (Stable to +-0.5 us.)
+    constexpr int PQ = PER <= 8 ? (PP & ~1) : 0;            // pairs taken two at a time
 #pragma unroll
-    for (int e = 0; e < PER; ++e) {
+    for (int q = 0; q < PQ; q += 2) {
+      const int e = 2 * q, f = e + 2;
+      const fps_f2 XA = {px[e], px[e + 1]}, YA = {py[e], py[e + 1]}, ZA = {pz[e], pz[e + 1]};
+      const fps_f2 XB = {px[f], px[f + 1]}, YB = {py[f], py[f + 1]}, ZB = {pz[f], pz[f + 1]};
+      const fps_f2 dxA = XA - cX, dxB = XB - cX, dyA = YA - cY, dyB = YB - cY, dzA = ZA - cZ, dzB = ZB - cZ;
+      const fps_f2 sA = dxA * dxA, sB = dxB * dxB, tA = dyA * dyA, tB = dyB * dyB, uA = dzA * dzA, uB = dzB * dzB;
+      const fps_f2 rA = sA + tA, rB = sB + tB;
+      const fps_f2 dA = rA + uA, dB = rB + uB;
+      float n0, n1, n2, n3;
+      asm("v_min_f32_e32 %0, %1, %2" : "=v"(n0) : "v"(dA[0]), "v"(dist[e]));
+      asm("v_min_f32_e32 %0, %1, %2" : "=v"(n1) : "v"(dA[1]), "v"(dist[e + 1]));
+      asm("v_min_f32_e32 %0, %1, %2" : "=v"(n2) : "v"(dB[0]), "v"(dist[f]));
+      asm("v_min_f32_e32 %0, %1, %2" : "=v"(n3) : "v"(dB[1]), "v"(dist[f + 1]));
+      dist[e] = n0, dist[e + 1] = n1, dist[f] = n2, dist[f + 1] = n3;
+      FPS_TRACK(e, n0) FPS_TRACK(e + 1, n1) FPS_TRACK(f, n2) FPS_TRACK(f + 1, n3)
+    }
+#pragma unroll
+    for (int q = PQ; q < PP; ++q) {
+      const int e = 2 * q;
+      const fps_f2 X = {px[e], px[e + 1]}, Y = {py[e], py[e + 1]}, Z = {pz[e], pz[e + 1]};
+      const fps_f2 dx = X - cX, dy = Y - cY, dz = Z - cZ;
+      const fps_f2 d = (dx * dx + dy * dy) + dz * dz;
+      float n0, n1;       // v_min_f32 returns its other operand for a quiet NaN: exactly (d < dist) ? d : dist, dist never NaN
+      asm("v_min_f32_e32 %0, %1, %2" : "=v"(n0) : "v"(d[0]), "v"(dist[e]));
+      asm("v_min_f32_e32 %0, %1, %2" : "=v"(n1) : "v"(d[1]), "v"(dist[e + 1]));
+      dist[e] = n0, dist[e + 1] = n1;
+      FPS_TRACK(e, n0) FPS_TRACK(e + 1, n1)
+    }
+#pragma unroll
+    for (int e = 2 * PP; e < PER; ++e) {                  // (PER = 1)
       const float dx = px[e] - cx, dy = py[e] - cy, dz = pz[e] - cz;
       const float d = (dx * dx + dy * dy) + dz * dz;
-      // min(d, dist): dist is never NaN and v_min_f32 returns its other operand for a quiet NaN, i.e. exactly
-      // (d < dist) ? d : dist — one instruction instead of compare + select in a loop that is issue-bound
       float nd;
       asm("v_min_f32_e32 %0, %1, %2" : "=v"(nd) : "v"(d), "v"(dist[e]));
       dist[e] = nd;
-      const int ndi = __builtin_bit_cast(int, nd);
-      // (hipcc turns this idiom back into v_cmp_lt_i32 + v_cndmask on VCC — 37 s_nop per step instead of 62 — and that is
-      // the faster form: forced through inline asm as sub / ashr / max / bfi, the select becomes one more dependent link
-      // per row: 737 us against 640 for 4096 -> 1024)
-      const int gt = (bvi - ndi) >> 31;                 // -1: nd > best so far
-      bvi = bvi > ndi ? bvi : ndi;
-      bi = (gt & (e * T + tid)) | (~gt & bi);
+      FPS_TRACK(e, nd)
     }
+#undef FPS_TRACK
     float bv = __builtin_bit_cast(float, bvi);
     // wave arg-max on DPP (the shuffle version cost ~800 cycles of LDS-crossbar latency per step): the maximum
     // first, then the lowest index among the lanes that hold it (= the reference's first-index tie rule)
