@@ -39,7 +39,9 @@ __global__ __launch_bounds__(T) void fps_kernel(FpsArgs a) {
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // A chain of dependent steps on one wavefront per SIMD, usually beside a chip-filling kernel of another stream (the
   // previous layer's MLP, the attack's searches): its instructions go first in the SIMD's issue arbitration.
+#ifndef PC3D_FPS_NOPRIO
   __builtin_amdgcn_s_setprio(3);
+#endif
   const float* xb = a.x.p + (int64_t)b * a.x.bs;
   float px[PER], py[PER], pz[PER], dist[PER];
 #pragma unroll

@@ -267,6 +267,37 @@ def test_oracle_geoa3_on_dgcnn_matches_reference():
         np.testing.assert_allclose(best.numpy(), fx[f"{nm}_best"], atol=1e-4)
 
 
+def test_oracle_geoa3_on_dgcnn_at_config_size_matches_reference():
+    """The same pin at configs[2]'s point count: the oracle's GeoA3 loop (as written, SURVEY A-2) on the oracle's DGCNN
+    against the real reference's geoA3_attack at N = 1024 (tests/golden/config_sizes.npz, generated on ONE thread — on one
+    thread this run reproduces it to rounding; any thread count stays inside the band two reference runs differ by), and
+    the stored intended-semantics curve the GPU tests compare with is what this oracle computes."""
+    import types
+    fx = np.load(os.path.join(GOLDEN, "config_sizes.npz"))
+    net = ort.DGCNN(types.SimpleNamespace(k=20, emb_dims=1024, dropout=0.5), output_channels=40)
+    sd = ort.seeded_state_dict(net, 5)
+    net.load_state_dict(sd)
+    net.eval()
+    assert ort.state_sha256(sd) == str(fx["dgcnn_sha256"])
+    was = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        nm = "margin_l2"
+        key = f"dgcnn_n1024_{nm}"
+        cfg = _geo_cfg(npoint=1024, **GEO_CASES[nm])
+        for as_written, ref in ((True, fx[f"{key}_losses"]), (False, fx[f"{key}_olosses"])):
+            torch.manual_seed(78)
+            np.random.seed(78)
+            best, tgt, mask, steps, losses = ort.GeoA3Oracle(as_written=as_written).attack(
+                net, torch.from_numpy(fx[f"{key}_pc"]), torch.from_numpy(fx[f"{key}_label"]), cfg, per_sample_label=True)
+            assert np.array_equal(mask, fx[f"{key}_mask"])
+            L = np.array(losses)
+            np.testing.assert_allclose(L[:3], ref[:3], rtol=1e-4, atol=1e-5)
+            np.testing.assert_allclose(L, ref, rtol=3e-2, atol=1e-3)
+    finally:
+        torch.set_num_threads(was)
+
+
 def test_oracle_f4_functors_match_reference():
     """FarthestDist / FarChamferDist / L2ChamferDist of the real reference (tests/golden/f4.npz)."""
     fx = np.load(os.path.join(GOLDEN, "f4.npz"))
