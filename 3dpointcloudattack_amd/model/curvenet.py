@@ -59,29 +59,34 @@ class CurveNet(_FrozenFusedMixin, nn.Module):
     def _geometry(self, pos, with_grad=False):
         """Everything in a forward that depends on the COORDINATES only — the FPS chain, the ball queries of the
         down-sampling blocks and the kNN graph of every resolution (curvenet_util.py:69-113, :10-17) — for detached
-        pos [B,N,3], on the current stream: one (pool, graph, event) entry per block. FPS is a chain of npoint dependent
+        pos [B,N,3], on the current stream: one (pool, graph, pool event, graph event) entry per block. FPS is a chain of npoint dependent
         arg-max steps on one workgroup per cloud (0.9 ms for 4096 -> 1024 at B=32, on 32 of 256 CUs): forward() runs
         this on a side stream beside the feature path, which waits for each level's event where it needs it."""
         B = pos.shape[0]
         levels, graphs, pts = [], {}, pos
         for blk in self._blocks():
-            pool = None
+            pool = ev_pool = None
             if pts.shape[1] != blk.npoint:
                 hold_rng_position(B, pts.shape[1])
                 fps_idx = ops.fps(pts, blk.npoint, None)
                 sub = ops.group_gather(pts, None, fps_idx.view(B, blk.npoint, 1)).view(B, blk.npoint, 3)
                 pool = (fps_idx, ops.ball_query(blk.radius, blk.k, pts, sub))
                 pts = sub
+                ev_pool = torch.cuda.Event()        # the block's max-pool + first 1x1 layer can start here ...
+                ev_pool.record()
             key = (pts.shape[1], blk.k)
             if key not in graphs:
-                graphs[key] = ops.knn_graph(pts, blk.k)     # (idx, idx[:, :, 1:], idx[:, :, :k]) from one launch
-                if with_grad:
-                    # the LPFA blocks of this resolution gather through the first k columns; their deterministic backward
-                    # gathers back through the sorted reverse index, built here once per graph, off the feature path
-                    ops.attach_rev_index(graphs[key][2], pts.shape[1])
-            ev = torch.cuda.Event()
-            ev.record()
-            levels.append((pool, graphs[key], ev))
+                g = ops.knn_graph(pts, blk.k)       # (idx, idx[:, :, 1:], idx[:, :, :k]) from one launch
+                ev = torch.cuda.Event()             # ... the walk and LPFA wait for the graph only
+                ev.record()
+                graphs[key] = (g, ev, pts.shape[1])
+            levels.append((pool, graphs[key][0], ev_pool, graphs[key][1]))
+        if with_grad:
+            # the LPFA blocks of a resolution gather through the first k columns of its graph; their deterministic backward
+            # gathers back through the sorted reverse index — read by the BACKWARD only, so it is built after everything the
+            # forward waits for (round 4: inside the level loop it sat on the forward's critical path: 54 us at the first level)
+            for g, _, n in graphs.values():
+                ops.attach_rev_index(g[2], n)
         return levels
 
     def forward(self, xyz):

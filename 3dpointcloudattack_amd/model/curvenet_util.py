@@ -378,14 +378,17 @@ class CIC(nn.Module):
         return g
 
     def _forward_cl(self, pts, x, geo=None):
-        pool = graph = None
+        pool = graph = ev_graph = None
         if geo is not None:
-            pool, graph, ready = geo
-            torch.cuda.current_stream().wait_event(ready)
+            pool, graph, ev_pool, ev_graph = geo
+            if ev_pool is not None:
+                torch.cuda.current_stream().wait_event(ev_pool)
         if pts.shape[1] != self.npoint:                            # FPS + ball-query max-pool down-sampling
             pts, x = self.maxpool(pts, x, cl=True, geo=pool)
         shortcut = x
         x = pw_cl(self.conv1, x)
+        if ev_graph is not None:                                   # the kNN graph is built while the layers above run
+            torch.cuda.current_stream().wait_event(ev_graph)
         _, adj, nbr = graph if graph is not None else self._graph(pts)
         if self.use_curve:
             curves = self.curvegrouping(x, pts, adj, cl=True)      # adj: no self-loops

@@ -38,7 +38,7 @@ ops.topk_desc, ops.att_scale = topk, att_scale
 orig_geo = model._geometry
 def geo(pos, with_grad=False):
     lv = orig_geo(pos, with_grad)
-    for i, (pool, graph, ev) in enumerate(lv):
+    for i, (pool, graph, ev_pool, ev) in enumerate(lv):
         if pool is not None:
             stash[f"L{i}_fps"], stash[f"L{i}_ball"] = pool
         stash[f"L{i}_knn"] = graph[0]
