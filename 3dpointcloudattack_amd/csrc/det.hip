@@ -36,6 +36,8 @@ struct ScatterArgs {
   int64_t out_bs, out_cs;   // batch / channel stride of out in elements (a [B,3,N] gradient: ldo = 1, out_cs = N)
   const float* row_bias;    // [B, N] or null  } a rank-1 term added on the way out: out[b,n,c] = sum + row_bias[b,n] * col_w[c]
   const float* col_w;       // [C]             } (the guided walk's score term; a separate product, then a separate add)
+  int NC;                   // destination rows per LDS tile: N when they all fit a CU's LDS (grid.z = 1); else grid.z chunks of NC
+                            // rows, every chunk walking ALL records and keeping those that land in it (same order, more passes)
 };
 
 // Lane = RECORD: a lane loads the CH contiguous channels of its record (one or two 16-byte loads when the slice is
@@ -51,9 +53,10 @@ __global__ __launch_bounds__(64 * W) void scatter_rows_own_kernel(ScatterArgs a)
   const int b = blockIdx.y, c0 = blockIdx.x * CH;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = min(CH, a.C - c0);
-  for (int e = threadIdx.x; e < W * a.N * ST; e += 64 * W) so_acc[e] = 0.f;
+  const int n0 = blockIdx.z * a.NC, nr = min(a.NC, a.N - n0);    // this workgroup's destination rows [n0, n0 + nr)
+  for (int e = threadIdx.x; e < W * a.NC * ST; e += 64 * W) so_acc[e] = 0.f;
   __syncthreads();
-  float* acc = so_acc + wave * a.N * ST;
+  float* acc = so_acc + wave * a.NC * ST;
   const int32_t* tg = a.tgt + (int64_t)b * a.R;
   const float* vb = a.val + (int64_t)b * a.R * a.ldv + c0;
   const float* ab = a.act ? a.act + (int64_t)b * a.R * a.lda + c0 : nullptr;
@@ -102,20 +105,21 @@ __global__ __launch_bounds__(64 * W) void scatter_rows_own_kernel(ScatterArgs a)
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      if ((unsigned)t[u] < (unsigned)a.N) {
+      const int tt = t[u] - n0;                                     // (t = -1 for lanes past the records: never inside)
+      if ((unsigned)t[u] < (unsigned)a.N && (unsigned)tt < (unsigned)nr) {
 #pragma unroll
         for (int q = 0; q < CH; ++q)
-          if (q < nch) atomicAdd(&acc[t[u] * ST + q], v[u][q]);    // ds_add_f32 into the wave-private tile
+          if (q < nch) atomicAdd(&acc[tt * ST + q], v[u][q]);      // ds_add_f32 into the wave-private tile
       }
     }
   }
   __syncthreads();
   float* ob = a.out + (int64_t)b * a.out_bs + (int64_t)c0 * a.out_cs;
-  for (int e = threadIdx.x; e < a.N * nch; e += 64 * W) {
-    const int n = e / nch, q = e - n * nch;
-    float sum = so_acc[n * ST + q];
+  for (int e = threadIdx.x; e < nr * nch; e += 64 * W) {
+    const int nl = e / nch, q = e - nl * nch, n = n0 + nl;
+    float sum = so_acc[nl * ST + q];
 #pragma unroll
-    for (int w = 1; w < W; ++w) sum += so_acc[(w * a.N + n) * ST + q];
+    for (int w = 1; w < W; ++w) sum += so_acc[(w * a.NC + nl) * ST + q];
     float* o = ob + (int64_t)n * a.ldo + (int64_t)q * a.out_cs;
     if (a.row_bias) {
       const float t = a.row_bias[(int64_t)b * a.N + n] * a.col_w[c0 + q];
@@ -141,6 +145,7 @@ struct ArgScatterArgs {
   float slope;
   float* dst;           // mode 0: gP [B,N,C]; mode 1: gPQ [B,N,2C]
   int mode;
+  int NC;               // destination rows per LDS tile (N when they fit; else grid.z chunks, as in ScatterArgs)
 };
 
 template <int CH>
@@ -150,7 +155,9 @@ __global__ __launch_bounds__(64) void arg_scatter_own_kernel(ArgScatterArgs a) {
   constexpr int U = CH >= 16 ? 1 : (CH >= 8 ? 2 : 4);
   const int b = blockIdx.y, c0 = blockIdx.x * CH, lane = threadIdx.x;
   const int nch = min(CH, a.C - c0);
-  for (int e = lane; e < a.N * ST; e += 64) as_acc[e] = 0.f;
+  const int n0 = blockIdx.z * a.NC, nr = min(a.NC, a.N - n0);
+  const bool first = blockIdx.z == 0;               // the chunk that also writes the centre half (mode 1)
+  for (int e = lane; e < a.NC * ST; e += 64) as_acc[e] = 0.f;
   wave_lds_sync();
   const int64_t ldd = a.mode ? 2 * (int64_t)a.C : (int64_t)a.C;
   const float* gb = a.g + (int64_t)b * a.S * a.ldg + c0;
@@ -182,7 +189,8 @@ __global__ __launch_bounds__(64) void arg_scatter_own_kernel(ArgScatterArgs a) {
             const float4 o = *reinterpret_cast<const float4*>(ob + (int64_t)i * a.C + q);
             v[u][q] *= o.x > 0.f ? 1.f : a.slope, v[u][q + 1] *= o.y > 0.f ? 1.f : a.slope;
             v[u][q + 2] *= o.z > 0.f ? 1.f : a.slope, v[u][q + 3] *= o.w > 0.f ? 1.f : a.slope;
-            *reinterpret_cast<float4*>(db + (int64_t)i * ldd + a.C + q) = make_float4(v[u][q], v[u][q + 1], v[u][q + 2], v[u][q + 3]);
+            if (first)
+              *reinterpret_cast<float4*>(db + (int64_t)i * ldd + a.C + q) = make_float4(v[u][q], v[u][q + 1], v[u][q + 2], v[u][q + 3]);
           }
         }
       } else {
@@ -193,7 +201,7 @@ __global__ __launch_bounds__(64) void arg_scatter_own_kernel(ArgScatterArgs a) {
             t[u][q] = rb[(int64_t)i * a.C + q];
             if (a.mode) {
               v[u][q] *= ob[(int64_t)i * a.C + q] > 0.f ? 1.f : a.slope;
-              db[(int64_t)i * ldd + a.C + q] = v[u][q];                       // dQ
+              if (first) db[(int64_t)i * ldd + a.C + q] = v[u][q];            // dQ
             }
           }
       }
@@ -202,21 +210,24 @@ __global__ __launch_bounds__(64) void arg_scatter_own_kernel(ArgScatterArgs a) {
     for (int u = 0; u < U; ++u)
       if (live[u]) {
 #pragma unroll
-        for (int q = 0; q < CH; ++q)    // (clamped like the forward's gather)
-          if (q < nch) atomicAdd(&as_acc[min(max(t[u][q], 0), a.N - 1) * ST + q], v[u][q]);
+        for (int q = 0; q < CH; ++q) {  // (clamped like the forward's gather)
+          const int tt = min(max(t[u][q], 0), a.N - 1) - n0;
+          if (q < nch && (unsigned)tt < (unsigned)nr) atomicAdd(&as_acc[tt * ST + q], v[u][q]);
+        }
       }
   }
   wave_lds_sync();
-  for (int n = lane; n < a.N; n += 64) {
+  for (int nl = lane; nl < nr; nl += 64) {
+    const int n = n0 + nl;
     if (vec) {
 #pragma unroll
       for (int q = 0; q < CH; q += 4)
         *reinterpret_cast<float4*>(db + (int64_t)n * ldd + q) =
-            make_float4(as_acc[n * ST + q], as_acc[n * ST + q + 1], as_acc[n * ST + q + 2], as_acc[n * ST + q + 3]);
+            make_float4(as_acc[nl * ST + q], as_acc[nl * ST + q + 1], as_acc[nl * ST + q + 2], as_acc[nl * ST + q + 3]);
     } else {
 #pragma unroll
       for (int q = 0; q < CH; ++q)
-        if (q < nch) db[(int64_t)n * ldd + q] = as_acc[n * ST + q];
+        if (q < nch) db[(int64_t)n * ldd + q] = as_acc[nl * ST + q];
     }
   }
 }
@@ -262,12 +273,18 @@ int scatter_rows_det(const char* nm, const int32_t* tgt, const float* val, int64
   // but no more than leave every wave >= 256 records.
   int ch = C >= 4 ? 4 : 1;
   while (ch > 1 && own_bytes(N, ch) > kOwnLds) ch >>= 1;
-  PC3D_REQUIRE(own_bytes(N, ch) <= kOwnLdsMax, "%s: N=%d destination rows do not fit a CU's LDS (deterministic scatter)", nm, N);
+  // More rows than a CU's LDS holds (N > ~40 000): tiles of NC rows, every tile walking all records (rounds 1-2
+  // took such sizes with atomics; refusing them made the deterministic default a regression). Same summation order per row.
+  int NC = N;
+  if (own_bytes(N, ch) > kOwnLdsMax) {
+    NC = (int)(kOwnLds / (sizeof(float) * (ch > 1 ? ch + 1 : 1)));
+    PC3D_REQUIRE(cdiv(N, NC) <= 65535, "%s: N=%d needs more than 65535 row tiles", nm, N);
+  }
   int w = 1;
-  while (w < 8 && own_bytes(N, ch, 2 * w) <= kOwnLds && R >= 2 * w * 256) w *= 2;
-  ScatterArgs a{tgt, val, act, ldv, lda, slope, R, N, C, out, ldo, accumulate, clamp, mbits, out_bs, out_cs, row_bias, col_w};
-  const size_t lds = own_bytes(N, ch, w);
-  const dim3 grid(cdiv(C, ch), B);
+  while (NC == N && w < 8 && own_bytes(N, ch, 2 * w) <= kOwnLds && R >= 2 * w * 256) w *= 2;
+  ScatterArgs a{tgt, val, act, ldv, lda, slope, R, N, C, out, ldo, accumulate, clamp, mbits, out_bs, out_cs, row_bias, col_w, NC};
+  const size_t lds = own_bytes(NC, ch, w);
+  const dim3 grid(cdiv(C, ch), B, cdiv(N, NC));
   hipStream_t st = as_stream(stream);
 #define PC3D_SR(CHV)                                                                                    \
   switch (w) {                                                                                          \
@@ -299,10 +316,15 @@ int arg_scatter_det(const char* nm, const float* g, int64_t ldg, const float* ou
     while (ch > 1 && own_bytes(N, ch) > 80 * 1024) ch >>= 1;      // (a tile may take 80 KB: two workgroups per CU)
   }
   PC3D_REQUIRE(ch == 1 || ch == 2 || ch == 4 || ch == 8 || ch == 16, "%s: slice width %d (1, 2, 4, 8, 16)", nm, ch);
-  PC3D_REQUIRE(own_bytes(N, ch) <= kOwnLdsMax, "%s: N=%d destination rows do not fit a CU's LDS (deterministic scatter)", nm, N);
-  ArgScatterArgs a{g, ldg, outv, arg, S, N, C, slope, dst, mode};
-  const size_t lds = own_bytes(N, ch);
-  const dim3 grid(cdiv(C, ch), B);
+  int NC = N;
+  if (own_bytes(N, ch) > kOwnLdsMax) {          // as scatter_rows_det: row tiles, all records per tile
+    PC3D_REQUIRE(slice == 0, "%s: N=%d destination rows do not fit a CU's LDS at slice width %d", nm, N, ch);
+    NC = (int)(kOwnLds / (sizeof(float) * (ch > 1 ? ch + 1 : 1)));
+    PC3D_REQUIRE(cdiv(N, NC) <= 65535, "%s: N=%d needs more than 65535 row tiles", nm, N);
+  }
+  ArgScatterArgs a{g, ldg, outv, arg, S, N, C, slope, dst, mode, NC};
+  const size_t lds = own_bytes(NC, ch);
+  const dim3 grid(cdiv(C, ch), B, cdiv(N, NC));
   hipStream_t st = as_stream(stream);
   switch (ch) {
     case 16: PC3D_OWN_LAUNCH(arg_scatter_own_kernel<16>, 64, grid, lds, st, a); break;

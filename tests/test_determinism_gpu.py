@@ -57,7 +57,9 @@ def _check(ops, make, B, wsum=True, rtol=2e-5, atol=1e-6):
 def test_scatter_rows_det_vs_float64(ops, dev):
     _lib = importlib.import_module("3dpointcloudattack_amd._lib")
     rng = np.random.default_rng(0)
-    for B, R, N, C, clamp in [(3, 1000, 257, 32, 0), (2, 5000, 64, 3, 0), (1, 77, 4096, 5, 1), (2, 300, 9000, 1, 0), (4, 2048, 1024, 131, 0)]:
+    # (the last two: more destination rows than a CU's LDS holds — row tiles, every tile walking all records)
+    for B, R, N, C, clamp in [(3, 1000, 257, 32, 0), (2, 5000, 64, 3, 0), (1, 77, 4096, 5, 1), (2, 300, 9000, 1, 0), (4, 2048, 1024, 131, 0),
+                              (2, 30000, 50000, 6, 0), (1, 5000, 100001, 3, 1)]:
         tgt = torch.from_numpy(rng.integers(-2, N + 2, size=(B, R)).astype(np.int32)).to(dev)
         val = torch.from_numpy(rng.standard_normal((B, R, C)).astype(np.float32)).to(dev)
         act = torch.from_numpy(rng.standard_normal((B, R, C)).astype(np.float32)).to(dev)
@@ -82,6 +84,27 @@ def test_scatter_rows_det_vs_float64(ops, dev):
                 _lib.call("pc3d_scatter_rows_det_f32", tgt.data_ptr(), val.data_ptr(), C, act.data_ptr() if use_act else 0, C,
                           0.2, B, R, N, C, out2.data_ptr(), C, 0, clamp, torch.cuda.current_stream().cuda_stream)
             assert torch.equal(out, out2)
+
+
+def test_arg_scatter_more_rows_than_lds(ops, dev):
+    """The per-channel-target scatter (the backward of a max over gathered rows) with 50 000 destination rows: row tiles
+    instead of the refusal of round 3; against a float64 scatter, twice bit-equal."""
+    _lib = importlib.import_module("3dpointcloudattack_amd._lib")
+    rng = np.random.default_rng(1)
+    B, N, C = 2, 50000, 8
+    g = torch.from_numpy(rng.standard_normal((B, N, C)).astype(np.float32)).to(dev)
+    arg = torch.from_numpy(rng.integers(0, N, size=(B, N, C)).astype(np.int32)).to(dev)
+    outs = []
+    for _ in range(2):
+        gp = torch.full((B, N, C), float("nan"), device=dev)
+        with torch.cuda.device(dev):
+            _lib.call("pc3d_gather_max_bwd_f32", g.data_ptr(), arg.data_ptr(), B, N, C, gp.data_ptr(), 1,
+                      torch.cuda.current_stream().cuda_stream)
+        outs.append(gp)
+    assert torch.equal(outs[0], outs[1])
+    ref = torch.zeros((B, N, C), dtype=torch.float64, device=dev)
+    ref.scatter_add_(1, arg.long(), g.double())
+    np.testing.assert_allclose(outs[0].cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=1e-5)
 
 
 @pytest.mark.parametrize("B,E,NA,C", [(3, 20480, 1024, 32), (2, 777, 64, 16), (2, 5000, 300, 3), (1, 64, 4096, 128)])
