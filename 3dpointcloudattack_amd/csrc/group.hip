@@ -25,7 +25,21 @@ struct FpsArgs {
   int N, S;
   const int32_t* start;  // [B] or null (=0: model/curvenet_util.py:81)
   int32_t* out;          // [B,S]
+#ifdef FPS_DIAG
+  long long* diag;       // [B, waves, 4] clocks per phase (diagnostic build only: tools/exp/fps_full_diag.py)
+#endif
 };
+#ifdef FPS_DIAG
+static long long* g_fps_diag = nullptr;
+#define FPS_STAMP(k)                                       \
+  do {                                                     \
+    const long long now_ = __builtin_amdgcn_s_memtime();   \
+    dg[k] += now_ - t_;                                    \
+    t_ = now_;                                             \
+  } while (0)
+#else
+#define FPS_STAMP(k)
+#endif
 
 template <int PER, int T = FPS_T>
 __global__ __launch_bounds__(T) void fps_kernel(FpsArgs a) {
@@ -60,6 +74,10 @@ __global__ __launch_bounds__(T) void fps_kernel(FpsArgs a) {
   far = far < 0 ? 0 : (far >= a.N ? a.N - 1 : far);  // a start index outside the cloud cannot fault the launch
   __syncthreads();
   int keep = 0;
+#ifdef FPS_DIAG
+  long long dg[4] = {0, 0, 0, 0};
+  long long t_ = __builtin_amdgcn_s_memtime();
+#endif
   for (int s = 0; s < a.S; ++s) {
     // the picks leave 64 at a time: lane (s % 64) of wave 0 keeps step s's pick, a coalesced store every 64 steps
     keep = (lane == (s & 63)) ? far : keep;
@@ -129,6 +147,7 @@ __global__ __launch_bounds__(T) void fps_kernel(FpsArgs a) {
     }
 #undef FPS_TRACK
     float bv = __builtin_bit_cast(float, bvi);
+    FPS_STAMP(0);      // pick bookkeeping + centre lookup + row updates
     // wave arg-max on DPP (the shuffle version cost ~800 cycles of LDS-crossbar latency per step): the maximum
     // first, then the lowest index among the lanes that hold it (= the reference's first-index tie rule)
     {
@@ -140,6 +159,7 @@ __global__ __launch_bounds__(T) void fps_kernel(FpsArgs a) {
       else bi = wave_min_dpp_i32(bv == wv ? bi : 0x7fffffff);
       bv = wv;
     }
+    FPS_STAMP(1);      // wave arg-max
     float fv = bv;
     int fi = bi;
     if (T > 64) {           // (one wavefront per cloud: the wave's arg-max is the cloud's — no exchange, no barrier)
@@ -147,6 +167,7 @@ __global__ __launch_bounds__(T) void fps_kernel(FpsArgs a) {
       if (lane == 0)
         red_k[buf][wave] = ((long long)__builtin_bit_cast(int, bv) << 32) | (long long)(unsigned)(0x7fffffff - bi);
       __syncthreads();
+      FPS_STAMP(2);    // key write + barrier
       long long best = red_k[buf][0];
 #pragma unroll
       for (int w = 1; w < T / 64; ++w) {
@@ -157,7 +178,12 @@ __global__ __launch_bounds__(T) void fps_kernel(FpsArgs a) {
       fi = 0x7fffffff - (int)(unsigned)(best & 0xffffffffll);
     }
     if (fi != 0x7fffffff) far = fi;  // no finite candidate (NaN cloud): stay put instead of indexing LDS at 2^31
+    FPS_STAMP(3);      // key reads + selection
   }
+#ifdef FPS_DIAG
+  if (lane == 0 && a.diag)
+    for (int k = 0; k < 4; ++k) a.diag[((int64_t)b * (T / 64) + wave) * 4 + k] = dg[k];
+#endif
   if ((a.S & 63) != 0 && wave == 0 && lane < (a.S & 63)) a.out[(int64_t)b * a.S + (a.S & ~63) + lane] = keep;
 }
 
@@ -1056,7 +1082,11 @@ static int fps_launch(const char* nm, int threads, const float* xyz, int64_t x_b
                threads * FPS_MAXPER < FPS_T * FPS_MAXPER ? threads * FPS_MAXPER : FPS_T * FPS_MAXPER, FPS_MAXPER);
   if (B == 0) return PC3D_OK;
   PC3D_REQUIRE(xyz && out, "%s: null pointer", nm);
+#ifdef FPS_DIAG
+  FpsArgs a{{xyz, x_bs, x_ps, x_cs}, N, S, start, out, g_fps_diag};
+#else
   FpsArgs a{{xyz, x_bs, x_ps, x_cs}, N, S, start, out};
+#endif
   const size_t lds = (size_t)3 * N * sizeof(float);
   hipStream_t st = as_stream(stream);
   const int per = cdiv(N, threads);
@@ -1078,6 +1108,10 @@ static int fps_launch(const char* nm, int threads, const float* xyz, int64_t x_b
   PC3D_LAUNCH_CHECK(nm);
   return PC3D_OK;
 }
+
+#ifdef FPS_DIAG
+extern "C" void fps_set_diag(long long* p) { g_fps_diag = p; }
+#endif
 
 extern "C" int pc3d_fps_f32(const float* xyz, int64_t x_bs, int64_t x_ps, int64_t x_cs, int B, int N, int S,
                             const int32_t* start, int32_t* out, void* stream) {
