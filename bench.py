@@ -593,7 +593,7 @@ def main():
         Vqt = Vq.transpose(1, 2).contiguous()
         adv_q = torch.randn(B, 3, NPTS, device=dev)
         bufs_q = [torch.empty_like(adv_q) for _ in range(3)]
-        whole(f"aof_taof_pointnet_B{B}_N{NPTS}", aof_run, 20, 100,      # (long slopes: every call carries one eigh of ~0.12 s whose jitter must cancel)
+        whole(f"aof_taof_pointnet_B{B}_N{NPTS}", aof_run, 100, 300,     # (long slopes: every call carries one eigh of ~0.12 s whose jitter must cancel)
               kernel_roof("rowdot3_kernel x2 (pc3d_spectral_reproject_f32: coeff = adv V, lfc / hfc = coeff_lo|hi V^T)",
                           lambda: ops.spectral_reproject(adv_q, Vq, Vqt, 100, *bufs_q), hbm_bytes=2.0 * B * NPTS * NPTS * 4,
                           note="both launches of one re-projection; algorithmic bytes = V and V^T read once each "

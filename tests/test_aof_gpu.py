@@ -75,6 +75,32 @@ def test_taof_batched(dev):
     assert out.shape == (3, 128, 3) and np.isfinite(out).all() and 0 <= sn <= 3
 
 
+def test_taof_deferred_success_check_books_the_same_bests(dev):
+    """The fused loop books iteration i's success check inside iteration i + 1 (one forward of lfc serves the check and the
+    next loss; the last iteration is flushed after the loop): best distances, best clouds and the success pattern are those
+    of the generic loop, which checks inside the iteration as the reference does (TAOF_attack.py:172-186)."""
+    ta, adv, dist, clip = _mods()
+    net, _ = hip_pointnet(0, dev)
+    rng = np.random.default_rng(8)
+    pcs = torch.from_numpy(np.stack([unit_cloud(rng, 192) for _ in range(6)]))
+    with torch.no_grad():
+        lp = net(pcs.transpose(1, 2).contiguous().to(dev))[0]
+    y, tgt = lp.argmax(1).cpu(), lp.topk(2)[1][:, 1].cpu()
+    res = {}
+    for fused in (False, True):
+        atk = ta.CWTAOF(net, adv.LogitsAdvLoss(0.), dist.L2Dist(), attack_lr=1e-2, binary_step=2, num_iter=12, low_pass=30,
+                        clip_func=clip.ClipPointsLinf(0.18), fused=fused)
+        torch.manual_seed(6)
+        res[fused] = atk.attack(pcs, tgt, y)
+    (bd0, out0, sn0), (bd1, out1, sn1) = res[False], res[True]
+    found = bd0 < 1e9
+    assert found.any(), "the case must exercise the best-so-far update"
+    assert np.array_equal(found, bd1 < 1e9) and sn0 == sn1
+    np.testing.assert_allclose(bd1[found], bd0[found], rtol=1e-3)
+    d = np.abs(out1 - out0)      # autograd vs the fused backward over 24 Adam steps; one step off would show as ~1e-2 (= lr)
+    assert d.max() < 1e-3 and np.median(d) < 1e-5
+
+
 def test_taof_graph_replay_equals_eager(dev):
     """The hipGraph-captured TAOF iteration reproduces the eager fused path bit for bit (same launches, same order)."""
     ta, adv, dist, clip = _mods()

@@ -88,7 +88,7 @@ if "geoa3_curvenet" in which:
     res["geoa3_curvenet_slopes_ms"] = slopes
     print(res, flush=True)
 if "geoa3" in which:
-    B, N, IT = 32, 1024, 60
+    B, N, IT = 32, 1024, 600      # long slopes: every call carries an eigh of ~0.12 s whose jitter (+-10 ms) must cancel
     net = mk("dgcnn", "DGCNN", 0, args=types.SimpleNamespace(k=20, emb_dims=1024, dropout=0.5), output_channels=40)
     pcs = torch.from_numpy(np.stack([unit_cloud(rng, N) for _ in range(B)]))
     with torch.no_grad():
@@ -131,7 +131,7 @@ if "knn" in which:
     res["knn_ssg_slopes_ms"] = slopes
     print(res, flush=True)
 if "aof" in which:
-    B, N, IT = 32, 1024, 60
+    B, N, IT = 32, 1024, 600      # long slopes: every call carries an eigh of ~0.12 s whose jitter (+-10 ms) must cancel
     net = mk("pointnet", "PointNetCls", 0, k=40)
     pcs = torch.from_numpy(np.stack([unit_cloud(rng, N) for _ in range(B)]))
     with torch.no_grad():
