@@ -7,8 +7,9 @@ component is optimised with two victim forward/backward passes per iteration (on
 
 On MI355X: the Laplacian is built from the O(N k) graph edges by pc3d_graph_laplacian_f32 (the reference materialises
 a [B,N,N,3] tensor); with a PointNet victim and this package's adversarial functors both forward/backward pairs and
-both success-check forwards use the launch-minimal fused path (no autograd); bookkeeping stays on the device (the
-reference copies the whole cloud to the host every iteration, :195-208).
+the success-check forward use the launch-minimal fused path (no autograd) — the check on model(lfc) reuses the forward
+of the next iteration's loss on the same tensor; bookkeeping stays on the device (the reference copies the whole cloud
+to the host every iteration, :195-208).
 """
 import numpy as np
 import torch

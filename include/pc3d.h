@@ -543,7 +543,7 @@ int pc3d_cw_step_f32(float* p, int64_t p_bs, int64_t p_ps, int64_t p_cs,
 int pc3d_fps_f32(const float* xyz, int64_t x_bs, int64_t x_ps, int64_t x_cs, int B, int N, int S,
                  const int32_t* start, int32_t* out, void* stream);
 /* The same sampling with the workgroup size named (64, 128, 256, 512 or 1024 threads per cloud, N <= 32 * threads; results
- * are identical; pc3d_fps_f32 takes 64 up to N = 1024, else 256): for tests and measurements. */
+ * are identical; pc3d_fps_f32 takes 64 up to N = 512, else 256): for tests and measurements. */
 int pc3d_fps_threads_f32(int threads, const float* xyz, int64_t x_bs, int64_t x_ps, int64_t x_cs, int B, int N, int S,
                          const int32_t* start, int32_t* out, void* stream);
 /* The same sampling on ONE wavefront per cloud with exact pruning (csrc/fps_pruned.hip): the cloud is split into rows of 64
