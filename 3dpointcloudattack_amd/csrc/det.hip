@@ -146,88 +146,145 @@ struct ArgScatterArgs {
   float* dst;           // mode 0: gP [B,N,C]; mode 1: gPQ [B,N,2C]
   int mode;
   int NC;               // destination rows per LDS tile (N when they fit; else grid.z chunks, as in ScatterArgs)
+  int B;
 };
 
-template <int CH>
-__global__ __launch_bounds__(64) void arg_scatter_own_kernel(ArgScatterArgs a) {
-  extern __shared__ float as_acc[];                 // [N][ST]
+// One trip of a wavefront: 64 * U source points, CH channels each. The load half only ISSUES the loads (nothing computed
+// on what they return, so the wave does not wait for them); the add half applies the activation's mask, writes the centre
+// half and issues the ds_add_f32 — one trip later.
+template <int CH, int U>
+struct ArgTrip {
+  int t[U][CH];
+  float v[U][CH], o[U][CH];
+  int i[U];          // source point, -1: none
+};
+
+template <int CH, int U, bool VEC, int MODE>
+__device__ __forceinline__ void arg_trip_load(ArgTrip<CH, U>& T, const ArgScatterArgs& a, const float* gb, const float* ob,
+                                              const int32_t* rb, int i0, int hi, int lane, int nch) {
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int i = i0 + u * 64 + lane;
+    T.i[u] = i < hi ? i : -1;
+    if (VEC) {      // no branch around the loads: lanes past the end re-read the last point and are dropped in the add half
+      const int ic = i < hi ? i : hi - 1;      // (branches would make the wait counters unknown at their joins: vmcnt(0) everywhere)
+#pragma unroll
+      for (int q = 0; q < CH; q += 4) {
+        const float4 x = *reinterpret_cast<const float4*>(gb + (int64_t)ic * a.ldg + q);
+        const int4 r = *reinterpret_cast<const int4*>(rb + (int64_t)ic * a.C + q);
+        T.v[u][q] = x.x, T.v[u][q + 1] = x.y, T.v[u][q + 2] = x.z, T.v[u][q + 3] = x.w;
+        T.t[u][q] = r.x, T.t[u][q + 1] = r.y, T.t[u][q + 2] = r.z, T.t[u][q + 3] = r.w;
+        if (MODE) {
+          const float4 o = *reinterpret_cast<const float4*>(ob + (int64_t)ic * a.C + q);
+          T.o[u][q] = o.x, T.o[u][q + 1] = o.y, T.o[u][q + 2] = o.z, T.o[u][q + 3] = o.w;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < CH; ++q) T.t[u][q] = 0, T.v[u][q] = 0.f, T.o[u][q] = 1.f;
+      if (i >= hi) continue;
+#pragma unroll
+      for (int q = 0; q < CH; ++q)
+        if (q < nch) {
+          T.v[u][q] = gb[(int64_t)i * a.ldg + q];
+          T.t[u][q] = rb[(int64_t)i * a.C + q];
+          if (MODE) T.o[u][q] = ob[(int64_t)i * a.C + q];
+        }
+    }
+  }
+}
+
+template <int CH, int U, bool VEC, int MODE, typename ACC>
+__device__ __forceinline__ void arg_trip_add(const ArgTrip<CH, U>& T, const ArgScatterArgs& a, ACC* acc, float* db, int64_t ldd,
+                                             int n0, int nr, int nch, bool first) {
   constexpr int ST = CH > 1 ? CH + 1 : 1;
-  constexpr int U = CH >= 16 ? 1 : (CH >= 8 ? 2 : 4);
-  const int b = blockIdx.y, c0 = blockIdx.x * CH, lane = threadIdx.x;
-  const int nch = min(CH, a.C - c0);
+  constexpr bool vec = VEC;
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+    if (T.i[u] >= 0) {
+      float v[CH];
+#pragma unroll
+      for (int q = 0; q < CH; ++q) v[q] = MODE ? T.v[u][q] * (T.o[u][q] > 0.f ? 1.f : a.slope) : T.v[u][q];
+      if (MODE && first) {                                                      // dQ
+        float* dq = db + (int64_t)T.i[u] * ldd + a.C;
+        if (vec) {
+#pragma unroll
+          for (int q = 0; q < CH; q += 4) *reinterpret_cast<float4*>(dq + q) = make_float4(v[q], v[q + 1], v[q + 2], v[q + 3]);
+        } else {
+#pragma unroll
+          for (int q = 0; q < CH; ++q)
+            if (q < nch) dq[q] = v[q];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < CH; ++q) {  // (clamped like the forward's gather)
+        const int tt = min(max(T.t[u][q], 0), a.N - 1) - n0;
+        if (q < nch && (unsigned)tt < (unsigned)nr) atomicAdd(&acc[tt * ST + q], (ACC)v[q]);
+      }
+    }
+}
+
+// W wavefronts per (cloud, channel slice), each with a PRIVATE tile and a contiguous piece of the source points (walked in
+// order, the next trip's loads issued before the current trip's ds_add_f32); the W tiles are added in ascending wave order
+// on the way out. The pieces depend on S alone (args_pieces), so a sum is the same function of its inputs whatever the
+// slice width and the batch size.
+// VEC: whole, 16-byte aligned slices (the launcher checks) — straight-line 16-byte loads and stores.
+// ACC: the tiles' element type. double by default — gfx950's LDS retires a ds_add_f64 in ~40 clocks per wavefront and a
+// ds_add_f32 in ~190 whatever the addresses (tools/exp/lds_atomic_rate.hip: the float form is serialised per lane, the
+// double and integer forms are not), and a sum of fp32 terms carried in fp64 is rounded once, on the way out.
+template <int CH, int W, bool VEC, int MODE, typename ACC>
+__global__ __launch_bounds__(64 * W) void arg_scatter_own_kernel(ArgScatterArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char as_raw[];
+  ACC* as_acc = reinterpret_cast<ACC*>(as_raw);                                  // [W][NC][ST]
+  constexpr int ST = CH > 1 ? CH + 1 : 1;
+  constexpr int U = CH >= 16 ? 2 : (CH >= 8 ? 4 : 8);      // two trips of 64 U points in flight: ~190 VGPRs (one wave per SIMD anyway)
+  // grid.x = (cloud, slice) in XCD bands: the slices of a cloud read the same lines of g / arg / out (a slice uses 16-64 bytes
+  // of each 128-byte line) — spread over the 8 XCDs every L2 pulled every line (24 MB as 192 MB at B=32, N=1024, C=64)
+  const int nsl = (a.C + CH - 1) / CH;
+  const int t = xcd_band_id(blockIdx.x, a.B * nsl);
+  if (t < 0) return;
+  const int b = t / nsl, c0 = (t - b * nsl) * CH, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = VEC ? CH : min(CH, a.C - c0);
   const int n0 = blockIdx.z * a.NC, nr = min(a.NC, a.N - n0);
   const bool first = blockIdx.z == 0;               // the chunk that also writes the centre half (mode 1)
-  for (int e = lane; e < a.NC * ST; e += 64) as_acc[e] = 0.f;
-  wave_lds_sync();
-  const int64_t ldd = a.mode ? 2 * (int64_t)a.C : (int64_t)a.C;
+  const int64_t ldd = MODE ? 2 * (int64_t)a.C : (int64_t)a.C;
   const float* gb = a.g + (int64_t)b * a.S * a.ldg + c0;
   const float* ob = a.out ? a.out + (int64_t)b * a.S * a.C + c0 : nullptr;
   const int32_t* rb = a.arg + (int64_t)b * a.S * a.C + c0;
   float* db = a.dst + (int64_t)b * a.N * ldd + c0;
-  const bool vec = CH >= 4 && nch == CH && (a.C & 3) == 0 && (a.ldg & 3) == 0 &&
-                   ((reinterpret_cast<uintptr_t>(a.g) | reinterpret_cast<uintptr_t>(a.arg) | reinterpret_cast<uintptr_t>(a.dst) |
-                     reinterpret_cast<uintptr_t>(a.out)) & 15) == 0;
-  for (int i0 = 0; i0 < a.S; i0 += 64 * U) {
-    int t[U][CH];
-    float v[U][CH];
-    bool live[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int i = i0 + u * 64 + lane;
-      live[u] = i < a.S;
-#pragma unroll
-      for (int q = 0; q < CH; ++q) t[u][q] = 0, v[u][q] = 0.f;
-      if (!live[u]) continue;
-      if (vec) {
-#pragma unroll
-        for (int q = 0; q < CH; q += 4) {
-          const float4 x = *reinterpret_cast<const float4*>(gb + (int64_t)i * a.ldg + q);
-          const int4 r = *reinterpret_cast<const int4*>(rb + (int64_t)i * a.C + q);
-          v[u][q] = x.x, v[u][q + 1] = x.y, v[u][q + 2] = x.z, v[u][q + 3] = x.w;
-          t[u][q] = r.x, t[u][q + 1] = r.y, t[u][q + 2] = r.z, t[u][q + 3] = r.w;
-          if (a.mode) {
-            const float4 o = *reinterpret_cast<const float4*>(ob + (int64_t)i * a.C + q);
-            v[u][q] *= o.x > 0.f ? 1.f : a.slope, v[u][q + 1] *= o.y > 0.f ? 1.f : a.slope;
-            v[u][q + 2] *= o.z > 0.f ? 1.f : a.slope, v[u][q + 3] *= o.w > 0.f ? 1.f : a.slope;
-            if (first)
-              *reinterpret_cast<float4*>(db + (int64_t)i * ldd + a.C + q) = make_float4(v[u][q], v[u][q + 1], v[u][q + 2], v[u][q + 3]);
-          }
-        }
-      } else {
-#pragma unroll
-        for (int q = 0; q < CH; ++q)
-          if (q < nch) {
-            v[u][q] = gb[(int64_t)i * a.ldg + q];
-            t[u][q] = rb[(int64_t)i * a.C + q];
-            if (a.mode) {
-              v[u][q] *= ob[(int64_t)i * a.C + q] > 0.f ? 1.f : a.slope;
-              if (first) db[(int64_t)i * ldd + a.C + q] = v[u][q];            // dQ
-            }
-          }
-      }
+  constexpr bool vec = VEC;
+  const int per = ((a.S + W - 1) / W + 63) / 64 * 64, lo = wave * per, hi = min(lo + per, a.S);
+  ArgTrip<CH, U> A, Bt;
+  const bool any = lo < hi;                                                              // (uniform per wavefront)
+  if (any) arg_trip_load<CH, U, VEC, MODE>(A, a, gb, ob, rb, lo, hi, lane, nch);        // in flight while the tiles are zeroed
+  for (int e = threadIdx.x; e < W * a.NC * ST; e += 64 * W) as_acc[e] = (ACC)0;
+  if (W > 1) __syncthreads(); else wave_lds_sync();
+  ACC* acc = as_acc + wave * a.NC * ST;
+  if (any)
+    for (int i0 = lo; i0 < hi; i0 += 2 * 64 * U) {
+      arg_trip_load<CH, U, VEC, MODE>(Bt, a, gb, ob, rb, i0 + 64 * U, hi, lane, nch);
+      arg_trip_add<CH, U, VEC, MODE, ACC>(A, a, acc, db, ldd, n0, nr, nch, first);
+      arg_trip_load<CH, U, VEC, MODE>(A, a, gb, ob, rb, i0 + 2 * 64 * U, hi, lane, nch);
+      arg_trip_add<CH, U, VEC, MODE, ACC>(Bt, a, acc, db, ldd, n0, nr, nch, first);
     }
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (live[u]) {
-#pragma unroll
-        for (int q = 0; q < CH; ++q) {  // (clamped like the forward's gather)
-          const int tt = min(max(t[u][q], 0), a.N - 1) - n0;
-          if (q < nch && (unsigned)tt < (unsigned)nr) atomicAdd(&as_acc[tt * ST + q], v[u][q]);
-        }
-      }
-  }
-  wave_lds_sync();
-  for (int nl = lane; nl < nr; nl += 64) {
+  if (W > 1) __syncthreads(); else wave_lds_sync();
+  for (int nl = threadIdx.x; nl < nr; nl += 64 * W) {
     const int n = n0 + nl;
+    float r[CH];
+#pragma unroll
+    for (int q = 0; q < CH; ++q) {
+      ACC sum = as_acc[nl * ST + q];
+#pragma unroll
+      for (int w = 1; w < W; ++w) sum += as_acc[(w * a.NC + nl) * ST + q];
+      r[q] = (float)sum;
+    }
     if (vec) {
 #pragma unroll
-      for (int q = 0; q < CH; q += 4)
-        *reinterpret_cast<float4*>(db + (int64_t)n * ldd + q) =
-            make_float4(as_acc[nl * ST + q], as_acc[nl * ST + q + 1], as_acc[nl * ST + q + 2], as_acc[nl * ST + q + 3]);
+      for (int q = 0; q < CH; q += 4) *reinterpret_cast<float4*>(db + (int64_t)n * ldd + q) = make_float4(r[q], r[q + 1], r[q + 2], r[q + 3]);
     } else {
 #pragma unroll
       for (int q = 0; q < CH; ++q)
-        if (q < nch) db[(int64_t)n * ldd + q] = as_acc[nl * ST + q];
+        if (q < nch) db[(int64_t)n * ldd + q] = r[q];
     }
   }
 }
@@ -299,40 +356,55 @@ int scatter_rows_det(const char* nm, const int32_t* tgt, const float* val, int64
   return PC3D_OK;
 }
 
-// slice = 0: chosen here; else the channel-slice width to run (1, 2, 4, 8, 16; PC3D_EINVAL when its tile does not fit)
+// slice: bits 0..7 the channel-slice width to run (1, 2, 4, 8, 16; 0: chosen here; PC3D_EINVAL when its tile does not fit),
+// bit 8: fp32 tiles where the library would take fp64 ones (measurements: tools/bench_det.py).
 int arg_scatter_det(const char* nm, const float* g, int64_t ldg, const float* outv, const int32_t* arg, int B, int S, int N, int C,
                     float slope, float* dst, int mode, void* stream, int slice) {
-  int ch = slice;
+  // Tiles in fp64 whenever a 4-channel slice of them fits a CU's LDS (N <= 4096) — a function of N alone, so that a cloud's
+  // sums do not depend on the batch it is in; the slice width does not change a sum (one wave, points in order).
+  const bool f64 = !(slice & 256) && own_bytes(N, 4) * 2 <= kOwnLdsMax;
+  const size_t eb = f64 ? 2 : 1;
+  int ch = slice & 0xff;
+  slice = ch;
   if (ch == 0) {
-    // measured at B=32, N=1024 (tools/bench_det.py, us; float-atomic LDS kernel beside them):
-    //   C     slice 4   8     16    atomics          wider slices read longer pieces of every row (a 16-channel slice
-    //   64      43     34     52      22             uses half of each 128-byte line it touches, a 4-channel slice an
-    //   128     88     55     61      43             eighth) but leave fewer waves: B * C / slice
-    //   256    180    126     79      91
-    //   32 (N=4096)  83 (slice 4; 8: 113)  209
+    // measured inside replayed graphs (tools/bench_det.py), us at B=32, N=1024, slice 4 / 8 / 16:
+    // C=64 16.6 / 17.9 / 26.2, C=128 28.8 / 28.6 / 30.4, C=256 56.9 / 47.4 / 55.3 (float atomics: 22 / 44 / 92);
+    // B=1, C=256: 9.4 / 15.1 / 25.2; N=4096, C=32: 36.3 (slice 4; atomics 209)
     ch = C >= 4 ? 4 : 1;
-    if (C % 8 == 0 && (long)B * (C / 8) >= 256 && own_bytes(N, 8) <= kOwnLds) ch = 8;
-    if (C % 16 == 0 && (long)B * (C / 16) >= 512 && own_bytes(N, 16) <= 80 * 1024) ch = 16;
-    while (ch > 1 && own_bytes(N, ch) > 80 * 1024) ch >>= 1;      // (a tile may take 80 KB: two workgroups per CU)
+    if (C % 8 == 0 && (long)B * (C / 8) >= 128 && own_bytes(N, 8) * eb <= kOwnLdsMax) ch = 8;
+    while (ch > 1 && own_bytes(N, ch) * eb > kOwnLdsMax) ch >>= 1;
   }
   PC3D_REQUIRE(ch == 1 || ch == 2 || ch == 4 || ch == 8 || ch == 16, "%s: slice width %d (1, 2, 4, 8, 16)", nm, ch);
   int NC = N;
-  if (own_bytes(N, ch) > kOwnLdsMax) {          // as scatter_rows_det: row tiles, all records per tile
+  if (own_bytes(N, ch) * eb > kOwnLdsMax) {          // as scatter_rows_det: row tiles, all records per tile
     PC3D_REQUIRE(slice == 0, "%s: N=%d destination rows do not fit a CU's LDS at slice width %d", nm, N, ch);
-    NC = (int)(kOwnLds / (sizeof(float) * (ch > 1 ? ch + 1 : 1)));
+    NC = (int)(kOwnLds / (sizeof(float) * eb * (ch > 1 ? ch + 1 : 1)));
     PC3D_REQUIRE(cdiv(N, NC) <= 65535, "%s: N=%d needs more than 65535 row tiles", nm, N);
   }
-  ArgScatterArgs a{g, ldg, outv, arg, S, N, C, slope, dst, mode, NC};
-  const size_t lds = own_bytes(NC, ch);
-  const dim3 grid(cdiv(C, ch), B, cdiv(N, NC));
+  ArgScatterArgs a{g, ldg, outv, arg, S, N, C, slope, dst, mode, NC, B};
+  const size_t lds = own_bytes(NC, ch) * eb;
+  const dim3 grid(xcd_grid(cdiv(C, ch) * B), 1, cdiv(N, NC));
   hipStream_t st = as_stream(stream);
+  const bool vec = ch >= 4 && C % ch == 0 && (C & 3) == 0 && (ldg & 3) == 0 &&
+                   ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(arg) | reinterpret_cast<uintptr_t>(dst) |
+                     reinterpret_cast<uintptr_t>(outv)) & 15) == 0;
+#define PC3D_AS2(CHV, VECV, MODEV)                                                                              \
+  if (f64) PC3D_OWN_LAUNCH((arg_scatter_own_kernel<CHV, 1, VECV, MODEV, double>), 64, grid, lds, st, a);         \
+  else PC3D_OWN_LAUNCH((arg_scatter_own_kernel<CHV, 1, VECV, MODEV, float>), 64, grid, lds, st, a);
+#define PC3D_AS(CHV)                                       \
+  if (vec && CHV >= 4 && mode) { PC3D_AS2(CHV, (CHV >= 4), 1) } \
+  else if (vec && CHV >= 4) { PC3D_AS2(CHV, (CHV >= 4), 0) }    \
+  else if (mode) { PC3D_AS2(CHV, false, 1) }               \
+  else { PC3D_AS2(CHV, false, 0) }
   switch (ch) {
-    case 16: PC3D_OWN_LAUNCH(arg_scatter_own_kernel<16>, 64, grid, lds, st, a); break;
-    case 8: PC3D_OWN_LAUNCH(arg_scatter_own_kernel<8>, 64, grid, lds, st, a); break;
-    case 4: PC3D_OWN_LAUNCH(arg_scatter_own_kernel<4>, 64, grid, lds, st, a); break;
-    case 2: PC3D_OWN_LAUNCH(arg_scatter_own_kernel<2>, 64, grid, lds, st, a); break;
-    default: PC3D_OWN_LAUNCH(arg_scatter_own_kernel<1>, 64, grid, lds, st, a); break;
+    case 16: PC3D_AS(16) break;
+    case 8: PC3D_AS(8) break;
+    case 4: PC3D_AS(4) break;
+    case 2: PC3D_AS(2) break;
+    default: PC3D_AS(1) break;
   }
+#undef PC3D_AS2
+#undef PC3D_AS
   PC3D_LAUNCH_CHECK(nm);
   return PC3D_OK;
 }

@@ -28,6 +28,7 @@ struct KnnFeatArgs {
   const float* x;  // [B,N,C] channels-last
   int N, C, K;
   int32_t* idx;    // [B,N,K]
+  int B;
 };
 
 // (Round 2, measured: a barrier-free variant — every wave owning 16 queries on v_mfma_f32_16x16x4_f32, distances
@@ -54,7 +55,9 @@ __global__ __launch_bounds__(KF_T) void knn_feat_kernel(KnnFeatArgs a) {
   const int ldq = a.C + 4;                                  // row stride of the query block (16-byte aligned rows)
   int (*strip)[KF_LD] = reinterpret_cast<int (*)[KF_LD]>(kf_lds);              // [32][132] block of distance KEYS (knn_key)
   float* qs = kf_lds + KF_Q * KF_LD;                                             // [32][C+4] query rows
-  const int b = blockIdx.y, q0 = blockIdx.x * KF_Q;
+  int bx, b;                                                // all query blocks of a cloud on one XCD: they stream the same rows
+  if (!xcd_block((a.N + KF_Q - 1) / KF_Q, a.B, bx, b)) return;
+  const int q0 = bx * KF_Q;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 31, h = lane >> 5;
@@ -189,11 +192,13 @@ struct GMaxArgs {
   float* out;           // [B,S,C]
   int32_t* arg;         // [B,S,C] winning neighbour (absolute point index) or null
   int S;                // output rows per cloud (S == N for a neighbour graph on the points themselves)
+  int B;
 };
 
 __global__ __launch_bounds__(256) void gather_max_kernel(GMaxArgs a) {
-  const int b = blockIdx.y;
-  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  int bx, b;
+  if (!xcd_block((a.S + 3) / 4, a.B, bx, b)) return;
+  const int i = bx * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (i >= a.S) return;
   const int32_t* nb = a.idx + ((int64_t)b * a.S + i) * a.K;
@@ -215,9 +220,10 @@ __global__ __launch_bounds__(256) void gather_max_kernel(GMaxArgs a) {
 // C % 4 == 0: a lane owns 4 consecutive channels (one 16-byte load per neighbour), C/4 lanes per point and
 // 256 / (C/4) points per workgroup; the K neighbour rows are independent loads, so they pipeline.
 __global__ __launch_bounds__(256) void gather_max4_kernel(GMaxArgs a, int lpp) {   // lpp = C / 4 lanes per point
-  const int b = blockIdx.y;
   const int ppw = 256 / lpp;                       // points per workgroup
-  const int i = blockIdx.x * ppw + threadIdx.x / lpp;
+  int bx, b;                                       // a cloud's workgroups on one XCD (see edge_max_kernel)
+  if (!xcd_block((a.S + ppw - 1) / ppw, a.B, bx, b)) return;
+  const int i = bx * ppw + threadIdx.x / lpp;
   const int l = threadIdx.x % lpp;
   if (threadIdx.x >= ppw * lpp || i >= a.S) return;
   const int32_t* nb = a.idx + ((int64_t)b * a.S + i) * a.K;
@@ -276,12 +282,14 @@ struct EdgeMaxArgs {
   float slope;
   float* out;           // [B,N,C]
   int32_t* arg;         // [B,N,C]
+  int B;
 };
 
 __global__ __launch_bounds__(256) void edge_max_kernel(EdgeMaxArgs a, int lpp) {
-  const int b = blockIdx.y;
   const int ppw = 256 / lpp;
-  const int i = blockIdx.x * ppw + threadIdx.x / lpp;
+  int bx, b;                                      // a cloud's workgroups on one XCD: its P rows (0.25-1 MB) stay in that L2
+  if (!xcd_block((a.N + ppw - 1) / ppw, a.B, bx, b)) return;
+  const int i = bx * ppw + threadIdx.x / lpp;
   const int l = threadIdx.x % lpp;
   if (threadIdx.x >= ppw * lpp || i >= a.N) return;
   const int32_t* nb = a.idx + ((int64_t)b * a.N + i) * a.K;
@@ -471,12 +479,12 @@ extern "C" int pc3d_knn_feat_f32(const float* x, int B, int N, int C, int K, int
   PC3D_REQUIRE(B <= 65535, "pc3d_knn_feat_f32: B=%d exceeds grid.y limit", B);
   if (B == 0) return PC3D_OK;
   PC3D_REQUIRE(x && idx, "pc3d_knn_feat_f32: null pointer");
-  KnnFeatArgs a{x, N, C, K, idx};
+  KnnFeatArgs a{x, N, C, K, idx, B};
   const size_t lds = (size_t)(KF_Q * KF_LD + KF_Q * (C + 4)) * sizeof(float);   // 25.6 KiB (C=64) / 33.8 KiB (C=128)
   auto* kern = C == 64 ? (K >= 2 ? knn_feat_kernel<8, true> : knn_feat_kernel<8, false>)
              : C == 128 ? (K >= 2 ? knn_feat_kernel<16, true> : knn_feat_kernel<16, false>)
                         : (K >= 2 ? knn_feat_kernel<0, true> : knn_feat_kernel<0, false>);
-  hipLaunchKernelGGL(kern, dim3(cdiv(N, KF_Q), B), dim3(KF_T), lds, as_stream(stream), a);
+  hipLaunchKernelGGL(kern, dim3(xcd_grid(cdiv(N, KF_Q) * B)), dim3(KF_T), lds, as_stream(stream), a);
   PC3D_LAUNCH_CHECK("pc3d_knn_feat_f32");
   return PC3D_OK;
 }
@@ -487,12 +495,12 @@ static int gather_max_launch(const char* name, const float* P, const int32_t* id
   PC3D_REQUIRE(B <= 65535, "%s: B=%d exceeds grid.y limit", name, B);
   if (B == 0) return PC3D_OK;
   PC3D_REQUIRE(P && idx && out, "%s: null pointer", name);
-  GMaxArgs a{P, idx, sign, N, C, K, out, arg, S};
+  GMaxArgs a{P, idx, sign, N, C, K, out, arg, S, B};
   if (C % 4 == 0 && C <= 1024) {
     const int lpp = C / 4, ppw = 256 / lpp;
-    hipLaunchKernelGGL(gather_max4_kernel, dim3(cdiv(S, ppw), B), dim3(256), 0, as_stream(stream), a, lpp);
+    hipLaunchKernelGGL(gather_max4_kernel, dim3(xcd_grid(cdiv(S, ppw) * B)), dim3(256), 0, as_stream(stream), a, lpp);
   } else {
-    hipLaunchKernelGGL(gather_max_kernel, dim3(cdiv(S, 4), B), dim3(256), 0, as_stream(stream), a);
+    hipLaunchKernelGGL(gather_max_kernel, dim3(xcd_grid(cdiv(S, 4) * B)), dim3(256), 0, as_stream(stream), a);
   }
   PC3D_LAUNCH_CHECK(name);
   return PC3D_OK;
@@ -544,9 +552,9 @@ extern "C" int pc3d_edge_max_f32(const float* PQ, const int32_t* idx, int B, int
   PC3D_REQUIRE(B <= 65535, "pc3d_edge_max_f32: B=%d exceeds grid.y limit", B);
   if (B == 0) return PC3D_OK;
   PC3D_REQUIRE(PQ && idx && out && arg, "pc3d_edge_max_f32: null pointer");
-  EdgeMaxArgs a{PQ, idx, N, C, K, slope, out, arg};
+  EdgeMaxArgs a{PQ, idx, N, C, K, slope, out, arg, B};
   const int lpp = C / 4, ppw = 256 / lpp;
-  hipLaunchKernelGGL(edge_max_kernel, dim3(cdiv(N, ppw), B), dim3(256), 0, as_stream(stream), a, lpp);
+  hipLaunchKernelGGL(edge_max_kernel, dim3(xcd_grid(cdiv(N, ppw) * B)), dim3(256), 0, as_stream(stream), a, lpp);
   PC3D_LAUNCH_CHECK("pc3d_edge_max_f32");
   return PC3D_OK;
 }

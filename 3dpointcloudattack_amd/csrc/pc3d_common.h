@@ -102,6 +102,25 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// XCD-aware order of a one-dimensional grid. Workgroup ids are dealt round-robin to the 8 XCDs, each with its own L2:
+// workgroups that read the same rows (the channel slices of one cloud) should sit on ONE of them, or every L2 fetches
+// every line. Launch xcd_grid(total) workgroups; xcd_band_id gives workgroup `wg` its place in an order in which each XCD
+// owns a contiguous band of ceil(total / 8) places, or -1 for the ids that pad the grid.
+__device__ __forceinline__ int xcd_band_id(int wg, int total) {
+  const int per = (total + 7) >> 3, t = (wg & 7) * per + (wg >> 3);
+  return t < total ? t : -1;
+}
+static inline int xcd_grid(int total) { return ((total + 7) >> 3) << 3; }
+// The same for kernels written for a (tiles, clouds) grid: launched as dim3(xcd_grid(gx * gy)), the (x, y) this workgroup
+// takes — every cloud's tiles on one XCD, whose L2 then holds that cloud's rows instead of a share of every cloud's.
+__device__ __forceinline__ bool xcd_block(int gx, int gy, int& bx, int& by) {
+  const int t = xcd_band_id(blockIdx.x, gx * gy);
+  if (t < 0) return false;
+  by = t / gx;
+  bx = t - by * gx;
+  return true;
+}
+
 // Wave-level reductions through DPP/ds_swizzle-backed shuffles (64 lanes).
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
