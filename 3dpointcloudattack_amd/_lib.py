@@ -53,6 +53,7 @@ SIGNATURES = {
     "pc3d_geoa3_record_f32": [_P, _I, _I, _I, _P, _I, _P, _P, _I, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P],
     "pc3d_group_act_bwd_mask_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _I, _P],
     "pc3d_knn_graph_i32": _PTS + [_I, _I, _I, _P, _P, _P, _I, _P],
+    "pc3d_knn_graph_hint_i32": _PTS + [_I, _I, _I, _P, _P, _P, _I, _P, _P],
     "pc3d_fps_threads_f32": [_I] + _PTS + [_I, _I, _I, _P, _P, _P],
     "pc3d_fps_pruned_f32": _PTS + [_I, _I, _I, _P, _P, _P],
     "pc3d_affine3_f32": _PTS + [_I, _I, _P, _P, _F, _I, _P, _L, _P],
@@ -86,6 +87,7 @@ SIGNATURES = {
     + [_P, _P, _L, _L, _F] + [_P, _P, _L, _L, _F]
     + _PTS + _PTS + [_I, _P],
     "pc3d_knn_f32": _PTS + _PTS + [_I, _I, _I, _I, _P, _P, _P],
+    "pc3d_knn_hint_f32": _PTS + _PTS + [_I, _I, _I, _I, _P, _P, _P, _P],
     "pc3d_knn_bwd_f32": _PTS + _PTS + [_I, _I, _I, _I, _P, _P] + _PTS + _PTS + [_I, _P, _P],
     "pc3d_knn_self_bwd_f32": _PTS + [_I, _I, _I, _P, _P, _P] + _PTS + [_I, _P, _P],
     "pc3d_knn_outlier_loss_f32": [_P, _I, _I, _I, _F, _P, _P, _P],

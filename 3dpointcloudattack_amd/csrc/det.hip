@@ -45,18 +45,23 @@ struct ScatterArgs {
 // workgroup, each with a PRIVATE tile and a contiguous range of the records; the W tiles are combined in ascending wave
 // order at the end — still one fixed summation order, W times the loads in flight. (The first version of this kernel
 // gave a record to CH lanes: 8-byte pieces of 128-byte rows per lane, 121 us for 20480 records x 32 channels.)
-template <int CH, int W>
+// ACC: the tiles' element type — double wherever the tiles fit (see arg_scatter_own_kernel: ds_add_f64 retires ~5x faster than
+// ds_add_f32 on gfx950, and the sum is rounded once).
+template <int CH, int W, typename ACC>
 __global__ __launch_bounds__(64 * W) void scatter_rows_own_kernel(ScatterArgs a) {
-  extern __shared__ float so_acc[];                 // [W][N][ST]
+  extern __shared__ __attribute__((aligned(16))) unsigned char so_raw[];
+  ACC* so_acc = reinterpret_cast<ACC*>(so_raw);      // [W][N][ST]
   constexpr int ST = CH > 1 ? CH + 1 : 1;            // odd row stride: the rows of one instruction spread over the banks
   constexpr int U = CH >= 4 ? 4 : 8;                 // records per lane in flight
-  const int b = blockIdx.y, c0 = blockIdx.x * CH;
+  int bx_, by_;
+  xcd_swizzle(bx_, by_);      // a cloud's workgroups on one XCD (pc3d_common.h)
+  const int b = by_, c0 = bx_ * CH;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = min(CH, a.C - c0);
   const int n0 = blockIdx.z * a.NC, nr = min(a.NC, a.N - n0);    // this workgroup's destination rows [n0, n0 + nr)
-  for (int e = threadIdx.x; e < W * a.NC * ST; e += 64 * W) so_acc[e] = 0.f;
+  for (int e = threadIdx.x; e < W * a.NC * ST; e += 64 * W) so_acc[e] = (ACC)0;
   __syncthreads();
-  float* acc = so_acc + wave * a.NC * ST;
+  ACC* acc = so_acc + wave * a.NC * ST;
   const int32_t* tg = a.tgt + (int64_t)b * a.R;
   const float* vb = a.val + (int64_t)b * a.R * a.ldv + c0;
   const float* ab = a.act ? a.act + (int64_t)b * a.R * a.lda + c0 : nullptr;
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(64 * W) void scatter_rows_own_kernel(ScatterArgs a)
       if ((unsigned)t[u] < (unsigned)a.N && (unsigned)tt < (unsigned)nr) {
 #pragma unroll
         for (int q = 0; q < CH; ++q)
-          if (q < nch) atomicAdd(&acc[tt * ST + q], v[u][q]);      // ds_add_f32 into the wave-private tile
+          if (q < nch) atomicAdd(&acc[tt * ST + q], (ACC)v[u][q]);      // ds_add_f64 / _f32 into the wave-private tile
       }
     }
   }
@@ -117,9 +122,10 @@ __global__ __launch_bounds__(64 * W) void scatter_rows_own_kernel(ScatterArgs a)
   float* ob = a.out + (int64_t)b * a.out_bs + (int64_t)c0 * a.out_cs;
   for (int e = threadIdx.x; e < nr * nch; e += 64 * W) {
     const int nl = e / nch, q = e - nl * nch, n = n0 + nl;
-    float sum = so_acc[nl * ST + q];
+    ACC sum_acc = so_acc[nl * ST + q];
 #pragma unroll
-    for (int w = 1; w < W; ++w) sum += so_acc[(w * a.NC + nl) * ST + q];
+    for (int w = 1; w < W; ++w) sum_acc += so_acc[(w * a.NC + nl) * ST + q];
+    float sum = (float)sum_acc;
     float* o = ob + (int64_t)n * a.ldo + (int64_t)q * a.out_cs;
     if (a.row_bias) {
       const float t = a.row_bias[(int64_t)b * a.N + n] * a.col_w[c0 + q];
@@ -326,7 +332,7 @@ int scatter_rows_det(const char* nm, const int32_t* tgt, const float* val, int64
   PC3D_REQUIRE(out != nullptr, "%s: null output", nm);
   PC3D_REQUIRE(!mbits || C % 4 == 0, "%s: the bit mask needs C %% 4 == 0", nm);
   // channel slice: 4 (one 16-byte load per record) when the rows have >= 4 channels, else 1; narrower if even that
-  // tile does not fit a CU's LDS. Waves per workgroup: as many private tiles as fit the default 64 KB window (<= 8),
+  // tile does not fit a CU's LDS. Waves per workgroup: as many private tiles as fit half a CU's LDS (<= 8),
   // but no more than leave every wave >= 256 records.
   int ch = C >= 4 ? 4 : 1;
   while (ch > 1 && own_bytes(N, ch) > kOwnLds) ch >>= 1;
@@ -337,20 +343,27 @@ int scatter_rows_det(const char* nm, const int32_t* tgt, const float* val, int64
     NC = (int)(kOwnLds / (sizeof(float) * (ch > 1 ? ch + 1 : 1)));
     PC3D_REQUIRE(cdiv(N, NC) <= 65535, "%s: N=%d needs more than 65535 row tiles", nm, N);
   }
+  // tiles in fp64 when one of them fits the default window (a function of N and C alone, like everything that shapes a sum here)
+  const bool f64 = NC == N && own_bytes(N, ch) * 2 <= kOwnLds;
+  const size_t eb = f64 ? 2 : 1;
   int w = 1;
-  while (NC == N && w < 8 && own_bytes(N, ch, 2 * w) <= kOwnLds && R >= 2 * w * 256) w *= 2;
+  while (NC == N && w < 8 && own_bytes(N, ch, 2 * w) * eb <= kOwnLdsMax / 2 && R >= 2 * w * 256) w *= 2;      // (80 KB: two workgroups per CU)
   ScatterArgs a{tgt, val, act, ldv, lda, slope, R, N, C, out, ldo, accumulate, clamp, mbits, out_bs, out_cs, row_bias, col_w, NC};
-  const size_t lds = own_bytes(NC, ch, w);
+  const size_t lds = own_bytes(NC, ch, w) * eb;
   const dim3 grid(cdiv(C, ch), B, cdiv(N, NC));
   hipStream_t st = as_stream(stream);
-#define PC3D_SR(CHV)                                                                                    \
-  switch (w) {                                                                                          \
-    case 8: PC3D_OWN_LAUNCH((scatter_rows_own_kernel<CHV, 8>), 512, grid, lds, st, a); break;           \
-    case 4: PC3D_OWN_LAUNCH((scatter_rows_own_kernel<CHV, 4>), 256, grid, lds, st, a); break;           \
-    case 2: PC3D_OWN_LAUNCH((scatter_rows_own_kernel<CHV, 2>), 128, grid, lds, st, a); break;           \
-    default: PC3D_OWN_LAUNCH((scatter_rows_own_kernel<CHV, 1>), 64, grid, lds, st, a); break;           \
+#define PC3D_SR1(CHV, WV)                                                                                        \
+  if (f64) PC3D_OWN_LAUNCH((scatter_rows_own_kernel<CHV, WV, double>), 64 * WV, grid, lds, st, a);                \
+  else PC3D_OWN_LAUNCH((scatter_rows_own_kernel<CHV, WV, float>), 64 * WV, grid, lds, st, a);
+#define PC3D_SR(CHV)                        \
+  switch (w) {                              \
+    case 8: PC3D_SR1(CHV, 8) break;         \
+    case 4: PC3D_SR1(CHV, 4) break;         \
+    case 2: PC3D_SR1(CHV, 2) break;         \
+    default: PC3D_SR1(CHV, 1) break;        \
   }
   if (ch == 4) { PC3D_SR(4) } else if (ch == 2) { PC3D_SR(2) } else { PC3D_SR(1) }
+#undef PC3D_SR1
 #undef PC3D_SR
   PC3D_LAUNCH_CHECK(nm);
   return PC3D_OK;
@@ -478,9 +491,11 @@ struct RevGatherArgs {
 // VEC: a lane owns 4 consecutive channels of one destination row (C / 4 lanes per row), else one channel.
 template <bool VEC>
 __global__ __launch_bounds__(256) void rev_gather_sum_kernel(RevGatherArgs a) {
-  const int b = blockIdx.y;
+  int bx_, by_;
+  xcd_swizzle(bx_, by_);      // a cloud's workgroups on one XCD (pc3d_common.h)
+  const int b = by_;
   const int lpt = VEC ? a.C >> 2 : a.C;                 // lanes per destination row
-  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t g = (int64_t)bx_ * 256 + threadIdx.x;
   const int t = (int)(g / lpt), l = (int)(g - (int64_t)t * lpt);
   if (t >= a.NA) return;
   const int* o = a.off + (int64_t)b * (a.NA + 1);

@@ -199,9 +199,11 @@ struct BallArgs {
 };
 
 __global__ __launch_bounds__(256) void ball_query_kernel(BallArgs a) {
-  const int b = blockIdx.y;
+  int bx_, by_;
+  xcd_swizzle(bx_, by_);      // a cloud's workgroups on one XCD (pc3d_common.h)
+  const int b = by_;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int s = blockIdx.x * 4 + wave;
+  const int s = bx_ * 4 + wave;
   if (s >= a.S) return;
   const float* cp = a.c.p + (int64_t)b * a.c.bs + (int64_t)s * a.c.ps;
   const float cx = cp[0], cy = cp[a.c.cs], cz = cp[2 * a.c.cs];
@@ -321,11 +323,13 @@ struct GatherArgs {
 };
 
 __global__ __launch_bounds__(256) void group_gather_kernel(GatherArgs a) {
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // one wave per (b,s,j) row
+  int bx_, by_;
+  xcd_swizzle(bx_, by_);      // a cloud's workgroups on one XCD (pc3d_common.h)
+  const int64_t row = (int64_t)bx_ * 4 + (threadIdx.x >> 6);  // one wave per (b,s,j) row
   const int lane = threadIdx.x & 63;
   const int64_t rows = (int64_t)gridDim.y * a.S * a.ns;
   (void)rows;
-  const int b = blockIdx.y;
+  const int b = by_;
   if (row >= (int64_t)a.S * a.ns) return;
   const int s = (int)(row / a.ns);
   const int i = a.idx[((int64_t)b * a.S) * a.ns + row];
@@ -367,7 +371,9 @@ constexpr int GGB_MAXC = 1024;   // channels whose padded-tail sum fits the LDS 
 __global__ __launch_bounds__(256) void group_gather_bwd_kernel(GatherBwdArgs a) {
   __shared__ float s_tail[4][GGB_MAXC];
   __shared__ float s_ctr[4][4];
-  const int s = blockIdx.x, b = blockIdx.y;
+  int bx_, by_;
+  xcd_swizzle(bx_, by_);      // a cloud's workgroups on one XCD (pc3d_common.h)
+  const int s = bx_, b = by_;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int32_t* idx = a.idx + ((int64_t)b * a.S + s) * a.ns;
   const float* gbase = a.g + (((int64_t)b * a.S + s) * a.ns) * a.C;
@@ -464,7 +470,9 @@ __global__ __launch_bounds__(256) void group_act_bwd_kernel(const float* __restr
                                                             float slope, float* __restrict__ gP,
                                                             float* __restrict__ gBc, const uint8_t* __restrict__ mask) {
   extern __shared__ float gab_lds[];            // [2][4][C]: per-wave group sums and padded-tail sums
-  const int s = blockIdx.x, b = blockIdx.y;
+  int bx_, by_;
+  xcd_swizzle(bx_, by_);      // a cloud's workgroups on one XCD (pc3d_common.h)
+  const int s = bx_, b = by_;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t g0 = ((int64_t)b * S + s) * K;
   const int* id = idx + g0;
@@ -961,8 +969,10 @@ __global__ __launch_bounds__(256) void group_act_bwd_groups_kernel(const float* 
                                                                    const int* __restrict__ idx, int S, int K, int C,
                                                                    float slope, float* __restrict__ gBc,
                                                                    float* __restrict__ tail_out) {
-  const int b = blockIdx.y, lane = threadIdx.x & 63;
-  const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+  int bx_, by_;
+  xcd_swizzle(bx_, by_);      // a cloud's workgroups on one XCD (pc3d_common.h)
+  const int b = by_, lane = threadIdx.x & 63;
+  const int s = bx_ * 4 + (threadIdx.x >> 6);
   if (s >= S) return;
   const int64_t g0 = ((int64_t)b * S + s) * K;
   const int* id = idx + g0;
@@ -1021,8 +1031,10 @@ __global__ __launch_bounds__(256) void group_act_bwd_points_kernel(const float* 
                                                                    const uint32_t* __restrict__ amask = nullptr) {
   // amask [B*S, ceil(K/32)] or null: bit j of group s = "row (s, j) of gH was written"; the other rows are all zero and
   // are skipped (their memory is not even defined)
-  const int b = blockIdx.y, lane = threadIdx.x & 63;
-  const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+  int bx_, by_;
+  xcd_swizzle(bx_, by_);      // a cloud's workgroups on one XCD (pc3d_common.h)
+  const int b = by_, lane = threadIdx.x & 63;
+  const int p = bx_ * 4 + (threadIdx.x >> 6);
   if (p >= NA) return;
   const int* o = off + (int64_t)b * (NA + 1);
   const int* l = lst + (int64_t)b * L;

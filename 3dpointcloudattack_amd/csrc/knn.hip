@@ -21,6 +21,7 @@ struct KnnArgs {
   int32_t* i_noself = nullptr;   // [B,N,K-1] or null: columns 1 .. K-1 of i
   int32_t* i_first = nullptr;    // [B,N,k2] or null: columns 0 .. k2-1 of i
   int k2 = 0;
+  const int32_t* hint = nullptr; // [B,N,K] or null: K reference indices per query from an earlier, similar search (may be `i`)
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -71,6 +72,55 @@ __global__ __launch_bounds__(kKwWaves * 64) void knn_wave_kernel(KnnArgs a) {
     }
 
   const float* rb = a.r.p + (int64_t)b * a.r.bs;
+  // ---- hint: K reference indices per query from an earlier search of (nearly) the same clouds — an attack moves its points
+  // by 1e-2 per iteration, so last iteration's neighbours bound this iteration's K-th distance tightly. ANY K distinct
+  // valid indices give an upper bound (their largest distance >= the K-th smallest of all), so the hint can only cost time,
+  // never change the result: the list starts EMPTY, candidates at or below the bound are inserted as they come (ascending
+  // index, after equal keys: the same tie order), everything else is rejected by one compare. Without a hint the expected
+  // number of insertions per query is K ln(M / K) (106 at M = 4096, K = 20: three quarters of the kernel's instructions);
+  // with one it is K plus the few points that moved inside the bound. The wave checks the hint (in range, pairwise
+  // distinct, finite bound) for its four queries and falls back to the seeded scan if any of them fails.
+  int cap[kKwPasses][kKwQPW];
+  bool hinted = a.hint != nullptr;
+#pragma unroll
+  for (int p = 0; p < kKwPasses; ++p)
+#pragma unroll
+    for (int u = 0; u < kKwQPW; ++u) cap[p][u] = 0x7fffffff;
+  if (hinted) {
+#pragma unroll
+    for (int p = 0; p < kKwPasses; ++p)
+#pragma unroll
+      for (int u = 0; u < kKwQPW; ++u) {
+        int qi = qbase + p * kKwQPW + u;
+        if (qi >= N) qi = N - 1;
+        const int h = lane < K ? a.hint[((int64_t)b * N + qi) * K + lane] : -1 - lane;     // (distinct fillers above K)
+        bool bad = lane < K && (unsigned)h >= (unsigned)M;
+        for (int t = 0; t < K; ++t) bad |= lane > t && h == __builtin_amdgcn_readlane(h, t);
+        int key = 0;
+        if (lane < K && !bad) {
+          const float* rp = rb + (int64_t)h * a.r.ps;
+          const float dx = rp[0] - qx[p][u], dy = rp[a.r.cs] - qy[p][u], dz = rp[2 * a.r.cs] - qz[p][u];
+          float t = dx * dx;
+          t = __builtin_fmaf(dy, dy, t);
+          t = __builtin_fmaf(dz, dz, t);
+          key = __builtin_bit_cast(int, t) & 0x7fffffff;      // the scan's arithmetic, bit for bit
+        }
+        const int hm = wave_max_i32(key);                     // (a NaN distance has a key above +inf's)
+        if (__builtin_amdgcn_ballot_w64(bad) != 0 || hm >= kKnnInfKey) hinted = false;
+        cap[p][u] = hm + 1;
+      }
+    if (hinted) {
+#pragma unroll
+      for (int p = 0; p < kKwPasses; ++p)
+#pragma unroll
+        for (int u = 0; u < kKwQPW; ++u) thr[p][u] = cap[p][u];
+    } else {
+#pragma unroll
+      for (int p = 0; p < kKwPasses; ++p)
+#pragma unroll
+        for (int u = 0; u < kKwQPW; ++u) cap[p][u] = 0x7fffffff;
+    }
+  }
   for (int m0 = 0; m0 < M; m0 += kKwTile) {
     const int mt = (M - m0) < kKwTile ? (M - m0) : kKwTile;
     __syncthreads();
@@ -99,7 +149,7 @@ __global__ __launch_bounds__(kKwWaves * 64) void knn_wave_kernel(KnnArgs a) {
           t = __builtin_fmaf(dz, dz, t);
           d[u] = t;
         }
-        if (m0 == 0 && j0 == 0) {
+        if (m0 == 0 && j0 == 0 && !hinted) {
           // seed: the K nearest of the first 64 candidates — K rounds of wave-min selection (ties: lowest lane) for small K
           float rem[kKwQPW], m[kKwQPW];
 #pragma unroll
@@ -131,7 +181,7 @@ __global__ __launch_bounds__(kKwWaves * 64) void knn_wave_kernel(KnnArgs a) {
         }
 #pragma unroll
         for (int u = 0; u < kKwQPW; ++u)
-          knn_scan_insert<KGE2>(lk[p][u], li[p][u], thr[p][u], __builtin_bit_cast(int, d[u]) & 0x7fffffff, m0 + j0, K);
+          knn_scan_insert<KGE2>(lk[p][u], li[p][u], thr[p][u], __builtin_bit_cast(int, d[u]) & 0x7fffffff, m0 + j0, K, cap[p][u]);
       }
     }
   }
@@ -390,16 +440,44 @@ extern "C" int pc3d_knn_bwd_f32(const float* q, int64_t q_bs, int64_t q_ps, int6
   return knn_bwd_launch("pc3d_knn_bwd_f32", a, B, grad_r, gr_bs, gr_ps, gr_cs, deterministic, det_ws, stream);
 }
 
-extern "C" int pc3d_knn_graph_i32(const float* pts, int64_t p_bs, int64_t p_ps, int64_t p_cs, int B, int N, int K, int32_t* idx,
-                                  int32_t* idx_noself, int32_t* idx_first, int k2, void* stream) {
-  const char* nm = "pc3d_knn_graph_i32";
+static int knn_graph_launch(const char* nm, const float* pts, int64_t p_bs, int64_t p_ps, int64_t p_cs, int B, int N, int K,
+                            int32_t* idx, int32_t* idx_noself, int32_t* idx_first, int k2, const int32_t* hint, void* stream) {
   PC3D_REQUIRE(B >= 0 && N >= 1 && K >= 2 && K <= 64 && K <= N && k2 >= 0 && k2 <= K, "%s: bad sizes B=%d N=%d K=%d k2=%d", nm, B, N, K, k2);
   PC3D_REQUIRE(B <= 65535, "%s: B=%d exceeds grid.y limit", nm, B);
   if (B == 0) return PC3D_OK;
   PC3D_REQUIRE(pts && idx, "%s: null pointer", nm);
   KnnArgs a{{pts, p_bs, p_ps, p_cs}, {pts, p_bs, p_ps, p_cs}, N, N, K, nullptr, idx};
-  a.i_noself = idx_noself, a.i_first = k2 > 0 ? idx_first : nullptr, a.k2 = k2;
+  a.i_noself = idx_noself, a.i_first = k2 > 0 ? idx_first : nullptr, a.k2 = k2, a.hint = hint;
   hipLaunchKernelGGL((knn_wave_kernel<4, true>), dim3(cdiv(N, 16), B), dim3(256), 0, as_stream(stream), a);
+  PC3D_LAUNCH_CHECK(nm);
+  return PC3D_OK;
+}
+
+extern "C" int pc3d_knn_graph_i32(const float* pts, int64_t p_bs, int64_t p_ps, int64_t p_cs, int B, int N, int K, int32_t* idx,
+                                  int32_t* idx_noself, int32_t* idx_first, int k2, void* stream) {
+  return knn_graph_launch("pc3d_knn_graph_i32", pts, p_bs, p_ps, p_cs, B, N, K, idx, idx_noself, idx_first, k2, nullptr, stream);
+}
+
+extern "C" int pc3d_knn_graph_hint_i32(const float* pts, int64_t p_bs, int64_t p_ps, int64_t p_cs, int B, int N, int K, int32_t* idx,
+                                       int32_t* idx_noself, int32_t* idx_first, int k2, const int32_t* hint, void* stream) {
+  return knn_graph_launch("pc3d_knn_graph_hint_i32", pts, p_bs, p_ps, p_cs, B, N, K, idx, idx_noself, idx_first, k2, hint, stream);
+}
+
+static int knn_launch(const char* nm, const float* q, int64_t q_bs, int64_t q_ps, int64_t q_cs,
+                      const float* r, int64_t r_bs, int64_t r_ps, int64_t r_cs,
+                      int B, int N, int M, int K, float* dists, int32_t* idx, const int32_t* hint, void* stream) {
+  PC3D_REQUIRE(B >= 0 && N >= 0 && M >= 1, "%s: bad sizes B=%d N=%d M=%d", nm, B, N, M);
+  PC3D_REQUIRE(K >= 1 && K <= 64, "%s: K=%d out of range [1,64]", nm, K);
+  PC3D_REQUIRE(K <= M, "%s: K=%d exceeds the reference set size M=%d", nm, K, M);
+  PC3D_REQUIRE(B <= 65535, "%s: B=%d exceeds grid.y limit", nm, B);
+  if (B == 0 || N == 0) return PC3D_OK;
+  PC3D_REQUIRE(q && r, "%s: null input pointer", nm);
+  KnnArgs a{{q, q_bs, q_ps, q_cs}, {r, r_bs, r_ps, r_cs}, N, M, K, dists, idx};
+  a.hint = hint;
+  hipStream_t st = as_stream(stream);
+  // 4 waves (16 queries) per workgroup: measured best of {2,4,8,16} — larger workgroups wait at the staging barriers
+  if (K >= 2) hipLaunchKernelGGL((knn_wave_kernel<4, true>), dim3(cdiv(N, 16), B), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((knn_wave_kernel<4, false>), dim3(cdiv(N, 16), B), dim3(256), 0, st, a);
   PC3D_LAUNCH_CHECK(nm);
   return PC3D_OK;
 }
@@ -407,17 +485,11 @@ extern "C" int pc3d_knn_graph_i32(const float* pts, int64_t p_bs, int64_t p_ps, 
 extern "C" int pc3d_knn_f32(const float* q, int64_t q_bs, int64_t q_ps, int64_t q_cs,
                             const float* r, int64_t r_bs, int64_t r_ps, int64_t r_cs,
                             int B, int N, int M, int K, float* dists, int32_t* idx, void* stream) {
-  PC3D_REQUIRE(B >= 0 && N >= 0 && M >= 1, "pc3d_knn_f32: bad sizes B=%d N=%d M=%d", B, N, M);
-  PC3D_REQUIRE(K >= 1 && K <= 64, "pc3d_knn_f32: K=%d out of range [1,64]", K);
-  PC3D_REQUIRE(K <= M, "pc3d_knn_f32: K=%d exceeds the reference set size M=%d", K, M);
-  PC3D_REQUIRE(B <= 65535, "pc3d_knn_f32: B=%d exceeds grid.y limit", B);
-  if (B == 0 || N == 0) return PC3D_OK;
-  PC3D_REQUIRE(q && r, "pc3d_knn_f32: null input pointer");
-  KnnArgs a{{q, q_bs, q_ps, q_cs}, {r, r_bs, r_ps, r_cs}, N, M, K, dists, idx};
-  hipStream_t st = as_stream(stream);
-  // 4 waves (16 queries) per workgroup: measured best of {2,4,8,16} — larger workgroups wait at the staging barriers
-  if (K >= 2) hipLaunchKernelGGL((knn_wave_kernel<4, true>), dim3(cdiv(N, 16), B), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((knn_wave_kernel<4, false>), dim3(cdiv(N, 16), B), dim3(256), 0, st, a);
-  PC3D_LAUNCH_CHECK("pc3d_knn_f32");
-  return PC3D_OK;
+  return knn_launch("pc3d_knn_f32", q, q_bs, q_ps, q_cs, r, r_bs, r_ps, r_cs, B, N, M, K, dists, idx, nullptr, stream);
+}
+
+extern "C" int pc3d_knn_hint_f32(const float* q, int64_t q_bs, int64_t q_ps, int64_t q_cs,
+                                 const float* r, int64_t r_bs, int64_t r_ps, int64_t r_cs,
+                                 int B, int N, int M, int K, float* dists, int32_t* idx, const int32_t* hint, void* stream) {
+  return knn_launch("pc3d_knn_hint_f32", q, q_bs, q_ps, q_cs, r, r_bs, r_ps, r_cs, B, N, M, K, dists, idx, hint, stream);
 }

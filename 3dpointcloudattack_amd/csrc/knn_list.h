@@ -107,6 +107,19 @@ __device__ __forceinline__ float wave_min_dpp(float v) {
   return readlane_f(v, 63);
 }
 
+// wave-wide maximum of one int per lane, the same way (integer: distance KEYS may be denormal bit patterns)
+__device__ __forceinline__ int wave_max_i32(int v) {
+#define PC3D_DPP_MAXI(ctrl) v = max(v, __builtin_amdgcn_update_dpp(v, v, ctrl, 0xf, 0xf, false))
+  PC3D_DPP_MAXI(0x111);
+  PC3D_DPP_MAXI(0x112);
+  PC3D_DPP_MAXI(0x114);
+  PC3D_DPP_MAXI(0x118);
+  PC3D_DPP_MAXI(0x142);
+  PC3D_DPP_MAXI(0x143);
+#undef PC3D_DPP_MAXI
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
 // v_writelane_b32 (hipcc 7.2 has no builtin; the LLVM intrinsic is reachable by name, and unlike inline asm it is seen
 // by the hazard recogniser)
 extern "C" __device__ int knn_writelane(int value, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
@@ -178,8 +191,10 @@ __device__ __forceinline__ void knn_list_step(int& lk, int& li, unsigned long lo
 // against 20 (18 + 2 s_nop) for knn_list_step + v_readlane + v_cmp + s_and.
 // Hazards as above; additionally: SALU reads of VALU-written SGPRs (s_max on kc / t2, s_bcnt1 / s_and on VCC) are
 // interlocked in hardware; v_readlane of lk follows the previous step's v_writelane by >= 4 instructions.
+// cap: an upper bound (exclusive) on the keys worth looking at that does not come from the list — the hinted searches start
+// from an EMPTY list and the bound of last call's neighbours (knn.hip); 0x7fffffff: none.
 __device__ __forceinline__ void knn_list_step_refilter(int& lk, int& li, unsigned long long& mask, int& thr, int key, int c,
-                                                       int jbase, int km2) {
+                                                       int jbase, int km2, int cap) {
   int kc, ic, t2;
   asm volatile(
       "v_readlane_b32 %[kc], %[key], %[c]\n\t"
@@ -187,6 +202,7 @@ __device__ __forceinline__ void knn_list_step_refilter(int& lk, int& li, unsigne
       "s_bitset0_b64 %[mask], %[c]\n\t"
       "s_add_i32 %[ic], %[jb], %[c]\n\t"
       "s_max_i32 %[thr], %[kc], %[t2]\n\t"
+      "s_min_i32 %[thr], %[thr], %[cap]\n\t"
       "v_cmp_ge_i32_e32 vcc, %[kc], %[lk]\n\t"
       "v_cndmask_b32_dpp %[lk], %[lk], %[lk], vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
       "v_cndmask_b32_dpp %[li], %[li], %[li], vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
@@ -196,7 +212,7 @@ __device__ __forceinline__ void knn_list_step_refilter(int& lk, int& li, unsigne
       "v_writelane_b32 %[lk], %[kc], m0\n\t"
       "v_writelane_b32 %[li], %[ic], m0"
       : [lk] "+v"(lk), [li] "+v"(li), [mask] "+s"(mask), [thr] "=&s"(thr), [kc] "=&s"(kc), [ic] "=&s"(ic), [t2] "=&s"(t2)
-      : [key] "v"(key), [c] "s"(c), [jb] "s"(jbase), [km2] "s"(km2)
+      : [key] "v"(key), [c] "s"(c), [jb] "s"(jbase), [km2] "s"(km2), [cap] "s"(cap)
       : "vcc", "scc");
 }
 
@@ -204,15 +220,15 @@ __device__ __forceinline__ void knn_list_step_refilter(int& lk, int& li, unsigne
 // Candidates are taken in ascending lane order; after every insertion the remaining ones are re-filtered against the
 // tightened threshold, so no iteration is spent on a candidate that no longer qualifies.
 template <bool KGE2>   // K >= 2 (decided per kernel instantiation: a run-time branch here doubles every unrolled call site)
-__device__ __forceinline__ void knn_scan_insert(int& lk, int& li, int& thr, int key, int jbase, int K) {
+__device__ __forceinline__ void knn_scan_insert(int& lk, int& li, int& thr, int key, int jbase, int K, int cap = 0x7fffffff) {
   unsigned long long mask = __builtin_amdgcn_ballot_w64(key < thr);
   if constexpr (KGE2) {
     const int km2 = K - 2;
-    while (mask) knn_list_step_refilter(lk, li, mask, thr, key, __builtin_ctzll(mask), jbase, km2);
+    while (mask) knn_list_step_refilter(lk, li, mask, thr, key, __builtin_ctzll(mask), jbase, km2, cap);
   } else {
     while (mask) {
       knn_list_step(lk, li, mask, key, __builtin_ctzll(mask), jbase);
-      thr = __builtin_amdgcn_readlane(lk, K - 1);
+      thr = min(__builtin_amdgcn_readlane(lk, K - 1), cap);
       mask &= __builtin_amdgcn_ballot_w64(key < thr);
     }
   }

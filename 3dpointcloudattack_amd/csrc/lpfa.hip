@@ -182,7 +182,9 @@ __global__ __launch_bounds__(256) void lpfa_fused_fwd_kernel(LpfaFusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lf_lds[];
   float* E = lf_lds;                                        // [P][K][C]
   int* nbr = reinterpret_cast<int*>(lf_lds + P * a.K * C);   // [P][K]
-  const int b = blockIdx.y, i0 = blockIdx.x * P;
+  int bx_, by_;
+  xcd_swizzle(bx_, by_);      // a cloud's workgroups on one XCD (pc3d_common.h)
+  const int b = by_, i0 = bx_ * P;
   lpfa_stage_edges<C>(a, b, i0, E, nbr);
   const int p = threadIdx.x / C, c = threadIdx.x - p * C, i = i0 + p;
   float w[C];
@@ -207,7 +209,9 @@ __global__ __launch_bounds__(256) void lpfa_fused_bwd_kernel(LpfaFusedArgs a) {
   float* E = lf_lds;                                        // [P][K][C]
   float* dZ = lf_lds + P * a.K * C;                          // [P][K][C]
   int* nbr = reinterpret_cast<int*>(lf_lds + 2 * P * a.K * C);
-  const int b = blockIdx.y, i0 = blockIdx.x * P;
+  int bx_, by_;
+  xcd_swizzle(bx_, by_);      // a cloud's workgroups on one XCD (pc3d_common.h)
+  const int b = by_, i0 = bx_ * P;
   lpfa_stage_edges<C>(a, b, i0, E, nbr);
   const int p = threadIdx.x / C, c = threadIdx.x - p * C, i = i0 + p;
   float w[C];

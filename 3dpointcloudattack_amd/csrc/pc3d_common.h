@@ -111,6 +111,16 @@ __device__ __forceinline__ int xcd_band_id(int wg, int total) {
   return t < total ? t : -1;
 }
 static inline int xcd_grid(int total) { return ((total + 7) >> 3) << 3; }
+// ... and without touching the launch: for a kernel on a dim3(tiles, clouds) grid whose size is a multiple of 8 (every
+// benchmark batch), the same re-deal computed from blockIdx (identity otherwise: correct, just not banded).
+__device__ __forceinline__ void xcd_swizzle(int& bx, int& by) {
+  const int gx = gridDim.x, total = gx * gridDim.y;
+  bx = blockIdx.x, by = blockIdx.y;
+  if (total & 7) return;
+  const int l = bx + gx * by, t = (l & 7) * (total >> 3) + (l >> 3);
+  by = t / gx;
+  bx = t - by * gx;
+}
 // The same for kernels written for a (tiles, clouds) grid: launched as dim3(xcd_grid(gx * gy)), the (x, y) this workgroup
 // takes — every cloud's tiles on one XCD, whose L2 then holds that cloud's rows instead of a share of every cloud's.
 __device__ __forceinline__ bool xcd_block(int gx, int gy, int& bx, int& by) {

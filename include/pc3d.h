@@ -480,6 +480,18 @@ int pc3d_knn_f32(const float* q, int64_t q_bs, int64_t q_ps, int64_t q_cs,
  * 1 .. K-1; idx_first [B,N,k2] (may be NULL, k2 <= K) = columns 0 .. k2-1. Same search and tie rule as pc3d_knn_f32. */
 int pc3d_knn_graph_i32(const float* pts, int64_t p_bs, int64_t p_ps, int64_t p_cs, int B, int N, int K, int32_t* idx,
                        int32_t* idx_noself, int32_t* idx_first, int k2, void* stream);
+/* The same two searches with a HINT: hint [B,N,K] int32 (may be NULL, may be `idx` itself — a wavefront reads the rows of
+ * its queries before it writes them) holds K reference indices per query from an earlier search of nearly the same clouds:
+ * the previous iteration of an attack loop (the reference re-runs its matrix + topk from scratch every iteration,
+ * model/curvenet_util.py:10-17, attack/CW/CW_utils/dist_utils.py:133-144). Their largest distance bounds the K-th
+ * distance, so only candidates at or below it are ever inserted (K + a few instead of K ln(M / K) per query). The RESULT
+ * does not depend on the hint — distances, indices and tie order are those of pc3d_knn_f32; a hint row that is out of
+ * range, repeats an index or has a non-finite bound makes its wavefront run the unhinted scan. */
+int pc3d_knn_hint_f32(const float* q, int64_t q_bs, int64_t q_ps, int64_t q_cs,
+                      const float* r, int64_t r_bs, int64_t r_ps, int64_t r_cs,
+                      int B, int N, int M, int K, float* dists, int32_t* idx, const int32_t* hint, void* stream);
+int pc3d_knn_graph_hint_i32(const float* pts, int64_t p_bs, int64_t p_ps, int64_t p_cs, int B, int N, int K, int32_t* idx,
+                            int32_t* idx_noself, int32_t* idx_first, int k2, const int32_t* hint, void* stream);
 
 
 /* Backward of the K distances with upstream w [B,N,K]: grad_q dense, grad_r scattered (float atomics; when

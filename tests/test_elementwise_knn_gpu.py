@@ -112,6 +112,100 @@ def test_knn_ties_prefer_lower_index(ops, dev):
             assert np.all(np.diff(row[4 * g:4 * g + 4]) == 700)
 
 
+def _knn_abi(dev, q, r, K, hint=None, alias=False, graph=False):
+    """pc3d_knn_f32 / pc3d_knn_hint_f32 (or the graph entries) straight through the C ABI on device tensors q [B,N,3], r [B,M,3]."""
+    lib = importlib.import_module("3dpointcloudattack_amd._lib")
+    B, N, M = q.shape[0], q.shape[1], r.shape[1]
+    d = torch.empty(B, N, K, device=dev)
+    i = torch.empty(B, N, K, dtype=torch.int32, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    if alias:
+        i.copy_(hint)
+        hint = i
+    if graph:
+        ns, fi = torch.empty(B, N, K - 1, dtype=torch.int32, device=dev), torch.empty(B, N, K - 1, dtype=torch.int32, device=dev)
+        if hint is None:
+            lib.call("pc3d_knn_graph_i32", q.data_ptr(), *q.stride(), B, N, K, i.data_ptr(), ns.data_ptr(), fi.data_ptr(), K - 1, st)
+        else:
+            lib.call("pc3d_knn_graph_hint_i32", q.data_ptr(), *q.stride(), B, N, K, i.data_ptr(), ns.data_ptr(), fi.data_ptr(), K - 1,
+                     hint.data_ptr(), st)
+        return i, ns, fi
+    if hint is None:
+        lib.call("pc3d_knn_f32", q.data_ptr(), *q.stride(), r.data_ptr(), *r.stride(), B, N, M, K, d.data_ptr(), i.data_ptr(), st)
+    else:
+        lib.call("pc3d_knn_hint_f32", q.data_ptr(), *q.stride(), r.data_ptr(), *r.stride(), B, N, M, K, d.data_ptr(), i.data_ptr(),
+                 hint.data_ptr(), st)
+    return d, i
+
+
+@pytest.mark.parametrize("B,N,M,K", [(2, 100, 100, 6), (2, 1024, 1024, 21), (1, 333, 4500, 20), (1, 70, 64, 64), (2, 130, 2113, 2),
+                                     (1, 4096, 4096, 21), (3, 50, 700, 17), (1, 40, 40, 1)])
+def test_knn_hint_never_changes_the_result(dev, B, N, M, K):
+    """pc3d_knn_hint_f32: distances and indices are those of pc3d_knn_f32 bit for bit whatever the hint is — last iteration's
+    neighbours (the intended use: points moved by 1e-2), the exact answer, the output buffer itself, random indices, rows with
+    repeated / out-of-range / negative entries (detected per wavefront: unhinted scan), and a hint whose bound is far too wide."""
+    rng = np.random.default_rng(N + M + K)
+    r = torch.from_numpy(np.stack([unit_cloud(rng, M) for _ in range(B)])).to(dev)
+    q = r.clone() if N == M else torch.from_numpy(np.stack([unit_cloud(rng, N) for _ in range(B)])).to(dev)
+    d0, i0 = _knn_abi(dev, q, r, K)
+    moved_r = r + 1e-2 * torch.randn_like(r)
+    _, prev = _knn_abi(dev, q if N != M else moved_r, moved_r, K)        # "last iteration"
+    g = torch.Generator(device="cpu").manual_seed(1)
+    rand = torch.randint(0, M, (B, N, K), generator=g, dtype=torch.int32).to(dev)       # repeats inside rows are likely
+    wild = torch.randint(-5, M + 5, (B, N, K), generator=g, dtype=torch.int32).to(dev)
+    far = torch.argsort(torch.rand(B, N, M, generator=g), dim=2)[:, :, :K].to(torch.int32).to(dev)      # distinct, arbitrary
+    dup = i0.clone(); dup[:, ::3, K - 1] = dup[:, ::3, 0]                                 # one repeated entry in every third row
+    for name, hint, alias in (("previous", prev, False), ("exact", i0, False), ("alias", prev, True), ("random", rand, False),
+                              ("wild", wild, False), ("distinct-far", far, False), ("repeat", dup, False), ("alias-wild", wild, True)):
+        if K == 1 and name == "repeat":
+            continue
+        d1, i1 = _knn_abi(dev, q, r, K, hint=hint, alias=alias)
+        assert torch.equal(i1, i0), name
+        assert torch.equal(d1.view(torch.int32), d0.view(torch.int32)), name
+
+
+def test_knn_hint_keeps_the_tie_order(dev):
+    """Duplicated points under a hint: the list starts empty and the equal keys at the bound are inserted in ascending index
+    order, so the lower index still comes first (the hint below lists the HIGHER copies first)."""
+    rng = np.random.default_rng(9)
+    base = unit_cloud(rng, 700)
+    r = torch.from_numpy(np.concatenate([base, base, base, base])[None]).to(dev)
+    q = torch.from_numpy(base[None, :90]).to(dev)
+    d0, i0 = _knn_abi(dev, q, r, 10)
+    assert np.array_equal(i0.cpu().numpy()[0, :, :4], np.arange(90)[:, None] + 700 * np.arange(4)[None])
+    rev = torch.flip(i0, dims=[2]).contiguous()
+    shifted = ((i0 + 700) % 2800).contiguous()          # same distances through other copies
+    for hint in (rev, shifted):
+        d1, i1 = _knn_abi(dev, q, r, 10, hint=hint)
+        assert torch.equal(i1, i0) and torch.equal(d1, d0)
+
+
+def test_knn_graph_hint_views_and_replay(ops, dev):
+    """pc3d_knn_graph_hint_i32 writes the graph and both views exactly as the unhinted entry; ops.knn_graph hints from the
+    last call of the same shape and, inside a hipGraph, from its own output buffer: replays on moving points stay exact."""
+    rng = np.random.default_rng(3)
+    x = torch.from_numpy(np.stack([unit_cloud(rng, 1024) for _ in range(2)])).to(dev)
+    ref = _knn_abi(dev, x, x, 21, graph=True)
+    got = _knn_abi(dev, x, x, 21, hint=ref[0], graph=True)
+    assert all(torch.equal(a, b) for a, b in zip(ref, got))
+    buf = x.clone()
+    for _ in range(2):
+        ops.knn_graph(buf, 20)                         # eager warm-up (also fills the hint cache)
+    side = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            out = ops.knn_graph(buf, 20)
+    for step in range(4):
+        buf.add_(1e-2 * torch.randn_like(buf))
+        g.replay()
+        torch.cuda.synchronize()
+        want = _knn_abi(dev, buf, buf, 21, graph=True)
+        assert all(torch.equal(a, b) for a, b in zip(want, out)), step
+        eager = ops.knn_graph(buf, 20)
+        assert all(torch.equal(a, b) for a, b in zip(want, eager)), step
+
+
 @pytest.mark.parametrize("K", [5, 20])            # the selection-round seed (K <= 10) and the sorted seed
 def test_knn_nan_points_are_never_neighbours(ops, dev, K):
     """A reference point with a NaN coordinate has NaN distances; their keys rank above +inf (knn_list.h), so it is in

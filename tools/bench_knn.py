@@ -46,3 +46,23 @@ for B, N in ((32, 4096), (32, 1024), (32, 256), (32, 64)):
     t_plain = graph_us(lambda: ops.knn_raw(x, x, 21))
     t_graph = graph_us(lambda: ops.knn_graph(x, 20))
     print(json.dumps({"B": B, "N": N, "k": 20, "knn_raw_us": round(t_plain, 1), "knn_graph_us": round(t_graph, 1)}), flush=True)
+
+# ---- hints (pc3d_knn_hint_f32): the same search unhinted, with last call's result as the hint (what a replayed graph does:
+# every captured call reads its own previous output) and with the hint of points that have since moved by 1e-2 per coordinate
+ops.KNN_HINTS = False
+for B, N, K in ((32, 4096, 21), (32, 1024, 21), (64, 2048, 6), (32, 1024, 20), (32, 256, 21)):
+    torch.manual_seed(N)
+    x = torch.rand(B, N, 3, device=dev)
+    row = {"B": B, "N": N, "K": K}
+    ops.KNN_HINTS = False
+    row["unhinted_us"] = round(graph_us(lambda: ops.knn_raw(x, x, K)), 1)
+    ops.KNN_HINTS = True
+    row["hint_same_points_us"] = round(graph_us(lambda: ops.knn_raw(x, x, K)), 1)
+    L = importlib.import_module("3dpointcloudattack_amd._lib")
+    _, stale = ops.knn_raw(x + 1e-2 * torch.randn_like(x), x + 1e-2 * torch.randn_like(x), K)
+    d = torch.empty(B, N, K, device=dev)
+    i = torch.empty(B, N, K, dtype=torch.int32, device=dev)
+    st = lambda: torch.cuda.current_stream().cuda_stream
+    row["hint_moved_1e-2_us"] = round(graph_us(lambda: L.call("pc3d_knn_hint_f32", x.data_ptr(), *x.stride(), x.data_ptr(), *x.stride(), B, N, N, K,
+                                                              d.data_ptr(), i.data_ptr(), stale.data_ptr(), st())), 1)
+    print(json.dumps(row), flush=True)
