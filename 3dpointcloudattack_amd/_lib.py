@@ -120,7 +120,9 @@ SIGNATURES = {
     "pc3d_act_mean_f32": [_P, _I, _I, _I, _I, _F, _P, _P],
     "pc3d_act_mean_bwd_f32": [_P, _P, _I, _I, _I, _I, _F, _P, _P],
     "pc3d_edge_max_f32": [_P, _P, _I, _I, _I, _I, _F, _P, _P, _P],
+    "pc3d_edge_max_cat_f32": [_P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _L, _P],
     "pc3d_edge_max_bwd_f32": [_P, _L, _P, _P, _I, _I, _I, _F, _P, _I, _P],
+    "pc3d_edge_max_bwd_sum_f32": [_P, _L, _P, _L, _P, _P, _I, _I, _I, _F, _P, _P],
     "pc3d_edge_max_bwd_slice_f32": [_P, _L, _P, _P, _I, _I, _I, _F, _P, _I, _P],
     "pc3d_group_max_linear_bwd_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
     "pc3d_cls_tail_f32": [_P, _I, _I, _P, _P, _I, _P, _I, _F, _F, _P, _P, _P, _P, _P, _P],

@@ -153,6 +153,8 @@ struct ArgScatterArgs {
   int mode;
   int NC;               // destination rows per LDS tile (N when they fit; else grid.z chunks, as in ScatterArgs)
   int B;
+  const float* g2;      // null, or a second upstream gradient [B,S,ldg2 >= C] ADDED to g on load (mode 1: an EdgeConv output
+  int64_t ldg2;         // feeds conv5 and the next layer — the sum of their two gradients without a launch of its own)
 };
 
 // One trip of a wavefront: 64 * U source points, CH channels each. The load half only ISSUES the loads (nothing computed
@@ -161,13 +163,13 @@ struct ArgScatterArgs {
 template <int CH, int U>
 struct ArgTrip {
   int t[U][CH];
-  float v[U][CH], o[U][CH];
+  float v[U][CH], o[U][CH], v2[U][CH];
   int i[U];          // source point, -1: none
 };
 
 template <int CH, int U, bool VEC, int MODE>
 __device__ __forceinline__ void arg_trip_load(ArgTrip<CH, U>& T, const ArgScatterArgs& a, const float* gb, const float* ob,
-                                              const int32_t* rb, int i0, int hi, int lane, int nch) {
+                                              const int32_t* rb, int i0, int hi, int lane, int nch, const float* g2b = nullptr) {
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int i = i0 + u * 64 + lane;
@@ -184,6 +186,10 @@ __device__ __forceinline__ void arg_trip_load(ArgTrip<CH, U>& T, const ArgScatte
           const float4 o = *reinterpret_cast<const float4*>(ob + (int64_t)ic * a.C + q);
           T.o[u][q] = o.x, T.o[u][q + 1] = o.y, T.o[u][q + 2] = o.z, T.o[u][q + 3] = o.w;
         }
+        if (g2b) {      // (uniform for the launch)
+          const float4 y = *reinterpret_cast<const float4*>(g2b + (int64_t)ic * a.ldg2 + q);
+          T.v2[u][q] = y.x, T.v2[u][q + 1] = y.y, T.v2[u][q + 2] = y.z, T.v2[u][q + 3] = y.w;
+        }
       }
     } else {
 #pragma unroll
@@ -195,6 +201,7 @@ __device__ __forceinline__ void arg_trip_load(ArgTrip<CH, U>& T, const ArgScatte
           T.v[u][q] = gb[(int64_t)i * a.ldg + q];
           T.t[u][q] = rb[(int64_t)i * a.C + q];
           if (MODE) T.o[u][q] = ob[(int64_t)i * a.C + q];
+          if (g2b) T.v2[u][q] = g2b[(int64_t)i * a.ldg2 + q];
         }
     }
   }
@@ -202,7 +209,7 @@ __device__ __forceinline__ void arg_trip_load(ArgTrip<CH, U>& T, const ArgScatte
 
 template <int CH, int U, bool VEC, int MODE, typename ACC>
 __device__ __forceinline__ void arg_trip_add(const ArgTrip<CH, U>& T, const ArgScatterArgs& a, ACC* acc, float* db, int64_t ldd,
-                                             int n0, int nr, int nch, bool first) {
+                                             int n0, int nr, int nch, bool first, bool two = false) {
   constexpr int ST = CH > 1 ? CH + 1 : 1;
   constexpr bool vec = VEC;
 #pragma unroll
@@ -210,7 +217,10 @@ __device__ __forceinline__ void arg_trip_add(const ArgTrip<CH, U>& T, const ArgS
     if (T.i[u] >= 0) {
       float v[CH];
 #pragma unroll
-      for (int q = 0; q < CH; ++q) v[q] = MODE ? T.v[u][q] * (T.o[u][q] > 0.f ? 1.f : a.slope) : T.v[u][q];
+      for (int q = 0; q < CH; ++q) {
+        const float gsum = two ? T.v[u][q] + T.v2[u][q] : T.v[u][q];       // (one fp32 add, then the mask: what autograd's add + this launch did)
+        v[q] = MODE ? gsum * (T.o[u][q] > 0.f ? 1.f : a.slope) : gsum;
+      }
       if (MODE && first) {                                                      // dQ
         float* dq = db + (int64_t)T.i[u] * ldd + a.C;
         if (vec) {
@@ -258,20 +268,22 @@ __global__ __launch_bounds__(64 * W) void arg_scatter_own_kernel(ArgScatterArgs 
   const float* ob = a.out ? a.out + (int64_t)b * a.S * a.C + c0 : nullptr;
   const int32_t* rb = a.arg + (int64_t)b * a.S * a.C + c0;
   float* db = a.dst + (int64_t)b * a.N * ldd + c0;
+  const float* g2b = a.g2 ? a.g2 + (int64_t)b * a.S * a.ldg2 + c0 : nullptr;
+  const bool two = a.g2 != nullptr;
   constexpr bool vec = VEC;
   const int per = ((a.S + W - 1) / W + 63) / 64 * 64, lo = wave * per, hi = min(lo + per, a.S);
   ArgTrip<CH, U> A, Bt;
   const bool any = lo < hi;                                                              // (uniform per wavefront)
-  if (any) arg_trip_load<CH, U, VEC, MODE>(A, a, gb, ob, rb, lo, hi, lane, nch);        // in flight while the tiles are zeroed
+  if (any) arg_trip_load<CH, U, VEC, MODE>(A, a, gb, ob, rb, lo, hi, lane, nch, g2b);        // in flight while the tiles are zeroed
   for (int e = threadIdx.x; e < W * a.NC * ST; e += 64 * W) as_acc[e] = (ACC)0;
   if (W > 1) __syncthreads(); else wave_lds_sync();
   ACC* acc = as_acc + wave * a.NC * ST;
   if (any)
     for (int i0 = lo; i0 < hi; i0 += 2 * 64 * U) {
-      arg_trip_load<CH, U, VEC, MODE>(Bt, a, gb, ob, rb, i0 + 64 * U, hi, lane, nch);
-      arg_trip_add<CH, U, VEC, MODE, ACC>(A, a, acc, db, ldd, n0, nr, nch, first);
-      arg_trip_load<CH, U, VEC, MODE>(A, a, gb, ob, rb, i0 + 2 * 64 * U, hi, lane, nch);
-      arg_trip_add<CH, U, VEC, MODE, ACC>(Bt, a, acc, db, ldd, n0, nr, nch, first);
+      arg_trip_load<CH, U, VEC, MODE>(Bt, a, gb, ob, rb, i0 + 64 * U, hi, lane, nch, g2b);
+      arg_trip_add<CH, U, VEC, MODE, ACC>(A, a, acc, db, ldd, n0, nr, nch, first, two);
+      arg_trip_load<CH, U, VEC, MODE>(A, a, gb, ob, rb, i0 + 2 * 64 * U, hi, lane, nch, g2b);
+      arg_trip_add<CH, U, VEC, MODE, ACC>(Bt, a, acc, db, ldd, n0, nr, nch, first, two);
     }
   if (W > 1) __syncthreads(); else wave_lds_sync();
   for (int nl = threadIdx.x; nl < nr; nl += 64 * W) {
@@ -372,7 +384,8 @@ int scatter_rows_det(const char* nm, const int32_t* tgt, const float* val, int64
 // slice: bits 0..7 the channel-slice width to run (1, 2, 4, 8, 16; 0: chosen here; PC3D_EINVAL when its tile does not fit),
 // bit 8: fp32 tiles where the library would take fp64 ones (measurements: tools/bench_det.py).
 int arg_scatter_det(const char* nm, const float* g, int64_t ldg, const float* outv, const int32_t* arg, int B, int S, int N, int C,
-                    float slope, float* dst, int mode, void* stream, int slice) {
+                    float slope, float* dst, int mode, void* stream, int slice, const float* g2, int64_t ldg2) {
+  PC3D_REQUIRE(!g2 || ldg2 >= C, "%s: row stride of the second gradient smaller than C", nm);
   // Tiles in fp64 whenever a 4-channel slice of them fits a CU's LDS (N <= 4096) — a function of N alone, so that a cloud's
   // sums do not depend on the batch it is in; the slice width does not change a sum (one wave, points in order).
   const bool f64 = !(slice & 256) && own_bytes(N, 4) * 2 <= kOwnLdsMax;
@@ -394,13 +407,13 @@ int arg_scatter_det(const char* nm, const float* g, int64_t ldg, const float* ou
     NC = (int)(kOwnLds / (sizeof(float) * eb * (ch > 1 ? ch + 1 : 1)));
     PC3D_REQUIRE(cdiv(N, NC) <= 65535, "%s: N=%d needs more than 65535 row tiles", nm, N);
   }
-  ArgScatterArgs a{g, ldg, outv, arg, S, N, C, slope, dst, mode, NC, B};
+  ArgScatterArgs a{g, ldg, outv, arg, S, N, C, slope, dst, mode, NC, B, g2, ldg2};
   const size_t lds = own_bytes(NC, ch) * eb;
   const dim3 grid(xcd_grid(cdiv(C, ch) * B), 1, cdiv(N, NC));
   hipStream_t st = as_stream(stream);
-  const bool vec = ch >= 4 && C % ch == 0 && (C & 3) == 0 && (ldg & 3) == 0 &&
+  const bool vec = ch >= 4 && C % ch == 0 && (C & 3) == 0 && (ldg & 3) == 0 && (ldg2 & 3) == 0 &&
                    ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(arg) | reinterpret_cast<uintptr_t>(dst) |
-                     reinterpret_cast<uintptr_t>(outv)) & 15) == 0;
+                     reinterpret_cast<uintptr_t>(outv) | reinterpret_cast<uintptr_t>(g2)) & 15) == 0;
 #define PC3D_AS2(CHV, VECV, MODEV)                                                                              \
   if (f64) PC3D_OWN_LAUNCH((arg_scatter_own_kernel<CHV, 1, VECV, MODEV, double>), 64, grid, lds, st, a);         \
   else PC3D_OWN_LAUNCH((arg_scatter_own_kernel<CHV, 1, VECV, MODEV, float>), 64, grid, lds, st, a);

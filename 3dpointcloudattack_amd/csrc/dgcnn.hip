@@ -283,6 +283,8 @@ struct EdgeMaxArgs {
   float* out;           // [B,N,C]
   int32_t* arg;         // [B,N,C]
   int B;
+  float* out2;          // null, or a second copy of out with row stride ld2 (a column slice of a wider [B,N,ld2] buffer)
+  int64_t ld2;
 };
 
 __global__ __launch_bounds__(256) void edge_max_kernel(EdgeMaxArgs a, int lpp) {
@@ -329,6 +331,7 @@ __global__ __launch_bounds__(256) void edge_max_kernel(EdgeMaxArgs a, int lpp) {
   const int64_t off = ((int64_t)b * a.N + i) * a.C + 4 * l;
   *reinterpret_cast<float4*>(a.out + off) = make_float4(o[0], o[1], o[2], o[3]);
   *reinterpret_cast<int4*>(a.arg + off) = make_int4(bj[0], bj[1], bj[2], bj[3]);
+  if (a.out2) *reinterpret_cast<float4*>(a.out2 + ((int64_t)b * a.N + i) * a.ld2 + 4 * l) = make_float4(o[0], o[1], o[2], o[3]);
 }
 
 // backward: one thread per (b, i, c): dQ written, dP scattered with float atomics into the zero-filled P half
@@ -546,17 +549,28 @@ extern "C" int pc3d_gather_max_rows_bwd_f32(const float* g, const int32_t* arg, 
   return gather_max_bwd_launch("pc3d_gather_max_rows_bwd_f32", g, arg, B, N, S, C, gP, deterministic, stream);
 }
 
-extern "C" int pc3d_edge_max_f32(const float* PQ, const int32_t* idx, int B, int N, int C, int K, float slope,
-                                 float* out, int32_t* arg, void* stream) {
-  PC3D_REQUIRE(B >= 0 && N >= 1 && C >= 4 && C % 4 == 0 && C <= 1024 && K >= 1, "pc3d_edge_max_f32: bad sizes (C %% 4 == 0, C <= 1024)");
-  PC3D_REQUIRE(B <= 65535, "pc3d_edge_max_f32: B=%d exceeds grid.y limit", B);
+static int edge_max_launch(const char* nm, const float* PQ, const int32_t* idx, int B, int N, int C, int K, float slope,
+                           float* out, int32_t* arg, float* out2, int64_t ld2, void* stream) {
+  PC3D_REQUIRE(B >= 0 && N >= 1 && C >= 4 && C % 4 == 0 && C <= 1024 && K >= 1, "%s: bad sizes (C %% 4 == 0, C <= 1024)", nm);
   if (B == 0) return PC3D_OK;
-  PC3D_REQUIRE(PQ && idx && out && arg, "pc3d_edge_max_f32: null pointer");
-  EdgeMaxArgs a{PQ, idx, N, C, K, slope, out, arg, B};
+  PC3D_REQUIRE(PQ && idx && out && arg, "%s: null pointer", nm);
+  PC3D_REQUIRE(!out2 || (ld2 >= C && ld2 % 4 == 0 && (reinterpret_cast<uintptr_t>(out2) & 15) == 0),
+               "%s: the second output needs a 16-byte aligned start and a row stride ld2 >= C, ld2 %% 4 == 0", nm);
+  EdgeMaxArgs a{PQ, idx, N, C, K, slope, out, arg, B, out2, ld2};
   const int lpp = C / 4, ppw = 256 / lpp;
   hipLaunchKernelGGL(edge_max_kernel, dim3(xcd_grid(cdiv(N, ppw) * B)), dim3(256), 0, as_stream(stream), a, lpp);
-  PC3D_LAUNCH_CHECK("pc3d_edge_max_f32");
+  PC3D_LAUNCH_CHECK(nm);
   return PC3D_OK;
+}
+
+extern "C" int pc3d_edge_max_f32(const float* PQ, const int32_t* idx, int B, int N, int C, int K, float slope,
+                                 float* out, int32_t* arg, void* stream) {
+  return edge_max_launch("pc3d_edge_max_f32", PQ, idx, B, N, C, K, slope, out, arg, nullptr, 0, stream);
+}
+
+extern "C" int pc3d_edge_max_cat_f32(const float* PQ, const int32_t* idx, int B, int N, int C, int K, float slope,
+                                     float* out, int32_t* arg, float* out2, int64_t ld2, void* stream) {
+  return edge_max_launch("pc3d_edge_max_cat_f32", PQ, idx, B, N, C, K, slope, out, arg, out2, ld2, stream);
 }
 
 extern "C" int pc3d_edge_max_bwd_f32(const float* g, int64_t ldg, const float* out, const int32_t* arg, int B, int N, int C,
@@ -592,6 +606,15 @@ extern "C" int pc3d_edge_max_bwd_f32(const float* g, int64_t ldg, const float* o
                      arg, N, C, slope, gPQ);
   PC3D_LAUNCH_CHECK("pc3d_edge_max_bwd_f32");
   return PC3D_OK;
+}
+
+extern "C" int pc3d_edge_max_bwd_sum_f32(const float* g, int64_t ldg, const float* g2, int64_t ldg2, const float* out,
+                                         const int32_t* arg, int B, int N, int C, float slope, float* gPQ, void* stream) {
+  const char* nm = "pc3d_edge_max_bwd_sum_f32";
+  PC3D_REQUIRE(B >= 0 && N >= 1 && C >= 1 && ldg >= C && ldg2 >= C, "%s: bad sizes (a row stride smaller than C)", nm);
+  if (B == 0) return PC3D_OK;
+  PC3D_REQUIRE(g && g2 && out && arg && gPQ, "%s: null pointer", nm);
+  return arg_scatter_det(nm, g, ldg, out, arg, B, N, N, C, slope, gPQ, 1, stream, 0, g2, ldg2);
 }
 
 extern "C" int pc3d_edge_max_bwd_slice_f32(const float* g, int64_t ldg, const float* out, const int32_t* arg, int B, int N, int C,

@@ -22,7 +22,7 @@ int scatter_rows_det(const char* nm, const int32_t* tgt, const float* val, int64
                      const float* row_bias = nullptr, const float* col_w = nullptr);   // + row_bias[b,n] * col_w[c] on the way out
 //   dst[b, arg[b,i,c], c] += w[b,i,c]  (mode 0: w = g; mode 1: w = g * leaky'(outv), dst = [dP | dQ] with dQ = w)
 int arg_scatter_det(const char* nm, const float* g, int64_t ldg, const float* outv, const int32_t* arg, int B, int S, int N, int C,
-                    float slope, float* dst, int mode, void* stream, int slice = 0);
+                    float slope, float* dst, int mode, void* stream, int slice = 0, const float* g2 = nullptr, int64_t ldg2 = 0);
 // ascending in-place sort of every segment of a CSR list (off [B,NA+1], lst [B,L]): arrival order -> a fixed order
 int sort_segments(const char* nm, const int32_t* off, int32_t* lst, int B, int NA, int64_t L, void* stream);
 // out[b,t,:] = sum over the sorted reverse-index segment of t (off [B,NA+1], lst [B,E]) of mask(val[b,e,:])

@@ -52,6 +52,72 @@ def _fold_edge(conv, bn):
 
 
 FIRST_LAYER_DIRECT = True      # the first EdgeConv's products and the input graph straight from the [B,3,N] input
+TRUNK_AS_ONE_FUNCTION = True   # the four EdgeConv layers + conv5 + pooling as ONE autograd node (_TrunkFn)
+
+
+class _TrunkFn(torch.autograd.Function):
+    """x [B,3,N] -> [max_n | mean_n] of conv5 over the four concatenated EdgeConv outputs ([B, 2 emb]), model/dgcnn.py:297-320,
+    as one autograd node with a hand-ordered backward. The launches are those of the layer-by-layer path; what goes is what
+    autograd put between them: the `torch.cat` copy (every EdgeConv launch also writes its slice of the [B,N,512] buffer,
+    pc3d_edge_max_cat_f32), the slicing of its gradient, and the three `aten::add` that summed an EdgeConv output's two
+    gradients (from conv5 and from the next layer) — the backward scatter of the layer adds the two on load
+    (pc3d_edge_max_bwd_sum_f32; the sum in the next layer's GEMM epilogue, R = Y on the 512-wide slice, measured slower than
+    the add it replaced: 20 -> 34 us per GEMM). 96 -> ~45 us of ATen launches per GeoA3 iteration at B=32, N=1024."""
+
+    @staticmethod
+    def forward(ctx, x, model, k):
+        edges, c5, _ = model.folded()
+        xd = x.detach()
+        B, _, N = xd.shape
+        dev = xd.device
+        f0 = xd.permute(0, 2, 1)                                  # [B,N,3] view of the channels-first input
+        widths = [UV.shape[0] // 2 for UV, _ in edges]
+        ctot = sum(widths)
+        cat = torch.empty((B, N, ctot), dtype=torch.float32, device=dev)
+        outs, args_, f, off = [], [], None, 0
+        for li, (UV, tb) in enumerate(edges):
+            C = widths[li]
+            if li == 0:
+                idx = ops.knn_raw(xd, xd, k, True, True)[1]
+                _graphed.note_input_knn(model, x, idx)            # the graph of the INPUT cloud: attacks may reuse it
+                PQ = ops._affine3_raw(f0, UV, tb, 1.0)
+            else:
+                idx = ops.knn_feat(f, k)
+                PQ = ops.gemm_nt(f.view(B * N, -1), UV, tb, unit_rows=N).view(B, N, 2 * C)
+            f, arg = ops.edge_max_raw(PQ, idx, 0.2, cat, off)
+            outs.append(f), args_.append(arg)
+            off += C
+        w5, b5 = c5
+        E = w5.shape[0]
+        Y = ops.gemm_nt(cat.view(B * N, ctot), w5, b5, unit_rows=N)
+        pooled, parg = ops.act_pool_raw(Y, B, N, E, 0.2)
+        ctx.save_for_backward(Y, parg, *outs, *args_)
+        ctx.model, ctx.meta = model, (B, N, widths, E)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, g):
+        B, N, widths, E = ctx.meta
+        saved = ctx.saved_tensors
+        Y, parg = saved[0], saved[1]
+        nl = len(widths)
+        outs, args_ = saved[2:2 + nl], saved[2 + nl:2 + 2 * nl]
+        edges, c5, _ = ctx.model.folded()
+        ctot = sum(widths)
+        dcat = ops.pool_bwd_gemm_raw(Y, g.contiguous(), parg, B, N, 0.2, c5[0], ctot, E)        # [B*N, ctot]: d loss / d cat
+        offs = [sum(widths[:l]) for l in range(nl)]
+        gx, gnext = None, None
+        for li in range(nl - 1, -1, -1):
+            C = widths[li]
+            # an EdgeConv output feeds conv5 (its slice of dcat, read in place) and the next layer (gnext): the scatter's loads add them
+            gPQ = ops.edge_max_bwd_raw(dcat, offs[li], ctot, outs[li], args_[li], B, N, C, 0.2, g2=gnext)   # [B,N,2C]
+            UV = edges[li][0]
+            if li > 0:
+                gnext = ops.gemm_nt(gPQ.view(B * N, 2 * C), ops._w_transposed(UV), unit_rows=N)           # d / d f_{l-1} through layer l
+            else:
+                gx = ops._affine3_bwd_raw(gPQ, UV, 1.0, None, ops._cf_grad(B, N, gPQ.device)).permute(0, 2, 1)
+        return gx, None, None
+
 
 
 class DGCNN(_FrozenFusedMixin, nn.Module):
@@ -101,6 +167,12 @@ class DGCNN(_FrozenFusedMixin, nn.Module):
         B = x.size(0)
         x = x.float()
         direct_in = FIRST_LAYER_DIRECT and x.is_cuda and edges[0][0].shape[0] % 4 == 0
+        if (TRUNK_AS_ONE_FUNCTION and direct_in and x.shape[2] % 128 == 0 and c5[0].shape[0] % 4 == 0
+                and all(UV.shape[0] % 16 == 0 for UV, _ in edges)):
+            g = _TrunkFn.apply(x, self, self.k)
+            g = ops.head_mlp(g, [(*head[0], "leaky", 0.2), (*head[1], "leaky", 0.2), (*head[2], None, 0.0)])
+            g = F.log_softmax(g, -1)
+            return g, g, g
         f = x.permute(0, 2, 1) if direct_in else x.transpose(2, 1).contiguous()    # [B,N,3] channels-last from here on
         feats = []
         for li, (UV, tb) in enumerate(edges):

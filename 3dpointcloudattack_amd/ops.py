@@ -1526,6 +1526,77 @@ class _EdgeMaxFn(torch.autograd.Function):
         return gPQ, None, None
 
 
+def edge_max_raw(PQ, idx, slope, cat=None, off=0):
+    """(out [B,N,C], arg int32 [B,N,C]) of pc3d_edge_max_f32, no autograd; with `cat` [B,N,Ct] the launch also writes out into
+    cat[:, :, off:off+C] (pc3d_edge_max_cat_f32)."""
+    B, N, C2 = PQ.shape
+    C = C2 // 2
+    out = torch.empty((B, N, C), dtype=torch.float32, device=PQ.device)
+    arg = torch.empty((B, N, C), dtype=torch.int32, device=PQ.device)
+    with torch.cuda.device(PQ.device):
+        if cat is None:
+            _lib.call("pc3d_edge_max_f32", PQ.data_ptr(), idx.data_ptr(), B, N, C, idx.shape[2], float(slope),
+                      out.data_ptr(), arg.data_ptr(), _stream())
+        else:
+            if not cat.is_contiguous() or cat.shape[:2] != (B, N) or off % 4 or off + C > cat.shape[2]:
+                raise ValueError("edge_max_raw: cat must be a contiguous [B,N,Ct] buffer and off a multiple of 4 inside it")
+            _lib.call("pc3d_edge_max_cat_f32", PQ.data_ptr(), idx.data_ptr(), B, N, C, idx.shape[2], float(slope),
+                      out.data_ptr(), arg.data_ptr(), cat.data_ptr() + 4 * off, cat.shape[2], _stream())
+    return out, arg
+
+
+def edge_max_bwd_raw(gcat, off, ld, out, arg, B, N, C, slope, g2=None):
+    """gPQ [B,N,2C] of pc3d_edge_max_bwd_f32 for the upstream gradient gcat[:, off:off+C] read in place (row stride ld);
+    g2 [B*N, C] contiguous or None: a second upstream gradient, added on load (deterministic mode) or by a launch of its own."""
+    gPQ = torch.empty((B, N, 2 * C), dtype=torch.float32, device=gcat.device)
+    with torch.cuda.device(gcat.device):
+        if g2 is not None and _det():
+            _lib.call("pc3d_edge_max_bwd_sum_f32", gcat.data_ptr() + 4 * off, ld, g2.data_ptr(), C, out.data_ptr(), arg.data_ptr(),
+                      B, N, C, float(slope), gPQ.data_ptr(), _stream())
+            return gPQ
+        if g2 is not None:
+            gsum = gcat.view(B, N, ld)[:, :, off:off + C] + g2.view(B, N, C)
+            _lib.call("pc3d_edge_max_bwd_f32", gsum.data_ptr(), C, out.data_ptr(), arg.data_ptr(), B, N, C,
+                      float(slope), gPQ.data_ptr(), 0, _stream())
+            return gPQ
+        _lib.call("pc3d_edge_max_bwd_f32", gcat.data_ptr() + 4 * off, ld, out.data_ptr(), arg.data_ptr(), B, N, C,
+                  float(slope), gPQ.data_ptr(), _det(), _stream())
+    return gPQ
+
+
+def act_pool_raw(Y, B, N, C, slope):
+    """([max_n z | mean_n z] [B,2C], arg-max rows int32 [B,C]) of z = leaky(Y) for Y [B*N, C] (pc3d_act_pool_f32), no autograd."""
+    out = torch.empty((B, 2 * C), dtype=torch.float32, device=Y.device)
+    arg = torch.empty((B, C), dtype=torch.int32, device=Y.device)
+    with torch.cuda.device(Y.device):
+        _lib.call("pc3d_act_pool_f32", Y.data_ptr(), B, N, C, float(slope), out.data_ptr(), arg.data_ptr(), _stream())
+    return out, arg
+
+
+def pool_bwd_gemm_raw(Y, g, arg, B, N, slope, w, K, C):
+    """d/dx [B*N, K] of act_maxmean_pool(x @ w.T + b) from the saved pre-activation Y [B*N, C], the upstream g [B,2C] and the
+    arg-max rows: ONE GEMM on W^T whose dY operand is generated on load (pc3d_gemm_nt_poolbwd_f32), no autograd."""
+    wt = _w_transposed(w)
+    gx = torch.empty((B * N, K), dtype=torch.float32, device=g.device)
+    with torch.cuda.device(g.device):
+        _lib.call("pc3d_gemm_nt_poolbwd_f32", Y.data_ptr(), Y.stride(0), g.data_ptr(), arg.data_ptr(), B, N, float(slope),
+                  wt.data_ptr(), K, C, gx.data_ptr(), K, _stream())
+    return gx
+
+
+def gemm_nt_res_into(x2d, w, buf, off, width, unit_rows=None):
+    """buf[:, off:off+width] += x2d [M,K] @ w [width,K]^T in the GEMM's epilogue (pc3d_gemm_nt_res_f32 with R = Y = the slice of
+    the contiguous [M, ld] buffer): a gradient accumulated where it already lives, without a product tensor and an add."""
+    M, K = x2d.shape
+    if w.shape != (width, K) or not w.is_contiguous() or not buf.is_contiguous() or buf.shape[0] != M or off % 4:
+        raise ValueError("gemm_nt_res_into: w [width,K] contiguous, buf [M,ld] contiguous, off % 4 == 0 expected")
+    ld = buf.shape[1]
+    ptr = buf.data_ptr() + 4 * off
+    with torch.cuda.device(x2d.device):
+        _lib.call("pc3d_gemm_nt_res_f32", x2d.data_ptr(), x2d.stride(0), w.data_ptr(), 0, ptr, ld, M, width, K, _ACTS[None], 0.0,
+                  ptr, ld, gemm_variant(unit_rows, width, K), _stream())
+
+
 def edge_max(PQ, idx, slope=0.2):
     """out[b,i,c] = leaky(max_j P[b,idx[b,i,j],c] + Q[b,i,c]) for PQ [B,N,2C] = [P | Q] (C % 4 == 0): the neighbour
     reduction, the centre term and the activation of an EdgeConv layer in one launch; differentiable in PQ."""

@@ -665,6 +665,10 @@ int pc3d_scatter_rows_det_f32(const int32_t* tgt, const float* val, int64_t ldv,
  * Backward: gPQ [B,N,2C] overwritten: dQ = g * leaky'(out), dP scattered to arg (float atomics). */
 int pc3d_edge_max_f32(const float* PQ, const int32_t* idx, int B, int N, int C, int K, float slope,
                       float* out, int32_t* arg, void* stream);
+/* The same launch also writing out into a column slice of a wider buffer (out2 + (b N + i) ld2, 16-byte aligned, ld2 % 4 == 0):
+ * DGCNN concatenates its four EdgeConv outputs for conv5 (model/dgcnn.py:315 `torch.cat`) — written here, the copy goes. */
+int pc3d_edge_max_cat_f32(const float* PQ, const int32_t* idx, int B, int N, int C, int K, float slope,
+                          float* out, int32_t* arg, float* out2, int64_t ld2, void* stream);
 /* Global pooling head (model/dgcnn.py:317-320, model/curvenet.py:64-67): z = leaky_slope(Y) (slope 0: ReLU),
  * out[b, 0:C] = max_i z[b,i,:], out[b, C:2C] = mean_i z[b,i,:], arg [B,C] = lowest arg-max row; one pass over
  * Y [B,N,C]. Backward: gY overwritten in one pass from gout [B,2C]. C % 4 == 0. Deterministic. */
@@ -677,6 +681,11 @@ int pc3d_edge_max_bwd_f32(const float* g, int64_t ldg, const float* out, const i
                           float slope, float* gPQ, int deterministic, void* stream);
 /* The deterministic form with the channel-slice width of its owner-wave kernel named (1, 2, 4, 8, 16; 0 = the library
  * chooses; identical results for every width — a wavefront per (cloud, slice) sums the points in order). */
+/* The deterministic form for an EdgeConv output with TWO consumers (DGCNN: conv5 through the concatenation, and the next
+ * layer): the upstream gradient is g + g2 (one fp32 add per element, on load), g2 [B,N,ldg2 >= C] — the sum autograd would
+ * form in a launch of its own (model/dgcnn.py:299-315 under autograd). */
+int pc3d_edge_max_bwd_sum_f32(const float* g, int64_t ldg, const float* g2, int64_t ldg2, const float* out,
+                              const int32_t* arg, int B, int N, int C, float slope, float* gPQ, void* stream);
 int pc3d_edge_max_bwd_slice_f32(const float* g, int64_t ldg, const float* out, const int32_t* arg, int B, int N, int C,
                                 float slope, float* gPQ, int slice, void* stream);
 
