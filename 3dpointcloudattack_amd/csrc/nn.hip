@@ -52,9 +52,10 @@ __global__ __launch_bounds__(WAVES * 64) void nn_kernel(NNArgs args, int mt_cap)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const NNDir& D = args.dir[blockIdx.z];
   const int N = D.N, M = D.M;
-  const int q0 = blockIdx.x * (kWave * Q);
+  int bx_, b;
+  xcd_swizzle(bx_, b);      // a cloud's workgroups on one XCD: its reference points are fetched into one L2, not eight
+  const int q0 = bx_ * (kWave * Q);
   if (q0 >= N) return;  // grid.x is sized for the larger direction
-  const int b = blockIdx.y;
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
 
