@@ -160,7 +160,6 @@ __global__ __launch_bounds__(T) void fps_kernel(FpsArgs a) {
       bv = wv;
     }
     FPS_STAMP(1);      // wave arg-max
-    float fv = bv;
     int fi = bi;
     if (T > 64) {           // (one wavefront per cloud: the wave's arg-max is the cloud's — no exchange, no barrier)
       const int buf = s & 1;  // double-buffered exchange: one barrier per step
@@ -174,7 +173,6 @@ __global__ __launch_bounds__(T) void fps_kernel(FpsArgs a) {
         const long long o = red_k[buf][w];
         best = o > best ? o : best;
       }
-      fv = __builtin_bit_cast(float, (int)(best >> 32));
       fi = 0x7fffffff - (int)(unsigned)(best & 0xffffffffll);
     }
     if (fi != 0x7fffffff) far = fi;  // no finite candidate (NaN cloud): stay put instead of indexing LDS at 2^31
