@@ -153,6 +153,7 @@ struct ArgScatterArgs {
   int mode;
   int NC;               // destination rows per LDS tile (N when they fit; else grid.z chunks, as in ScatterArgs)
   int B;
+  int blind;            // measurements only: workgroup ids in launch order (XCD-blind), the order before round 4
   const float* g2;      // null, or a second upstream gradient [B,S,ldg2 >= C] ADDED to g on load (mode 1: an EdgeConv output
   int64_t ldg2;         // feeds conv5 and the next layer — the sum of their two gradients without a launch of its own)
 };
@@ -255,9 +256,9 @@ __global__ __launch_bounds__(64 * W) void arg_scatter_own_kernel(ArgScatterArgs 
   constexpr int ST = CH > 1 ? CH + 1 : 1;
   constexpr int U = CH >= 16 ? 2 : (CH >= 8 ? 4 : 8);      // two trips of 64 U points in flight: ~190 VGPRs (one wave per SIMD anyway)
   // grid.x = (cloud, slice) in XCD bands: the slices of a cloud read the same lines of g / arg / out (a slice uses 16-64 bytes
-  // of each 128-byte line) — spread over the 8 XCDs every L2 pulled every line (24 MB as 192 MB at B=32, N=1024, C=64)
+  // of each 128-byte line) — spread over the XCDs every line was pulled by four L2s (FETCH_SIZE 101 MB against 25 MB at B=32, N=1024, C=64)
   const int nsl = (a.C + CH - 1) / CH;
-  const int t = xcd_band_id(blockIdx.x, a.B * nsl);
+  const int t = a.blind ? ((int)blockIdx.x < a.B * nsl ? (int)blockIdx.x : -1) : xcd_band_id(blockIdx.x, a.B * nsl);
   if (t < 0) return;
   const int b = t / nsl, c0 = (t - b * nsl) * CH, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = VEC ? CH : min(CH, a.C - c0);
@@ -382,12 +383,15 @@ int scatter_rows_det(const char* nm, const int32_t* tgt, const float* val, int64
 }
 
 // slice: bits 0..7 the channel-slice width to run (1, 2, 4, 8, 16; 0: chosen here; PC3D_EINVAL when its tile does not fit),
-// bit 8: fp32 tiles where the library would take fp64 ones (measurements: tools/bench_det.py).
+// bit 8: fp32 tiles where the library would take fp64 ones, bit 9: workgroups in launch order instead of XCD bands
+// (measurements: tools/bench_det.py).
 int arg_scatter_det(const char* nm, const float* g, int64_t ldg, const float* outv, const int32_t* arg, int B, int S, int N, int C,
                     float slope, float* dst, int mode, void* stream, int slice, const float* g2, int64_t ldg2) {
   PC3D_REQUIRE(!g2 || ldg2 >= C, "%s: row stride of the second gradient smaller than C", nm);
   // Tiles in fp64 whenever a 4-channel slice of them fits a CU's LDS (N <= 4096) — a function of N alone, so that a cloud's
   // sums do not depend on the batch it is in; the slice width does not change a sum (one wave, points in order).
+  const int blind = (slice >> 9) & 1;
+  slice &= 511;
   const bool f64 = !(slice & 256) && own_bytes(N, 4) * 2 <= kOwnLdsMax;
   const size_t eb = f64 ? 2 : 1;
   int ch = slice & 0xff;
@@ -407,7 +411,7 @@ int arg_scatter_det(const char* nm, const float* g, int64_t ldg, const float* ou
     NC = (int)(kOwnLds / (sizeof(float) * eb * (ch > 1 ? ch + 1 : 1)));
     PC3D_REQUIRE(cdiv(N, NC) <= 65535, "%s: N=%d needs more than 65535 row tiles", nm, N);
   }
-  ArgScatterArgs a{g, ldg, outv, arg, S, N, C, slope, dst, mode, NC, B, g2, ldg2};
+  ArgScatterArgs a{g, ldg, outv, arg, S, N, C, slope, dst, mode, NC, B, blind, g2, ldg2};
   const size_t lds = own_bytes(NC, ch) * eb;
   const dim3 grid(xcd_grid(cdiv(C, ch) * B), 1, cdiv(N, NC));
   hipStream_t st = as_stream(stream);

@@ -679,8 +679,9 @@ int pc3d_act_pool_bwd_f32(const float* Y, const float* gout, const int32_t* arg,
  * EdgeConv outputs hands over [B,N,512] column slices) is read in place. */
 int pc3d_edge_max_bwd_f32(const float* g, int64_t ldg, const float* out, const int32_t* arg, int B, int N, int C,
                           float slope, float* gPQ, int deterministic, void* stream);
-/* The deterministic form with the channel-slice width of its owner-wave kernel named (1, 2, 4, 8, 16; 0 = the library
- * chooses; identical results for every width — a wavefront per (cloud, slice) sums the points in order). */
+/* The deterministic form with the channel-slice width of its owner-wave kernel named (slice & 255: 1, 2, 4, 8, 16; 0 = the
+ * library chooses; identical results for every width — a wavefront per (cloud, slice) sums the points in order). Two more bits
+ * for measurements: 256 = fp32 instead of fp64 LDS tiles, 512 = workgroups in launch order instead of XCD bands. */
 /* The deterministic form for an EdgeConv output with TWO consumers (DGCNN: conv5 through the concatenation, and the next
  * layer): the upstream gradient is g + g2 (one fp32 add per element, on load), g2 [B,N,ldg2 >= C] — the sum autograd would
  * form in a launch of its own (model/dgcnn.py:299-315 under autograd). */
