@@ -81,7 +81,10 @@ def _graphed():
     return importlib.import_module("3dpointcloudattack_amd.graphed")
 
 
-def graph_ms(fn, per=10, reps=20):
+CLOCK_WARM_MS = 150.0     # device time of sustained load before the sweep's per-kernel measurements (graph_ms, warm_ms)
+
+
+def graph_ms(fn, per=10, reps=20, warm_ms=0.0):
     """ms per call of fn, timed as `per` calls captured into ONE hipGraph and replayed `reps` times (HIP events
     on the replay stream). At N <= 2048 an eager Python call costs more host time than these kernels run, so
     event timing around eager calls measures the host; the attack loops replay graphs as well."""
@@ -96,6 +99,15 @@ def graph_ms(fn, per=10, reps=20):
         g.replay()
         side.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        if warm_ms > 0:      # sustained load first: MI355X raises its clocks over tens of ms of load (conv5's forward GEMM: 370 us in
+                             # the first 4 ms after an idle gap, 357 after 14 ms, 324 after 65 ms — tools/exp/gemm_sustain.py), and the
+                             # attack loops these kernels sit in run for seconds (GeoA3 loop profile: 322 us)
+            e0.record(side)
+            g.replay()
+            e1.record(side)
+            e1.synchronize()
+            for _ in range(int(warm_ms / max(e0.elapsed_time(e1), 1e-3)) + 1):
+                g.replay()
         e0.record(side)
         for _ in range(reps):
             g.replay()
@@ -359,8 +371,10 @@ def main():
                                                      "valu_frac_with_idx", "valu_frac_two_scan")}
                                   for n in (1024, 2048)}
         # ---- roofline of the dominant kernel: the fused per-point MLP + max forward (fp32 MFMA), measured immediately
-        # before the headline loop after 50 untimed launches (the power management needs a few ms to settle when the load
-        # changes from the VALU-bound search kernels above to matrix work)
+        # before the headline loop after 50 untimed launches — deliberately NOT after a long sustained run of itself: 150 ms of
+        # back-to-back tower launches raise the clocks and the launch drops to 73.7 us (0.78 of the peak), but inside the
+        # iteration, between a dozen small launches, it runs at 79 us (rocprof, profiles/r04_bench_kernel_stats.*), and that is
+        # the figure the roofline of the STEP should carry
         x = st["adv"].detach()
         tower = model.feat.folded()
         flops = 2.0 * B * NPTS * (3 * 64 + 64 * 128 + 128 * 1024)   # algorithmic flops per launch
@@ -463,7 +477,9 @@ def main():
             for _ in range(3):
                 fn()
             try:
-                us, how = graph_ms(fn, per=per, reps=reps) * 1e3, f"{per} calls per replayed hipGraph, HIP events around {reps} replays"
+                us, how = (graph_ms(fn, per=per, reps=reps, warm_ms=CLOCK_WARM_MS) * 1e3,
+                           f"{per} calls per replayed hipGraph, HIP events around {reps} replays after {CLOCK_WARM_MS:.0f} ms of the same replays "
+                           "(clock ramp)")
             except Exception as e:      # noqa: BLE001 — a call that syncs with the host cannot be captured
                 torch.cuda.synchronize()
                 us, how = ev_ms(fn, 20, stream) * 1e3, f"eager calls, HIP events (capture failed: {type(e).__name__})"
