@@ -44,6 +44,19 @@ if os.environ.get("PC3D_SA_PACKED") == "0":
     M("3dpointcloudattack_amd.ops").SA_BWD_PACKED = False
 if os.environ.get("PC3D_REV_INDEX") == "0":
     M("3dpointcloudattack_amd.model.pointnet2_utils").REVERSE_INDEX = False
+if os.environ.get("PC3D_EXP_DELAY_STEPS"):
+    # EXPERIMENT: a delay on the main stream every iteration — one workgroup running a sampling chain of that many steps (~0.57 us
+    # each) after the update launch. If the loop is bound by the device the iteration grows by the delay; if the device waits for
+    # the host somewhere, less. (How much of an iteration is host-bound cannot be read off a profiled trace: the profiler slows the host.)
+    _ops = M("3dpointcloudattack_amd.ops")
+    _dummy = torch.rand(1, 4096, 3, device=dev)
+    _steps = int(os.environ["PC3D_EXP_DELAY_STEPS"])
+    _adam_old = _ops.adam_clip_step
+    def _adam_delayed(*a, **k):
+        r = _adam_old(*a, **k)
+        _ops.fps(_dummy, _steps)
+        return r
+    _ops.adam_clip_step = _adam_delayed
 res = {}
 if "cw_curvenet" in which:
     B, N, IT = 32, 4096, 30
