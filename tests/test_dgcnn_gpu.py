@@ -164,6 +164,31 @@ def test_edge_max_cat_and_backward_sum_entries(ops, dev):
     assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("B,N,C,ld,ld2", [(2, 333, 12, 12, 12), (1, 90, 6, 8, 7), (3, 1024, 256, 512, 256), (2, 4100, 32, 40, 32), (1, 5000, 8, 8, 12)])
+def test_edge_max_backward_sum_shapes(dev, B, N, C, ld, ld2):
+    """pc3d_edge_max_bwd_sum_f32 on ragged shapes: unaligned / odd row strides (scalar loads), C % 4 != 0, more points than the
+    fp64 tiles hold (N > 4096: fp32 tiles, row tiles), against a float64 scatter of (g + g2) * mask; twice bit-equal."""
+    lib = importlib.import_module("3dpointcloudattack_amd._lib")
+    torch.manual_seed(N + C)
+    out = torch.randn(B, N, C, device=dev)
+    arg = torch.randint(0, N, (B, N, C), device=dev, dtype=torch.int32)
+    g = torch.randn(B * N, ld, device=dev)
+    g2 = torch.randn(B * N, ld2, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    res = []
+    for _ in range(2):
+        gPQ = torch.empty(B, N, 2 * C, device=dev)
+        lib.call("pc3d_edge_max_bwd_sum_f32", g.data_ptr(), ld, g2.data_ptr(), ld2, out.data_ptr(), arg.data_ptr(), B, N, C, 0.2,
+                 gPQ.data_ptr(), st)
+        res.append(gPQ)
+    assert torch.equal(res[0], res[1])
+    w = ((g[:, :C] + g2[:, :C]).view(B, N, C) * torch.where(out > 0, 1.0, 0.2)).double()
+    dP = torch.zeros(B, N, C, dtype=torch.float64, device=dev)
+    dP.scatter_add_(1, arg.long(), w)
+    torch.testing.assert_close(res[0][:, :, :C].double(), dP, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(res[0][:, :, C:].double(), w, rtol=1e-6, atol=1e-7)
+
+
 @pytest.mark.parametrize("C,N", [(64, 90), (256, 90), (12, 90), (64, 1024), (32, 2500), (8, 5000), (4, 33)])
 def test_edge_max_fwd_bwd_vs_torch(ops, dev, C, N):
     """ops.edge_max = leaky(max_j P_j + Q_i) on [P | Q] rows, forward and backward, vs torch gather/max/leaky. The sizes
